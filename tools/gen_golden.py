@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the SSFM hot path by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference); never on the GPU box.
+The reference needs ``numba`` (absent here): a throw-away stub whose ``njit`` is
+the identity decorator is registered first -- every ``@njit`` function on the
+hot path is a plain numpy expression.
+
+Output: tests/golden/<case>.npz, each holding
+    Ei        input field                                  (N,) or (N, 2K)
+    out       reference output
+    cfg       JSON: function name + every parameter that was set
+    hz, iters per-step step size and iteration count       (Manakov/DBP only)
+    lims      all convergence values, flattened            (Manakov/DBP only)
+    margin    min |lim - tol| / tol over the run           (Manakov/DBP only)
+    extra_*   case-specific extras (e.g. linear-channel output, edfa noise)
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+
+_nb = types.ModuleType("numba")
+
+
+def _identity_decorator(*a, **k):
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+
+
+_nb.njit = _nb.jit = _identity_decorator
+_nb.prange = range
+_nb_typed = types.ModuleType("numba.typed")
+_nb_typed.List = list
+_nb.typed = _nb_typed
+sys.modules["numba"] = _nb
+sys.modules["numba.typed"] = _nb_typed
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+import optic.models.channels as ref_ch  # noqa: E402
+from optic.dsp.equalization import manakovDBP as ref_dbp  # noqa: E402
+from optic.utils import parameters  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def synth_field(N, ncols, seed, p_dbm, dtype=np.complex128):
+    """SURVEY.md 8d recipe: band-limited complex Gaussian, each column P/2."""
+    rng = np.random.default_rng(seed)
+    E = (rng.normal(size=(N, ncols)) + 1j * rng.normal(size=(N, ncols))) / np.sqrt(2)
+    F = np.fft.fft(E, axis=0)
+    F[N // 4: 3 * N // 4, :] = 0
+    E = np.fft.ifft(F, axis=0)
+    p_lin = 10 ** (p_dbm / 10) * 1e-3
+    E = E * np.sqrt((p_lin / 2) / np.mean(np.abs(E) ** 2, axis=0))
+    return E.astype(dtype)
+
+
+class Tracer:
+    """Wraps reference.convergenceCondition / np.exp-free bookkeeping to record
+    lim values and infer per-step iteration counts and step sizes."""
+
+    def __init__(self, mod, name="convergenceCondition"):
+        self.mod, self.name = mod, name
+        self.lims = []
+
+    def __enter__(self):
+        self.orig = getattr(self.mod, self.name)
+
+        def wrapped(*a):
+            v = self.orig(*a)
+            self.lims.append(float(v))
+            return v
+
+        setattr(self.mod, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.mod, self.name, self.orig)
+
+
+def mk_param(**kw):
+    p = parameters()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def cfg_json(func, kw):
+    d = {"func": func}
+    for k, v in kw.items():
+        if k == "prec":
+            v = np.dtype(v).name
+        d[k] = v
+    return json.dumps(d)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez(path, **arrs)
+    return os.path.getsize(path)
+
+
+def split_iters(lims, tol, maxIter):
+    """lims (flat) -> per-step iteration counts, replaying the reference's
+    break rule (channels.py:429-434)."""
+    iters, n = [], 0
+    for v in lims:
+        n += 1
+        if v < tol or n == maxIter:
+            iters.append(n)
+            n = 0
+    assert n == 0
+    return iters
+
+
+def run_manakov(name, func, Ei, kw, extra=None):
+    import optic.dsp.equalization as ref_eq
+    mod = ref_ch if func == "manakovSSF" else ref_eq
+    p = mk_param(**kw)
+    with Tracer(mod) as tr:
+        out = ref_ch.manakovSSF(Ei, p) if func == "manakovSSF" else ref_dbp(Ei, p)
+    lims = np.array(tr.lims)
+    iters = np.array(split_iters(tr.lims, p.tol, p.maxIter))
+    margin = float(np.min(np.abs(lims - p.tol) / p.tol))
+    arrs = dict(Ei=Ei, out=out, cfg=cfg_json(func, kw), iters=iters, lims=lims, margin=margin)
+    if extra:
+        arrs.update(extra)
+    sz = save(name, **arrs)
+    print(f"{name:34s} steps={len(iters):4d} iters={iters.sum():5d} "
+          f"(min {iters.min()} max {iters.max()}) margin={margin:.2e} out={out.dtype}{out.shape} {sz/1024:.0f} KiB")
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    base = dict(Fc=193.1e12, prgsBar=False)
+
+    # ---------------- ssfm: the reference's own three TestSSFM setups ----------------
+    rng = np.random.default_rng(8)
+    sig = 1e-3 * (rng.normal(size=4096) + 1j * rng.normal(size=4096))
+    kw = dict(Ltotal=80, Lspan=80, hz=1, alpha=0.2, D=16, gamma=0, Fs=64e9, amp=None, **base)
+    out = ref_ch.ssfm(sig, mk_param(**kw))
+    lin = ref_ch.linearFiberChannel(sig, mk_param(L=80, alpha=0.2, D=16, Fc=193.1e12, Fs=64e9))
+    np.testing.assert_allclose(out, lin, atol=1e-12)
+    save("ssfm_ref_gamma0", Ei=sig, out=out, cfg=cfg_json("ssfm", kw), extra_linear=lin)
+
+    rng = np.random.default_rng(9)
+    sig = rng.normal(size=4096) + 1j * rng.normal(size=4096)
+    kw = dict(Ltotal=80, Lspan=80, hz=1, alpha=0, D=0, gamma=1.3, Fs=64e9, amp=None, **base)
+    out = ref_ch.ssfm(sig, mk_param(**kw))
+    kw0 = dict(kw, gamma=0)
+    out0 = ref_ch.ssfm(sig, mk_param(**kw0))
+    assert not np.allclose(np.abs(np.fft.fft(out)), np.abs(np.fft.fft(out0)))
+    save("ssfm_ref_spm", Ei=sig, out=out, cfg=cfg_json("ssfm", kw), extra_gamma0=out0)
+
+    rng = np.random.default_rng(10)
+    sig = rng.normal(size=4096) + 1j * rng.normal(size=4096)
+    kw = dict(Ltotal=80, Lspan=80, hz=1, alpha=0, D=16, gamma=1.3, Fs=64e9, amp=None, **base)
+    out = ref_ch.ssfm(sig, mk_param(**kw))
+    save("ssfm_ref_power", Ei=sig, out=out, cfg=cfg_json("ssfm", kw))
+
+    # ---------------- ssfm: BASELINE config-1 shape + spans/amp variants ----------------
+    E = synth_field(4096, 1, 1, 0.0).reshape(-1)
+    E = E * np.sqrt(2)  # single pol carries the whole 0 dBm
+    kw = dict(Ltotal=50, Lspan=50, hz=0.5, alpha=0.2, D=16, gamma=1.3, Fs=512e9, amp=None, **base)
+    save("ssfm_c1shape", Ei=E, out=ref_ch.ssfm(E, mk_param(**kw)), cfg=cfg_json("ssfm", kw))
+    kw = dict(Ltotal=100, Lspan=50, hz=1.0, alpha=0.2, D=16, gamma=1.3, Fs=512e9, amp="ideal", **base)
+    save("ssfm_2span_ideal", Ei=E, out=ref_ch.ssfm(E, mk_param(**kw)), cfg=cfg_json("ssfm", kw))
+    kw = dict(Ltotal=90, Lspan=40, hz=0.7, alpha=0.25, D=17, gamma=1.5, Fs=256e9, amp=None, **base)
+    save("ssfm_truncating", Ei=E.reshape(-1, 1), out=ref_ch.ssfm(E.reshape(-1, 1), mk_param(**kw)),
+         cfg=cfg_json("ssfm", kw))
+    # non power-of-two length (a typical SpS x Nsymb product)
+    E3 = synth_field(3000, 1, 4, 3.0).reshape(-1) * np.sqrt(2)
+    kw = dict(Ltotal=30, Lspan=30, hz=0.5, alpha=0.2, D=16, gamma=1.3, Fs=512e9, amp="ideal", **base)
+    save("ssfm_n3000", Ei=E3, out=ref_ch.ssfm(E3, mk_param(**kw)), cfg=cfg_json("ssfm", kw))
+    # edfa with a fixed seed: under the numba stub the noise is numpy's legacy global RNG
+    kw = dict(Ltotal=40, Lspan=20, hz=1.0, alpha=0.2, D=16, gamma=1.3, Fs=512e9, amp="edfa", NF=5.0,
+              seed=77, **base)
+    save("ssfm_edfa_seed77", Ei=E, out=ref_ch.ssfm(E, mk_param(**kw)), cfg=cfg_json("ssfm", kw))
+
+    # ---------------- manakovSSF ----------------
+    N = 1024
+    mk = dict(alpha=0.2, D=16, gamma=1.3, Fs=512e9, maxIter=10, tol=1e-5, **base)
+    E0 = synth_field(N, 2, 20, 0.0)
+    E8 = synth_field(N, 2, 21, 8.4)
+    E13 = synth_field(N, 2, 22, 13.0)
+    E13k2 = synth_field(N, 4, 23, 13.0)
+    E8k2 = synth_field(N, 4, 24, 8.4)
+
+    run_manakov("mk_fix_p0_none", "manakovSSF", E0,
+                dict(mk, Ltotal=20, Lspan=20, hz=0.5, nlprMethod=False, amp=None))
+    run_manakov("mk_fix_p8_ideal_2span", "manakovSSF", E8,
+                dict(mk, Ltotal=40, Lspan=20, hz=0.5, nlprMethod=False, amp="ideal", saveSpanN=[1, 2]))
+    run_manakov("mk_fix_p13_ideal_k2", "manakovSSF", E13k2,
+                dict(mk, Ltotal=20, Lspan=10, hz=0.25, nlprMethod=False, amp="ideal", saveSpanN=[]))
+    run_manakov("mk_fix_nonint_lastspan", "manakovSSF", E8,
+                dict(mk, Ltotal=25, Lspan=10, hz=0.3, nlprMethod=False, amp=None, saveSpanN=[2]))
+    run_manakov("mk_fix_p13_hz1", "manakovSSF", E13,
+                dict(mk, Ltotal=20, Lspan=20, hz=1.0, nlprMethod=False, amp="ideal", saveSpanN=[]))
+    run_manakov("mk_adp_p8_none", "manakovSSF", E8,
+                dict(mk, Ltotal=20, Lspan=20, hz=0.5, nlprMethod=True, maxNlinPhaseRot=2e-2, amp=None))
+    run_manakov("mk_adp_p13_ideal_2span", "manakovSSF", E13,
+                dict(mk, Ltotal=20, Lspan=10, hz=0.5, nlprMethod=True, maxNlinPhaseRot=2e-2, amp="ideal",
+                     saveSpanN=[1, 2]))
+    run_manakov("mk_adp_p8_k2", "manakovSSF", E8k2,
+                dict(mk, Ltotal=10, Lspan=10, hz=0.5, nlprMethod=True, maxNlinPhaseRot=2e-2, amp=None,
+                     saveSpanN=[]))
+    run_manakov("mk_maxiter_hit", "manakovSSF", E13,
+                dict(mk, Ltotal=5, Lspan=5, hz=1.0, nlprMethod=False, amp=None, maxIter=3, tol=1e-9,
+                     saveSpanN=[]))
+    # defaults path: only Fs and the lengths given (amp='edfa' default would add noise -> amp None)
+    run_manakov("mk_defaults", "manakovSSF", E0,
+                dict(Fs=512e9, Ltotal=10, Lspan=5, amp=None, prgsBar=False))
+    # complex64 field + prec=complex64
+    E8c = E8.astype(np.complex64)
+    run_manakov("mk_fix_p8_c64", "manakovSSF", E8c,
+                dict(mk, Ltotal=20, Lspan=20, hz=0.5, nlprMethod=False, amp="ideal", prec=np.complex64,
+                     saveSpanN=[]))
+    run_manakov("mk_adp_p8_c64", "manakovSSF", E8c,
+                dict(mk, Ltotal=10, Lspan=10, hz=0.5, nlprMethod=True, amp=None, prec=np.complex64))
+    # larger N, few steps (exercises the two-pass FFT decomposition at a non-trivial size)
+    E8big = synth_field(4096, 2, 25, 8.4)
+    run_manakov("mk_fix_p8_n4096", "manakovSSF", E8big,
+                dict(mk, Ltotal=2, Lspan=2, hz=0.25, nlprMethod=False, amp="ideal", saveSpanN=[]))
+    # non power-of-two
+    E8n = synth_field(1500, 2, 26, 8.4)
+    run_manakov("mk_fix_p8_n1500", "manakovSSF", E8n,
+                dict(mk, Ltotal=10, Lspan=10, hz=0.5, nlprMethod=False, amp="ideal", saveSpanN=[]))
+    # edfa with seed (CPU reference: same seed every span, x and y share the noise)
+    run_manakov("mk_edfa_seed5", "manakovSSF", E8,
+                dict(mk, Ltotal=20, Lspan=10, hz=0.5, nlprMethod=False, amp="edfa", NF=4.5, seed=5,
+                     saveSpanN=[1, 2]))
+
+    # ---------------- manakovDBP ----------------
+    run_manakov("dbp_fix_hz10", "manakovDBP", E8,
+                dict(mk, Ltotal=80, Lspan=40, hz=10, nlprMethod=False, amp="edfa", saveSpanN=[]))
+    run_manakov("dbp_fix_hz05_none", "manakovDBP", E13,
+                dict(mk, Ltotal=10, Lspan=10, hz=0.5, nlprMethod=False, amp=None))
+    run_manakov("dbp_adp_ideal", "manakovDBP", E8,
+                dict(mk, Ltotal=20, Lspan=10, hz=0.5, nlprMethod=True, maxNlinPhaseRot=2e-2, amp="ideal",
+                     saveSpanN=[1, 2]))
+    # forward -> DBP round trip
+    fkw = dict(mk, Ltotal=20, Lspan=10, hz=0.5, nlprMethod=False, amp="ideal", saveSpanN=[])
+    fwd = ref_ch.manakovSSF(E8, mk_param(**fkw))
+    back = run_manakov("dbp_roundtrip", "manakovDBP", fwd, dict(fkw), extra=dict(extra_orig=E8))
+    rt = np.linalg.norm(back - E8) / np.linalg.norm(E8)
+    print(f"round trip rel-L2 = {rt:.2e}")
+
+
+if __name__ == "__main__":
+    main()
