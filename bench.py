@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- SSFM steps/s on MI355X for BASELINE.json's headline configuration.
+
+Workload (config 2, SURVEY.md 8d "C2"): dual-pol manakovSSF, N = 2^20 complex128
+samples, Fs 512 GS/s, 8.4 dBm band-limited Gaussian field (seed 2), alpha 0.2,
+D 16, gamma 1.3, hz 0.08 km fixed step, maxIter 10, tol 1e-5, amp 'ideal',
+saveSpanN = [].  One "step" = one pass of `while z_current < Lspan`
+(reference optic/models/channels.py:387).  The timed region runs EXACTLY K
+steps with the field already resident in HBM (upload before, download after).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU;
+every rank propagates its own independent field (weak scaling, no data-path
+collective -- SURVEY.md 8e); torch.distributed (RCCL) is used only for the
+barriers and the max-over-ranks reduction of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def synth_field(N, ncols, seed, p_dbm, dtype=np.complex128):
+    rng = np.random.default_rng(seed)
+    E = (rng.normal(size=(N, ncols)) + 1j * rng.normal(size=(N, ncols))) / np.sqrt(2)
+    F = np.fft.fft(E, axis=0)
+    F[N // 4: 3 * N // 4, :] = 0
+    E = np.fft.ifft(F, axis=0)
+    p_lin = 10 ** (p_dbm / 10) * 1e-3
+    E = E * np.sqrt((p_lin / 2) / np.mean(np.abs(E) ** 2, axis=0))
+    return E.astype(dtype)
+
+
+def make_params(lib_mod, steps, hz, prec_fs=512e9):
+    cp = lib_mod.Params()
+    cp.model, cp.direction = lib_mod.MODEL_MANAKOV, 1
+    cp.Fs, cp.Fc, cp.alpha, cp.D, cp.gamma = prec_fs, 193.1e12, 0.2, 16.0, 1.3
+    cp.Lspan = (steps - 0.5) * hz          # exactly `steps` passes of the while loop (last one is half a step)
+    cp.Nspans, cp.hz, cp.maxIter, cp.tol = 1, hz, 10, 1e-5
+    cp.nlprMethod, cp.maxNlinPhaseRot, cp.amp, cp.NF = 0, 2e-2, lib_mod.AMP_IDEAL, 4.5
+    cp.n_save, cp.save_spans = 0, None
+    return cp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--prec", default="c128", choices=["c128", "c64"])
+    ap.add_argument("--engine", default=os.environ.get("SSF_ENGINE", "auto"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from opticommpy_amd import _lib
+    lib = _lib.load()
+    if lib.ssf_device_count() <= 0:
+        raise SystemExit("bench.py needs a GPU: no HIP device visible (there is no CPU fallback)")
+
+    N = 1 << args.log2n
+    dtype = np.complex128 if args.prec == "c128" else np.complex64
+    prec = _lib.SSF_C128 if args.prec == "c128" else _lib.SSF_C64
+    engine = {"auto": 0, "rocfft": 1, "fused": 2}[args.engine]
+    E = synth_field(N, 2, 2 + rank, 8.4, dtype)
+    soa = np.ascontiguousarray(E.T)
+
+    h = C.c_void_p()
+    _lib.raise_for(lib, None, lib.ssf_plan_create(local_rank, N, 2, prec, engine, C.byref(h)))
+
+    def run(steps, field):
+        st = _lib.Stats()
+        cp = make_params(_lib, steps, 0.08)
+        _lib.raise_for(lib, h, lib.ssf_upload(h, field.ctypes.data_as(C.c_void_p)))      # field resident in HBM
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        rc = lib.ssf_execute(h, C.byref(cp), 1, 1, None, C.byref(st), None)              # synchronous at return
+        t1 = time.perf_counter()
+        _lib.raise_for(lib, h, rc)
+        return t1 - t0, st
+
+    if args.warmup > 0:
+        run(args.warmup, soa)
+    dt, st = run(args.steps, soa)
+    assert st.steps == args.steps, (st.steps, args.steps)
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+
+    out_soa = np.empty_like(soa)
+    _lib.raise_for(lib, h, lib.ssf_download(h, out_soa.ctypes.data_as(C.c_void_p)))
+
+    if rank == 0:
+        s = 16 if args.prec == "c128" else 8
+        steps_total = args.steps * world
+        value = steps_total / dt
+        dev_s = st.device_ms * 1e-3
+        achieved = st.bytes_algorithmic / dev_s / 1e9
+        rec = {
+            "metric": "SSFM steps/sec (2-pol, 2^%d samples)" % args.log2n, "value": value, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64" if args.prec == "c128" else "f32", "data": "synthetic",
+            "config": {"workload": "manakovSSF config-2: 2-pol N=2^%d %s, hz=0.08 km fixed, 8.4 dBm, amp=ideal, "
+                                   "1 independent field per GPU" % (args.log2n, "complex128" if s == 16 else "complex64"),
+                       "engine": _lib.ENGINE_NAMES[st.engine], "fields_per_gpu": 1,
+                       "iterations_per_step": st.iterations / st.steps,
+                       "transforms_per_step": st.transforms / st.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "whole step pipeline (HIP events around the K timed steps on the plan stream)",
+                         "algorithmic_bytes_per_step": st.bytes_algorithmic / st.steps,
+                         "device_ms_per_step": st.device_ms / st.steps},
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic_bytes_per_step.json")
+        if os.path.exists(traffic_file):
+            try:
+                rec["roofline"]["traffic"] = json.load(open(traffic_file)).get(_lib.ENGINE_NAMES[st.engine])
+            except Exception:
+                pass
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import ssf_oracle as orc
+            n = max(2, args.cpu_steps)
+            p = orc.parameters()
+            p.Fs, p.Fc, p.alpha, p.D, p.gamma = 512e9, 193.1e12, 0.2, 16, 1.3
+            p.Ltotal = p.Lspan = (n - 0.5) * 0.08
+            p.hz, p.maxIter, p.tol, p.nlprMethod, p.amp, p.saveSpanN, p.prgsBar = 0.08, 10, 1e-5, False, "ideal", [], False
+            p.prec = dtype
+            tr = {}
+            t0 = time.perf_counter()
+            ref = orc.manakovSSF(E, p, trace=tr)
+            tc = time.perf_counter() - t0
+            # same n steps on the GPU for the in-run parity gate
+            _, stp = run(n, soa)
+            got = np.empty_like(soa)
+            _lib.raise_for(lib, h, lib.ssf_download(h, got.ctypes.data_as(C.c_void_p)))
+            err = float(np.linalg.norm(got.T.astype(np.complex128) - ref) / np.linalg.norm(ref))
+            cpu_model = "unknown"
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        cpu_model = line.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
+            rec["cpu_baseline"] = {"value": n / tc, "unit": "steps/s", "cores": 1, "kind": "port",
+                                   "sample": "%d steps of the same config-2 field (numpy oracle, single thread; "
+                                             "%d cores available; %s; numpy %s)" % (n, os.cpu_count(), cpu_model, np.__version__),
+                                   "iterations_per_step": tr["iterations"] / tr["steps"]}
+            rec["parity"] = {"rel_l2_vs_oracle": err, "steps": n,
+                             "iterations_gpu": int(stp.iterations), "iterations_oracle": int(tr["iterations"]),
+                             "gate": 1e-10 if s == 16 else 5e-4, "ok": bool(err <= (1e-10 if s == 16 else 5e-4))}
+            rec["speedup_vs_cpu"] = value / (n / tc)
+        print(json.dumps(rec))
+    lib.ssf_plan_destroy(h)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

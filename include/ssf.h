@@ -1,0 +1,164 @@
+/* ssf.h -- C ABI of the MI355X-native split-step Fourier fiber-propagation library
+ * (libssf_hip.so).  POD types only, no C++ exceptions cross this boundary, every
+ * entry point returns an ssf_status (0 = OK, negative = error) unless stated.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * OptiCommPy checkout; the reference has no FFI, its "plugin API" is the set of
+ * Python functions a notebook imports from optic.models.modelsGPU):
+ *
+ *   ssf_device_count / ssf_device_info   optic/dsp/coreGPU.py:11-24   (checkGPU)
+ *   ssf_plan_create / ssf_plan_destroy   implicit cupy allocations + cuFFT plan cache,
+ *                                        optic/models/modelsGPU.py:404,450-451 (manakovSSF)
+ *   ssf_upload                           cp.asarray(Ei).astype(prec)      modelsGPU.py:216,404
+ *   ssf_execute  (model NLSE)            ssfm hot loop                    modelsGPU.py:241-269
+ *                                        == optic/models/channels.py:215-238
+ *   ssf_execute  (model MANAKOV, +1)     manakovSSF span/step/iteration loops
+ *                                        modelsGPU.py:420-498 == channels.py:380-456
+ *   ssf_execute  (model MANAKOV, -1)     manakovDBP                       modelsGPU.py:564-772
+ *                                        == optic/dsp/equalization.py:1087-1160
+ *   ssf_download                         cp.asnumpy(...)                  modelsGPU.py:271,501-509
+ *   ssf_run                              one whole reference call (upload+execute+download)
+ *   ssf_mgpu_run                         (no reference equivalent) independent fields
+ *                                        sharded over the GPUs of one node, SURVEY.md 8e
+ *   ssf_linear_channel                   linearFiberChannel               channels.py:30-109
+ *
+ * Data layout at the boundary: struct-of-arrays.  A "row" is one column of the
+ * reference's (N, ncols) field, stored contiguously: rows = [x0, y0, x1, y1, ...]
+ * for the Manakov model (nrows = 2K), or independent scalar fields for NLSE.
+ * Complex samples are interleaved (re, im) float (SSF_C64) or double (SSF_C128).
+ *
+ * Ownership: the caller owns every host buffer it passes, for the duration of
+ * the call only.  The library owns all device memory, FFT plans and its HIP
+ * stream inside the opaque plan handle.  A plan is NOT thread-safe: use one
+ * plan per (thread, device).  All calls are synchronous at return.
+ */
+#ifndef SSF_H
+#define SSF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ssf_plan ssf_plan;
+
+typedef enum {
+    SSF_OK = 0,
+    SSF_ERR_BAD_ARG = -1,
+    SSF_ERR_HIP = -2,
+    SSF_ERR_OOM = -3,
+    SSF_ERR_FFT = -4,
+    SSF_ERR_NO_DEVICE = -5,
+    SSF_ERR_UNSUPPORTED = -6,
+    SSF_ERR_STATE = -7
+} ssf_status;
+
+enum { SSF_C64 = 0, SSF_C128 = 1 };                       /* field precision            */
+enum { SSF_MODEL_NLSE = 0, SSF_MODEL_MANAKOV = 1 };       /* ssfm | manakovSSF/DBP      */
+enum { SSF_AMP_NONE = 0, SSF_AMP_IDEAL = 1, SSF_AMP_EDFA = 2 };
+enum { SSF_ENGINE_AUTO = 0, SSF_ENGINE_ROCFFT = 1, SSF_ENGINE_FUSED = 2 };
+
+/* Raw physical parameters exactly as the reference's parameters object holds them
+ * (channels.py:305-322); every derived constant (alpha [1/km], beta2, lambda,
+ * G_lin, nsp, p_noise) is computed inside the library with scipy's literals
+ * c = 299792458.0, h = 6.62607015e-34. */
+typedef struct {
+    int32_t model;            /* SSF_MODEL_*                                             */
+    int32_t direction;        /* +1 forward (ssfm, manakovSSF); -1 back-propagation      */
+    double  Fs;               /* sampling rate [Hz]                                      */
+    double  Fc;               /* carrier [Hz]                                            */
+    double  alpha;            /* [dB/km]                                                 */
+    double  D;                /* [ps/nm/km]                                              */
+    double  gamma;            /* [1/W/km]                                                */
+    double  Lspan;            /* [km]                                                    */
+    int32_t Nspans;           /* floor(Ltotal/Lspan)                                     */
+    int32_t maxIter;          /* Manakov: max fixed-point iterations per step            */
+    double  hz;               /* [km] fixed step (also the cap-less nominal step)        */
+    double  tol;              /* Manakov: convergence tolerance                          */
+    int32_t nlprMethod;       /* Manakov: 1 = adaptive step from max nonlinear phase     */
+    int32_t amp;              /* SSF_AMP_*                                               */
+    double  maxNlinPhaseRot;  /* [rad]                                                   */
+    double  NF;               /* EDFA noise figure [dB]                                  */
+    int32_t n_save;           /* number of entries of save_spans (0 = final field only)  */
+    int32_t reserved;
+    const int32_t *save_spans;/* 1-based span indexes to snapshot (reference saveSpanN)  */
+} ssf_params;
+
+typedef struct {
+    int64_t steps;               /* passes of `while z_current < Lspan` / inner `for`    */
+    int64_t iterations;          /* Manakov fixed-point iterations, summed               */
+    int64_t transforms;          /* length-N FFT/IFFTs of one row, summed                */
+    int64_t nonconverged_steps;  /* steps that hit maxIter (reference logs a warning)    */
+    double  device_ms;           /* HIP-event time of the propagation on the plan stream */
+    double  bytes_algorithmic;   /* transforms * 2 * sizeof(complex) * N      */
+    int32_t engine;              /* SSF_ENGINE_* actually used                           */
+    int32_t n_snapshots;         /* snapshots captured so far                            */
+} ssf_stats;
+
+/* Optional per-step trace (for parity checks of the data-dependent control flow).
+ * Arrays are caller-owned; the library writes at most `capacity` steps. */
+typedef struct {
+    int64_t  capacity;        /* in: number of steps the arrays can hold                 */
+    int64_t  count;           /* out: steps written                                      */
+    double  *hz;              /* [capacity]            step size of each step            */
+    int32_t *iters;           /* [capacity]            iterations of each step           */
+    double  *lims;            /* [capacity * maxIter]  convergence values (NaN = unused) */
+} ssf_trace;
+
+typedef struct {
+    char     name[128];
+    char     arch[32];           /* e.g. "gfx950"                                        */
+    int32_t  compute_units;
+    int32_t  reserved;
+    int64_t  total_mem_bytes;
+    int64_t  lds_per_block_bytes;
+} ssf_device_info_t;
+
+/* ---- discovery --------------------------------------------------------------------- */
+int  ssf_device_count(void);                                /* >= 0, or negative status */
+int  ssf_device_info(int device, ssf_device_info_t *out);
+const char *ssf_version(void);
+
+/* ---- plan life cycle ---------------------------------------------------------------- */
+/* N samples per row, nrows rows (2K for Manakov), precision SSF_C64/SSF_C128,
+ * engine SSF_ENGINE_AUTO picks the fused radix-2^n pipeline when N is a supported
+ * power of two and the rocFFT pipeline otherwise. */
+int  ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision,
+                     int32_t engine, ssf_plan **out);
+int  ssf_plan_destroy(ssf_plan *plan);
+const char *ssf_last_error(const ssf_plan *plan);           /* never NULL; plan may be NULL */
+
+/* ---- staged execution (field stays resident in HBM between calls) ------------------- */
+int  ssf_upload(ssf_plan *plan, const void *field_soa);     /* (nrows, N) complex        */
+/* Propagate spans [span_first, span_last] (1-based, inclusive) of `params`.
+ * noise: NULL, or host array (span_last-span_first+1, nrows, N) complex added after
+ *        the span gain when amp == SSF_AMP_EDFA (row r of span s at
+ *        ((s-span_first)*nrows + r)*N); NULL with EDFA = gain only.
+ * stats/trace may be NULL; stats accumulate until ssf_upload resets them. */
+int  ssf_execute(ssf_plan *plan, const ssf_params *params, int32_t span_first,
+                 int32_t span_last, const void *noise, ssf_stats *stats, ssf_trace *trace);
+int  ssf_download(ssf_plan *plan, void *field_soa);         /* (nrows, N) complex        */
+int  ssf_download_snapshots(ssf_plan *plan, void *snap_soa);/* (n_snapshots, nrows, N)   */
+
+/* ---- one-shot: upload + execute all spans + download -------------------------------- */
+int  ssf_run(ssf_plan *plan, const ssf_params *params, const void *field_in_soa,
+             void *field_out_soa, void *snapshots_soa, const void *noise,
+             ssf_stats *stats, ssf_trace *trace);
+
+/* ---- multi-GPU: independent units sharded over devices (one host thread per device) -- */
+/* n_units fields of (rows_per_unit, N) each, contiguous in in/out; unit u runs on
+ * device dev_ids[u * n_dev / n_units ...] (contiguous blocks).  stats: [n_units]. */
+int  ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_t N,
+                  int32_t rows_per_unit, int32_t precision, int32_t engine,
+                  const ssf_params *params, const void *fields_in, void *fields_out,
+                  ssf_stats *stats);
+
+/* ---- linear channel (gamma = 0 closed form): one FFT . H . IFFT over the whole length */
+int  ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, double D,
+                        double L, const void *field_in_soa, void *field_out_soa);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSF_H */

@@ -1,0 +1,17 @@
+"""opticommpy_amd -- MI355X-native split-step Fourier fiber propagation.
+
+Drop-in for the fiber-channel functions of OptiCommPy's ``optic.models.modelsGPU``
+(``ssfm``, ``manakovSSF``, ``manakovDBP``, ``edfa``, ``setPowerforParSSFM``) plus
+``checkGPU``: numpy in, numpy out, same parameters-object API.  Host code is plain
+Python + numpy calling hand-written HIP kernels (gfx950) through the C ABI declared
+in ``include/ssf.h`` (``libssf_hip.so``).  There is no CPU fallback: without the
+library or without a GPU every propagation call raises.
+"""
+from .utils import parameters  # noqa: F401
+from .models import (  # noqa: F401
+    checkGPU, edfa, linearFiberChannel, manakovDBP, manakovSSF, setPowerforParSSFM, ssfm,
+    last_run, set_device, set_engine,
+)
+
+__all__ = ["parameters", "ssfm", "manakovSSF", "manakovDBP", "edfa", "linearFiberChannel",
+           "setPowerforParSSFM", "checkGPU", "last_run", "set_device", "set_engine"]

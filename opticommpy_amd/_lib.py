@@ -1,0 +1,106 @@
+"""ctypes binding of libssf_hip.so (C ABI: include/ssf.h).  No fallback: if the
+shared library is missing, importing a propagation function still works but the
+first call raises RuntimeError telling the user to build it."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SSF_LIB", os.path.join(_HERE, "libssf_hip.so"))
+
+SSF_C64, SSF_C128 = 0, 1
+MODEL_NLSE, MODEL_MANAKOV = 0, 1
+AMP_NONE, AMP_IDEAL, AMP_EDFA = 0, 1, 2
+ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_FUSED = 0, 1, 2
+ENGINE_NAMES = {ENGINE_AUTO: "auto", ENGINE_ROCFFT: "rocfft", ENGINE_FUSED: "fused"}
+
+STATUS = {0: "OK", -1: "bad argument", -2: "HIP error", -3: "out of device memory", -4: "FFT error",
+          -5: "no device", -6: "unsupported", -7: "bad call order"}
+
+
+class Params(C.Structure):
+    _fields_ = [("model", C.c_int32), ("direction", C.c_int32), ("Fs", C.c_double), ("Fc", C.c_double),
+                ("alpha", C.c_double), ("D", C.c_double), ("gamma", C.c_double), ("Lspan", C.c_double),
+                ("Nspans", C.c_int32), ("maxIter", C.c_int32), ("hz", C.c_double), ("tol", C.c_double),
+                ("nlprMethod", C.c_int32), ("amp", C.c_int32), ("maxNlinPhaseRot", C.c_double),
+                ("NF", C.c_double), ("n_save", C.c_int32), ("reserved", C.c_int32),
+                ("save_spans", C.POINTER(C.c_int32))]
+
+
+class Stats(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("iterations", C.c_int64), ("transforms", C.c_int64),
+                ("nonconverged_steps", C.c_int64), ("device_ms", C.c_double),
+                ("bytes_algorithmic", C.c_double), ("engine", C.c_int32), ("n_snapshots", C.c_int32)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["engine"] = ENGINE_NAMES.get(d["engine"], str(d["engine"]))
+        return d
+
+
+class Trace(C.Structure):
+    _fields_ = [("capacity", C.c_int64), ("count", C.c_int64), ("hz", C.POINTER(C.c_double)),
+                ("iters", C.POINTER(C.c_int32)), ("lims", C.POINTER(C.c_double))]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int32),
+                ("reserved", C.c_int32), ("total_mem_bytes", C.c_int64), ("lds_per_block_bytes", C.c_int64)]
+
+
+# every symbol include/ssf.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ssf_device_count": (C.c_int, []),
+    "ssf_device_info": (C.c_int, [C.c_int, C.POINTER(DeviceInfo)]),
+    "ssf_version": (C.c_char_p, []),
+    "ssf_plan_create": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ssf_plan_destroy": (C.c_int, [C.c_void_p]),
+    "ssf_last_error": (C.c_char_p, [C.c_void_p]),
+    "ssf_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ssf_execute": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_int32, C.c_void_p,
+                              C.POINTER(Stats), C.POINTER(Trace)]),
+    "ssf_download": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ssf_download_snapshots": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ssf_run": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.POINTER(Stats), C.POINTER(Trace)]),
+    "ssf_mgpu_run": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                               C.c_int32, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    "ssf_linear_channel": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                     C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libssf_hip.so and bind every ABI symbol.  Raises RuntimeError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"HIP extension not built: {LIB_PATH} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C opticommpy_amd/csrc`. "
+            "opticommpy_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)        # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def error_message(lib, handle, rc):
+    msg = lib.ssf_last_error(handle)
+    msg = msg.decode(errors="replace") if msg else ""
+    return f"{STATUS.get(rc, rc)}: {msg}" if msg else str(STATUS.get(rc, rc))
+
+
+def raise_for(lib, handle, rc):
+    if rc == 0:
+        return
+    text = error_message(lib, handle, rc)
+    if rc == -1:
+        raise ValueError(text)
+    if rc == -3:
+        raise MemoryError(text)
+    raise RuntimeError(text)

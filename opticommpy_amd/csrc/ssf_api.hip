@@ -1,0 +1,215 @@
+// ssf_api.hip -- the extern "C" boundary declared in include/ssf.h.
+#include <thread>
+
+#include "ssf_internal.h"
+
+using namespace ssf;
+
+namespace {
+thread_local std::string g_err;   // errors raised without a plan (plan creation, discovery)
+
+int set_err(int code, const std::string &m) {
+    g_err = m;
+    return code;
+}
+
+int check_params(ssf_plan *pl, const ssf_params *p, int s0, int s1) {
+    if (!p) return fail(pl, SSF_ERR_BAD_ARG, "params is NULL");
+    if (p->model != SSF_MODEL_NLSE && p->model != SSF_MODEL_MANAKOV) return fail(pl, SSF_ERR_BAD_ARG, "bad model");
+    if (p->model == SSF_MODEL_MANAKOV && (pl->nrows % 2)) return fail(pl, SSF_ERR_BAD_ARG, "Manakov model needs an even number of rows");
+    if (p->model == SSF_MODEL_NLSE && p->direction < 0) return fail(pl, SSF_ERR_BAD_ARG, "NLSE model has no back-propagation mode");
+    if (!(p->Fs > 0) || !(p->Fc > 0)) return fail(pl, SSF_ERR_BAD_ARG, "Fs and Fc must be positive");
+    if (!(p->Lspan > 0)) return fail(pl, SSF_ERR_BAD_ARG, "Lspan must be positive");
+    if (!(p->hz > 0) && !(p->model == SSF_MODEL_MANAKOV && p->nlprMethod)) return fail(pl, SSF_ERR_BAD_ARG, "hz must be positive");
+    if (p->model == SSF_MODEL_MANAKOV && p->maxIter < 1) return fail(pl, SSF_ERR_BAD_ARG, "maxIter must be >= 1");
+    if (p->Nspans < 0 || s0 < 1 || s1 > p->Nspans) return fail(pl, SSF_ERR_BAD_ARG, "span range outside [1, Nspans]");
+    if (p->amp < SSF_AMP_NONE || p->amp > SSF_AMP_EDFA) return fail(pl, SSF_ERR_BAD_ARG, "bad amp");
+    if (p->amp == SSF_AMP_EDFA && p->direction >= 0) {
+        if (!(p->alpha * p->Lspan > 0)) return fail(pl, SSF_ERR_BAD_ARG, "EDFA gain should be a positive scalar");   // devices.py:709
+        if (!(p->NF >= 3)) return fail(pl, SSF_ERR_BAD_ARG, "The minimal EDFA noise figure is 3 dB");                 // devices.py:710
+    }
+    if (p->n_save < 0 || (p->n_save > 0 && !p->save_spans)) return fail(pl, SSF_ERR_BAD_ARG, "bad save_spans");
+    return SSF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char *ssf_version(void) { return "opticommpy_amd-ssf 0.1 (gfx950)"; }
+
+int ssf_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) return set_err(SSF_ERR_HIP, hipGetErrorString(e));
+    return n;
+}
+
+int ssf_device_info(int device, ssf_device_info_t *out) {
+    if (!out) return set_err(SSF_ERR_BAD_ARG, "out is NULL");
+    hipDeviceProp_t pr;
+    hipError_t e = hipGetDeviceProperties(&pr, device);
+    if (e != hipSuccess) return set_err(SSF_ERR_NO_DEVICE, hipGetErrorString(e));
+    std::memset(out, 0, sizeof(*out));
+    std::snprintf(out->name, sizeof(out->name), "%s", pr.name);
+    std::snprintf(out->arch, sizeof(out->arch), "%s", pr.gcnArchName);
+    out->compute_units = pr.multiProcessorCount;
+    out->total_mem_bytes = (int64_t)pr.totalGlobalMem;
+    out->lds_per_block_bytes = (int64_t)pr.sharedMemPerBlock;
+    return SSF_OK;
+}
+
+const char *ssf_last_error(const ssf_plan *plan) { return plan ? plan->err.c_str() : g_err.c_str(); }
+
+int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int32_t engine, ssf_plan **out) {
+    if (!out) return set_err(SSF_ERR_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (N < 2 || nrows < 1) return set_err(SSF_ERR_BAD_ARG, "N must be >= 2 and nrows >= 1");
+    if (precision != SSF_C64 && precision != SSF_C128) return set_err(SSF_ERR_BAD_ARG, "bad precision");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_err(SSF_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return set_err(SSF_ERR_NO_DEVICE, "device index out of range");
+    if (hipSetDevice(device) != hipSuccess) return set_err(SSF_ERR_HIP, "hipSetDevice failed");
+    auto *pl = new ssf_plan();
+    pl->device = device;
+    pl->N = N;
+    pl->nrows = nrows;
+    pl->precision = precision;
+    if (hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete pl;
+        return set_err(SSF_ERR_HIP, "hipStreamCreate failed");
+    }
+    int want = engine;
+    if (want == SSF_ENGINE_AUTO) want = fused_supports(N, nrows, precision) ? SSF_ENGINE_FUSED : SSF_ENGINE_ROCFFT;
+    if (want == SSF_ENGINE_FUSED && !fused_supports(N, nrows, precision)) {
+        (void)hipStreamDestroy(pl->stream);
+        delete pl;
+        return set_err(SSF_ERR_UNSUPPORTED, "fused engine needs N = 2^m within its supported range");
+    }
+    pl->engine = want == SSF_ENGINE_FUSED ? make_fused_engine(pl) : make_rocfft_engine(pl);
+    if (!pl->engine) {
+        const int code = pl->err.find("out of memory") != std::string::npos ? SSF_ERR_OOM : SSF_ERR_HIP;
+        set_err(code, pl->err.empty() ? "engine creation failed" : pl->err);
+        (void)hipStreamDestroy(pl->stream);
+        delete pl;
+        return code;
+    }
+    pl->engine_id = pl->engine->id();
+    *out = pl;
+    return SSF_OK;
+}
+
+int ssf_plan_destroy(ssf_plan *plan) {
+    if (!plan) return SSF_OK;
+    (void)hipSetDevice(plan->device);
+    delete plan->engine;
+    if (plan->stream) (void)hipStreamDestroy(plan->stream);
+    delete plan;
+    return SSF_OK;
+}
+
+int ssf_upload(ssf_plan *plan, const void *field_soa) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    if (!field_soa) return fail(plan, SSF_ERR_BAD_ARG, "field is NULL");
+    SSF_HIP(plan, hipSetDevice(plan->device));
+    int rc = plan->engine->upload(field_soa);
+    if (rc) return rc;
+    plan->stats = ssf_stats{};
+    plan->stats.engine = plan->engine_id;
+    plan->has_field = true;
+    return SSF_OK;
+}
+
+int ssf_execute(ssf_plan *plan, const ssf_params *params, int32_t span_first, int32_t span_last, const void *noise,
+                ssf_stats *stats, ssf_trace *trace) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    if (!plan->has_field) return fail(plan, SSF_ERR_STATE, "ssf_execute before ssf_upload");
+    int rc = check_params(plan, params, span_first, span_last);
+    if (rc) return rc;
+    SSF_HIP(plan, hipSetDevice(plan->device));
+    if (trace) trace->count = 0;
+    if (span_first <= span_last) {
+        rc = plan->engine->execute(*params, span_first, span_last, noise, &plan->stats, trace);
+        if (rc) return rc;
+    }
+    const double s = plan->precision == SSF_C128 ? 16.0 : 8.0;
+    plan->stats.bytes_algorithmic = (double)plan->stats.transforms * 2.0 * s * (double)plan->N;
+    if (stats) *stats = plan->stats;
+    return SSF_OK;
+}
+
+int ssf_download(ssf_plan *plan, void *field_soa) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    if (!field_soa) return fail(plan, SSF_ERR_BAD_ARG, "field is NULL");
+    if (!plan->has_field) return fail(plan, SSF_ERR_STATE, "ssf_download before ssf_upload");
+    SSF_HIP(plan, hipSetDevice(plan->device));
+    return plan->engine->download(field_soa);
+}
+
+int ssf_download_snapshots(ssf_plan *plan, void *snap_soa) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    if (!snap_soa) return fail(plan, SSF_ERR_BAD_ARG, "snapshot buffer is NULL");
+    SSF_HIP(plan, hipSetDevice(plan->device));
+    return plan->engine->download_snapshots(snap_soa);
+}
+
+int ssf_run(ssf_plan *plan, const ssf_params *params, const void *in, void *out, void *snaps, const void *noise,
+            ssf_stats *stats, ssf_trace *trace) {
+    int rc = ssf_upload(plan, in);
+    if (rc) return rc;
+    rc = ssf_execute(plan, params, 1, params ? params->Nspans : 0, noise, stats, trace);
+    if (rc) return rc;
+    if (out && (rc = ssf_download(plan, out))) return rc;
+    if (snaps && plan->stats.n_snapshots > 0 && (rc = ssf_download_snapshots(plan, snaps))) return rc;
+    return SSF_OK;
+}
+
+int ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, double D, double L, const void *in,
+                       void *out) {
+    int rc = ssf_upload(plan, in);
+    if (rc) return rc;
+    if ((rc = plan->engine->linear_channel(Fs, Fc, alpha, D, L))) return rc;
+    return ssf_download(plan, out);
+}
+
+int ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_t N, int32_t rows_per_unit,
+                 int32_t precision, int32_t engine, const ssf_params *params, const void *fields_in,
+                 void *fields_out, ssf_stats *stats) {
+    if (n_dev < 1 || !dev_ids || n_units < 1 || !params || !fields_in || !fields_out)
+        return set_err(SSF_ERR_BAD_ARG, "ssf_mgpu_run: bad argument");
+    const size_t unit_bytes = (size_t)rows_per_unit * (size_t)N * (precision == SSF_C128 ? 16 : 8);
+    std::vector<int> rcs((size_t)n_dev, SSF_OK);
+    std::vector<std::string> errs((size_t)n_dev);
+    std::vector<std::thread> th;
+    for (int d = 0; d < n_dev; ++d) {
+        // contiguous block of units per device: [u0, u1)
+        const int u0 = (int)((int64_t)n_units * d / n_dev), u1 = (int)((int64_t)n_units * (d + 1) / n_dev);
+        th.emplace_back([=, &rcs, &errs] {
+            if (u0 >= u1) return;
+            ssf_plan *pl = nullptr;
+            int rc = ssf_plan_create(dev_ids[d], N, rows_per_unit, precision, engine, &pl);
+            if (rc) {
+                rcs[(size_t)d] = rc;
+                errs[(size_t)d] = ssf_last_error(nullptr);
+                return;
+            }
+            for (int u = u0; u < u1 && rc == SSF_OK; ++u) {
+                ssf_stats st{};
+                rc = ssf_run(pl, params, (const char *)fields_in + (size_t)u * unit_bytes,
+                             (char *)fields_out + (size_t)u * unit_bytes, nullptr, nullptr, &st, nullptr);
+                if (stats) stats[u] = st;
+            }
+            if (rc) {
+                rcs[(size_t)d] = rc;
+                errs[(size_t)d] = ssf_last_error(pl);
+            }
+            ssf_plan_destroy(pl);
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int d = 0; d < n_dev; ++d)
+        if (rcs[(size_t)d]) return set_err(rcs[(size_t)d], "device " + std::to_string(dev_ids[d]) + ": " + errs[(size_t)d]);
+    return SSF_OK;
+}
+
+}  // extern "C"

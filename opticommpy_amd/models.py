@@ -1,0 +1,445 @@
+"""Host side of the MI355X split-step Fourier path: the functions a notebook
+imports instead of ``optic.models.modelsGPU`` (reference optic/models/modelsGPU.py).
+
+    from opticommpy_amd.modelsGPU import manakovSSF, manakovDBP, ssfm, edfa
+
+Same ``f(Ei, param)`` parameters-object API (defaults written back onto ``param``,
+``returnParameters``, ``saveSpanN``, ``prgsBar``), numpy in / numpy out.  All
+propagation runs in hand-written HIP kernels behind the C ABI of include/ssf.h;
+this module only validates arguments, converts the (N, ncols) field to the
+struct-of-arrays layout the ABI takes, and drives the per-span progress bar.
+"""
+import atexit
+import ctypes as C
+import logging as logg
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from .utils import parameters
+
+_H_PLANCK = 6.62607015e-34          # scipy.constants.h (devices.py:721)
+
+NONCONV_WARNING = "Warning: target SSFM error tolerance was not achieved in {} iterations"
+
+_state = {"device": int(os.environ.get("SSF_DEVICE", os.environ.get("LOCAL_RANK", "0")) or 0),
+          "engine": {"auto": 0, "rocfft": 1, "fused": 2}[os.environ.get("SSF_ENGINE", "auto").lower()]}
+
+#: stats (and trace, when requested) of the most recent propagation call
+last_run = {}
+
+
+def set_device(index):
+    """Select the GPU used by subsequent calls (default: $SSF_DEVICE / $LOCAL_RANK / 0)."""
+    _state["device"] = int(index)
+
+
+def set_engine(name):
+    """'auto' (default) | 'rocfft' (any N) | 'fused' (N = 2^m, roofline pipeline)."""
+    _state["engine"] = {"auto": 0, "rocfft": 1, "fused": 2}[name]
+
+
+def checkGPU():
+    """True when a HIP device is usable (reference optic/dsp/coreGPU.py:11-24)."""
+    try:
+        return _lib.load().ssf_device_count() > 0
+    except (RuntimeError, OSError, AttributeError):
+        return False
+
+
+# ----------------------------------------------------------------------------
+# plan cache: one handle per (device, N, nrows, precision, engine)
+# ----------------------------------------------------------------------------
+class _Plan:
+    def __init__(self, device, N, nrows, prec_code, engine):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.ssf_plan_create(device, N, nrows, prec_code, engine, C.byref(h))
+        _lib.raise_for(self.lib, None, rc)
+        self.h, self.N, self.nrows, self.prec_code = h, N, nrows, prec_code
+        self.dtype = np.complex128 if prec_code == _lib.SSF_C128 else np.complex64
+
+    def check(self, rc):
+        _lib.raise_for(self.lib, self.h, rc)
+
+    def close(self):
+        if self.h:
+            self.lib.ssf_plan_destroy(self.h)
+            self.h = None
+
+
+_plans = OrderedDict()
+_MAX_PLANS = 4
+
+
+def _get_plan(N, nrows, prec_code):
+    key = (_state["device"], int(N), int(nrows), prec_code, _state["engine"])
+    pl = _plans.pop(key, None)
+    if pl is None:
+        while len(_plans) >= _MAX_PLANS:
+            _plans.popitem(last=False)[1].close()
+        pl = _Plan(*key)
+    _plans[key] = pl
+    return pl
+
+
+def engine_supported(name, N, nrows=2, prec=np.complex128):
+    """True when engine `name` can build a plan for this shape on the current device."""
+    eng = {"auto": 0, "rocfft": 1, "fused": 2}[name]
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.ssf_plan_create(_state["device"], int(N), int(nrows), _prec_code(prec), eng, C.byref(h))
+    if rc == 0:
+        lib.ssf_plan_destroy(h)
+    return rc == 0
+
+
+def release_plans():
+    """Free every cached plan (device memory, FFT plans, streams)."""
+    while _plans:
+        _plans.popitem()[1].close()
+
+
+atexit.register(release_plans)
+
+
+# ----------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------
+def _require_fs(param):
+    try:
+        return param.Fs
+    except AttributeError:
+        logg.error("Simulation sampling frequency (Fs) not provided.")
+        raise AttributeError("Simulation sampling frequency (Fs) not provided: set param.Fs") from None
+
+
+def _prec_code(prec):
+    return _lib.SSF_C64 if np.dtype(prec) == np.dtype(np.complex64) else _lib.SSF_C128
+
+
+def _amp_code(amp):
+    return {"edfa": _lib.AMP_EDFA, "ideal": _lib.AMP_IDEAL}.get(amp, _lib.AMP_NONE) if isinstance(amp, str) else _lib.AMP_NONE
+
+
+def _edfa_noise_power(G, NF, Fc, Fs):
+    """devices.py:712-722 -> (G_lin, p_noise)."""
+    NF_lin = 10 ** (NF / 10)
+    G_lin = 10 ** (G / 10)
+    nsp = (G_lin * NF_lin - 1) / (2 * (G_lin - 1))
+    return G_lin, (G_lin - 1) * nsp * _H_PLANCK * Fc * Fs
+
+
+def gaussianComplexNoise(shapeOut, σ2=1.0, seed=None):
+    """Complex circular Gaussian noise from numpy's global RNG (optic/dsp/core.py:739-763)."""
+    if seed is not None:
+        np.random.seed(seed)
+    return np.random.normal(0, np.sqrt(σ2 / 2), shapeOut) + 1j * np.random.normal(0, np.sqrt(σ2 / 2), shapeOut)
+
+
+def _span_noise(nrows, N, p_noise, seed, pairs, dtype):
+    """ASE noise of one span in SoA layout.  For the Manakov model the reference
+    calls edfa(Ech_x) then edfa(Ech_y), each on a (K, N) block and each re-seeding
+    with the same seed (channels.py:444-445) -- reproduced here draw for draw."""
+    if pairs:
+        K = nrows // 2
+        out = np.empty((nrows, N), dtype=dtype)
+        out[0::2] = gaussianComplexNoise((K, N), p_noise, seed)
+        out[1::2] = gaussianComplexNoise((K, N), p_noise, seed)
+        return out
+    return np.ascontiguousarray(gaussianComplexNoise((nrows, N), p_noise, seed).astype(dtype))
+
+
+def _captured_spans(save_list, Nspans):
+    """Spans that `spanN in saveSpanN` (channels.py:453) would hit, in encounter order."""
+    return [s for s in range(1, Nspans + 1) if s in save_list]
+
+
+def _tqdm(iterable, disable):
+    if disable:
+        return iterable
+    try:
+        from tqdm.auto import tqdm
+        return tqdm(iterable)
+    except Exception:           # tqdm is optional
+        return iterable
+
+
+def _execute(pl, cp, Nspans, save, prgs, noise_fn, want_trace, max_steps_hint):
+    """Upload done by the caller; runs all spans, span by span when a progress
+    bar or per-span noise is needed, otherwise in one ABI call."""
+    lib = pl.lib
+    st = _lib.Stats()
+    traces = []
+
+    def one(s0, s1, noise):
+        tr = None
+        if want_trace:
+            cap = max_steps_hint * (s1 - s0 + 1)
+            hz = np.full(cap, np.nan)
+            it = np.zeros(cap, dtype=np.int32)
+            lm = np.full(cap * max(cp.maxIter, 1), np.nan)
+            tr = _lib.Trace(cap, 0, hz.ctypes.data_as(C.POINTER(C.c_double)),
+                            it.ctypes.data_as(C.POINTER(C.c_int32)), lm.ctypes.data_as(C.POINTER(C.c_double)))
+        nptr = noise.ctypes.data_as(C.c_void_p) if noise is not None else None
+        pl.check(lib.ssf_execute(pl.h, C.byref(cp), s0, s1, nptr, C.byref(st), C.byref(tr) if tr else None))
+        if tr:
+            n = min(tr.count, tr.capacity)
+            traces.append((hz[:n], it[:n], lm[: n * max(cp.maxIter, 1)].reshape(n, -1), tr.count))
+
+    if Nspans >= 1:
+        if prgs or noise_fn is not None:
+            for span in _tqdm(range(1, Nspans + 1), disable=not prgs):
+                one(span, span, noise_fn(span) if noise_fn else None)
+        else:
+            one(1, Nspans, None)
+    info = st.as_dict()
+    if want_trace:
+        info["hz"] = np.concatenate([t[0] for t in traces]) if traces else np.zeros(0)
+        info["iters"] = np.concatenate([t[1] for t in traces]) if traces else np.zeros(0, np.int32)
+        info["lims"] = [row[~np.isnan(row)] for t in traces for row in t[2]]
+        info["trace_truncated"] = any(t[3] > len(t[0]) for t in traces)
+    last_run.clear()
+    last_run.update(info)
+    return st
+
+
+def _fill_params(model, direction, param, Fs, Nspans, save_arr):
+    cp = _lib.Params()
+    cp.model, cp.direction = model, direction
+    cp.Fs, cp.Fc, cp.alpha, cp.D, cp.gamma = float(Fs), float(param.Fc), float(param.alpha), float(param.D), float(param.gamma)
+    cp.Lspan, cp.Nspans, cp.hz = float(param.Lspan), int(Nspans), float(param.hz)
+    cp.maxIter = int(getattr(param, "maxIter", 1))
+    cp.tol = float(getattr(param, "tol", 0.0))
+    cp.nlprMethod = int(bool(getattr(param, "nlprMethod", False)))
+    cp.maxNlinPhaseRot = float(getattr(param, "maxNlinPhaseRot", 0.0))
+    cp.amp = _amp_code(param.amp)
+    cp.NF = float(getattr(param, "NF", 4.5))
+    cp.n_save = len(save_arr)
+    cp.save_spans = save_arr.ctypes.data_as(C.POINTER(C.c_int32)) if len(save_arr) else None
+    return cp
+
+
+# ----------------------------------------------------------------------------
+# ssfm
+# ----------------------------------------------------------------------------
+def ssfm(Ei, param=None, _trace=False, _cpu_seed_policy=False):
+    """Split-step Fourier method (symmetric, single-pol.) on the GPU.
+
+    Same parameters as the reference (optic/models/modelsGPU.py:117-278 /
+    optic/models/channels.py:112-249): Ltotal [400], Lspan [80], hz [0.5], alpha
+    [0.2], D [16], gamma [1.3], Fc [193.1e12], Fs (mandatory), prec [complex128],
+    amp ['edfa'], NF [4.5], seed [None], prgsBar [True], saveSpanN
+    [[Ltotal // Lspan]], returnParameters [False].
+
+    Returns the field after the last saved span, shape (N,) (or (N, len(saveSpanN))),
+    dtype ``param.prec``; ``(Ech, param)`` when ``param.returnParameters``.
+    """
+    Fs = _require_fs(param)
+    for name, dflt in (("Ltotal", 400), ("Lspan", 80), ("hz", 0.5), ("alpha", 0.2), ("D", 16),
+                       ("gamma", 1.3), ("Fc", 193.1e12), ("prec", np.complex128), ("amp", "edfa"),
+                       ("NF", 4.5), ("seed", None), ("prgsBar", True)):
+        setattr(param, name, getattr(param, name, dflt))
+    param.saveSpanN = getattr(param, "saveSpanN", [param.Ltotal // param.Lspan])
+    param.returnParameters = getattr(param, "returnParameters", False)
+
+    Ei = np.asarray(Ei)
+    N = len(Ei)
+    E = Ei.reshape(N)                                   # raises like the reference for ncols > 1
+    Nspans = int(np.floor(param.Ltotal / param.Lspan))
+    prec = _prec_code(param.prec)
+    pl = _get_plan(N, 1, prec)
+    soa = np.ascontiguousarray(E.reshape(1, N), dtype=pl.dtype)
+
+    save_list = list(param.saveSpanN) if param.saveSpanN is not None else []
+    captured = _captured_spans(save_list, Nspans)
+    save_arr = np.array(captured, dtype=np.int32)
+    cp = _fill_params(_lib.MODEL_NLSE, +1, param, Fs, Nspans, save_arr)
+
+    noise_fn = None
+    if cp.amp == _lib.AMP_EDFA:
+        G = param.alpha * param.Lspan
+        assert G > 0, "EDFA gain should be a positive scalar"
+        assert param.NF >= 3, "The minimal EDFA noise figure is 3 dB"
+        _, p_noise = _edfa_noise_power(G, param.NF, param.Fc, Fs)
+        seed = param.seed
+
+        def noise_fn(span):
+            s = seed if (seed is None or _cpu_seed_policy) else seed + span        # modelsGPU.py:259-260
+            return _span_noise(1, N, p_noise, s, False, pl.dtype)
+
+    pl.check(pl.lib.ssf_upload(pl.h, soa.ctypes.data_as(C.c_void_p)))
+    nsteps = int(np.floor(param.Lspan / param.hz))
+    st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, nsteps + 1)
+
+    if save_list:
+        out = np.zeros((N, len(save_list)), dtype=pl.dtype)
+        if st.n_snapshots:
+            snaps = np.empty((st.n_snapshots, 1, N), dtype=pl.dtype)
+            pl.check(pl.lib.ssf_download_snapshots(pl.h, snaps.ctypes.data_as(C.c_void_p)))
+            out[:, : st.n_snapshots] = snaps[:, 0, :].T
+        if out.shape[1] == 1:
+            out = out.reshape(N)
+    else:
+        res = np.empty((1, N), dtype=pl.dtype)
+        pl.check(pl.lib.ssf_download(pl.h, res.ctypes.data_as(C.c_void_p)))
+        out = res.reshape(N)
+    return (out, param) if param.returnParameters else out
+
+
+# ----------------------------------------------------------------------------
+# manakovSSF / manakovDBP
+# ----------------------------------------------------------------------------
+def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
+    Fs = _require_fs(param)
+    defaults = [("Ltotal", 400), ("Lspan", 80), ("hz", 0.5), ("alpha", 0.2), ("D", 16), ("gamma", 1.3),
+                ("Fc", 193.1e12), ("prec", np.complex128), ("amp", "edfa")]
+    if direction > 0:
+        defaults += [("NF", 4.5)]
+    defaults += [("maxIter", 10), ("tol", 1e-5), ("nlprMethod", True), ("maxNlinPhaseRot", 2e-2)]
+    if direction > 0:
+        defaults += [("seed", None)]
+    defaults += [("prgsBar", True)]
+    for name, dflt in defaults:
+        setattr(param, name, getattr(param, name, dflt))
+    param.saveSpanN = getattr(param, "saveSpanN", [param.Ltotal // param.Lspan])
+    param.returnParameters = getattr(param, "returnParameters", False)
+
+    Ei = np.asarray(Ei)
+    if Ei.ndim != 2 or Ei.shape[1] % 2 or Ei.shape[1] == 0:
+        raise IndexError("manakov models need a 2-D field of shape (N, 2K): columns [x0, y0, x1, y1, ...]")
+    N, ncols = Ei.shape
+    K = ncols // 2
+    save_list = list(param.saveSpanN) if param.saveSpanN is not None else []
+    if save_list and K > 1:
+        # the reference's snapshot write only broadcasts for K = 1 (channels.py:454-455)
+        raise ValueError(f"could not broadcast input array from shape ({N},{K}) into shape ({N},1): "
+                         "with more than one polarisation pair set param.saveSpanN = []")
+    Nspans = int(np.floor(param.Ltotal / param.Lspan))
+    prec = _prec_code(param.prec)
+    pl = _get_plan(N, ncols, prec)
+    soa = np.ascontiguousarray(Ei.T, dtype=pl.dtype)            # (2K, N): rows x0, y0, x1, y1, ...
+
+    captured = _captured_spans(save_list, Nspans)
+    save_arr = np.array(captured, dtype=np.int32)
+    cp = _fill_params(_lib.MODEL_MANAKOV, direction, param, Fs, Nspans, save_arr)
+
+    noise_fn = None
+    if direction > 0 and cp.amp == _lib.AMP_EDFA:
+        G = param.alpha * param.Lspan
+        assert G > 0, "EDFA gain should be a positive scalar"
+        assert param.NF >= 3, "The minimal EDFA noise figure is 3 dB"
+        _, p_noise = _edfa_noise_power(G, param.NF, param.Fc, Fs)
+        seed = param.seed
+
+        def noise_fn(span):
+            if _noise is not None:
+                return np.ascontiguousarray(_noise[span - 1], dtype=pl.dtype)
+            s = seed if (seed is None or _cpu_seed_policy) else seed + span        # modelsGPU.py:486-487
+            return _span_noise(ncols, N, p_noise, s, True, pl.dtype)
+
+    logg.info("Running Manakov SSF model on GPU (HIP, %s)..." % ("forward" if direction > 0 else "DBP"))
+    pl.check(pl.lib.ssf_upload(pl.h, soa.ctypes.data_as(C.c_void_p)))
+    if param.nlprMethod:
+        hint = 1 << 16
+    else:
+        hint = int(np.ceil(param.Lspan / param.hz)) + 1
+    st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, hint)
+    for _ in range(int(st.nonconverged_steps)):
+        logg.warning(NONCONV_WARNING.format(param.maxIter))
+
+    if save_list:
+        out = np.zeros((N, ncols * len(save_list)), dtype=pl.dtype)
+        if st.n_snapshots:
+            snaps = np.empty((st.n_snapshots, ncols, N), dtype=pl.dtype)
+            pl.check(pl.lib.ssf_download_snapshots(pl.h, snaps.ctypes.data_as(C.c_void_p)))
+            for i in range(st.n_snapshots):
+                out[:, 2 * i: 2 * i + 2] = snaps[i].T
+    else:
+        res = np.empty((ncols, N), dtype=pl.dtype)
+        pl.check(pl.lib.ssf_download(pl.h, res.ctypes.data_as(C.c_void_p)))
+        out = Ei.copy()
+        out[:, :] = res.T
+    return (out, param) if param.returnParameters else out
+
+
+def manakovSSF(Ei, param, _trace=False, _cpu_seed_policy=False, _noise=None):
+    """Manakov split-step Fourier model (symmetric, dual-pol.) on the GPU.
+
+    Reference: optic/models/modelsGPU.py:281-511 == optic/models/channels.py:252-468.
+    ``Ei``: (N, 2K) complex, columns [x0, y0, x1, y1, ...].  Parameters (defaults):
+    Ltotal [400], Lspan [80], hz [0.5], alpha [0.2], D [16], gamma [1.3], Fc
+    [193.1e12], Fs (mandatory), prec [complex128], amp ['edfa'], NF [4.5], maxIter
+    [10], tol [1e-5], nlprMethod [True], maxNlinPhaseRot [2e-2], prgsBar [True],
+    saveSpanN [[Ltotal // Lspan]], seed [None], returnParameters [False].
+    """
+    return _manakov(Ei, param, +1, _trace, _cpu_seed_policy, _noise)
+
+
+def manakovDBP(Ei, param, _trace=False):
+    """Manakov SSF digital back-propagation on the GPU.
+
+    Reference: optic/models/modelsGPU.py:564-772 == optic/dsp/equalization.py:976-1173.
+    """
+    return _manakov(Ei, param, -1, _trace, False, None)
+
+
+# ----------------------------------------------------------------------------
+# edfa, linearFiberChannel, setPowerforParSSFM
+# ----------------------------------------------------------------------------
+def edfa(Ei, param=None):
+    """Simple EDFA model: gain + ASE noise (optic/models/modelsGPU.py:56-114 ==
+    optic/models/devices.py:671-726).  Host-side numpy: it is a once-per-call
+    elementwise op on data that already lives on the host at this API level."""
+    Fs = _require_fs(param)
+    G = getattr(param, "G", 20)
+    NF = getattr(param, "NF", 4.5)
+    Fc = getattr(param, "Fc", 193.1e12)
+    seed = getattr(param, "seed", None)
+    assert G > 0, "EDFA gain should be a positive scalar"
+    assert NF >= 3, "The minimal EDFA noise figure is 3 dB"
+    G_lin, p_noise = _edfa_noise_power(G, NF, Fc, Fs)
+    Ei = np.asarray(Ei)
+    return Ei * np.sqrt(G_lin) + gaussianComplexNoise(Ei.shape, p_noise, seed)
+
+
+def linearFiberChannel(Ei, param):
+    """Linear fiber channel (optic/models/channels.py:30-109) as one fused
+    FFT . H . IFFT on the GPU.  Parameters: L [50], alpha [0.2], D [17], Fc
+    [193.1e12], Fs (mandatory), returnParameters [False]."""
+    Fs = _require_fs(param)
+    param.L = getattr(param, "L", 50)
+    param.alpha = getattr(param, "alpha", 0.2)
+    param.D = getattr(param, "D", 17)
+    param.Fc = getattr(param, "Fc", 193.1e12)
+    param.returnParameters = getattr(param, "returnParameters", False)
+    Ei = np.asarray(Ei)
+    N = Ei.shape[0]
+    E2 = Ei.reshape(N, -1)
+    pl = _get_plan(N, E2.shape[1], _lib.SSF_C128)
+    soa = np.ascontiguousarray(E2.T, dtype=np.complex128)
+    res = np.empty_like(soa)
+    pl.check(pl.lib.ssf_linear_channel(pl.h, float(Fs), float(param.Fc), float(param.alpha), float(param.D),
+                                       float(param.L), soa.ctypes.data_as(C.c_void_p),
+                                       res.ctypes.data_as(C.c_void_p)))
+    Eo = np.ascontiguousarray(res.T)
+    if E2.shape[1] == 1:
+        Eo = Eo.reshape(N)
+    return (Eo, param) if param.returnParameters else Eo
+
+
+def signalPower(x):
+    """Total power of x (optic/dsp/core.py:69-84)."""
+    return np.sum(np.mean(x * np.conj(x), axis=0).real)
+
+
+def setPowerforParSSFM(sig, powers):
+    """Per-pair launch-power normalisation for K > 1 batches (modelsGPU.py:775-788)."""
+    powers_lin = (10 ** (np.asarray(powers) / 10) * 1e-3).repeat(2) / 2
+    for i in np.arange(0, sig.shape[1], 2):
+        for k in range(2):
+            sig[:, i + k] = np.sqrt(powers_lin[i] / signalPower(sig[:, i + k])) * sig[:, i + k]
+            print("power mode %d: %.2f dBm" % (i + k, 10 * np.log10(signalPower(sig[:, i + k]) / 1e-3)))
+    return sig

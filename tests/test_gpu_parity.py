@@ -1,0 +1,254 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the
+C ABI via the host wrapper, against
+  * the committed golden vectors produced by the reference (tests/golden),
+  * the CPU oracle on seeded inputs at sizes it finishes in seconds,
+  * size-independent physics properties at BASELINE.json's full sizes.
+
+Tolerances: complex128 rel-L2 <= 1e-10 and identical per-step
+iteration counts; complex64 rel-L2 <= 5e-4 (iteration totals reported, a flip at
+a threshold crossing is allowed and bounded by tol)."""
+import numpy as np
+import pytest
+
+import opticommpy_amd as oa
+from helpers import golden_names, load_golden, make_param, rel_l2, synth_field
+from opticommpy_amd import models
+from oracle import ssf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_C128 = 1e-10
+TOL_C64 = 5e-4
+ENGINES = ["rocfft", "fused"]
+FUNCS = {"ssfm": oa.ssfm, "manakovSSF": oa.manakovSSF, "manakovDBP": oa.manakovDBP}
+ORC = {"ssfm": orc.ssfm, "manakovSSF": orc.manakovSSF, "manakovDBP": orc.manakovDBP}
+
+
+def _is_pow2(n):
+    return n & (n - 1) == 0
+
+
+@pytest.fixture(autouse=True)
+def _reset_engine():
+    yield
+    oa.set_engine("auto")
+
+
+def _select(engine, N):
+    if engine == "fused" and not _is_pow2(N):
+        pytest.skip("fused engine handles N = 2^m; other lengths run on the rocFFT engine")
+    if engine == "fused" and not models.engine_supported("fused", N):
+        pytest.skip("fused engine does not support this length (yet)")
+    oa.set_engine(engine)
+
+
+def _run_hip(cfg, Ei, **kw):
+    p = make_param(oa.parameters, cfg)
+    out = FUNCS[cfg["func"]](Ei, p, _trace=True, **kw)
+    return out, p, dict(models.last_run)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_vectors(name, engine):
+    d, cfg = load_golden(name)
+    _select(engine, d["Ei"].shape[0])
+    kw = {}
+    if cfg.get("amp") == "edfa" and cfg["func"] != "manakovDBP":
+        kw["_cpu_seed_policy"] = True          # goldens come from the CPU reference (one seed for all spans)
+    out, p, run = _run_hip(cfg, d["Ei"], **kw)
+    ref = d["out"]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert run["engine"] == engine
+    c64 = cfg.get("prec") == "complex64"
+    assert rel_l2(out, ref) <= (TOL_C64 if c64 else TOL_C128)
+    if "iters" in d:
+        assert run["steps"] == len(d["iters"])
+        if not c64:
+            assert list(run["iters"]) == list(d["iters"])
+            flat = np.concatenate(run["lims"])
+            np.testing.assert_allclose(flat, d["lims"], rtol=1e-6)
+        else:
+            assert abs(int(run["iterations"]) - int(d["iters"].sum())) <= 2
+        assert run["transforms"] == d["Ei"].shape[1] * (2 * run["steps"] + 2 * run["iterations"])
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_reference_property_gamma0_equals_linear_channel(engine):
+    d, cfg = load_golden("ssfm_ref_gamma0")
+    _select(engine, 4096)
+    out, _, _ = _run_hip(cfg, d["Ei"])
+    lp = oa.parameters()
+    lp.L, lp.alpha, lp.D, lp.Fc, lp.Fs = 80, 0.2, 16, 193.1e12, 64e9
+    lin = oa.linearFiberChannel(d["Ei"], lp)
+    np.testing.assert_allclose(out, lin, atol=1e-12)
+    np.testing.assert_allclose(lin, d["extra_linear"], atol=1e-12)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_reference_property_spm_and_power(engine):
+    d, cfg = load_golden("ssfm_ref_spm")
+    _select(engine, 4096)
+    out, _, _ = _run_hip(cfg, d["Ei"])
+    out0, _, _ = _run_hip(dict(cfg, gamma=0), d["Ei"])
+    assert not np.allclose(np.abs(np.fft.fft(out)), np.abs(np.fft.fft(out0)))
+    d, cfg = load_golden("ssfm_ref_power")
+    out, _, _ = _run_hip(cfg, d["Ei"])
+    assert orc.signalPower(out) == pytest.approx(orc.signalPower(d["Ei"]), rel=1e-9)
+
+
+def _mk_cfg(**kw):
+    base = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5,
+                prgsBar=False)
+    base.update(kw)
+    return base
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("N,adaptive,prec", [(1 << 14, False, "complex128"), (1 << 16, False, "complex128"),
+                                             (1 << 14, True, "complex128"), (1 << 16, False, "complex64"),
+                                             (12000, False, "complex128")])
+def test_manakov_vs_oracle_seeded(engine, N, adaptive, prec):
+    _select(engine, N)
+    E = synth_field(N, 2, 31, 8.4, np.dtype(prec).type)
+    cfg = _mk_cfg(Ltotal=4, Lspan=2, hz=0.08, nlprMethod=adaptive, maxNlinPhaseRot=2e-2, amp="ideal",
+                  saveSpanN=[], prec=prec)
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+    out, _, run = _run_hip(cfg, E)
+    c64 = prec == "complex64"
+    assert rel_l2(out, ref) <= (TOL_C64 if c64 else TOL_C128)
+    assert run["steps"] == tr["steps"]
+    if not c64:
+        assert list(run["iters"]) == tr["iters"]
+        np.testing.assert_allclose(run["hz"], tr["hz"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_manakov_batched_pairs_vs_oracle(engine):
+    N = 1 << 13
+    _select(engine, N)
+    E = synth_field(N, 6, 32, 10.0)
+    cfg = _mk_cfg(Ltotal=2, Lspan=1, hz=0.1, nlprMethod=True, amp=None, saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+    out, _, run = _run_hip(cfg, E)
+    assert rel_l2(out, ref) <= TOL_C128
+    assert list(run["iters"]) == tr["iters"]
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_dbp_and_ssfm_vs_oracle_seeded(engine):
+    N = 1 << 15
+    _select(engine, N)
+    E = synth_field(N, 2, 33, 6.0)
+    cfg = _mk_cfg(func="manakovDBP", Ltotal=40, Lspan=20, hz=10, nlprMethod=False, amp="edfa", saveSpanN=[])
+    tr = {}
+    ref = orc.manakovDBP(E, make_param(orc.parameters, cfg), trace=tr)
+    out, _, run = _run_hip(cfg, E)
+    assert rel_l2(out, ref) <= TOL_C128
+    assert list(run["iters"]) == tr["iters"]
+    e1 = E[:, 0].copy()
+    cfg = dict(func="ssfm", Ltotal=10, Lspan=5, hz=0.25, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9,
+               amp="ideal", prgsBar=False, saveSpanN=[1, 2])
+    ref = orc.ssfm(e1, make_param(orc.parameters, cfg))
+    out, _, _ = _run_hip(cfg, e1)
+    assert out.shape == ref.shape == (N, 2)
+    assert rel_l2(out, ref) <= TOL_C128
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_edfa_gain_exact_with_host_noise_and_noise_variance(engine):
+    N = 1 << 12
+    _select(engine, N)
+    E = synth_field(N, 2, 34, 3.0)
+    cfg = _mk_cfg(Ltotal=20, Lspan=10, hz=0.5, nlprMethod=False, amp="edfa", NF=5.0, saveSpanN=[])
+    rng = np.random.default_rng(1)
+    noise = 1e-4 * (rng.normal(size=(2, 2, N)) + 1j * rng.normal(size=(2, 2, N)))
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), noise=noise)
+    p = make_param(oa.parameters, cfg)
+    out = oa.manakovSSF(E, p, _noise=noise)
+    assert rel_l2(out, ref) <= TOL_C128
+    # statistical check of the library's own draw (GPU-twin seed policy: seed + span)
+    p = make_param(oa.parameters, dict(cfg, Ltotal=10, seed=3))
+    o1 = oa.manakovSSF(E, p)
+    pz = make_param(oa.parameters, dict(cfg, Ltotal=10))
+    oz = oa.manakovSSF(E, pz, _noise=np.zeros((1, 2, N), complex))
+    _, p_noise = orc.edfa_noise_power(0.2 * 10, 5.0, 193.1e12, 512e9)
+    assert np.mean(np.abs(o1 - oz) ** 2) == pytest.approx(p_noise, rel=0.1)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_api_contract_on_device(engine):
+    N = 2048
+    _select(engine, N)
+    E = synth_field(N, 2, 35, 0.0)
+    E_before = E.copy()
+    p = oa.parameters()
+    p.Fs, p.Ltotal, p.Lspan, p.amp, p.prgsBar, p.returnParameters = 512e9, 10, 5, "ideal", True, True
+    out, p2 = oa.manakovSSF(E, p)
+    assert p2 is p and np.array_equal(E, E_before)              # input never modified
+    assert out.shape == (N, 2) and out.dtype == np.complex128   # default saveSpanN = [2] -> one snapshot
+    assert p.saveSpanN == [2] and p.hz == 0.5 and p.nlprMethod is True
+    q = oa.parameters()
+    q.Fs, q.Ltotal, q.Lspan, q.amp, q.prgsBar, q.saveSpanN = 512e9, 10, 5, "ideal", False, [1, 2, 7]
+    out = oa.manakovSSF(E, q)
+    assert out.shape == (N, 6) and np.all(out[:, 4:] == 0) and np.any(out[:, :4] != 0)
+
+
+# ---------------------------------------------------------------------------
+# full-size (BASELINE.json configs) property tests -- no oracle needed
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("engine", ENGINES)
+def test_full_size_power_conservation_and_roundtrip(engine):
+    N = 1 << 20
+    _select(engine, N)
+    E = synth_field(N, 2, 2, 8.4)
+    cfg = _mk_cfg(Ltotal=1.6, Lspan=1.6, hz=0.08, nlprMethod=False, alpha=0.0, amp=None, saveSpanN=[])
+    out, _, run = _run_hip(cfg, E)
+    assert orc.signalPower(out) == pytest.approx(orc.signalPower(E), rel=1e-9)      # lossless fiber
+    assert run["steps"] == 20 and run["iterations"] >= 40
+    assert rel_l2(out, E) > 1e-3                                                     # it did propagate
+    back, _, _ = _run_hip(dict(cfg, func="manakovDBP"), out)
+    assert rel_l2(back, E) < 1e-6                                                    # DBP o SSF ~ identity
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_full_size_gamma0_equals_linear_channel_and_linearity(engine):
+    N = 1 << 20
+    _select(engine, N)
+    E = synth_field(N, 2, 5, 0.0)
+    cfg = _mk_cfg(Ltotal=0.8, Lspan=0.8, hz=0.08, nlprMethod=False, gamma=0.0, amp=None, saveSpanN=[])
+    out, _, _ = _run_hip(cfg, E)
+    lp = oa.parameters()
+    lp.L, lp.alpha, lp.D, lp.Fc, lp.Fs = 0.8, 0.2, 16, 193.1e12, 512e9
+    lin = oa.linearFiberChannel(E, lp)
+    assert rel_l2(out, lin) <= 1e-11
+    out2, _, _ = _run_hip(cfg, (2 - 1j) * E)
+    assert rel_l2(out2, (2 - 1j) * out) <= 1e-12                                     # gamma = 0 => linear
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_full_size_config2_short_vs_oracle(engine):
+    """BASELINE config 2 inputs (N = 2^20, seed 2, 8.4 dBm, hz 0.08) for 3 steps."""
+    N = 1 << 20
+    _select(engine, N)
+    E = synth_field(N, 2, 2, 8.4)
+    cfg = _mk_cfg(Ltotal=0.24, Lspan=0.24, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+    out, _, run = _run_hip(cfg, E)
+    assert rel_l2(out, ref) <= TOL_C128
+    assert list(run["iters"]) == tr["iters"]
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_full_size_config3_c64(engine):
+    """BASELINE config 3 shape (N = 2^22, complex64): power bookkeeping over one short span."""
+    N = 1 << 22
+    _select(engine, N)
+    E = synth_field(N, 2, 3, 8.4, np.complex64)
+    cfg = _mk_cfg(Ltotal=0.8, Lspan=0.8, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[], prec="complex64")
+    out, _, run = _run_hip(cfg, E)
+    assert out.dtype == np.complex64 and run["steps"] == 10
+    assert orc.signalPower(out) == pytest.approx(orc.signalPower(E), rel=1e-4)       # ideal amp restores the power
