@@ -187,7 +187,7 @@ def _execute(pl, cp, Nspans, save, prgs, noise_fn, want_trace, max_steps_hint):
         pl.check(lib.ssf_execute(pl.h, C.byref(cp), s0, s1, nptr, C.byref(st), C.byref(tr) if tr else None))
         if tr:
             n = min(tr.count, tr.capacity)
-            traces.append((hz[:n], it[:n], lm[: n * max(cp.maxIter, 1)].reshape(n, -1), tr.count))
+            traces.append((hz[:n], it[:n], lm[: n * max(cp.maxIter, 1)].reshape(n, max(cp.maxIter, 1)), tr.count))
 
     if Nspans >= 1:
         if prgs or noise_fn is not None:
