@@ -1,0 +1,235 @@
+// fused_core.h -- arithmetic core of the fused radix-2^n pipeline: complex POD, register
+// butterflies (radix 2/4/8/16), the mixed-radix pass plan and its index maps.
+//
+// Everything here is `SSF_HD`: it compiles for gfx950 with hipcc AND as plain C++ with g++,
+// so the very same source runs inside the CPU kernel emulator used by tests/ (tests/emu).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SSF_HD __host__ __device__ __forceinline__
+#else
+#define SSF_HD inline
+#endif
+
+namespace ssf {
+namespace fused {
+
+constexpr double kTwoPi = 6.28318530717958647692;
+
+template <typename T> struct cx {
+    T re, im;
+};
+template <typename T> SSF_HD cx<T> mk(T a, T b) {
+    cx<T> r;
+    r.re = a;
+    r.im = b;
+    return r;
+}
+template <typename T> SSF_HD cx<T> operator+(cx<T> a, cx<T> b) { return mk<T>(a.re + b.re, a.im + b.im); }
+template <typename T> SSF_HD cx<T> operator-(cx<T> a, cx<T> b) { return mk<T>(a.re - b.re, a.im - b.im); }
+template <typename T> SSF_HD cx<T> operator*(cx<T> a, cx<T> b) {
+    return mk<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+template <typename T> SSF_HD cx<T> operator*(cx<T> a, T s) { return mk<T>(a.re * s, a.im * s); }
+template <typename T> SSF_HD cx<T> conj(cx<T> a) { return mk<T>(a.re, -a.im); }
+template <typename T> SSF_HD T norm2(cx<T> a) { return a.re * a.re + a.im * a.im; }
+// a * (SIGN * j)
+template <int SIGN, typename T> SSF_HD cx<T> mulj(cx<T> a) {
+    return SIGN > 0 ? mk<T>(-a.im, a.re) : mk<T>(a.im, -a.re);
+}
+
+// cis(2*pi*frac) evaluated in double (frac is exact: integer / power of two)
+SSF_HD void cis2pi_d(double frac, double &c, double &s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincospi(2.0 * frac, &s, &c);
+#else
+    const double a = kTwoPi * frac;
+    c = std::cos(a);
+    s = std::sin(a);
+#endif
+}
+SSF_HD void sincos_d(double a, double &s, double &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(a, &s, &c);
+#else
+    s = std::sin(a);
+    c = std::cos(a);
+#endif
+}
+SSF_HD void sincos_f(float a, float &s, float &c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincosf(a, &s, &c);
+#else
+    s = std::sin(a);
+    c = std::cos(a);
+#endif
+}
+template <typename T> SSF_HD cx<T> cis2pi(double frac) {
+    double c, s;
+    cis2pi_d(frac, c, s);
+    return mk<T>((T)c, (T)s);
+}
+template <typename T> SSF_HD cx<T> cis_t(T a);
+template <> SSF_HD cx<double> cis_t<double>(double a) {
+    double s, c;
+    sincos_d(a, s, c);
+    return mk<double>(c, s);
+}
+template <> SSF_HD cx<float> cis_t<float>(float a) {
+    float s, c;
+    sincos_f(a, s, c);
+    return mk<float>(c, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// register butterflies: in-place DFT of R values, natural order in and out,
+// X[s] = sum_q x[q] * cis(SIGN * 2 pi q s / R).   SIGN = -1 forward, +1 inverse (unscaled).
+// ---------------------------------------------------------------------------------------
+template <int SIGN, typename T> SSF_HD void dft2(cx<T> &a, cx<T> &b) {
+    const cx<T> t = a - b;
+    a = a + b;
+    b = t;
+}
+template <int SIGN, typename T> SSF_HD void dft4(cx<T> &a0, cx<T> &a1, cx<T> &a2, cx<T> &a3) {
+    const cx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mulj<SIGN>(a1 - a3);
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = t1 + t3;
+    a3 = t1 - t3;
+}
+template <int SIGN, typename T> SSF_HD void dft8(cx<T> *v) {   // v[0..7]
+    constexpr T h = (T)0.70710678118654752440;
+    cx<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cx<T> o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4<SIGN>(e0, e1, e2, e3);
+    dft4<SIGN>(o0, o1, o2, o3);
+    // o_s *= W8^s
+    o1 = mk<T>(h * (o1.re - SIGN * o1.im), h * (o1.im + SIGN * o1.re));           // (1 + SIGN j)/sqrt2
+    o2 = mulj<SIGN>(o2);
+    o3 = mk<T>(h * (-o3.re - SIGN * o3.im), h * (-o3.im + SIGN * o3.re));         // (-1 + SIGN j)/sqrt2
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + o1; v[5] = e1 - o1;
+    v[2] = e2 + o2; v[6] = e2 - o2;
+    v[3] = e3 + o3; v[7] = e3 - o3;
+}
+template <int SIGN, typename T> SSF_HD void dft16(cx<T> *v) {  // v[0..15]
+    constexpr T h = (T)0.70710678118654752440;
+    constexpr T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173;   // cos, sin(pi/8)
+    cx<T> e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        e[i] = v[2 * i];
+        o[i] = v[2 * i + 1];
+    }
+    dft8<SIGN>(e);
+    dft8<SIGN>(o);
+    // o_s *= W16^s = cis(SIGN * pi s / 8)
+    o[1] = o[1] * mk<T>(c1, SIGN * s1);
+    o[2] = mk<T>(h * (o[2].re - SIGN * o[2].im), h * (o[2].im + SIGN * o[2].re));
+    o[3] = o[3] * mk<T>(s1, SIGN * c1);
+    o[4] = mulj<SIGN>(o[4]);
+    o[5] = o[5] * mk<T>(-s1, SIGN * c1);
+    o[6] = mk<T>(h * (-o[6].re - SIGN * o[6].im), h * (-o[6].im + SIGN * o[6].re));
+    o[7] = o[7] * mk<T>(-c1, SIGN * s1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = e[i] + o[i];
+        v[i + 8] = e[i] - o[i];
+    }
+}
+
+// powers w^0..w^15 of a unit phasor, multiplication depth <= 4
+template <typename T> SSF_HD void powers16(cx<T> w, cx<T> *p) {
+    p[0] = mk<T>((T)1, (T)0);
+    p[1] = w;
+    p[2] = w * w;
+    p[3] = p[2] * w;
+    p[4] = p[2] * p[2];
+    p[5] = p[4] * w;
+    p[6] = p[3] * p[3];
+    p[7] = p[4] * p[3];
+    p[8] = p[4] * p[4];
+    p[9] = p[8] * w;
+    p[10] = p[8] * p[2];
+    p[11] = p[8] * p[3];
+    p[12] = p[8] * p[4];
+    p[13] = p[8] * p[5];
+    p[14] = p[8] * p[6];
+    p[15] = p[8] * p[7];
+}
+
+// ---------------------------------------------------------------------------------------
+// Mixed-radix pass plan for one length-L transform (L = 2^m, 16 <= L <= 65536), 16 values
+// per thread, L/16 threads per transform.
+//   radices r_0..r_{p-1}:  [16, (2^rem), 16, 16, ...]   with rem = (m - 4) mod 4
+//   L_0 = L, L_{i+1} = L_i / r_i   (L_p = 1)
+// Pass i works in place on positions  block*L_i + j + L_{i+1}*q  (q = 0..r_i-1),
+// butterfly id bb = block*L_{i+1} + j  in [0, L / r_i).
+// DIF(natural in) leaves X[k] at position pos with k = rev(pos):
+//   pos = sum_i s_i * L_{i+1},   k = sum_i s_i * (r_0 ... r_{i-1}).
+// ---------------------------------------------------------------------------------------
+struct PassPlan {
+    int L, log2L, npass, tpf;      // tpf = threads per transform = L/16
+    unsigned lg_pk;                // 4 bits per pass: log2 r_i
+    unsigned long long lgLn_pk;    // 8 bits per pass: log2 L_{i+1} (stride of pass i)
+    // packed (not arrays) so that a runtime pass index never forces the plan into scratch memory
+    SSF_HD int lg(int i) const { return (int)((lg_pk >> (4 * i)) & 15u); }
+    SSF_HD int r(int i) const { return 1 << lg(i); }
+    SSF_HD int lgLn(int i) const { return (int)((lgLn_pk >> (8 * i)) & 255ull); }
+};
+
+SSF_HD PassPlan make_plan(int log2L) {
+    PassPlan p;
+    p.L = 1 << log2L;
+    p.log2L = log2L;
+    p.tpf = p.L >> 4;
+    p.lg_pk = 0;
+    p.lgLn_pk = 0;
+    int n = 0, left = log2L;
+    const int rem = (log2L - 4) & 3, n16 = (log2L - 4) >> 2;
+    for (int i = 0; i < 2 + n16; ++i) {
+        int lg;
+        if (i == 0) lg = 4;
+        else if (i == 1) lg = rem;
+        else lg = 4;
+        if (lg == 0) continue;
+        left -= lg;
+        p.lg_pk |= (unsigned)lg << (4 * n);
+        p.lgLn_pk |= (unsigned long long)left << (8 * n);
+        ++n;
+    }
+    p.npass = n;
+    return p;
+}
+
+// position (element index inside the transform) of value q of butterfly bb in pass i
+SSF_HD int pass_pos(const PassPlan &p, int i, int bb, int q) {
+    const int lgS = p.lgLn(i);                 // stride L_{i+1}
+    const int j = bb & ((1 << lgS) - 1);
+    const int block = bb >> lgS;
+    return (block << (lgS + p.lg(i))) + j + (q << lgS);
+}
+// j (twiddle index) of butterfly bb in pass i, and log2 L_i
+SSF_HD int pass_j(const PassPlan &p, int i, int bb) { return bb & ((1 << p.lgLn(i)) - 1); }
+SSF_HD int pass_lgLi(const PassPlan &p, int i) { return p.lgLn(i) + p.lg(i); }
+
+// digit reversal: position -> natural index
+SSF_HD int rev_pos(const PassPlan &p, int pos) {
+    int k = 0, shift = 0;
+    for (int i = 0; i < p.npass; ++i) {
+        const int s = (pos >> p.lgLn(i)) & (p.r(i) - 1);
+        k += s << shift;
+        shift += p.lg(i);
+    }
+    return k;
+}
+
+// LDS slot of transform-local position pos (pad one slot per 16 to spread banks)
+SSF_HD int lds_slot(int pos) { return pos + (pos >> 4); }
+SSF_HD int lds_slots_per_fft(int L) { return L + (L >> 4) + 1; }
+
+}  // namespace fused
+}  // namespace ssf

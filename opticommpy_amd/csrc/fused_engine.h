@@ -1,0 +1,398 @@
+// fused_engine.h -- host side of the fused radix-2^n engine, templated on a Backend so the
+// same control code drives real HIP launches (engine_fused.hip) and the CPU emulator
+// (tests/emu).  No host<->device synchronisation inside a step: the data-dependent control
+// flow (iteration count, adaptive step, span end) lives in a device-resident Ctrl block that
+// every launch reads and forwards; the host only enqueues a uniform launch sequence
+// [Row, ColA, ColB]* in chunks and looks at the Ctrl block between chunks.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fused_kernels.h"
+#include "ssf_derived.h"
+
+namespace ssf {
+namespace fused {
+
+struct Split {
+    int l1, l2;   // log2 N1 (column length), log2 N2 (row length)
+};
+
+// How N = 2^m is split.  Columns want >= 256 B contiguous per row of a tile
+// (C = 4096/N1 columns x sizeof(complex)); rows are bounded by the 160 KiB LDS.
+inline bool choose_split(int log2N, int precision, Split *s) {
+    if (log2N < 8) return false;
+    const bool dbl = precision == SSF_C128;
+    const int l1pref = dbl ? 8 : 7, l2max = dbl ? 13 : 14;
+    int l1 = std::min(l1pref, log2N / 2);
+    int l2 = log2N - l1;
+    const int l2soft = l2max - 1;          // prefer two workgroups per CU
+    if (l2 > l2soft) {
+        l1 = std::min(log2N - l2soft, l1pref + 1);
+        l2 = log2N - l1;
+    }
+    if (l2 > l2max || l1 < 4 || l2 < 4) return false;
+    s->l1 = l1;
+    s->l2 = l2;
+    return true;
+}
+
+template <typename T, class Backend> class FusedCore {
+  public:
+    using C = cx<T>;
+    Backend &be;
+    int64_t N;
+    int nrows, log2N;
+    Split sp;
+    size_t field_bytes;
+    C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
+    T *P = nullptr;
+    Ctrl *ctrl = nullptr;        // [2]
+    LinOp *linops = nullptr;     // [2]
+    double *part = nullptr;      // 3 * npart_max
+    double *tr_hz = nullptr, *tr_lim = nullptr;
+    int *tr_it = nullptr;
+    long long tr_cap = 0;
+    int tr_maxIter = 0;
+    std::vector<C *> snaps;
+    int cur = 0;                 // which of T0/T1 holds the current field
+    unsigned seq = 0;
+    // launch geometry
+    int row_block, row_grid, col_block_mk, col_grid_mk, col_block_1, col_grid_1, npart_max;
+    size_t row_lds, col_lds_mk, col_lds_1;
+    std::string err;
+
+    FusedCore(Backend &b, int64_t N_, int nrows_, int precision) : be(b), N(N_), nrows(nrows_) {
+        log2N = 0;
+        while ((1ll << log2N) < N) ++log2N;
+        choose_split(log2N, precision, &sp);
+        field_bytes = sizeof(C) * (size_t)N * (size_t)nrows;
+    }
+
+    void col_geometry(int groups, int *block, int *grid, size_t *lds) const {
+        const int tpf = (1 << sp.l1) / 16, N2 = 1 << sp.l2;
+        int blk = 256;
+        if (blk / tpf > N2) blk = N2 * tpf;
+        const int Cc = blk / tpf;
+        *block = blk;
+        *grid = groups * (N2 / Cc);
+        *lds = std::max((size_t)Cc * lds_slots_per_fft(1 << sp.l1) * sizeof(C), (size_t)blk * 8 + 1024);
+    }
+
+    int init() {
+        const int tpf2 = (1 << sp.l2) / 16;
+        const int64_t nfft = (int64_t)nrows << sp.l1;
+        int fpw = tpf2 >= 256 ? 1 : 256 / tpf2;               // row transforms per workgroup
+        while (nfft % fpw) fpw >>= 1;                          // (nrows need not be a power of two)
+        row_block = fpw * tpf2;
+        row_grid = (int)(nfft / fpw);
+        row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 8 + 2048);
+        col_geometry(std::max(nrows / 2, 1), &col_block_mk, &col_grid_mk, &col_lds_mk);
+        col_geometry(nrows, &col_block_1, &col_grid_1, &col_lds_1);
+        npart_max = std::max(col_grid_mk, col_grid_1);
+        void **ptrs[] = {(void **)&G, (void **)&T0, (void **)&T1, (void **)&Ehd};
+        for (auto pp : ptrs)
+            if (!(*pp = be.alloc(field_bytes))) return oom();
+        if (!(P = (T *)be.alloc(sizeof(T) * (size_t)N * (size_t)((nrows + 1) / 2)))) return oom();
+        if (!(ctrl = (Ctrl *)be.alloc(2 * sizeof(Ctrl)))) return oom();
+        if (!(linops = (LinOp *)be.alloc(2 * sizeof(LinOp)))) return oom();
+        if (!(part = (double *)be.alloc(sizeof(double) * 3 * (size_t)npart_max))) return oom();
+        be.prepare(row_lds, std::max(col_lds_mk, col_lds_1));
+        return SSF_OK;
+    }
+    int oom() {
+        err = "out of memory allocating fused-engine buffers: " + be.last_error();
+        return SSF_ERR_OOM;
+    }
+    ~FusedCore() {
+        for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)ctrl, (void *)linops,
+                        (void *)part, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
+            if (p) be.free(p);
+        for (C *s : snaps) be.free(s);
+    }
+
+    C *Tcur() { return cur ? T1 : T0; }
+
+    int upload(const void *soa) {
+        cur = 0;
+        be.h2d(T0, soa, field_bytes);
+        for (C *s : snaps) be.free(s);
+        snaps.clear();
+        return be.ok() ? SSF_OK : hiperr();
+    }
+    int download(void *soa) {
+        be.d2h(soa, Tcur(), field_bytes);
+        return be.ok() ? SSF_OK : hiperr();
+    }
+    int download_snapshots(void *soa) {
+        for (size_t i = 0; i < snaps.size(); ++i) be.d2h((char *)soa + i * field_bytes, snaps[i], field_bytes);
+        return be.ok() ? SSF_OK : hiperr();
+    }
+    int hiperr() {
+        err = be.last_error();
+        return SSF_ERR_HIP;
+    }
+
+    // ---------------------------------------------------------------- launch helpers
+    RowArgs<T> row_args() const {
+        RowArgs<T> a{};
+        a.G = G;
+        a.log2N1 = sp.l1;
+        a.log2N2 = sp.l2;
+        a.nfft = (int)((int64_t)nrows << sp.l1);
+        return a;
+    }
+    ColArgs<T> col_args(int npol, int mode) const {
+        ColArgs<T> a{};
+        a.G = G;
+        a.T0 = T0;
+        a.T1 = T1;
+        a.Ehd = Ehd;
+        a.P = P;
+        a.log2N1 = sp.l1;
+        a.log2N2 = sp.l2;
+        a.npol = npol;
+        a.mode = mode;
+        a.pmax = part;
+        a.pnum = part + npart_max;
+        a.pden = part + 2 * (size_t)npart_max;
+        return a;
+    }
+    void launch_row_lin(const LinOp *lin) {
+        RowArgs<T> a = row_args();
+        a.use_ctrl = 0;
+        a.lin = lin;
+        be.launch_row(a, row_grid, row_block, row_lds);
+    }
+    void launch_col_plain(int mode, C *timebuf, T g_hz) {
+        ColArgs<T> a = col_args(1, mode);
+        a.T0 = timebuf;
+        a.g_hz = g_hz;
+        a.npart = col_grid_1;
+        be.launch_col(a, col_grid_1, col_block_1, col_lds_1);
+    }
+    void launch_amp(C *E, T gain, const C *noise) {
+        AmpArgs<T> a{};
+        a.E = E;
+        a.noise = noise;
+        a.total = (long long)N * nrows;
+        a.gain = gain;
+        be.launch_amp(a, 1024, 256);
+    }
+    int snapshot() {
+        C *s = (C *)be.alloc(field_bytes);
+        if (!s) return oom();
+        snaps.push_back(s);
+        be.d2d(s, Tcur(), field_bytes);
+        return SSF_OK;
+    }
+    static bool wants_snapshot(const ssf_params &p, int span) {
+        for (int i = 0; i < p.n_save; ++i)
+            if (p.save_spans[i] == span) return true;
+        return false;
+    }
+    int amp_fwd(const ssf_params &p, const Derived &d, int span_rel, const void *noise, double ideal_gain) {
+        if (p.amp == SSF_AMP_EDFA) {
+            const C *nz = nullptr;
+            if (noise) {
+                if (!noise_d && !(noise_d = (C *)be.alloc(field_bytes))) return oom();
+                be.h2d(noise_d, (const char *)noise + (size_t)span_rel * field_bytes, field_bytes);
+                nz = noise_d;
+            }
+            launch_amp(Tcur(), (T)std::sqrt(d.G_lin), nz);
+        } else if (p.amp == SSF_AMP_IDEAL) {
+            launch_amp(Tcur(), (T)ideal_gain, nullptr);
+        }
+        return SSF_OK;
+    }
+
+    // ---------------------------------------------------------------- scalar NLSE
+    int run_nlse(const ssf_params &p, const Derived &d, int s0, int s1, const void *noise, ssf_stats *st) {
+        const int nsteps = (int)std::floor(p.Lspan / p.hz);
+        const double w2 = (d.w_scale / (double)N) * (d.w_scale / (double)N);
+        LinOp lo[2];
+        lo[0] = make_linop(p.hz / 2, d.lin_a, d.lin_b, w2, 1.0 / (double)N, log2N);
+        lo[1] = make_linop(p.hz, d.lin_a, d.lin_b, w2, 1.0 / (double)N, log2N);     // lin * lin
+        be.h2d(linops, lo, sizeof(lo));
+        for (int span = s0; span <= s1; ++span) {
+            C *E = Tcur();
+            if (nsteps >= 1) {
+                launch_col_plain(CM_NLSE_FIRST, E, (T)0);                              // channels.py:216
+                launch_row_lin(linops + 0);
+                for (int s = 1; s < nsteps; ++s) {
+                    launch_col_plain(CM_NLSE_STEP, E, (T)(p.gamma * p.hz));
+                    launch_row_lin(linops + 1);
+                }
+                launch_col_plain(CM_NLSE_STEP, E, (T)(p.gamma * p.hz));
+                launch_row_lin(linops + 0);
+                launch_col_plain(CM_NLSE_LAST, E, (T)0);                               // channels.py:232
+            }
+            int rc = amp_fwd(p, d, span - s0, noise, std::exp(d.alpha_lin / 2 * nsteps * p.hz));
+            if (rc) return rc;
+            if (wants_snapshot(p, span) && (rc = snapshot())) return rc;
+            st->steps += nsteps;
+            st->transforms += (int64_t)nrows * (2 * (int64_t)nsteps + 2);
+        }
+        be.sync();
+        return be.ok() ? SSF_OK : hiperr();
+    }
+
+    // ---------------------------------------------------------------- Manakov / DBP
+    MkConst mk_const(const ssf_params &p, const Derived &d) const {
+        MkConst k{};
+        k.Lspan = p.Lspan;
+        k.hz_fixed = p.hz;
+        k.tol = p.tol;
+        k.maxRot = p.maxNlinPhaseRot;
+        k.c8g = d.c8g;
+        k.sgn = p.direction >= 0 ? 1.0 : -1.0;
+        k.lin_a = d.lin_a;
+        k.lin_b = d.lin_b;
+        k.w2 = (d.w_scale / (double)N) * (d.w_scale / (double)N);
+        k.invN = 1.0 / (double)N;
+        k.maxIter = p.maxIter;
+        k.adaptive = p.nlprMethod ? 1 : 0;
+        k.log2N = log2N;
+        k.trace_cap = tr_cap;
+        k.tr_hz = tr_hz;
+        k.tr_it = tr_it;
+        k.tr_lim = tr_lim;
+        return k;
+    }
+    void launch_mk_row(const MkConst &k) {
+        RowArgs<T> a = row_args();
+        a.use_ctrl = 1;
+        a.cin = ctrl + (seq & 1);
+        a.cout = ctrl + ((seq + 1) & 1);
+        a.k = k;
+        a.pmax = part;
+        a.npart = col_grid_mk;
+        be.launch_row(a, row_grid, row_block, row_lds);
+        ++seq;
+    }
+    void launch_mk_col(const MkConst &k, int mode) {
+        ColArgs<T> a = col_args(2, mode);
+        a.cin = ctrl + (seq & 1);
+        a.cout = ctrl + ((seq + 1) & 1);
+        a.k = k;
+        a.npart = col_grid_mk;
+        be.launch_col(a, col_grid_mk, col_block_mk, col_lds_mk);
+        ++seq;
+    }
+    int prepare_trace(ssf_trace *trace, int maxIter) {
+        const long long cap = trace ? trace->capacity : 0;
+        if (cap > tr_cap || maxIter != tr_maxIter) {
+            for (void *q : {(void *)tr_hz, (void *)tr_lim, (void *)tr_it})
+                if (q) be.free(q);
+            tr_hz = tr_lim = nullptr;
+            tr_it = nullptr;
+            tr_cap = 0;
+            if (cap > 0) {
+                tr_hz = (double *)be.alloc(sizeof(double) * (size_t)cap);
+                tr_it = (int *)be.alloc(sizeof(int) * (size_t)cap);
+                tr_lim = (double *)be.alloc(sizeof(double) * (size_t)cap * (size_t)maxIter);
+                if (!tr_hz || !tr_it || !tr_lim) return oom();
+                tr_cap = cap;
+                tr_maxIter = maxIter;
+            }
+        }
+        if (tr_cap > 0) be.memset(tr_lim, 0xFF, sizeof(double) * (size_t)tr_cap * (size_t)maxIter);   // NaN pattern
+        return SSF_OK;
+    }
+
+    int run_manakov(const ssf_params &p, const Derived &d, int s0, int s1, const void *noise, ssf_stats *st,
+                    ssf_trace *trace) {
+        int rc = prepare_trace(trace, p.maxIter);
+        if (rc) return rc;
+        MkConst k = mk_const(p, d);
+        if (!trace) k.trace_cap = 0;
+        Ctrl c{};
+        long long trace_n = 0;
+        double avg_it = 3.0;
+        for (int span = s0; span <= s1; ++span) {
+            if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))      // equalization.py:1090-1092
+                launch_amp(Tcur(), (T)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);
+            std::memset(&c, 0, sizeof(c));
+            c.state = ST_NEED_S;
+            c.cur = cur;
+            c.trace_n = trace_n;
+            be.h2d(ctrl + (seq & 1), &c, sizeof(Ctrl));
+            launch_mk_col(k, CM_MK_B);                                                     // first step start
+            int guard = 0;
+            for (;;) {
+                // estimate the [Row, ColA, ColB] triples still needed for this span
+                double steps_rem;
+                if (c.steps == 0 && c.state == ST_NEED_S)
+                    steps_rem = p.nlprMethod ? 8.0 : std::ceil(p.Lspan / p.hz);
+                else
+                    steps_rem = std::max(1.0, std::ceil((p.Lspan - c.z) / (c.hz > 0 ? c.hz : p.hz)));
+                double est = steps_rem * (1.0 + avg_it) * (p.nlprMethod ? 0.6 : 0.95);
+                int chunk = (int)std::min(512.0, std::max(2.0, est));
+                for (int i = 0; i < chunk; ++i) {
+                    launch_mk_row(k);
+                    launch_mk_col(k, CM_MK_A);
+                    launch_mk_col(k, CM_MK_B);
+                }
+                be.d2h(&c, ctrl + (seq & 1), sizeof(Ctrl));                               // synchronising read
+                if (!be.ok()) return hiperr();
+                if (c.steps > 0) avg_it = (double)c.iterations / (double)c.steps;
+                if (c.state == ST_SPAN_DONE) break;
+                if (++guard > (1 << 22)) {
+                    err = "fused engine: span did not terminate";
+                    return SSF_ERR_STATE;
+                }
+            }
+            cur = c.cur;
+            trace_n = c.trace_n;
+            st->steps += c.steps;
+            st->iterations += c.iterations;
+            st->nonconverged_steps += c.nonconv;
+            st->transforms += (int64_t)nrows * (2 * c.steps + 2 * c.iterations);
+            if (p.direction >= 0 && (rc = amp_fwd(p, d, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
+            if (wants_snapshot(p, span) && (rc = snapshot())) return rc;
+        }
+        be.sync();
+        if (!be.ok()) return hiperr();
+        if (trace) {
+            trace->count = trace_n;
+            const long long n = std::min(trace_n, (long long)trace->capacity);
+            if (n > 0) {
+                if (trace->hz) be.d2h(trace->hz, tr_hz, sizeof(double) * (size_t)n);
+                if (trace->iters) be.d2h(trace->iters, tr_it, sizeof(int) * (size_t)n);
+                if (trace->lims) be.d2h(trace->lims, tr_lim, sizeof(double) * (size_t)n * (size_t)p.maxIter);
+            }
+        }
+        return be.ok() ? SSF_OK : hiperr();
+    }
+
+    int execute(const ssf_params &p, int s0, int s1, const void *noise, ssf_stats *st, ssf_trace *trace) {
+        const Derived d = derive(p);
+        be.time_begin();
+        int rc = p.model == SSF_MODEL_NLSE ? run_nlse(p, d, s0, s1, noise, st) : run_manakov(p, d, s0, s1, noise, st, trace);
+        if (rc) return rc;
+        st->device_ms += be.time_end();
+        st->n_snapshots = (int32_t)snaps.size();
+        return SSF_OK;
+    }
+
+    // Eo = ifft(fft(Ei) * exp(-alpha/2 L + j beta2/2 w^2 L))     (channels.py:97)
+    int linear_channel(double Fs, double Fc, double alpha, double D, double L) {
+        ssf_params p{};
+        p.Fs = Fs; p.Fc = Fc; p.alpha = alpha; p.D = D; p.direction = 1; p.Lspan = 1; p.NF = 4.5;
+        const Derived d = derive(p);
+        const double w2 = (d.w_scale / (double)N) * (d.w_scale / (double)N);
+        LinOp lo = make_linop(L, d.lin_a, d.lin_b, w2, 1.0 / (double)N, log2N);
+        be.h2d(linops, &lo, sizeof(lo));
+        launch_col_plain(CM_PLAIN_FWD, Tcur(), (T)0);
+        launch_row_lin(linops);
+        launch_col_plain(CM_PLAIN_INV, Tcur(), (T)0);
+        be.sync();
+        return be.ok() ? SSF_OK : hiperr();
+    }
+};
+
+}  // namespace fused
+}  // namespace ssf

@@ -1,0 +1,652 @@
+// fused_kernels.h -- kernel bodies of the fused pipeline, written against an execution
+// context `Ctx` (tid / bid / nthreads / nblocks / lds / sync()) so that the same source is
+// launched as HIP kernels on gfx950 (engine_fused.hip) and stepped by the CPU emulator in
+// tests/emu (fibers; sync() yields).  No wave intrinsics: block reductions go through LDS.
+//
+// Decomposition of one length-N transform of a row (N = N1*N2, n = n1*N2 + n2,
+// k = k1 + N1*k2), all buffers in the natural [row][n1][n2] matrix layout:
+//
+//   column kernel (C columns x N1 per workgroup, both polarisations of a pair):
+//        [G -> inverse column FFT (DIF, natural k1 in, digit-reversed n1 in registers)]
+//        -> time-domain work on registers (power, Kerr rotation, norms, E_hd / E_conv I/O)
+//        -> [forward column FFT (DIT, digit-reversed in, natural k1 out) -> G]
+//   row kernel (one contiguous row of N2 per transform):
+//        G * W_N^{n2 k1} -> forward row FFT (DIF) -> * linear operator (from the bin index)
+//        -> inverse row FFT (DIT) -> * conj(W_N^{n2 k1}) / N -> G
+//
+// so FFT . H . IFFT costs two HBM round trips and no transposes.  Reference semantics:
+// optic/models/channels.py:387-441 (Manakov step), :219-229 (NLSE step).
+#pragma once
+#include "fused_core.h"
+
+namespace ssf {
+namespace fused {
+
+// ------------------------------------------------------------------------------- control
+enum {
+    ST_NEED_S = 0,     // ColB: step start on T[cur]: Pch, forward column FFT
+    ST_AFTER_S = 1,    // Row : first half linear step (and adaptive step size)
+    ST_NEED_H = 2,     // ColA: E_hd = ..., first rotation, forward column FFT
+    ST_ROW_ITER = 3,   // Row : second linear step of the current iterate
+    ST_NEED_I = 4,     // ColA: E_fd -> T[cur^1], convergence partial sums
+    ST_NEED_D = 5,     // ColB: decide: next iterate | next step | span done
+    ST_SPAN_DONE = 6
+};
+
+struct LinOp {          // exp(argLimOp * hz/2) / N evaluated from the bin index (row kernel)
+    double cth;         // phase = cth * kk^2, kk = signed bin index
+    double mag;         // exp(lin_a * hzh) / N
+    double Cre[9], Cim[9];   // cis(cth * (N/16)^2 * m^2), m = 0..8
+};
+
+struct Ctrl {           // device-resident step state, double-buffered by launch parity
+    int state, it, cur, hz_valid;
+    double z, hz;
+    long long steps, iterations, nonconv, trace_n;
+    LinOp lin;
+};
+
+struct MkConst {        // per-execute constants (by value)
+    double Lspan, hz_fixed, tol, maxRot, c8g, sgn, lin_a, lin_b, w2, invN;
+    int maxIter, adaptive, log2N, pad_;
+    long long trace_cap;
+    double *tr_hz;
+    int *tr_it;
+    double *tr_lim;
+};
+
+SSF_HD LinOp make_linop(double hzh, double lin_a, double lin_b, double w2, double invN, int log2N) {
+    LinOp l;
+    l.cth = lin_b * w2 * hzh;
+    l.mag = exp(lin_a * hzh) * invN;
+    const double d = (double)(1ll << (log2N - 4));
+    for (int m = 0; m < 9; ++m) {
+        double s, c;
+        sincos_d(l.cth * d * d * (double)(m * m), s, c);
+        l.Cre[m] = c;
+        l.Cim[m] = s;
+    }
+    return l;
+}
+
+// channels.py:392-403
+SSF_HD double pick_hz(const MkConst &k, double z, double maxphi) {
+    if (k.adaptive) {
+        const double cand = k.maxRot / maxphi;
+        return (k.Lspan - z >= cand) ? cand : k.Lspan - z;
+    }
+    return (k.Lspan - z < k.hz_fixed) ? k.Lspan - z : k.hz_fixed;
+}
+
+// ------------------------------------------------------------------------ thread-level FFT
+template <typename T> SSF_HD cx<T> tw_unit(int sign, int j, int lgL);
+template <> SSF_HD cx<double> tw_unit<double>(int sign, int j, int lgL) {
+    double c, s;
+    cis2pi_d((double)(sign * j) / (double)(1 << lgL), c, s);
+    return mk<double>(c, s);
+}
+template <> SSF_HD cx<float> tw_unit<float>(int sign, int j, int lgL) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float c, s;
+    sincospif(2.0f * (float)(sign * j) / (float)(1 << lgL), &s, &c);
+    return mk<float>(c, s);
+#else
+    double c, s;
+    cis2pi_d((double)(sign * j) / (double)(1 << lgL), c, s);
+    return mk<float>((float)c, (float)s);
+#endif
+}
+
+// butterflies of pass i for thread b (values v[u*r + q]); DIF: DFT then twiddle w^s
+template <int SIGN, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, int b, cx<T> *v) {
+    const int lgLi = pass_lgLi(p, i);
+    const bool tw = p.lgLn(i) > 0;
+    switch (p.lg(i)) {
+    case 4: {
+        dft16<SIGN>(v);
+        if (tw) {
+            cx<T> w[16];
+            powers16(tw_unit<T>(SIGN, pass_j(p, i, b), lgLi), w);
+#pragma unroll
+            for (int s = 1; s < 16; ++s) v[s] = v[s] * w[s];
+        }
+    } break;
+    case 3:
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            dft8<SIGN>(v + 8 * u);
+            if (tw) {
+                const cx<T> w1 = tw_unit<T>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi);
+                const cx<T> w2 = w1 * w1, w3 = w2 * w1, w4 = w2 * w2;
+                v[8 * u + 1] = v[8 * u + 1] * w1;
+                v[8 * u + 2] = v[8 * u + 2] * w2;
+                v[8 * u + 3] = v[8 * u + 3] * w3;
+                v[8 * u + 4] = v[8 * u + 4] * w4;
+                v[8 * u + 5] = v[8 * u + 5] * (w4 * w1);
+                v[8 * u + 6] = v[8 * u + 6] * (w3 * w3);
+                v[8 * u + 7] = v[8 * u + 7] * (w4 * w3);
+            }
+        }
+        break;
+    case 2:
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            dft4<SIGN>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+            if (tw) {
+                const cx<T> w1 = tw_unit<T>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi);
+                const cx<T> w2 = w1 * w1;
+                v[4 * u + 1] = v[4 * u + 1] * w1;
+                v[4 * u + 2] = v[4 * u + 2] * w2;
+                v[4 * u + 3] = v[4 * u + 3] * (w2 * w1);
+            }
+        }
+        break;
+    default:
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            dft2<SIGN>(v[2 * u], v[2 * u + 1]);
+            if (tw) v[2 * u + 1] = v[2 * u + 1] * tw_unit<T>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi);
+        }
+        break;
+    }
+}
+
+// DIT: twiddle w^s then DFT (exact mirror of dif_pass with the opposite SIGN)
+template <int SIGN, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, int b, cx<T> *v) {
+    const int lgLi = pass_lgLi(p, i);
+    const bool tw = p.lgLn(i) > 0;
+    switch (p.lg(i)) {
+    case 4: {
+        if (tw) {
+            cx<T> w[16];
+            powers16(tw_unit<T>(SIGN, pass_j(p, i, b), lgLi), w);
+#pragma unroll
+            for (int s = 1; s < 16; ++s) v[s] = v[s] * w[s];
+        }
+        dft16<SIGN>(v);
+    } break;
+    case 3:
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (tw) {
+                const cx<T> w1 = tw_unit<T>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi);
+                const cx<T> w2 = w1 * w1, w3 = w2 * w1, w4 = w2 * w2;
+                v[8 * u + 1] = v[8 * u + 1] * w1;
+                v[8 * u + 2] = v[8 * u + 2] * w2;
+                v[8 * u + 3] = v[8 * u + 3] * w3;
+                v[8 * u + 4] = v[8 * u + 4] * w4;
+                v[8 * u + 5] = v[8 * u + 5] * (w4 * w1);
+                v[8 * u + 6] = v[8 * u + 6] * (w3 * w3);
+                v[8 * u + 7] = v[8 * u + 7] * (w4 * w3);
+            }
+            dft8<SIGN>(v + 8 * u);
+        }
+        break;
+    case 2:
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (tw) {
+                const cx<T> w1 = tw_unit<T>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi);
+                const cx<T> w2 = w1 * w1;
+                v[4 * u + 1] = v[4 * u + 1] * w1;
+                v[4 * u + 2] = v[4 * u + 2] * w2;
+                v[4 * u + 3] = v[4 * u + 3] * (w2 * w1);
+            }
+            dft4<SIGN>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+        }
+        break;
+    default:
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (tw) v[2 * u + 1] = v[2 * u + 1] * tw_unit<T>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi);
+            dft2<SIGN>(v[2 * u], v[2 * u + 1]);
+        }
+        break;
+    }
+}
+
+// transform-local position of register idx (0..15) of thread b in pass i
+SSF_HD int reg_pos(const PassPlan &p, int i, int b, int idx) {
+    const int lg = p.lg(i);
+    return pass_pos(p, i, b + p.tpf * (idx >> lg), idx & ((1 << lg) - 1));
+}
+
+template <typename T> SSF_HD void lds_put(const PassPlan &p, int i, int b, const cx<T> *v, cx<T> *lds) {
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) lds[lds_slot(reg_pos(p, i, b, idx))] = v[idx];
+}
+template <typename T> SSF_HD void lds_get(const PassPlan &p, int i, int b, cx<T> *v, const cx<T> *lds) {
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) v[idx] = lds[lds_slot(reg_pos(p, i, b, idx))];
+}
+
+// DIF transform: v holds pass-0 positions on entry, pass-(p-1) positions (digit-reversed) on exit
+template <int SIGN, typename T, class Ctx>
+SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
+    dif_pass<SIGN>(p, 0, b, v);
+    for (int i = 1; i < p.npass; ++i) {
+        lds_put(p, i - 1, b, v, lds);
+        ctx.sync();
+        lds_get(p, i, b, v, lds);
+        dif_pass<SIGN>(p, i, b, v);
+    }
+}
+// DIT transform: v holds pass-(p-1) positions on entry, pass-0 positions (natural) on exit
+template <int SIGN, typename T, class Ctx>
+SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
+    for (int i = p.npass - 1; i >= 1; --i) {
+        dit_pass<SIGN>(p, i, b, v);
+        lds_put(p, i, b, v, lds);
+        ctx.sync();
+        lds_get(p, i - 1, b, v, lds);
+    }
+    dit_pass<SIGN>(p, 0, b, v);
+}
+
+// ------------------------------------------------------------------------ block reductions
+// every thread gets the result; `red` is LDS scratch of nthreads doubles; 2 barriers
+template <class Ctx> SSF_HD double block_sum(Ctx &ctx, double v, double *red) {
+    ctx.sync();
+    red[ctx.tid] = v;
+    ctx.sync();
+    double s = 0;
+    for (int i = 0; i < ctx.nthreads; ++i) s += red[i];
+    return s;
+}
+template <class Ctx> SSF_HD double block_max(Ctx &ctx, double v, double *red) {
+    ctx.sync();
+    red[ctx.tid] = v;
+    ctx.sync();
+    double s = red[0];
+    for (int i = 1; i < ctx.nthreads; ++i) s = red[i] > s ? red[i] : s;
+    return s;
+}
+// deterministic reduction of a global partial array by the whole block (same order in every block)
+template <class Ctx> SSF_HD double global_sum(Ctx &ctx, const double *a, int n, double *red) {
+    double s = 0;
+    for (int i = ctx.tid; i < n; i += ctx.nthreads) s += a[i];
+    return block_sum(ctx, s, red);
+}
+template <class Ctx> SSF_HD double global_max(Ctx &ctx, const double *a, int n, double *red) {
+    double s = -INFINITY;
+    for (int i = ctx.tid; i < n; i += ctx.nthreads) s = a[i] > s ? a[i] : s;
+    return block_max(ctx, s, red);
+}
+
+// ------------------------------------------------------------------------------ row kernel
+template <typename T> struct RowArgs {
+    cx<T> *G;                 // (nrows, N1, N2)
+    int log2N1, log2N2, nfft; // nfft = nrows * N1 row transforms
+    int use_ctrl;             // 1: Manakov state machine (ctrl), 0: explicit LinOp (NLSE / linear channel)
+    const LinOp *lin;         // use_ctrl == 0
+    const Ctrl *cin;          // ctrl[seq & 1]
+    Ctrl *cout;               // ctrl[(seq + 1) & 1]
+    MkConst k;
+    const double *pmax;       // adaptive: block maxima of phi written by the S stage
+    int npart;
+};
+
+// linear operator for the 16 registers of a last-radix-16 butterfly: bins k0 + (N/16) q
+template <typename T>
+SSF_HD void apply_lin16(const LinOp &lo, long long k0, int log2N, cx<T> *v) {
+    const double dk = (double)(1ll << (log2N - 4));
+    const double k0d = (double)k0;
+    double s, c;
+    sincos_d(lo.cth * k0d * k0d, s, c);
+    const cx<double> A = mk<double>(lo.mag * c, lo.mag * s);
+    sincos_d(2.0 * lo.cth * k0d * dk, s, c);
+    cx<double> Bp[9];
+    Bp[0] = mk<double>(1.0, 0.0);
+    Bp[1] = mk<double>(c, s);
+    Bp[2] = Bp[1] * Bp[1];
+    Bp[3] = Bp[2] * Bp[1];
+    Bp[4] = Bp[2] * Bp[2];
+    Bp[5] = Bp[4] * Bp[1];
+    Bp[6] = Bp[3] * Bp[3];
+    Bp[7] = Bp[4] * Bp[3];
+    Bp[8] = Bp[4] * Bp[4];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int m = q < 8 ? q : 16 - q;                       // |q'|, q' = q (q<8) or q-16
+        const cx<double> bq = q < 8 ? Bp[m] : conj(Bp[m]);
+        const cx<double> h = A * bq * mk<double>(lo.Cre[m], lo.Cim[m]);
+        v[q] = v[q] * mk<T>((T)h.re, (T)h.im);
+    }
+}
+// general (slow) form for short rows whose last radix is not 16
+template <typename T> SSF_HD cx<T> lin_at(const LinOp &lo, long long k, int log2N) {
+    const long long N = 1ll << log2N;
+    const double kk = (double)(k < N / 2 ? k : k - N);
+    double s, c;
+    sincos_d(lo.cth * kk * kk, s, c);
+    return mk<T>((T)(lo.mag * c), (T)(lo.mag * s));
+}
+
+template <typename T, class Ctx> SSF_HD void row_body(Ctx &ctx, const RowArgs<T> &a) {
+    cx<T> *lds = (cx<T> *)ctx.lds;
+    LinOp *lsh = (LinOp *)ctx.lds;            // only used before the FFT touches the LDS
+    LinOp lo;
+    if (a.use_ctrl) {
+        const Ctrl c = *a.cin;
+        const bool act = c.state == ST_AFTER_S || c.state == ST_ROW_ITER;
+        Ctrl n = c;
+        if (act && !c.hz_valid) {             // adaptive step: every block derives the same hz
+            double *red = (double *)(ctx.lds) + 64;
+            const double mx = global_max(ctx, a.pmax, a.npart, red);
+            ctx.sync();
+            if (ctx.tid == 0) {
+                const double hz = pick_hz(a.k, c.z, mx);
+                lsh[0] = make_linop(hz / 2, a.k.lin_a, a.k.lin_b, a.k.w2, a.k.invN, a.k.log2N);
+                ((double *)(lsh + 1))[0] = hz;
+            }
+            ctx.sync();
+            n.hz = ((double *)(lsh + 1))[0];
+            n.lin = lsh[0];
+            n.hz_valid = 1;
+            ctx.sync();
+        }
+        if (act) n.state = c.state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
+        if (ctx.bid == 0 && ctx.tid == 0) *a.cout = n;
+        if (!act) return;
+        lo = n.lin;
+    } else {
+        lo = *a.lin;
+    }
+    const PassPlan p = make_plan(a.log2N2);
+    const int fpw = ctx.nthreads / p.tpf;                  // row transforms per workgroup
+    const int f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
+    const long long rr = (long long)ctx.bid * fpw + f;     // global row-transform index
+    if (rr >= a.nfft) return;                              // (grid is exact; kept for safety)
+    const int N1 = 1 << a.log2N1, log2N = a.log2N1 + a.log2N2;
+    const int k1 = (int)(rr & (N1 - 1));
+    cx<T> *g = a.G + (rr << a.log2N2);
+    cx<T> *l = lds + (size_t)f * lds_slots_per_fft(p.L);
+    cx<T> v[16];
+    // load natural n2 = b + tpf*q, times W_N^{n2 k1}
+    {
+        const long long N = 1ll << log2N;
+        const cx<T> w0 = cis2pi<T>(-(double)(((long long)k1 * b) & (N - 1)) / (double)N);
+        const cx<T> ws = cis2pi<T>(-(double)(((long long)k1 * p.tpf) & (N - 1)) / (double)N);
+        cx<T> w[16];
+        powers16(ws, w);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = g[b + p.tpf * q] * (w0 * w[q]);
+    }
+    fft_dif<-1>(ctx, p, b, v, l);
+    // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
+    const int last = p.npass - 1;
+    if (p.lg(last) == 4) {
+        const long long k0 = k1 + ((long long)rev_pos(p, reg_pos(p, last, b, 0)) << a.log2N1);
+        apply_lin16(lo, k0, log2N, v);
+    } else {
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+            const long long k = k1 + ((long long)rev_pos(p, reg_pos(p, last, b, idx)) << a.log2N1);
+            v[idx] = v[idx] * lin_at<T>(lo, k, log2N);
+        }
+    }
+    fft_dit<+1>(ctx, p, b, v, l);
+    {
+        const long long N = 1ll << log2N;
+        const cx<T> w0 = cis2pi<T>((double)(((long long)k1 * b) & (N - 1)) / (double)N);
+        const cx<T> ws = cis2pi<T>((double)(((long long)k1 * p.tpf) & (N - 1)) / (double)N);
+        cx<T> w[16];
+        powers16(ws, w);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) g[b + p.tpf * q] = v[q] * (w0 * w[q]);
+    }
+}
+
+// --------------------------------------------------------------------------- column kernel
+enum {
+    CM_NLSE_FIRST = 0,   // time -> forward -> G
+    CM_NLSE_STEP = 1,    // G -> inverse -> E *= exp(j g_hz |E|^2) -> forward -> G
+    CM_NLSE_LAST = 2,    // G -> inverse -> time
+    CM_MK_A = 3,         // Manakov ColA (H | I by state)
+    CM_MK_B = 4,         // Manakov ColB (S | D by state)
+    CM_PLAIN_FWD = 5,    // time -> forward -> G            (linear channel)
+    CM_PLAIN_INV = 6     // G -> inverse -> time            (linear channel)
+};
+
+template <typename T> struct ColArgs {
+    cx<T> *G;                 // (nrows, N1, N2)
+    cx<T> *T0, *T1;           // time-domain fields, (nrows, N); Manakov: E(z)/E_conv ping-pong
+    cx<T> *Ehd;               // (nrows, N)
+    T *P;                     // (K, N)
+    int log2N1, log2N2, npol, mode;
+    T g_hz;                   // NLSE: gamma * hz
+    const Ctrl *cin;
+    Ctrl *cout;
+    MkConst k;
+    double *pmax, *pnum, *pden;
+    int npart;                // number of column workgroups (partials per array)
+};
+
+template <typename T, class Ctx> struct ColGeom {
+    PassPlan p;
+    int C, c, b, n2;
+    long long rowbase[2];     // element offset of row r = 2*pair + pol (or the single row)
+    int N2;
+    SSF_HD ColGeom(Ctx &ctx, const ColArgs<T> &a) {
+        p = make_plan(a.log2N1);
+        C = ctx.nthreads / p.tpf;
+        c = ctx.tid % C;
+        b = ctx.tid / C;
+        N2 = 1 << a.log2N2;
+        const int tpp = N2 / C;                      // tiles per field row group
+        const int grp = ctx.bid / tpp, tile = ctx.bid % tpp;
+        n2 = tile * C + c;
+        const long long N = 1ll << (a.log2N1 + a.log2N2);
+        rowbase[0] = (long long)(grp * a.npol) * N;
+        rowbase[1] = rowbase[0] + N;
+    }
+    // frequency side: register q <-> k1 = b + tpf*q (pass-0 positions)
+    SSF_HD long long freq_off(int q) const { return ((long long)(b + p.tpf * q) << 0) * N2 + n2; }
+    // time side: register idx <-> n1 = rev(position in the last pass)
+    SSF_HD long long time_off(int idx) const {
+        return (long long)rev_pos(p, reg_pos(p, p.npass - 1, b, idx)) * N2 + n2;
+    }
+};
+
+template <typename T, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
+    // ---- what does this launch do? ------------------------------------------------------
+    bool do_inv = false, do_fwd = false;
+    int op = -1;   // Manakov: 0 = S, 1 = H, 2 = I, 3 = D(a) next iterate
+    Ctrl c{}, n{};
+    double *red = (double *)ctx.lds;
+    if (a.mode == CM_MK_A || a.mode == CM_MK_B) {
+        c = *a.cin;
+        n = c;
+        if (a.mode == CM_MK_A) {
+            if (c.state == ST_NEED_H) { op = 1; do_inv = do_fwd = true; n.state = ST_ROW_ITER; n.it = 0; }
+            else if (c.state == ST_NEED_I) { op = 2; do_inv = true; n.state = ST_NEED_D; }
+        } else {
+            if (c.state == ST_NEED_S) { op = 0; do_fwd = true; }
+            else if (c.state == ST_NEED_D) {
+                const double num = global_sum(ctx, a.pnum, a.npart, red);
+                const double den = global_sum(ctx, a.pden, a.npart, red);
+                ctx.sync();
+                const double lim = sqrt(num) / sqrt(den);                 // channels.py:517-519
+                const bool conv = lim < a.k.tol, last = c.it == a.k.maxIter - 1;
+                const bool lead = ctx.bid == 0 && ctx.tid == 0;
+                if (lead && c.trace_n < a.k.trace_cap && a.k.tr_lim)
+                    a.k.tr_lim[c.trace_n * a.k.maxIter + c.it] = lim;
+                n.cur = c.cur ^ 1;                                        // E_conv = E_fd
+                if (conv || last) {                                       // the step is over
+                    if (lead && c.trace_n < a.k.trace_cap) {
+                        if (a.k.tr_hz) a.k.tr_hz[c.trace_n] = c.hz;
+                        if (a.k.tr_it) a.k.tr_it[c.trace_n] = c.it + 1;
+                    }
+                    n.trace_n = c.trace_n + 1;
+                    n.steps = c.steps + 1;
+                    n.iterations = c.iterations + c.it + 1;
+                    if (!conv) n.nonconv = c.nonconv + 1;
+                    n.z = c.z + c.hz;
+                    n.it = 0;
+                    if (n.z < a.k.Lspan) { op = 0; do_fwd = true; }
+                    else n.state = ST_SPAN_DONE;
+                } else {
+                    n.it = c.it + 1;
+                    n.state = ST_ROW_ITER;
+                    op = 3;
+                    do_fwd = true;
+                }
+            }
+        }
+        if (op == 0) {                                                    // step start bookkeeping
+            n.state = ST_AFTER_S;
+            if (a.k.adaptive) n.hz_valid = 0;
+            else {
+                n.hz = pick_hz(a.k, n.z, 0.0);
+                n.hz_valid = 1;
+            }
+        }
+        if (ctx.bid == 0 && ctx.tid == 0) {
+            if (op == 0 && !a.k.adaptive) n.lin = make_linop(n.hz / 2, a.k.lin_a, a.k.lin_b, a.k.w2, a.k.invN, a.k.log2N);
+            *a.cout = n;
+        }
+        if (op < 0) return;
+    } else {
+        do_inv = a.mode == CM_NLSE_STEP || a.mode == CM_NLSE_LAST || a.mode == CM_PLAIN_INV;
+        do_fwd = a.mode == CM_NLSE_STEP || a.mode == CM_NLSE_FIRST || a.mode == CM_PLAIN_FWD;
+    }
+
+    ColGeom<T, Ctx> g(ctx, a);
+    const PassPlan &p = g.p;
+    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)g.c * lds_slots_per_fft(p.L);
+    const int npol = a.npol;
+    cx<T> vx[16], vy[16];
+
+    // buffers by role (Manakov): the field at the step start / last iterate, and the next iterate
+    cx<T> *Tcur = a.T0, *Tnew = a.T1;
+    if (a.mode == CM_MK_A || a.mode == CM_MK_B) {
+        const int cur = (op == 2) ? c.cur : n.cur;     // I reads E_conv = T[c.cur]; S / D(a) use the new current
+        Tcur = cur ? a.T1 : a.T0;
+        Tnew = cur ? a.T0 : a.T1;
+    }
+
+    // ---- inverse column transform: G -> time samples in registers -------------------------
+    if (do_inv) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vx[q] = a.G[g.rowbase[0] + g.freq_off(q)];
+        if (npol == 2) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vy[q] = a.G[g.rowbase[1] + g.freq_off(q)];
+        }
+        fft_dif<+1>(ctx, p, g.b, vx, lds);
+        if (npol == 2) {
+            ctx.sync();
+            fft_dif<+1>(ctx, p, g.b, vy, lds);
+        }
+    } else {
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) vx[idx] = Tcur[g.rowbase[0] + g.time_off(idx)];
+        if (npol == 2) {
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) vy[idx] = Tcur[g.rowbase[1] + g.time_off(idx)];
+        }
+    }
+
+    // ---- time-domain work ---------------------------------------------------------------
+    const long long N = 1ll << (a.log2N1 + a.log2N2);
+    const long long pbase = (g.rowbase[0] / N / 2) * N;    // Manakov: P row of this pair
+    if (a.mode == CM_NLSE_STEP) {                                        // channels.py:225
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) vx[idx] = vx[idx] * cis_t<T>(a.g_hz * norm2(vx[idx]));
+    } else if (a.mode == CM_NLSE_LAST || a.mode == CM_PLAIN_INV) {
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) a.T0[g.rowbase[0] + g.time_off(idx)] = vx[idx];
+    } else if (op == 0) {                                                // S: Pch and max phi (channels.py:388-395)
+        double m = -INFINITY;
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+            const T ax = norm2(vx[idx]), ay = norm2(vy[idx]);
+            const T pw = ax + ay;
+            a.P[pbase + g.time_off(idx)] = pw;
+            const T phi = (T)a.k.c8g * (pw + ax + ay) / (T)2;
+            m = (double)phi > m ? (double)phi : m;
+        }
+        if (a.k.adaptive) {
+            ctx.sync();
+            m = block_max(ctx, m, red);
+            if (ctx.tid == 0) a.pmax[ctx.bid] = m;
+            ctx.sync();
+        }
+    } else if (op == 1) {                                                // H: E_hd, first rotation (channels.py:409-417)
+        const T shz = (T)(a.k.sgn * c.hz), c8g = (T)a.k.c8g;
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+            const long long t = g.time_off(idx);
+            a.Ehd[g.rowbase[0] + t] = vx[idx];
+            a.Ehd[g.rowbase[1] + t] = vy[idx];
+            const T pw = a.P[pbase + t];
+            const cx<T> rot = cis_t<T>(shz * (c8g * (pw + pw) / (T)2));
+            vx[idx] = vx[idx] * rot;
+            vy[idx] = vy[idx] * rot;
+        }
+    } else if (op == 2) {                                                // I: E_fd out, convergence sums
+        double num = 0, den = 0;
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+            const long long t = g.time_off(idx);
+            const cx<T> ex = Tcur[g.rowbase[0] + t], ey = Tcur[g.rowbase[1] + t];
+            Tnew[g.rowbase[0] + t] = vx[idx];
+            Tnew[g.rowbase[1] + t] = vy[idx];
+            const double dxr = (double)vx[idx].re - (double)ex.re, dxi = (double)vx[idx].im - (double)ex.im;
+            const double dyr = (double)vy[idx].re - (double)ey.re, dyi = (double)vy[idx].im - (double)ey.im;
+            num += dxr * dxr + dxi * dxi + dyr * dyr + dyi * dyi;
+            den += (double)ex.re * ex.re + (double)ex.im * ex.im + (double)ey.re * ey.re + (double)ey.im * ey.im;
+        }
+        ctx.sync();
+        num = block_sum(ctx, num, red);
+        den = block_sum(ctx, den, red);
+        if (ctx.tid == 0) {
+            a.pnum[ctx.bid] = num;
+            a.pden[ctx.bid] = den;
+        }
+    } else if (op == 3) {                                                // D(a): next iterate (channels.py:436, 414-417)
+        const T shz = (T)(a.k.sgn * c.hz), c8g = (T)a.k.c8g;
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+            const long long t = g.time_off(idx);
+            const T pw = a.P[pbase + t];
+            const T phi = c8g * (pw + norm2(vx[idx]) + norm2(vy[idx])) / (T)2;
+            const cx<T> rot = cis_t<T>(shz * phi);
+            vx[idx] = a.Ehd[g.rowbase[0] + t] * rot;
+            vy[idx] = a.Ehd[g.rowbase[1] + t] * rot;
+        }
+    }
+
+    // ---- forward column transform: registers -> G -------------------------------------------
+    if (do_fwd) {
+        if (do_inv && npol == 2) ctx.sync();        // lds still being read by slower threads (y inverse)
+        if (do_inv && npol == 1) ctx.sync();
+        fft_dit<-1>(ctx, p, g.b, vx, lds);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a.G[g.rowbase[0] + g.freq_off(q)] = vx[q];
+        if (npol == 2) {
+            ctx.sync();
+            fft_dit<-1>(ctx, p, g.b, vy, lds);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a.G[g.rowbase[1] + g.freq_off(q)] = vy[q];
+        }
+    }
+}
+
+// --------------------------------------------------------------------- elementwise helpers
+template <typename T> struct AmpArgs {
+    cx<T> *E;
+    const cx<T> *noise;   // may be null
+    long long total;
+    T gain;
+};
+template <typename T, class Ctx> SSF_HD void amp_body(Ctx &ctx, const AmpArgs<T> &a) {
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < a.total; i += (long long)ctx.nblocks * ctx.nthreads) {
+        cx<T> e = a.E[i] * a.gain;
+        if (a.noise) e = e + a.noise[i];
+        a.E[i] = e;
+    }
+}
+
+}  // namespace fused
+}  // namespace ssf

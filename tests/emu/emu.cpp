@@ -1,0 +1,217 @@
+// emu.cpp -- CPU emulator for the fused-engine kernels.  TEST INFRASTRUCTURE ONLY: it is
+// built into tests/emu/libssf_emu.so, loaded only by tests/test_emu_fused.py, and is not
+// reachable from the opticommpy_amd package (the product has no CPU path).
+//
+// It compiles the SAME kernel bodies (opticommpy_amd/csrc/fused_kernels.h) and the SAME host
+// control code (fused_engine.h) as libssf_hip.so, with a backend that "launches" a kernel by
+// stepping every workgroup's threads as fibers: ctx.sync() yields to a round-robin scheduler,
+// so one scheduler round == one __syncthreads() interval.  Workgroups run on a few host
+// threads.  This checks the index maps, twiddles, LDS exchange pattern, device-side control
+// state machine and host enqueue logic against the oracle without a GPU.
+#include <ucontext.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#include "fused_engine.h"
+
+namespace {
+
+struct EmuCtx {
+    int tid, bid, nthreads, nblocks;
+    char *lds;
+    void sync();
+};
+
+struct Fiber {
+    ucontext_t uc;
+    char *stack = nullptr;
+    bool done = true;
+    EmuCtx ctx;
+};
+
+constexpr size_t kStack = 96 * 1024;
+
+struct Pool {
+    std::vector<Fiber> f;
+    ucontext_t main_uc;
+    Fiber *cur = nullptr;
+    const std::function<void(EmuCtx &)> *body = nullptr;
+    std::vector<char> lds;
+    ~Pool() {
+        for (auto &x : f) free(x.stack);
+    }
+};
+thread_local Pool g_pool;
+
+void trampoline() {
+    Pool &p = g_pool;
+    Fiber *me = p.cur;
+    (*p.body)(me->ctx);
+    me->done = true;
+    swapcontext(&me->uc, &p.main_uc);
+}
+
+void EmuCtx::sync() {
+    Pool &p = g_pool;
+    Fiber *me = p.cur;
+    swapcontext(&me->uc, &p.main_uc);
+}
+
+void run_block(int bid, int nblocks, int nthreads, size_t lds_bytes, const std::function<void(EmuCtx &)> &body) {
+    Pool &p = g_pool;
+    if ((int)p.f.size() < nthreads) {
+        const size_t old = p.f.size();
+        p.f.resize((size_t)nthreads);
+        for (size_t i = old; i < p.f.size(); ++i) p.f[i].stack = (char *)malloc(kStack);
+    }
+    if (p.lds.size() < lds_bytes + 64) p.lds.resize(lds_bytes + 64);
+    // poison the LDS so that reads of never-written slots show up as NaNs
+    memset(p.lds.data(), 0xFF, lds_bytes + 64);
+    p.body = &body;
+    for (int t = 0; t < nthreads; ++t) {
+        Fiber &f = p.f[(size_t)t];
+        getcontext(&f.uc);
+        f.uc.uc_stack.ss_sp = f.stack;
+        f.uc.uc_stack.ss_size = kStack;
+        f.uc.uc_link = nullptr;
+        makecontext(&f.uc, trampoline, 0);
+        f.done = false;
+        f.ctx = EmuCtx{t, bid, nthreads, nblocks, p.lds.data()};
+    }
+    int alive = nthreads;
+    while (alive > 0) {
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber &f = p.f[(size_t)t];
+            if (f.done) continue;
+            p.cur = &f;
+            swapcontext(&p.main_uc, &f.uc);
+            if (f.done) --alive;
+        }
+    }
+}
+
+void run_grid(int grid, int block, size_t lds, const std::function<void(EmuCtx &)> &body) {
+    const int nw = std::max(1, std::min(8, grid));
+    if (nw == 1) {
+        for (int b = 0; b < grid; ++b) run_block(b, grid, block, lds, body);
+        return;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    for (int w = 0; w < nw; ++w)
+        th.emplace_back([&] {
+            for (;;) {
+                const int b = next.fetch_add(1);
+                if (b >= grid) break;
+                run_block(b, grid, block, lds, body);
+            }
+        });
+    for (auto &t : th) t.join();
+}
+
+struct EmuBackend {
+    long launches = 0;
+    void *alloc(size_t n) { return calloc(n ? n : 1, 1); }
+    void free(void *p) { ::free(p); }
+    void h2d(void *d, const void *h, size_t n) { memcpy(d, h, n); }
+    void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
+    void d2d(void *d, const void *s, size_t n) { memcpy(d, s, n); }
+    void memset(void *d, int v, size_t n) { ::memset(d, v, n); }
+    void prepare(size_t, size_t) {}
+    void sync() {}
+    bool ok() const { return true; }
+    std::string last_error() const { return ""; }
+    void time_begin() {}
+    double time_end() { return 0.0; }
+    template <typename T> void launch_row(const ssf::fused::RowArgs<T> &a, int grid, int block, size_t lds) {
+        ++launches;
+        run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T>(c, a); });
+    }
+    template <typename T> void launch_col(const ssf::fused::ColArgs<T> &a, int grid, int block, size_t lds) {
+        ++launches;
+        run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::col_body<T>(c, a); });
+    }
+    template <typename T> void launch_amp(const ssf::fused::AmpArgs<T> &a, int grid, int block) {
+        ++launches;
+        run_grid(std::min(grid, 8), block, 64, [&](EmuCtx &c) { ssf::fused::amp_body<T>(c, a); });
+    }
+};
+
+template <typename T>
+int run_t(int64_t N, int nrows, int prec, const ssf_params *p, const void *in, void *out, void *snaps,
+          const void *noise, ssf_stats *st, ssf_trace *tr, long *launches) {
+    EmuBackend be;
+    ssf::fused::FusedCore<T, EmuBackend> core(be, N, nrows, prec);
+    int rc = core.init();
+    if (rc) return rc;
+    if ((rc = core.upload(in))) return rc;
+    ssf_stats s{};
+    if (tr) tr->count = 0;
+    if ((rc = core.execute(*p, 1, p->Nspans, noise, &s, tr))) {
+        fprintf(stderr, "emu: %s\n", core.err.c_str());
+        return rc;
+    }
+    s.bytes_algorithmic = (double)s.transforms * 2.0 * sizeof(ssf::fused::cx<T>) * (double)N;
+    s.engine = SSF_ENGINE_FUSED;
+    if (st) *st = s;
+    if (out && (rc = core.download(out))) return rc;
+    if (snaps && !core.snaps.empty() && (rc = core.download_snapshots(snaps))) return rc;
+    if (launches) *launches = be.launches;
+    return SSF_OK;
+}
+
+template <typename T>
+int lin_t(int64_t N, int nrows, int prec, double Fs, double Fc, double alpha, double D, double L, const void *in,
+          void *out) {
+    EmuBackend be;
+    ssf::fused::FusedCore<T, EmuBackend> core(be, N, nrows, prec);
+    int rc = core.init();
+    if (rc) return rc;
+    if ((rc = core.upload(in))) return rc;
+    if ((rc = core.linear_channel(Fs, Fc, alpha, D, L))) return rc;
+    return core.download(out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int emu_supported(int64_t N, int precision) {
+    if (N < 2 || (N & (N - 1))) return 0;
+    int l = 0;
+    while ((1ll << l) < N) ++l;
+    ssf::fused::Split s;
+    return ssf::fused::choose_split(l, precision, &s) ? 1 : 0;
+}
+
+int emu_split(int64_t N, int precision, int *l1, int *l2) {
+    int l = 0;
+    while ((1ll << l) < N) ++l;
+    ssf::fused::Split s;
+    if (!ssf::fused::choose_split(l, precision, &s)) return -1;
+    *l1 = s.l1;
+    *l2 = s.l2;
+    return 0;
+}
+
+int emu_run(int64_t N, int nrows, int precision, const ssf_params *p, const void *in, void *out, void *snaps,
+            const void *noise, ssf_stats *st, ssf_trace *tr, long *launches) {
+    if (!emu_supported(N, precision)) return SSF_ERR_UNSUPPORTED;
+    return precision == SSF_C128 ? run_t<double>(N, nrows, precision, p, in, out, snaps, noise, st, tr, launches)
+                                 : run_t<float>(N, nrows, precision, p, in, out, snaps, noise, st, tr, launches);
+}
+
+int emu_linear_channel(int64_t N, int nrows, int precision, double Fs, double Fc, double alpha, double D, double L,
+                       const void *in, void *out) {
+    if (!emu_supported(N, precision)) return SSF_ERR_UNSUPPORTED;
+    return precision == SSF_C128 ? lin_t<double>(N, nrows, precision, Fs, Fc, alpha, D, L, in, out)
+                                 : lin_t<float>(N, nrows, precision, Fs, Fc, alpha, D, L, in, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+"""ctypes binding of tests/emu/libssf_emu.so (CPU emulator of the fused-engine kernels).
+Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from opticommpy_amd import _lib
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+_emu = None
+
+
+def load():
+    global _emu
+    if _emu is None:
+        subprocess.check_call(["make", "-C", EMU_DIR, "-s"])
+        _emu = C.CDLL(os.path.join(EMU_DIR, "libssf_emu.so"))
+        _emu.emu_run.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(_lib.Params), C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.POINTER(_lib.Stats), C.POINTER(_lib.Trace),
+                                 C.POINTER(C.c_long)]
+        _emu.emu_linear_channel.argtypes = [C.c_int64, C.c_int, C.c_int] + [C.c_double] * 5 + [C.c_void_p, C.c_void_p]
+        _emu.emu_supported.argtypes = [C.c_int64, C.c_int]
+        _emu.emu_split.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    return _emu
+
+
+def _amp(amp):
+    return {"edfa": 2, "ideal": 1}.get(amp, 0) if isinstance(amp, str) else 0
+
+
+def run(func, Ei, cfg, noise=None, max_steps=4096):
+    """Run ssfm / manakovSSF / manakovDBP of a cfg dict on the emulator.  Returns (out, info)."""
+    emu = load()
+    dt = np.complex64 if cfg.get("prec") == "complex64" else np.complex128
+    prec = 0 if dt == np.complex64 else 1
+    Ei = np.asarray(Ei)
+    N = Ei.shape[0]
+    E2 = Ei.reshape(N, -1)
+    ncols = E2.shape[1]
+    soa = np.ascontiguousarray(E2.T, dtype=dt)
+    Ltotal, Lspan = cfg.get("Ltotal", 400), cfg.get("Lspan", 80)
+    Nspans = int(np.floor(Ltotal / Lspan))
+    save = cfg.get("saveSpanN", [Ltotal // Lspan] if func != "ssfm_final" else [])
+    captured = [s for s in range(1, Nspans + 1) if s in save]
+    save_arr = np.array(captured, dtype=np.int32)
+    p = _lib.Params()
+    p.model = 0 if func.startswith("ssfm") else 1
+    p.direction = -1 if func == "manakovDBP" else 1
+    p.Fs, p.Fc = cfg["Fs"], cfg.get("Fc", 193.1e12)
+    p.alpha, p.D, p.gamma = cfg.get("alpha", 0.2), cfg.get("D", 16), cfg.get("gamma", 1.3)
+    p.Lspan, p.Nspans, p.hz = Lspan, Nspans, cfg.get("hz", 0.5)
+    p.maxIter, p.tol = cfg.get("maxIter", 10), cfg.get("tol", 1e-5)
+    p.nlprMethod = int(cfg.get("nlprMethod", True)) if p.model == 1 else 0
+    p.maxNlinPhaseRot = cfg.get("maxNlinPhaseRot", 2e-2)
+    p.amp, p.NF = _amp(cfg.get("amp", "edfa")), cfg.get("NF", 4.5)
+    p.n_save = len(save_arr)
+    p.save_spans = save_arr.ctypes.data_as(C.POINTER(C.c_int32)) if len(save_arr) else None
+    out = np.empty_like(soa)
+    snaps = np.zeros((max(len(captured), 1), ncols, N), dtype=dt)
+    st = _lib.Stats()
+    hz = np.full(max_steps, np.nan)
+    it = np.zeros(max_steps, dtype=np.int32)
+    lm = np.full(max_steps * p.maxIter, np.nan)
+    tr = _lib.Trace(max_steps, 0, hz.ctypes.data_as(C.POINTER(C.c_double)), it.ctypes.data_as(C.POINTER(C.c_int32)),
+                    lm.ctypes.data_as(C.POINTER(C.c_double)))
+    launches = C.c_long(0)
+    nz = None
+    if noise is not None:
+        nz = np.ascontiguousarray(noise, dtype=dt)
+    rc = emu.emu_run(N, ncols, prec, C.byref(p), soa.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                     snaps.ctypes.data_as(C.c_void_p), nz.ctypes.data_as(C.c_void_p) if nz is not None else None,
+                     C.byref(st), C.byref(tr), C.byref(launches))
+    assert rc == 0, f"emu_run rc={rc}"
+    n = int(tr.count)
+    info = st.as_dict()
+    info.update(hz=hz[:n], iters=it[:n], lims=[r[~np.isnan(r)] for r in lm[: n * p.maxIter].reshape(n, p.maxIter)],
+                launches=launches.value, snaps=snaps[: st.n_snapshots])
+    return out, info
+
+
+def linear_channel(Ei, Fs, Fc, alpha, D, L, dtype=np.complex128):
+    emu = load()
+    Ei = np.asarray(Ei)
+    N = Ei.shape[0]
+    soa = np.ascontiguousarray(Ei.reshape(N, -1).T, dtype=dtype)
+    out = np.empty_like(soa)
+    rc = emu.emu_linear_channel(N, soa.shape[0], 0 if dtype == np.complex64 else 1, Fs, Fc, alpha, D, L,
+                                soa.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0, f"emu_linear_channel rc={rc}"
+    return out.T.reshape(Ei.shape)

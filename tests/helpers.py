@@ -57,3 +57,30 @@ def split_iters(lims, tol, maxIter):
             iters.append(n)
             n = 0
     return iters
+
+
+def oracle_sensitivity(func, Ei, cfg, eps=1e-15, seed=12345):
+    """rel-L2 change of the ORACLE output under a relative input perturbation of size eps.
+    Two of the reference's own TestSSFM set-ups (2 W mean power, gamma 1.3, 80 x 1 km steps)
+    are chaotic: 1e-15 at the input becomes O(1) at the output, so no implementation with a
+    different FFT rounding can reproduce those values; the reference itself only asserts
+    properties on them (tests/test_channels.py:182-224)."""
+    from oracle import ssf_oracle as orc
+    rng = np.random.default_rng(seed)
+    f = {"ssfm": orc.ssfm, "manakovSSF": orc.manakovSSF, "manakovDBP": orc.manakovDBP}[func]
+    Ep = Ei * (1 + eps * (rng.normal(size=Ei.shape) + 1j * rng.normal(size=Ei.shape)))
+    a = f(Ei, make_param(orc.parameters, cfg))
+    b = f(Ep.astype(Ei.dtype), make_param(orc.parameters, cfg))
+    return rel_l2(b, a)
+
+
+def parity_gate(func, Ei, cfg, base_tol):
+    """Tolerance for comparing an independent implementation with the reference values:
+    base_tol for well-conditioned cases, 30x the oracle's own 1e-15-perturbation response
+    otherwise; None when the case is chaotic (value comparison meaningless)."""
+    if cfg.get("amp") == "edfa" and func != "manakovDBP":
+        return base_tol
+    sens = oracle_sensitivity(func, Ei, cfg)
+    if sens > 1e-6:
+        return None
+    return max(base_tol, 30 * sens)

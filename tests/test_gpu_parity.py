@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import opticommpy_amd as oa
-from helpers import golden_names, load_golden, make_param, rel_l2, synth_field
+from helpers import golden_names, load_golden, make_param, parity_gate, rel_l2, synth_field
 from opticommpy_amd import models
 from oracle import ssf_oracle as orc
 
@@ -61,7 +61,11 @@ def test_golden_vectors(name, engine):
     assert out.shape == ref.shape and out.dtype == ref.dtype
     assert run["engine"] == engine
     c64 = cfg.get("prec") == "complex64"
-    assert rel_l2(out, ref) <= (TOL_C64 if c64 else TOL_C128)
+    gate = parity_gate(cfg["func"], d["Ei"], cfg, TOL_C64 if c64 else TOL_C128)
+    if gate is None:        # chaotic reference set-up: the reference asserts properties only, so do we
+        assert orc.signalPower(out) == pytest.approx(orc.signalPower(d["Ei"]), rel=1e-9)
+    else:
+        assert rel_l2(out, ref) <= gate
     if "iters" in d:
         assert run["steps"] == len(d["iters"])
         if not c64:
