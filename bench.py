@@ -117,6 +117,35 @@ def main():
 
     out_soa = np.empty_like(soa)
     _lib.raise_for(lib, h, lib.ssf_download(h, out_soa.ctypes.data_as(C.c_void_p)))
+    if dist is not None:
+        # "gather of results only" (SURVEY.md 8e): one RCCL all-gather of a per-rank checksum
+        import torch
+        cs = torch.tensor([float(np.sum(np.abs(out_soa) ** 2))], dtype=torch.float64, device="cuda")
+        allcs = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(allcs, cs)
+        checksums = [float(x.item()) for x in allcs]
+
+    # per-kernel timing pass (HIP events around every launch on the plan stream; separate from the
+    # headline run because the events themselves cost a few microseconds per launch)
+    kernels = None
+    if rank == 0 and lib.ssf_set_profiling(h, 1) == 0:
+        nprof = min(args.steps, 200)
+        _, stp = run(nprof, soa)
+        kt = _lib.KernelTimes()
+        lib.ssf_get_kernel_times(h, C.byref(kt))
+        lib.ssf_set_profiling(h, 0)
+        bytes_per_launch = 2 * (16 if args.prec == "c128" else 8) * N * 2       # one transform-equivalent per row
+        kernels = {}
+        for name, ms, n in (("row (FFT.H.IFFT of rows)", kt.row_ms, kt.row_n), ("colA (H | I stage)", kt.colA_ms, kt.colA_n),
+                            ("colB (S | D stage, idle once per step)", kt.colB_ms, kt.colB_n)):
+            if n:
+                avg_us = ms / n * 1e3
+                kernels[name] = {"launches": int(n), "avg_us": avg_us}
+                if name.startswith("row"):
+                    kernels[name].update(algorithmic_bytes_per_launch=bytes_per_launch,
+                                         achieved_GBs=bytes_per_launch / (avg_us * 1e-6) / 1e9,
+                                         frac=bytes_per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+        kernels["profiled_steps"] = int(stp.steps)
 
     if rank == 0:
         s = 16 if args.prec == "c128" else 8
@@ -138,8 +167,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "whole step pipeline (HIP events around the K timed steps on the plan stream)",
                          "algorithmic_bytes_per_step": st.bytes_algorithmic / st.steps,
-                         "device_ms_per_step": st.device_ms / st.steps},
+                         "device_ms_per_step": st.device_ms / st.steps,
+                         "kernels": kernels},
         }
+        if dist is not None:
+            rec["rank_checksums"] = checksums
         traffic_file = os.path.join(ROOT, "profiles", "traffic_bytes_per_step.json")
         if os.path.exists(traffic_file):
             try:

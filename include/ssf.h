@@ -21,6 +21,8 @@
  *   ssf_mgpu_run                         (no reference equivalent) independent fields
  *                                        sharded over the GPUs of one node, SURVEY.md 8e
  *   ssf_linear_channel                   linearFiberChannel               channels.py:30-109
+ *   ssf_set_profiling / ssf_get_kernel_times   time.time() pairs around calls in
+ *                                        examples/benchmarck_GPU_processing.ipynb:389-395
  *
  * Data layout at the boundary: struct-of-arrays.  A "row" is one column of the
  * reference's (N, ncols) field, stored contiguously: rows = [x0, y0, x1, y1, ...]
@@ -153,6 +155,20 @@ int  ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_
                   int32_t rows_per_unit, int32_t precision, int32_t engine,
                   const ssf_params *params, const void *fields_in, void *fields_out,
                   ssf_stats *stats);
+
+/* ---- per-kernel timing (measurement aid; fused engine only) ------------------------------ */
+/* With profiling enabled every kernel launch of ssf_execute is bracketed by HIP events on the
+ * plan's stream (costs a few microseconds per launch: do not enable for the headline timing).
+ * Totals accumulate until ssf_upload.  Kernel classes of the fused Manakov pipeline:
+ *   row  = FFT_rows . H . IFFT_rows        (one transform-equivalent per row per launch)
+ *   colA = inverse/forward column FFTs around E_hd / E_fd work (never idle in steady state)
+ *   colB = step-start / decision stage     (idle once per step)                            */
+typedef struct {
+    double  row_ms, colA_ms, colB_ms, other_ms;
+    int64_t row_n, colA_n, colB_n, other_n;
+} ssf_kernel_times;
+int  ssf_set_profiling(ssf_plan *plan, int32_t enable);
+int  ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out);
 
 /* ---- linear channel (gamma = 0 closed form): one FFT . H . IFFT over the whole length */
 int  ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, double D,

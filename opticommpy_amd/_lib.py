@@ -42,6 +42,11 @@ class Trace(C.Structure):
                 ("iters", C.POINTER(C.c_int32)), ("lims", C.POINTER(C.c_double))]
 
 
+class KernelTimes(C.Structure):
+    _fields_ = [("row_ms", C.c_double), ("colA_ms", C.c_double), ("colB_ms", C.c_double), ("other_ms", C.c_double),
+                ("row_n", C.c_int64), ("colA_n", C.c_int64), ("colB_n", C.c_int64), ("other_n", C.c_int64)]
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int32),
                 ("reserved", C.c_int32), ("total_mem_bytes", C.c_int64), ("lds_per_block_bytes", C.c_int64)]
@@ -64,6 +69,8 @@ SYMBOLS = {
                           C.POINTER(Stats), C.POINTER(Trace)]),
     "ssf_mgpu_run": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    "ssf_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ssf_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "ssf_linear_channel": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p, C.c_void_p]),
 }

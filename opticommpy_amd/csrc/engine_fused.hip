@@ -2,6 +2,7 @@
 // the kernel bodies of fused_kernels.h plus the Backend that FusedCore (fused_engine.h)
 // drives.  All launches go to the plan's stream; nothing here synchronises inside a step.
 #include <cstdlib>
+#include <vector>
 
 #include "fused_engine.h"
 #include "ssf_internal.h"
@@ -23,18 +24,64 @@ struct DevCtx {
 
 // OCC = minimum waves per SIMD the register allocator must leave room for: 1 = up to 512
 // registers per lane and no spills (one 256-thread workgroup per CU), 2 = 256 registers
-// (two workgroups per CU, some spills in the fp64 kernels).  Picked per plan by $SSF_FUSED_OCC.
-template <typename T, int MAXT, int OCC> __global__ void __launch_bounds__(MAXT, OCC) k_row(const RowArgs<T> a) {
+// (two workgroups per CU).  LG = compile-time log2 of the transform length (0 = runtime).
+template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds__(MAXT, OCC) k_row(const RowArgs<T> a) {
     SSF_DEV_CTX();
-    row_body<T>(ctx, a);
+    row_body<T, LG>(ctx, a);
 }
-template <typename T, int OCC> __global__ void __launch_bounds__(256, OCC) k_col(const ColArgs<T> a) {
+// Manakov column kernels run 512 threads (x half | y half); the single-row modes run 256
+template <typename T, int LG, int MODE>
+__global__ void __launch_bounds__((MODE == CM_MK_A || MODE == CM_MK_B) ? 512 : 256) k_col(const ColArgs<T> a) {
     SSF_DEV_CTX();
-    col_body<T>(ctx, a);
+    col_body<T, LG, MODE>(ctx, a);
 }
 template <typename T> __global__ void __launch_bounds__(256) k_amp(const AmpArgs<T> a) {
     SSF_DEV_CTX();
     amp_body<T>(ctx, a);
+}
+
+template <typename T> using RowFn = void (*)(const RowArgs<T>);
+template <typename T> using ColFn = void (*)(const ColArgs<T>);
+
+// kernel selection: specialised lengths for the sizes that matter, generic otherwise
+template <typename T> RowFn<T> pick_row(int lg2, int block, int occ) {
+    if (block <= 256) {
+        if (occ == 2) {
+            switch (lg2) {
+            case 10: return k_row<T, 256, 2, 10>;
+            case 11: return k_row<T, 256, 2, 11>;
+            case 12: return k_row<T, 256, 2, 12>;
+            default: return k_row<T, 256, 2, 0>;
+            }
+        }
+        switch (lg2) {
+        case 10: return k_row<T, 256, 1, 10>;
+        case 11: return k_row<T, 256, 1, 11>;
+        case 12: return k_row<T, 256, 1, 12>;
+        default: return k_row<T, 256, 1, 0>;
+        }
+    }
+    if (block <= 512) return lg2 == 13 ? k_row<T, 512, 1, 13> : k_row<T, 512, 1, 0>;
+    return lg2 == 14 ? k_row<T, 1024, 1, 14> : k_row<T, 1024, 1, 0>;
+}
+template <typename T, int LG> ColFn<T> pick_col_mode(int mode) {
+    switch (mode) {
+    case CM_NLSE_FIRST: return k_col<T, LG, CM_NLSE_FIRST>;
+    case CM_NLSE_STEP: return k_col<T, LG, CM_NLSE_STEP>;
+    case CM_NLSE_LAST: return k_col<T, LG, CM_NLSE_LAST>;
+    case CM_MK_A: return k_col<T, LG, CM_MK_A>;
+    case CM_MK_B: return k_col<T, LG, CM_MK_B>;
+    case CM_PLAIN_FWD: return k_col<T, LG, CM_PLAIN_FWD>;
+    default: return k_col<T, LG, CM_PLAIN_INV>;
+    }
+}
+template <typename T> ColFn<T> pick_col(int lg1, int mode) {
+    switch (lg1) {
+    case 7: return pick_col_mode<T, 7>(mode);
+    case 8: return pick_col_mode<T, 8>(mode);
+    case 9: return pick_col_mode<T, 9>(mode);
+    default: return pick_col_mode<T, 0>(mode);
+    }
 }
 
 struct HipBackend {
@@ -43,16 +90,53 @@ struct HipBackend {
     std::string where;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-    int row_occ = 2, col_occ = 1;
+    int row_occ = 2;
+    // optional per-launch event timing (ssf_set_profiling)
+    bool profiling = false;
+    struct Stamp { hipEvent_t a, b; int cat; };
+    std::vector<Stamp> stamps;
+    std::vector<hipEvent_t> pool;
+    ssf_kernel_times kt{};
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        chk(hipEventCreate(&e), "hipEventCreate");
+        return e;
+    }
+    void stamp_begin(int cat) {
+        if (!profiling) return;
+        Stamp s{get_event(), get_event(), cat};
+        chk(hipEventRecord(s.a, pl->stream), "hipEventRecord");
+        stamps.push_back(s);
+    }
+    void stamp_end() {
+        if (!profiling) return;
+        chk(hipEventRecord(stamps.back().b, pl->stream), "hipEventRecord");
+    }
+    void collect() {        // call after a stream synchronise
+        for (auto &s : stamps) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+                double *t = s.cat == 0 ? &kt.row_ms : s.cat == 1 ? &kt.colA_ms : s.cat == 2 ? &kt.colB_ms : &kt.other_ms;
+                int64_t *n = s.cat == 0 ? &kt.row_n : s.cat == 1 ? &kt.colA_n : s.cat == 2 ? &kt.colB_n : &kt.other_n;
+                *t += ms;
+                *n += 1;
+            }
+            pool.push_back(s.a);
+            pool.push_back(s.b);
+        }
+        stamps.clear();
+    }
     explicit HipBackend(ssf_plan *p) : pl(p) {
         if (const char *s = getenv("SSF_FUSED_ROW_OCC")) row_occ = atoi(s) == 1 ? 1 : 2;
-        if (const char *s = getenv("SSF_FUSED_COL_OCC")) col_occ = atoi(s) == 2 ? 2 : 1;
         chk(hipEventCreate(&ev0), "hipEventCreate");
         chk(hipEventCreate(&ev1), "hipEventCreate");
     }
     ~HipBackend() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        for (auto &s : stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+        for (auto e : pool) (void)hipEventDestroy(e);
     }
     void chk(hipError_t e, const char *what) {
         if (e != hipSuccess && first_err == hipSuccess) {
@@ -89,43 +173,43 @@ struct HipBackend {
         chk(hipStreamSynchronize(pl->stream), "hipStreamSynchronize");
         float ms = 0;
         chk(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
+        collect();
         return ms;
     }
-    template <typename F> void set_lds(F f, size_t bytes) {
-        chk(hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
-            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
+    size_t row_lds_max = 0, col_lds_max = 0;
     void prepare(size_t row_lds, size_t col_lds) {
-        set_lds(k_row<double, 256, 1>, row_lds);
-        set_lds(k_row<double, 256, 2>, row_lds);
-        set_lds(k_row<double, 512, 1>, row_lds);
-        set_lds(k_row<double, 1024, 1>, row_lds);
-        set_lds(k_row<float, 256, 1>, row_lds);
-        set_lds(k_row<float, 256, 2>, row_lds);
-        set_lds(k_row<float, 512, 1>, row_lds);
-        set_lds(k_row<float, 1024, 1>, row_lds);
-        set_lds(k_col<double, 1>, col_lds);
-        set_lds(k_col<double, 2>, col_lds);
-        set_lds(k_col<float, 1>, col_lds);
-        set_lds(k_col<float, 2>, col_lds);
+        row_lds_max = row_lds;
+        col_lds_max = col_lds;
     }
     template <typename T> void launch_row(const RowArgs<T> &a, int grid, int block, size_t lds) {
-        if (block <= 256 && row_occ == 2)
-            k_row<T, 256, 2><<<grid, block, lds, pl->stream>>>(a);
-        else if (block <= 256)
-            k_row<T, 256, 1><<<grid, block, lds, pl->stream>>>(a);
-        else if (block <= 512)
-            k_row<T, 512, 1><<<grid, block, lds, pl->stream>>>(a);
-        else
-            k_row<T, 1024, 1><<<grid, block, lds, pl->stream>>>(a);
+        static thread_local const void *armed[64];
+        static thread_local int narmed = 0;
+        RowFn<T> f = pick_row<T>(a.log2N2, block, row_occ);
+        arm((const void *)f, row_lds_max, armed, narmed);
+        stamp_begin(0);
+        f<<<grid, block, lds, pl->stream>>>(a);
+        stamp_end();
         chk(hipGetLastError(), "launch k_row");
     }
     template <typename T> void launch_col(const ColArgs<T> &a, int grid, int block, size_t lds) {
-        if (col_occ == 2)
-            k_col<T, 2><<<grid, block, lds, pl->stream>>>(a);
-        else
-            k_col<T, 1><<<grid, block, lds, pl->stream>>>(a);
+        static thread_local const void *armed[64];
+        static thread_local int narmed = 0;
+        ColFn<T> f = pick_col<T>(a.log2N1, a.mode);
+        arm((const void *)f, col_lds_max, armed, narmed);
+        stamp_begin(a.mode == CM_MK_A ? 1 : a.mode == CM_MK_B ? 2 : 3);
+        f<<<grid, block, lds, pl->stream>>>(a);
+        stamp_end();
         chk(hipGetLastError(), "launch k_col");
+    }
+    // raise the dynamic-LDS cap of a kernel the first time this (thread, device) uses it
+    void arm(const void *f, size_t bytes, const void **armed, int &narmed) {
+        const size_t want = bytes > 160 * 1024 ? 160 * 1024 : bytes;
+        for (int i = 0; i < narmed; ++i)
+            if (armed[i] == f) return;
+        chk(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        (void)want;
+        if (narmed < 64) armed[narmed++] = f;
     }
     template <typename T> void launch_amp(const AmpArgs<T> &a, int grid, int block) {
         k_amp<T><<<grid, block, 0, pl->stream>>>(a);
@@ -146,7 +230,10 @@ template <typename T> class FusedEngine final : public Engine {
         return rc;
     }
     int init() { return ret(core.init()); }
-    int upload(const void *soa) override { return ret(core.upload(soa)); }
+    int upload(const void *soa) override {
+        be.kt = ssf_kernel_times{};
+        return ret(core.upload(soa));
+    }
     int download(void *soa) override { return ret(core.download(soa)); }
     int download_snapshots(void *soa) override { return ret(core.download_snapshots(soa)); }
     int execute(const ssf_params &p, int s0, int s1, const void *noise, ssf_stats *st, ssf_trace *tr) override {
@@ -155,6 +242,15 @@ template <typename T> class FusedEngine final : public Engine {
     int linear_channel(double Fs, double Fc, double alpha, double D, double L) override {
         return ret(core.linear_channel(Fs, Fc, alpha, D, L));
     }
+    int set_profiling(int on) override {
+        be.profiling = on != 0;
+        return SSF_OK;
+    }
+    int kernel_times(ssf_kernel_times *out) override {
+        *out = be.kt;
+        return SSF_OK;
+    }
+    void reset_times() { be.kt = ssf_kernel_times{}; }
 };
 
 }  // namespace

@@ -67,6 +67,27 @@ SSF_HD void sincos_f(float a, float &s, float &c) {
     c = std::cos(a);
 #endif
 }
+// x * 2^-k (exact)
+SSF_HD double scale_pow2(double x, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ldexp(x, -k);
+#else
+    return std::ldexp(x, -k);
+#endif
+}
+// cis(a) for an angle in radians of any size: one multiply + round instead of the generic
+// sincos (whose Payne-Hanek path bloats the kernel); the reduction error |a| * 2^-53 is the
+// rounding a itself already carries
+SSF_HD void cis_rad_d(double a, double &c, double &s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double t = a * 0.15915494309189533577;   // 1 / (2 pi)
+    t -= rint(t);
+    sincospi(2.0 * t, &s, &c);
+#else
+    c = std::cos(a);
+    s = std::sin(a);
+#endif
+}
 template <typename T> SSF_HD cx<T> cis2pi(double frac) {
     double c, s;
     cis2pi_d(frac, c, s);
@@ -75,7 +96,7 @@ template <typename T> SSF_HD cx<T> cis2pi(double frac) {
 template <typename T> SSF_HD cx<T> cis_t(T a);
 template <> SSF_HD cx<double> cis_t<double>(double a) {
     double s, c;
-    sincos_d(a, s, c);
+    cis_rad_d(a, c, s);
     return mk<double>(c, s);
 }
 template <> SSF_HD cx<float> cis_t<float>(float a) {

@@ -72,14 +72,15 @@ template <typename T, class Backend> class FusedCore {
         field_bytes = sizeof(C) * (size_t)N * (size_t)nrows;
     }
 
-    void col_geometry(int groups, int *block, int *grid, size_t *lds) const {
+    // npol = 2: a workgroup carries both rows of a polarisation pair (x threads | y threads)
+    void col_geometry(int groups, int npol, int *block, int *grid, size_t *lds) const {
         const int tpf = (1 << sp.l1) / 16, N2 = 1 << sp.l2;
-        int blk = 256;
-        if (blk / tpf > N2) blk = N2 * tpf;
-        const int Cc = blk / tpf;
-        *block = blk;
+        int half = 256;
+        if (half / tpf > N2) half = N2 * tpf;
+        const int Cc = half / tpf;
+        *block = half * npol;
         *grid = groups * (N2 / Cc);
-        *lds = std::max((size_t)Cc * lds_slots_per_fft(1 << sp.l1) * sizeof(C), (size_t)blk * 8 + 1024);
+        *lds = std::max((size_t)npol * Cc * lds_slots_per_fft(1 << sp.l1) * sizeof(C), (size_t)half * npol * 8 + 1024);
     }
 
     int init() {
@@ -90,8 +91,8 @@ template <typename T, class Backend> class FusedCore {
         row_block = fpw * tpf2;
         row_grid = (int)(nfft / fpw);
         row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 8 + 2048);
-        col_geometry(std::max(nrows / 2, 1), &col_block_mk, &col_grid_mk, &col_lds_mk);
-        col_geometry(nrows, &col_block_1, &col_grid_1, &col_lds_1);
+        col_geometry(std::max(nrows / 2, 1), 2, &col_block_mk, &col_grid_mk, &col_lds_mk);
+        col_geometry(nrows, 1, &col_block_1, &col_grid_1, &col_lds_1);
         npart_max = std::max(col_grid_mk, col_grid_1);
         void **ptrs[] = {(void **)&G, (void **)&T0, (void **)&T1, (void **)&Ehd};
         for (auto pp : ptrs)

@@ -82,17 +82,17 @@ SSF_HD double pick_hz(const MkConst &k, double z, double maxphi) {
 template <typename T> SSF_HD cx<T> tw_unit(int sign, int j, int lgL);
 template <> SSF_HD cx<double> tw_unit<double>(int sign, int j, int lgL) {
     double c, s;
-    cis2pi_d((double)(sign * j) / (double)(1 << lgL), c, s);
+    cis2pi_d(scale_pow2((double)(sign * j), lgL), c, s);
     return mk<double>(c, s);
 }
 template <> SSF_HD cx<float> tw_unit<float>(int sign, int j, int lgL) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float c, s;
-    sincospif(2.0f * (float)(sign * j) / (float)(1 << lgL), &s, &c);
+    sincospif((float)scale_pow2((double)(2 * sign * j), lgL), &s, &c);
     return mk<float>(c, s);
 #else
     double c, s;
-    cis2pi_d((double)(sign * j) / (double)(1 << lgL), c, s);
+    cis2pi_d(scale_pow2((double)(sign * j), lgL), c, s);
     return mk<float>((float)c, (float)s);
 #endif
 }
@@ -224,6 +224,7 @@ template <typename T> SSF_HD void lds_get(const PassPlan &p, int i, int b, cx<T>
 template <int SIGN, typename T, class Ctx>
 SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
     dif_pass<SIGN>(p, 0, b, v);
+#pragma unroll
     for (int i = 1; i < p.npass; ++i) {
         lds_put(p, i - 1, b, v, lds);
         ctx.sync();
@@ -234,6 +235,7 @@ SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
 // DIT transform: v holds pass-(p-1) positions on entry, pass-0 positions (natural) on exit
 template <int SIGN, typename T, class Ctx>
 SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
+#pragma unroll
     for (int i = p.npass - 1; i >= 1; --i) {
         dit_pass<SIGN>(p, i, b, v);
         lds_put(p, i, b, v, lds);
@@ -244,23 +246,30 @@ SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
 }
 
 // ------------------------------------------------------------------------ block reductions
-// every thread gets the result; `red` is LDS scratch of nthreads doubles; 2 barriers
-template <class Ctx> SSF_HD double block_sum(Ctx &ctx, double v, double *red) {
+// Every thread gets the result; `red` is LDS scratch of nthreads doubles.  Two stages (<= 64
+// partial sums), fixed order: deterministic and identical in every workgroup.
+template <bool MAX, class Ctx> SSF_HD double block_reduce(Ctx &ctx, double v, double *red) {
     ctx.sync();
     red[ctx.tid] = v;
     ctx.sync();
-    double s = 0;
-    for (int i = 0; i < ctx.nthreads; ++i) s += red[i];
-    return s;
-}
-template <class Ctx> SSF_HD double block_max(Ctx &ctx, double v, double *red) {
+    const int nt = ctx.nthreads, ng = nt < 64 ? nt : 64, per = nt / ng;     // nt is a power of two
+    if (ctx.tid < ng) {
+        double s = red[ctx.tid * per];
+        for (int i = 1; i < per; ++i) {
+            const double x = red[ctx.tid * per + i];
+            s = MAX ? (x > s ? x : s) : s + x;
+        }
+        v = s;
+    }
     ctx.sync();
-    red[ctx.tid] = v;
+    if (ctx.tid < ng) red[ctx.tid] = v;
     ctx.sync();
     double s = red[0];
-    for (int i = 1; i < ctx.nthreads; ++i) s = red[i] > s ? red[i] : s;
+    for (int i = 1; i < ng; ++i) s = MAX ? (red[i] > s ? red[i] : s) : s + red[i];
     return s;
 }
+template <class Ctx> SSF_HD double block_sum(Ctx &ctx, double v, double *red) { return block_reduce<false>(ctx, v, red); }
+template <class Ctx> SSF_HD double block_max(Ctx &ctx, double v, double *red) { return block_reduce<true>(ctx, v, red); }
 // deterministic reduction of a global partial array by the whole block (same order in every block)
 template <class Ctx> SSF_HD double global_sum(Ctx &ctx, const double *a, int n, double *red) {
     double s = 0;
@@ -292,9 +301,9 @@ SSF_HD void apply_lin16(const LinOp &lo, long long k0, int log2N, cx<T> *v) {
     const double dk = (double)(1ll << (log2N - 4));
     const double k0d = (double)k0;
     double s, c;
-    sincos_d(lo.cth * k0d * k0d, s, c);
+    cis_rad_d(lo.cth * k0d * k0d, c, s);
     const cx<double> A = mk<double>(lo.mag * c, lo.mag * s);
-    sincos_d(2.0 * lo.cth * k0d * dk, s, c);
+    cis_rad_d(2.0 * lo.cth * k0d * dk, c, s);
     cx<double> Bp[9];
     Bp[0] = mk<double>(1.0, 0.0);
     Bp[1] = mk<double>(c, s);
@@ -318,11 +327,12 @@ template <typename T> SSF_HD cx<T> lin_at(const LinOp &lo, long long k, int log2
     const long long N = 1ll << log2N;
     const double kk = (double)(k < N / 2 ? k : k - N);
     double s, c;
-    sincos_d(lo.cth * kk * kk, s, c);
+    cis_rad_d(lo.cth * kk * kk, c, s);
     return mk<T>((T)(lo.mag * c), (T)(lo.mag * s));
 }
 
-template <typename T, class Ctx> SSF_HD void row_body(Ctx &ctx, const RowArgs<T> &a) {
+// LG > 0: row length fixed at compile time (index math folds to immediates); 0: runtime
+template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const RowArgs<T> &a) {
     cx<T> *lds = (cx<T> *)ctx.lds;
     LinOp *lsh = (LinOp *)ctx.lds;            // only used before the FFT touches the LDS
     LinOp lo;
@@ -352,7 +362,7 @@ template <typename T, class Ctx> SSF_HD void row_body(Ctx &ctx, const RowArgs<T>
     } else {
         lo = *a.lin;
     }
-    const PassPlan p = make_plan(a.log2N2);
+    const PassPlan p = make_plan(LG > 0 ? LG : a.log2N2);
     const int fpw = ctx.nthreads / p.tpf;                  // row transforms per workgroup
     const int f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
     const long long rr = (long long)ctx.bid * fpw + f;     // global row-transform index
@@ -365,8 +375,8 @@ template <typename T, class Ctx> SSF_HD void row_body(Ctx &ctx, const RowArgs<T>
     // load natural n2 = b + tpf*q, times W_N^{n2 k1}
     {
         const long long N = 1ll << log2N;
-        const cx<T> w0 = cis2pi<T>(-(double)(((long long)k1 * b) & (N - 1)) / (double)N);
-        const cx<T> ws = cis2pi<T>(-(double)(((long long)k1 * p.tpf) & (N - 1)) / (double)N);
+        const cx<T> w0 = cis2pi<T>(-scale_pow2((double)(((long long)k1 * b) & (N - 1)), log2N));
+        const cx<T> ws = cis2pi<T>(-scale_pow2((double)(((long long)k1 * p.tpf) & (N - 1)), log2N));
         cx<T> w[16];
         powers16(ws, w);
 #pragma unroll
@@ -388,8 +398,8 @@ template <typename T, class Ctx> SSF_HD void row_body(Ctx &ctx, const RowArgs<T>
     fft_dit<+1>(ctx, p, b, v, l);
     {
         const long long N = 1ll << log2N;
-        const cx<T> w0 = cis2pi<T>((double)(((long long)k1 * b) & (N - 1)) / (double)N);
-        const cx<T> ws = cis2pi<T>((double)(((long long)k1 * p.tpf) & (N - 1)) / (double)N);
+        const cx<T> w0 = cis2pi<T>(scale_pow2((double)(((long long)k1 * b) & (N - 1)), log2N));
+        const cx<T> ws = cis2pi<T>(scale_pow2((double)(((long long)k1 * p.tpf) & (N - 1)), log2N));
         cx<T> w[16];
         powers16(ws, w);
 #pragma unroll
@@ -422,42 +432,82 @@ template <typename T> struct ColArgs {
     int npart;                // number of column workgroups (partials per array)
 };
 
-template <typename T, class Ctx> struct ColGeom {
+// Thread geometry of the column kernel.  A workgroup owns C adjacent columns of one field
+// group (Manakov: one polarisation pair; the x row is handled by the first half of the
+// threads, the y row by the second half; NLSE: a single row, no split).
+template <typename T, int LG, class Ctx> struct ColGeom {
     PassPlan p;
-    int C, c, b, n2;
-    long long rowbase[2];     // element offset of row r = 2*pair + pol (or the single row)
-    int N2;
+    int half, pol, t, C, c, b, n2, N2;
+    long long rowbase;        // element offset of this thread's row
+    long long pbase;          // element offset of the pair's row in P
     SSF_HD ColGeom(Ctx &ctx, const ColArgs<T> &a) {
-        p = make_plan(a.log2N1);
-        C = ctx.nthreads / p.tpf;
-        c = ctx.tid % C;
-        b = ctx.tid / C;
+        p = make_plan(LG > 0 ? LG : a.log2N1);
+        half = ctx.nthreads / a.npol;
+        pol = ctx.tid / half;
+        t = ctx.tid - pol * half;
+        C = half / p.tpf;
+        c = t % C;
+        b = t / C;
         N2 = 1 << a.log2N2;
-        const int tpp = N2 / C;                      // tiles per field row group
-        const int grp = ctx.bid / tpp, tile = ctx.bid % tpp;
+        const int tpp = N2 / C;                      // tiles per field group
+        const int grp = ctx.bid / tpp, tile = ctx.bid - grp * tpp;
         n2 = tile * C + c;
         const long long N = 1ll << (a.log2N1 + a.log2N2);
-        rowbase[0] = (long long)(grp * a.npol) * N;
-        rowbase[1] = rowbase[0] + N;
+        rowbase = (long long)(grp * a.npol + pol) * N;
+        pbase = (long long)grp * N;
     }
     // frequency side: register q <-> k1 = b + tpf*q (pass-0 positions)
-    SSF_HD long long freq_off(int q) const { return ((long long)(b + p.tpf * q) << 0) * N2 + n2; }
+    SSF_HD long long freq_off(int q) const { return (long long)(b + p.tpf * q) * N2 + n2; }
     // time side: register idx <-> n1 = rev(position in the last pass)
     SSF_HD long long time_off(int idx) const {
         return (long long)rev_pos(p, reg_pos(p, p.npass - 1, b, idx)) * N2 + n2;
     }
 };
 
-template <typename T, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
+// exchange 16 per-thread values with the partner thread (same column/butterfly, other
+// polarisation) through LDS scratch `sh` (2*16*half values); one barrier inside.
+// The caller guarantees (barrier) that `sh` is free on entry.
+template <typename V, class Ctx, class G> SSF_HD void pair_swap(Ctx &ctx, const G &g, const V *mine, V *other, V *sh) {
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) sh[(size_t)(g.pol * 16 + idx) * g.half + g.t] = mine[idx];
+    ctx.sync();
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) other[idx] = sh[(size_t)((g.pol ^ 1) * 16 + idx) * g.half + g.t];
+}
+
+// rot[idx] = cis(ang[idx]) for all 16 registers; with a polarisation pair each partner
+// evaluates 8 of the 16 sincos and they swap through LDS scratch `sh` (16*half complex).
+template <typename T, class Ctx, class G>
+SSF_HD void pair_cis(Ctx &ctx, const G &g, int npol, const T *ang, cx<T> *rot, cx<T> *sh) {
+    if (npol == 2) {
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx)
+            if ((idx >> 3) == g.pol) {
+                rot[idx] = cis_t<T>(ang[idx]);
+                sh[(size_t)idx * g.half + g.t] = rot[idx];
+            }
+        ctx.sync();
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx)
+            if ((idx >> 3) != g.pol) rot[idx] = sh[(size_t)idx * g.half + g.t];
+    } else {
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) rot[idx] = cis_t<T>(ang[idx]);
+    }
+}
+
+// MODE is one of CM_*; the Manakov modes pick their operation from the Ctrl state.
+template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
+    constexpr bool kMk = MODE == CM_MK_A || MODE == CM_MK_B;
     // ---- what does this launch do? ------------------------------------------------------
     bool do_inv = false, do_fwd = false;
     int op = -1;   // Manakov: 0 = S, 1 = H, 2 = I, 3 = D(a) next iterate
     Ctrl c{}, n{};
     double *red = (double *)ctx.lds;
-    if (a.mode == CM_MK_A || a.mode == CM_MK_B) {
+    if (kMk) {
         c = *a.cin;
         n = c;
-        if (a.mode == CM_MK_A) {
+        if (MODE == CM_MK_A) {
             if (c.state == ST_NEED_H) { op = 1; do_inv = do_fwd = true; n.state = ST_ROW_ITER; n.it = 0; }
             else if (c.state == ST_NEED_I) { op = 2; do_inv = true; n.state = ST_NEED_D; }
         } else {
@@ -507,19 +557,19 @@ template <typename T, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T>
         }
         if (op < 0) return;
     } else {
-        do_inv = a.mode == CM_NLSE_STEP || a.mode == CM_NLSE_LAST || a.mode == CM_PLAIN_INV;
-        do_fwd = a.mode == CM_NLSE_STEP || a.mode == CM_NLSE_FIRST || a.mode == CM_PLAIN_FWD;
+        do_inv = MODE == CM_NLSE_STEP || MODE == CM_NLSE_LAST || MODE == CM_PLAIN_INV;
+        do_fwd = MODE == CM_NLSE_STEP || MODE == CM_NLSE_FIRST || MODE == CM_PLAIN_FWD;
     }
 
-    ColGeom<T, Ctx> g(ctx, a);
+    ColGeom<T, LG, Ctx> g(ctx, a);
     const PassPlan &p = g.p;
-    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)g.c * lds_slots_per_fft(p.L);
-    const int npol = a.npol;
-    cx<T> vx[16], vy[16];
+    const int npol = kMk ? 2 : 1;
+    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_slots_per_fft(p.L);
+    cx<T> v[16];
 
     // buffers by role (Manakov): the field at the step start / last iterate, and the next iterate
     cx<T> *Tcur = a.T0, *Tnew = a.T1;
-    if (a.mode == CM_MK_A || a.mode == CM_MK_B) {
+    if (kMk) {
         const int cur = (op == 2) ? c.cur : n.cur;     // I reads E_conv = T[c.cur]; S / D(a) use the new current
         Tcur = cur ? a.T1 : a.T0;
         Tnew = cur ? a.T0 : a.T1;
@@ -528,108 +578,98 @@ template <typename T, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T>
     // ---- inverse column transform: G -> time samples in registers -------------------------
     if (do_inv) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) vx[q] = a.G[g.rowbase[0] + g.freq_off(q)];
-        if (npol == 2) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) vy[q] = a.G[g.rowbase[1] + g.freq_off(q)];
-        }
-        fft_dif<+1>(ctx, p, g.b, vx, lds);
-        if (npol == 2) {
-            ctx.sync();
-            fft_dif<+1>(ctx, p, g.b, vy, lds);
-        }
+        for (int q = 0; q < 16; ++q) v[q] = a.G[g.rowbase + g.freq_off(q)];
+        fft_dif<+1>(ctx, p, g.b, v, lds);
     } else {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) vx[idx] = Tcur[g.rowbase[0] + g.time_off(idx)];
-        if (npol == 2) {
-#pragma unroll
-            for (int idx = 0; idx < 16; ++idx) vy[idx] = Tcur[g.rowbase[1] + g.time_off(idx)];
-        }
+        for (int idx = 0; idx < 16; ++idx) v[idx] = Tcur[g.rowbase + g.time_off(idx)];
     }
 
     // ---- time-domain work ---------------------------------------------------------------
-    const long long N = 1ll << (a.log2N1 + a.log2N2);
-    const long long pbase = (g.rowbase[0] / N / 2) * N;    // Manakov: P row of this pair
-    if (a.mode == CM_NLSE_STEP) {                                        // channels.py:225
+    if (MODE == CM_NLSE_STEP) {                                          // channels.py:225
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) vx[idx] = vx[idx] * cis_t<T>(a.g_hz * norm2(vx[idx]));
-    } else if (a.mode == CM_NLSE_LAST || a.mode == CM_PLAIN_INV) {
+        for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * cis_t<T>(a.g_hz * norm2(v[idx]));
+    } else if (MODE == CM_NLSE_LAST || MODE == CM_PLAIN_INV) {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) a.T0[g.rowbase[0] + g.time_off(idx)] = vx[idx];
-    } else if (op == 0) {                                                // S: Pch and max phi (channels.py:388-395)
-        double m = -INFINITY;
+        for (int idx = 0; idx < 16; ++idx) a.T0[g.rowbase + g.time_off(idx)] = v[idx];
+    } else if (kMk) {
+        T *shT = (T *)ctx.lds;                       // scratch: norms  [2][16][half]
+        cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));   // scratch: rotations [16][half] (disjoint)
+        const T c8g = (T)a.k.c8g, shz = (T)(a.k.sgn * c.hz);
+        if (op == 0 || op == 3) {                    // both need |Ex|^2 + |Ey|^2 of the registers
+            T mine[16], oth[16], ang[16];
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) {
-            const T ax = norm2(vx[idx]), ay = norm2(vy[idx]);
-            const T pw = ax + ay;
-            a.P[pbase + g.time_off(idx)] = pw;
-            const T phi = (T)a.k.c8g * (pw + ax + ay) / (T)2;
-            m = (double)phi > m ? (double)phi : m;
-        }
-        if (a.k.adaptive) {
+            for (int idx = 0; idx < 16; ++idx) mine[idx] = norm2(v[idx]);
+            if (do_inv) ctx.sync();
+            pair_swap(ctx, g, mine, oth, shT);
+            if (op == 0) {                                               // S: Pch, max phi (channels.py:388-395)
+                double m = -INFINITY;
+#pragma unroll
+                for (int idx = 0; idx < 16; ++idx) {
+                    const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
+                    const T pw = ax + ay;
+                    if (g.pol == 0) a.P[g.pbase + g.time_off(idx)] = pw;
+                    const T phi = c8g * (pw + ax + ay) / (T)2;
+                    m = (double)phi > m ? (double)phi : m;
+                }
+                if (a.k.adaptive) {
+                    m = block_max(ctx, m, red);
+                    if (ctx.tid == 0) a.pmax[ctx.bid] = m;
+                }
+            } else {                                                     // D(a): next iterate (channels.py:436, 414-417)
+#pragma unroll
+                for (int idx = 0; idx < 16; ++idx) {
+                    const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
+                    const T pw = a.P[g.pbase + g.time_off(idx)];
+                    ang[idx] = shz * (c8g * (pw + ax + ay) / (T)2);
+                }
+                cx<T> rot[16];
+                pair_cis(ctx, g, npol, ang, rot, shC);
+#pragma unroll
+                for (int idx = 0; idx < 16; ++idx) v[idx] = a.Ehd[g.rowbase + g.time_off(idx)] * rot[idx];
+            }
+            ctx.sync();                              // scratch reads done before the FFT reuses the LDS
+        } else if (op == 1) {                                            // H: E_hd, first rotation (channels.py:409-417)
+            T ang[16];
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) {
+                const long long t = g.time_off(idx);
+                a.Ehd[g.rowbase + t] = v[idx];
+                const T pw = a.P[g.pbase + t];
+                ang[idx] = shz * (c8g * (pw + pw) / (T)2);
+            }
+            cx<T> rot[16];
+            ctx.sync();                              // inverse transform's LDS reads are done
+            pair_cis(ctx, g, npol, ang, rot, shC);
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * rot[idx];
             ctx.sync();
-            m = block_max(ctx, m, red);
-            if (ctx.tid == 0) a.pmax[ctx.bid] = m;
-            ctx.sync();
-        }
-    } else if (op == 1) {                                                // H: E_hd, first rotation (channels.py:409-417)
-        const T shz = (T)(a.k.sgn * c.hz), c8g = (T)a.k.c8g;
+        } else if (op == 2) {                                            // I: E_fd out, convergence sums
+            double num = 0, den = 0;
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) {
-            const long long t = g.time_off(idx);
-            a.Ehd[g.rowbase[0] + t] = vx[idx];
-            a.Ehd[g.rowbase[1] + t] = vy[idx];
-            const T pw = a.P[pbase + t];
-            const cx<T> rot = cis_t<T>(shz * (c8g * (pw + pw) / (T)2));
-            vx[idx] = vx[idx] * rot;
-            vy[idx] = vy[idx] * rot;
-        }
-    } else if (op == 2) {                                                // I: E_fd out, convergence sums
-        double num = 0, den = 0;
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx) {
-            const long long t = g.time_off(idx);
-            const cx<T> ex = Tcur[g.rowbase[0] + t], ey = Tcur[g.rowbase[1] + t];
-            Tnew[g.rowbase[0] + t] = vx[idx];
-            Tnew[g.rowbase[1] + t] = vy[idx];
-            const double dxr = (double)vx[idx].re - (double)ex.re, dxi = (double)vx[idx].im - (double)ex.im;
-            const double dyr = (double)vy[idx].re - (double)ey.re, dyi = (double)vy[idx].im - (double)ey.im;
-            num += dxr * dxr + dxi * dxi + dyr * dyr + dyi * dyi;
-            den += (double)ex.re * ex.re + (double)ex.im * ex.im + (double)ey.re * ey.re + (double)ey.im * ey.im;
-        }
-        ctx.sync();
-        num = block_sum(ctx, num, red);
-        den = block_sum(ctx, den, red);
-        if (ctx.tid == 0) {
-            a.pnum[ctx.bid] = num;
-            a.pden[ctx.bid] = den;
-        }
-    } else if (op == 3) {                                                // D(a): next iterate (channels.py:436, 414-417)
-        const T shz = (T)(a.k.sgn * c.hz), c8g = (T)a.k.c8g;
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx) {
-            const long long t = g.time_off(idx);
-            const T pw = a.P[pbase + t];
-            const T phi = c8g * (pw + norm2(vx[idx]) + norm2(vy[idx])) / (T)2;
-            const cx<T> rot = cis_t<T>(shz * phi);
-            vx[idx] = a.Ehd[g.rowbase[0] + t] * rot;
-            vy[idx] = a.Ehd[g.rowbase[1] + t] * rot;
+            for (int idx = 0; idx < 16; ++idx) {
+                const long long t = g.time_off(idx);
+                const cx<T> e = Tcur[g.rowbase + t];
+                Tnew[g.rowbase + t] = v[idx];
+                const double dr = (double)v[idx].re - (double)e.re, di = (double)v[idx].im - (double)e.im;
+                num += dr * dr + di * di;
+                den += (double)e.re * e.re + (double)e.im * e.im;
+            }
+            num = block_sum(ctx, num, red);
+            den = block_sum(ctx, den, red);
+            if (ctx.tid == 0) {
+                a.pnum[ctx.bid] = num;
+                a.pden[ctx.bid] = den;
+            }
         }
     }
 
     // ---- forward column transform: registers -> G -------------------------------------------
     if (do_fwd) {
-        if (do_inv && npol == 2) ctx.sync();        // lds still being read by slower threads (y inverse)
-        if (do_inv && npol == 1) ctx.sync();
-        fft_dit<-1>(ctx, p, g.b, vx, lds);
+        if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
+        fft_dit<-1>(ctx, p, g.b, v, lds);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a.G[g.rowbase[0] + g.freq_off(q)] = vx[q];
-        if (npol == 2) {
-            ctx.sync();
-            fft_dit<-1>(ctx, p, g.b, vy, lds);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) a.G[g.rowbase[1] + g.freq_off(q)] = vy[q];
-        }
+        for (int q = 0; q < 16; ++q) a.G[g.rowbase + g.freq_off(q)] = v[q];
     }
 }
 

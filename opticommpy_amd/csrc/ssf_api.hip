@@ -164,6 +164,19 @@ int ssf_run(ssf_plan *plan, const ssf_params *params, const void *in, void *out,
     return SSF_OK;
 }
 
+int ssf_set_profiling(ssf_plan *plan, int32_t enable) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    int rc = plan->engine->set_profiling(enable);
+    return rc ? fail(plan, rc, "per-kernel profiling is only available on the fused engine") : SSF_OK;
+}
+
+int ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    if (!out) return fail(plan, SSF_ERR_BAD_ARG, "out is NULL");
+    int rc = plan->engine->kernel_times(out);
+    return rc ? fail(plan, rc, "per-kernel profiling is only available on the fused engine") : SSF_OK;
+}
+
 int ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, double D, double L, const void *in,
                        void *out) {
     int rc = ssf_upload(plan, in);

@@ -131,11 +131,20 @@ struct EmuBackend {
     double time_end() { return 0.0; }
     template <typename T> void launch_row(const ssf::fused::RowArgs<T> &a, int grid, int block, size_t lds) {
         ++launches;
-        run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T>(c, a); });
+        run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
     }
     template <typename T> void launch_col(const ssf::fused::ColArgs<T> &a, int grid, int block, size_t lds) {
         ++launches;
-        run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::col_body<T>(c, a); });
+        using namespace ssf::fused;
+        switch (a.mode) {
+        case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST>(c, a); }); break;
+        case CM_NLSE_STEP: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_STEP>(c, a); }); break;
+        case CM_NLSE_LAST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST>(c, a); }); break;
+        case CM_MK_A: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK_A>(c, a); }); break;
+        case CM_MK_B: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK_B>(c, a); }); break;
+        case CM_PLAIN_FWD: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD>(c, a); }); break;
+        default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV>(c, a); }); break;
+        }
     }
     template <typename T> void launch_amp(const ssf::fused::AmpArgs<T> &a, int grid, int block) {
         ++launches;

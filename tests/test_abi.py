@@ -34,7 +34,7 @@ def test_struct_layouts_match_header(tmp_path):
     """Compile include/ssf.h with gcc and compare sizeof/offsetof with the ctypes mirror."""
     import subprocess
     structs = {"ssf_params": _lib.Params, "ssf_stats": _lib.Stats, "ssf_trace": _lib.Trace,
-               "ssf_device_info_t": _lib.DeviceInfo}
+               "ssf_device_info_t": _lib.DeviceInfo, "ssf_kernel_times": _lib.KernelTimes}
     lines = []
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -257,3 +257,38 @@ def test_full_size_config3_c64(engine):
     assert out.dtype == np.complex64 and run["steps"] == 11     # 0.08 accumulates to just under 0.8: the
     # reference also takes an 11th, rounding-sized step (channels.py:387, 398-400)
     assert orc.signalPower(out) == pytest.approx(orc.signalPower(E), rel=1e-4)       # ideal amp restores the power
+
+
+def test_single_process_multi_device_entry_point():
+    """ssf_mgpu_run (one host thread per device): 3 independent units on device 0 must equal
+    three separate reference calls."""
+    import ctypes as C
+    from opticommpy_amd import _lib, mgpu
+    N = 1 << 12
+    fields = np.stack([synth_field(N, 2, 60 + u, 6.0 + u).T for u in range(3)])       # (U, rows, N)
+    cfg = _mk_cfg(Ltotal=2, Lspan=1, hz=0.1, nlprMethod=False, amp="ideal", saveSpanN=[])
+    cp = models._fill_params(_lib.MODEL_MANAKOV, +1, make_param(oa.parameters, dict(cfg, NF=4.5)), 512e9, 2,
+                             np.zeros(0, np.int32))
+    outs, stats = mgpu.run_threads(fields, cp, devices=[0])
+    for u in range(3):
+        ref = orc.manakovSSF(fields[u].T.copy(), make_param(orc.parameters, cfg))
+        assert rel_l2(outs[u].T, ref) <= TOL_C128
+        assert stats[u]["steps"] == 20
+
+
+def test_kernel_profiling_api():
+    import ctypes as C
+    from opticommpy_amd import _lib
+    N = 1 << 14
+    oa.set_engine("fused")
+    E = synth_field(N, 2, 70, 8.0)
+    p = make_param(oa.parameters, _mk_cfg(Ltotal=1, Lspan=1, hz=0.1, nlprMethod=False, amp=None, saveSpanN=[]))
+    oa.manakovSSF(E, p)
+    pl = models._get_plan(N, 2, _lib.SSF_C128)
+    assert pl.lib.ssf_set_profiling(pl.h, 1) == 0
+    out = oa.manakovSSF(E, p)
+    kt = _lib.KernelTimes()
+    assert pl.lib.ssf_get_kernel_times(pl.h, C.byref(kt)) == 0
+    pl.lib.ssf_set_profiling(pl.h, 0)
+    steps, iters = models.last_run["steps"], models.last_run["iterations"]
+    assert kt.row_n >= steps + iters and kt.colA_n >= steps + iters and kt.row_ms > 0
