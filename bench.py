@@ -136,8 +136,8 @@ def main():
         lib.ssf_set_profiling(h, 0)
         bytes_per_launch = 2 * (16 if args.prec == "c128" else 8) * N * 2       # one transform-equivalent per row
         kernels = {}
-        for name, ms, n in (("row (FFT.H.IFFT of rows)", kt.row_ms, kt.row_n), ("colA (H | I stage)", kt.colA_ms, kt.colA_n),
-                            ("colB (S | D stage, idle once per step)", kt.colB_ms, kt.colB_n)):
+        for name, ms, n in (("row (decision + FFT.H.IFFT of rows)", kt.row_ms, kt.row_n),
+                            ("col (S | H | I+anticipated continuation)", kt.colA_ms, kt.colA_n)):
             if n:
                 avg_us = ms / n * 1e3
                 kernels[name] = {"launches": int(n), "avg_us": avg_us}

@@ -96,6 +96,8 @@ typedef struct {
     double  bytes_algorithmic;   /* transforms * 2 * sizeof(complex) * N      */
     int32_t engine;              /* SSF_ENGINE_* actually used                           */
     int32_t n_snapshots;         /* snapshots captured so far                            */
+    int64_t spec_hits;           /* fused engine: iterations whose continuation was      */
+    int64_t spec_misses;         /*   anticipated correctly / had to be redone           */
 } ssf_stats;
 
 /* Optional per-step trace (for parity checks of the data-dependent control flow).

@@ -31,7 +31,7 @@ template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds
 }
 // Manakov column kernels run 512 threads (x half | y half); the single-row modes run 256
 template <typename T, int LG, int MODE>
-__global__ void __launch_bounds__((MODE == CM_MK_A || MODE == CM_MK_B) ? 512 : 256) k_col(const ColArgs<T> a) {
+__global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs<T> a) {
     SSF_DEV_CTX();
     col_body<T, LG, MODE>(ctx, a);
 }
@@ -69,8 +69,7 @@ template <typename T, int LG> ColFn<T> pick_col_mode(int mode) {
     case CM_NLSE_FIRST: return k_col<T, LG, CM_NLSE_FIRST>;
     case CM_NLSE_STEP: return k_col<T, LG, CM_NLSE_STEP>;
     case CM_NLSE_LAST: return k_col<T, LG, CM_NLSE_LAST>;
-    case CM_MK_A: return k_col<T, LG, CM_MK_A>;
-    case CM_MK_B: return k_col<T, LG, CM_MK_B>;
+    case CM_MK: return k_col<T, LG, CM_MK>;
     case CM_PLAIN_FWD: return k_col<T, LG, CM_PLAIN_FWD>;
     default: return k_col<T, LG, CM_PLAIN_INV>;
     }
@@ -196,7 +195,7 @@ struct HipBackend {
         static thread_local int narmed = 0;
         ColFn<T> f = pick_col<T>(a.log2N1, a.mode);
         arm((const void *)f, col_lds_max, armed, narmed);
-        stamp_begin(a.mode == CM_MK_A ? 1 : a.mode == CM_MK_B ? 2 : 3);
+        stamp_begin(a.mode == CM_MK ? 1 : 3);
         f<<<grid, block, lds, pl->stream>>>(a);
         stamp_end();
         chk(hipGetLastError(), "launch k_col");

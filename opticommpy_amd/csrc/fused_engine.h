@@ -3,7 +3,7 @@
 // (tests/emu).  No host<->device synchronisation inside a step: the data-dependent control
 // flow (iteration count, adaptive step, span end) lives in a device-resident Ctrl block that
 // every launch reads and forwards; the host only enqueues a uniform launch sequence
-// [Row, ColA, ColB]* in chunks and looks at the Ctrl block between chunks.
+// Col [Row, Col]* in chunks and looks at the Ctrl block between chunks.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -97,7 +97,7 @@ template <typename T, class Backend> class FusedCore {
         void **ptrs[] = {(void **)&G, (void **)&T0, (void **)&T1, (void **)&Ehd};
         for (auto pp : ptrs)
             if (!(*pp = be.alloc(field_bytes))) return oom();
-        if (!(P = (T *)be.alloc(sizeof(T) * (size_t)N * (size_t)((nrows + 1) / 2)))) return oom();
+        if (!(P = (T *)be.alloc(2 * sizeof(T) * (size_t)N * (size_t)((nrows + 1) / 2)))) return oom();   // two Pch buffers
         if (!(ctrl = (Ctrl *)be.alloc(2 * sizeof(Ctrl)))) return oom();
         if (!(linops = (LinOp *)be.alloc(2 * sizeof(LinOp)))) return oom();
         if (!(part = (double *)be.alloc(sizeof(double) * 3 * (size_t)npart_max))) return oom();
@@ -157,6 +157,7 @@ template <typename T, class Backend> class FusedCore {
         a.log2N2 = sp.l2;
         a.npol = npol;
         a.mode = mode;
+        a.ngroups = std::max(nrows / 2, 1);
         a.pmax = part;
         a.pnum = part + npart_max;
         a.pden = part + 2 * (size_t)npart_max;
@@ -270,6 +271,8 @@ template <typename T, class Backend> class FusedCore {
         a.cout = ctrl + ((seq + 1) & 1);
         a.k = k;
         a.pmax = part;
+        a.pnum = part + npart_max;
+        a.pden = part + 2 * (size_t)npart_max;
         a.npart = col_grid_mk;
         be.launch_row(a, row_grid, row_block, row_lds);
         ++seq;
@@ -316,15 +319,17 @@ template <typename T, class Backend> class FusedCore {
         for (int span = s0; span <= s1; ++span) {
             if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))      // equalization.py:1090-1092
                 launch_amp(Tcur(), (T)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);
+            const int pred = c.pred_iters;
             std::memset(&c, 0, sizeof(c));
+            c.pred_iters = pred;
             c.state = ST_NEED_S;
             c.cur = cur;
             c.trace_n = trace_n;
             be.h2d(ctrl + (seq & 1), &c, sizeof(Ctrl));
-            launch_mk_col(k, CM_MK_B);                                                     // first step start
+            launch_mk_col(k, CM_MK);                                                       // first step start
             int guard = 0;
             for (;;) {
-                // estimate the [Row, ColA, ColB] triples still needed for this span
+                // estimate the [Row, Col] pairs still needed for this span
                 double steps_rem;
                 if (c.steps == 0 && c.state == ST_NEED_S)
                     steps_rem = p.nlprMethod ? 8.0 : std::ceil(p.Lspan / p.hz);
@@ -334,8 +339,7 @@ template <typename T, class Backend> class FusedCore {
                 int chunk = (int)std::min(512.0, std::max(2.0, est));
                 for (int i = 0; i < chunk; ++i) {
                     launch_mk_row(k);
-                    launch_mk_col(k, CM_MK_A);
-                    launch_mk_col(k, CM_MK_B);
+                    launch_mk_col(k, CM_MK);
                 }
                 be.d2h(&c, ctrl + (seq & 1), sizeof(Ctrl));                               // synchronising read
                 if (!be.ok()) return hiperr();
@@ -351,6 +355,8 @@ template <typename T, class Backend> class FusedCore {
             st->steps += c.steps;
             st->iterations += c.iterations;
             st->nonconverged_steps += c.nonconv;
+            st->spec_hits += c.spec_hit;
+            st->spec_misses += c.spec_miss;
             st->transforms += (int64_t)nrows * (2 * c.steps + 2 * c.iterations);
             if (p.direction >= 0 && (rc = amp_fwd(p, d, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
             if (wants_snapshot(p, span) && (rc = snapshot())) return rc;

@@ -23,14 +23,19 @@ namespace ssf {
 namespace fused {
 
 // ------------------------------------------------------------------------------- control
+// Launch sequence per span: Col, then [Row, Col] pairs.  Every launch reads the state, does the
+// matching stage (or nothing) and forwards the state; the host never looks inside a chunk.
 enum {
-    ST_NEED_S = 0,     // ColB: step start on T[cur]: Pch, forward column FFT
-    ST_AFTER_S = 1,    // Row : first half linear step (and adaptive step size)
-    ST_NEED_H = 2,     // ColA: E_hd = ..., first rotation, forward column FFT
-    ST_ROW_ITER = 3,   // Row : second linear step of the current iterate
-    ST_NEED_I = 4,     // ColA: E_fd -> T[cur^1], convergence partial sums
-    ST_NEED_D = 5,     // ColB: decide: next iterate | next step | span done
-    ST_SPAN_DONE = 6
+    ST_NEED_S = 0,     // Col: step start on T[cur]: Pch, forward column FFT            -> AFTER_S
+    ST_AFTER_S = 1,    // Row: (adaptive step size,) first half linear step             -> NEED_H
+    ST_NEED_H = 2,     // Col: E_hd out, first rotation, forward column FFT             -> ROW_ITER
+    ST_ROW_ITER = 3,   // Row: second linear step of the current iterate                -> NEED_I
+    ST_NEED_I = 4,     // Col: E_fd -> T[cur^1], convergence partial sums, anticipated continuation -> NEED_D
+    ST_NEED_D = 5,     // Row: convergence decision; if the anticipation was right carry on with the
+                       //      linear step (-> NEED_I | NEED_H), else -> FIX_A | FIX_S | SPAN_DONE
+    ST_SPAN_DONE = 6,
+    ST_FIX_A = 7,      // Col: next iterate that was not anticipated                    -> ROW_ITER
+    ST_FIX_S = 8       // Col: step start that was not anticipated                      -> AFTER_S
 };
 
 struct LinOp {          // exp(argLimOp * hz/2) / N evaluated from the bin index (row kernel)
@@ -41,8 +46,12 @@ struct LinOp {          // exp(argLimOp * hz/2) / N evaluated from the bin index
 
 struct Ctrl {           // device-resident step state, double-buffered by launch parity
     int state, it, cur, hz_valid;
+    int pred_iters;     // iterations of the previous step (0 = unknown): drives the speculation
+    int spec;           // what ColA's I stage already did beyond E_fd: 0 nothing, 1 next iterate, 2 next step start
+    int pcur, pad_;     // which of the two Pch buffers holds the current step's power
     double z, hz;
     long long steps, iterations, nonconv, trace_n;
+    long long spec_hit, spec_miss;
     LinOp lin;
 };
 
@@ -291,7 +300,8 @@ template <typename T> struct RowArgs {
     const Ctrl *cin;          // ctrl[seq & 1]
     Ctrl *cout;               // ctrl[(seq + 1) & 1]
     MkConst k;
-    const double *pmax;       // adaptive: block maxima of phi written by the S stage
+    const double *pmax;       // adaptive: block maxima of phi written by the step-start stage
+    const double *pnum, *pden;// convergence partial sums written by the I stage
     int npart;
 };
 
@@ -338,14 +348,67 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     LinOp lo;
     if (a.use_ctrl) {
         const Ctrl c = *a.cin;
-        const bool act = c.state == ST_AFTER_S || c.state == ST_ROW_ITER;
         Ctrl n = c;
-        if (act && !c.hz_valid) {             // adaptive step: every block derives the same hz
-            double *red = (double *)(ctx.lds) + 64;
-            const double mx = global_max(ctx, a.pmax, a.npart, red);
+        double *red = (double *)(ctx.lds) + 64;
+        bool act = c.state == ST_AFTER_S || c.state == ST_ROW_ITER;
+        if (c.state == ST_NEED_D) {           // convergence decision (channels.py:424-434), same in every block
+            const double num = global_sum(ctx, a.pnum, a.npart, red);
+            const double den = global_sum(ctx, a.pden, a.npart, red);
+            const double lim = sqrt(num) / sqrt(den);                     // channels.py:517-519
+            const bool conv = lim < a.k.tol, last = c.it == a.k.maxIter - 1;
+            const bool lead = ctx.bid == 0 && ctx.tid == 0;
+            if (lead && c.trace_n < a.k.trace_cap && a.k.tr_lim)
+                a.k.tr_lim[c.trace_n * a.k.maxIter + c.it] = lim;
+            n.cur = c.cur ^ 1;                                            // E_conv = E_fd
+            n.spec = 0;
+            if (conv || last) {                                           // the step is over
+                if (lead && c.trace_n < a.k.trace_cap) {
+                    if (a.k.tr_hz) a.k.tr_hz[c.trace_n] = c.hz;
+                    if (a.k.tr_it) a.k.tr_it[c.trace_n] = c.it + 1;
+                }
+                n.trace_n = c.trace_n + 1;
+                n.steps = c.steps + 1;
+                n.iterations = c.iterations + c.it + 1;
+                if (!conv) n.nonconv = c.nonconv + 1;
+                n.z = c.z + c.hz;
+                n.pred_iters = c.it + 1;
+                n.it = 0;
+                if (!(n.z < a.k.Lspan)) n.state = ST_SPAN_DONE;
+                else {
+                    if (a.k.adaptive) n.hz_valid = 0;             // hz_valid == 0: (hz and) operator to be derived
+                    else {
+                        n.hz = pick_hz(a.k, n.z, 0.0);
+                        if (n.hz != c.hz) n.hz_valid = 0;
+                    }
+                    if (c.spec == 2) {                                    // the step start is already in G
+                        n.pcur = c.pcur ^ 1;
+                        n.spec_hit = c.spec_hit + 1;
+                        n.state = ST_AFTER_S;
+                        act = true;
+                    } else {
+                        n.spec_miss = c.spec_miss + 1;
+                        n.state = ST_FIX_S;
+                    }
+                }
+            } else {
+                n.it = c.it + 1;
+                if (c.spec == 1) {                                        // the next iterate is already in G
+                    n.spec_hit = c.spec_hit + 1;
+                    n.state = ST_ROW_ITER;
+                    act = true;
+                } else {
+                    n.spec_miss = c.spec_miss + 1;
+                    n.state = ST_FIX_A;
+                }
+            }
+            ctx.sync();
+        }
+        if (act && !n.hz_valid) {             // new step size: every block derives the same hz / operator
+            double mx = 0.0;
+            if (a.k.adaptive) mx = global_max(ctx, a.pmax, a.npart, red);
             ctx.sync();
             if (ctx.tid == 0) {
-                const double hz = pick_hz(a.k, c.z, mx);
+                const double hz = pick_hz(a.k, n.z, mx);
                 lsh[0] = make_linop(hz / 2, a.k.lin_a, a.k.lin_b, a.k.w2, a.k.invN, a.k.log2N);
                 ((double *)(lsh + 1))[0] = hz;
             }
@@ -355,7 +418,7 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
             n.hz_valid = 1;
             ctx.sync();
         }
-        if (act) n.state = c.state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
+        if (act) n.state = n.state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
         if (ctx.bid == 0 && ctx.tid == 0) *a.cout = n;
         if (!act) return;
         lo = n.lin;
@@ -412,8 +475,7 @@ enum {
     CM_NLSE_FIRST = 0,   // time -> forward -> G
     CM_NLSE_STEP = 1,    // G -> inverse -> E *= exp(j g_hz |E|^2) -> forward -> G
     CM_NLSE_LAST = 2,    // G -> inverse -> time
-    CM_MK_A = 3,         // Manakov ColA (H | I by state)
-    CM_MK_B = 4,         // Manakov ColB (S | D by state)
+    CM_MK = 3,           // Manakov column stage picked by the Ctrl state (S | H | I | unanticipated next iterate)
     CM_PLAIN_FWD = 5,    // time -> forward -> G            (linear channel)
     CM_PLAIN_INV = 6     // G -> inverse -> time            (linear channel)
 };
@@ -424,6 +486,7 @@ template <typename T> struct ColArgs {
     cx<T> *Ehd;               // (nrows, N)
     T *P;                     // (K, N)
     int log2N1, log2N2, npol, mode;
+    int ngroups;              // Manakov: polarisation pairs K (P holds 2 x K x N values: two buffers)
     T g_hz;                   // NLSE: gamma * hz
     const Ctrl *cin;
     Ctrl *cout;
@@ -496,65 +559,109 @@ SSF_HD void pair_cis(Ctx &ctx, const G &g, int npol, const T *ang, cx<T> *rot, c
     }
 }
 
+// ---- Manakov time-domain building blocks (registers v = this thread's 16 samples of its row) ----
+// step start (channels.py:388-395): Pch = |Ex|^2 + |Ey|^2 -> Pbuf, block max of phi -> pmax
+template <typename T, class Ctx, class G>
+SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T> *v, T *Pbuf, bool lds_busy) {
+    T *shT = (T *)ctx.lds;
+    T mine[16], oth[16];
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) mine[idx] = norm2(v[idx]);
+    if (lds_busy) ctx.sync();
+    pair_swap(ctx, g, mine, oth, shT);
+    const T c8g = (T)a.k.c8g;
+    double m = -INFINITY;
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) {
+        const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
+        const T pw = ax + ay;
+        if (g.pol == 0) Pbuf[g.pbase + g.time_off(idx)] = pw;
+        const T phi = c8g * (pw + ax + ay) / (T)2;
+        m = (double)phi > m ? (double)phi : m;
+    }
+    if (a.k.adaptive) {
+        m = block_max(ctx, m, (double *)ctx.lds);
+        if (ctx.tid == 0) a.pmax[ctx.bid] = m;
+    }
+    ctx.sync();                                  // scratch reads done before the FFT reuses the LDS
+}
+// next iterate (channels.py:436, 414-417): v holds E_conv (the latest E_fd); returns E_hd * rot
+template <typename T, class Ctx, class G>
+SSF_HD void mk_next_iterate(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, const T *Pbuf, T shz, bool lds_busy) {
+    T *shT = (T *)ctx.lds;
+    cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));
+    T mine[16], oth[16], ang[16];
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) mine[idx] = norm2(v[idx]);
+    if (lds_busy) ctx.sync();
+    pair_swap(ctx, g, mine, oth, shT);
+    const T c8g = (T)a.k.c8g;
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) {
+        const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
+        const T pw = Pbuf[g.pbase + g.time_off(idx)];
+        ang[idx] = shz * (c8g * (pw + ax + ay) / (T)2);
+    }
+    cx<T> rot[16];
+    pair_cis(ctx, g, 2, ang, rot, shC);
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) v[idx] = a.Ehd[g.rowbase + g.time_off(idx)] * rot[idx];
+    ctx.sync();
+}
+
 // MODE is one of CM_*; the Manakov modes pick their operation from the Ctrl state.
+//
+// Speculation: the I stage (ColA) already knows E_fd in registers.  If the previous step took
+// more iterations than done so far it goes straight on to the next iterate (spec 1); if this is
+// the iteration the previous step converged at, it starts the next step (spec 2: Pch into the
+// alternate buffer + forward transform).  The D stage (ColB) then only validates: when the
+// guess was right it touches no field data; otherwise it redoes the right thing as before.
 template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
-    constexpr bool kMk = MODE == CM_MK_A || MODE == CM_MK_B;
+    constexpr bool kMk = MODE == CM_MK;
     // ---- what does this launch do? ------------------------------------------------------
     bool do_inv = false, do_fwd = false;
-    int op = -1;   // Manakov: 0 = S, 1 = H, 2 = I, 3 = D(a) next iterate
+    int op = -1;     // Manakov: 0 = S, 1 = H, 2 = I, 3 = D(a) next iterate
+    int want = 0;    // I stage: speculative continuation (0 none, 1 next iterate, 2 next step start)
     Ctrl c{}, n{};
     double *red = (double *)ctx.lds;
     if (kMk) {
         c = *a.cin;
         n = c;
-        if (MODE == CM_MK_A) {
-            if (c.state == ST_NEED_H) { op = 1; do_inv = do_fwd = true; n.state = ST_ROW_ITER; n.it = 0; }
-            else if (c.state == ST_NEED_I) { op = 2; do_inv = true; n.state = ST_NEED_D; }
-        } else {
-            if (c.state == ST_NEED_S) { op = 0; do_fwd = true; }
-            else if (c.state == ST_NEED_D) {
-                const double num = global_sum(ctx, a.pnum, a.npart, red);
-                const double den = global_sum(ctx, a.pden, a.npart, red);
-                ctx.sync();
-                const double lim = sqrt(num) / sqrt(den);                 // channels.py:517-519
-                const bool conv = lim < a.k.tol, last = c.it == a.k.maxIter - 1;
-                const bool lead = ctx.bid == 0 && ctx.tid == 0;
-                if (lead && c.trace_n < a.k.trace_cap && a.k.tr_lim)
-                    a.k.tr_lim[c.trace_n * a.k.maxIter + c.it] = lim;
-                n.cur = c.cur ^ 1;                                        // E_conv = E_fd
-                if (conv || last) {                                       // the step is over
-                    if (lead && c.trace_n < a.k.trace_cap) {
-                        if (a.k.tr_hz) a.k.tr_hz[c.trace_n] = c.hz;
-                        if (a.k.tr_it) a.k.tr_it[c.trace_n] = c.it + 1;
-                    }
-                    n.trace_n = c.trace_n + 1;
-                    n.steps = c.steps + 1;
-                    n.iterations = c.iterations + c.it + 1;
-                    if (!conv) n.nonconv = c.nonconv + 1;
-                    n.z = c.z + c.hz;
-                    n.it = 0;
-                    if (n.z < a.k.Lspan) { op = 0; do_fwd = true; }
-                    else n.state = ST_SPAN_DONE;
-                } else {
-                    n.it = c.it + 1;
-                    n.state = ST_ROW_ITER;
-                    op = 3;
-                    do_fwd = true;
+        if (c.state == ST_NEED_S || c.state == ST_FIX_S) {
+            op = 0;
+            do_fwd = true;
+            n.state = ST_AFTER_S;
+            if (c.state == ST_NEED_S) {                                   // span start: nothing decided yet
+                if (a.k.adaptive) n.hz_valid = 0;
+                else {
+                    n.hz = pick_hz(a.k, n.z, 0.0);
+                    n.hz_valid = 0;                                       // the Row derives the operator
                 }
             }
-        }
-        if (op == 0) {                                                    // step start bookkeeping
-            n.state = ST_AFTER_S;
-            if (a.k.adaptive) n.hz_valid = 0;
-            else {
-                n.hz = pick_hz(a.k, n.z, 0.0);
-                n.hz_valid = 1;
+        } else if (c.state == ST_NEED_H) {
+            op = 1;
+            do_inv = do_fwd = true;
+            n.state = ST_ROW_ITER;
+            n.it = 0;
+            n.spec = 0;
+        } else if (c.state == ST_NEED_I) {
+            op = 2;
+            do_inv = true;
+            n.state = ST_NEED_D;
+            const bool more_span = c.z + c.hz < a.k.Lspan;
+            if (c.it == a.k.maxIter - 1) want = more_span ? 2 : 0;        // the step ends here for sure
+            else if (c.pred_iters > 0) {
+                if (c.it + 1 < c.pred_iters) want = 1;
+                else if (c.it + 1 == c.pred_iters) want = more_span ? 2 : 0;
             }
+            n.spec = want;
+            do_fwd = want != 0;
+        } else if (c.state == ST_FIX_A) {
+            op = 3;
+            do_fwd = true;
+            n.state = ST_ROW_ITER;
         }
-        if (ctx.bid == 0 && ctx.tid == 0) {
-            if (op == 0 && !a.k.adaptive) n.lin = make_linop(n.hz / 2, a.k.lin_a, a.k.lin_b, a.k.w2, a.k.invN, a.k.log2N);
-            *a.cout = n;
-        }
+        if (ctx.bid == 0 && ctx.tid == 0) *a.cout = n;
         if (op < 0) return;
     } else {
         do_inv = MODE == CM_NLSE_STEP || MODE == CM_NLSE_LAST || MODE == CM_PLAIN_INV;
@@ -563,16 +670,18 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
 
     ColGeom<T, LG, Ctx> g(ctx, a);
     const PassPlan &p = g.p;
-    const int npol = kMk ? 2 : 1;
     cx<T> *lds = (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_slots_per_fft(p.L);
     cx<T> v[16];
 
     // buffers by role (Manakov): the field at the step start / last iterate, and the next iterate
     cx<T> *Tcur = a.T0, *Tnew = a.T1;
+    T *Pcur = a.P, *Palt = a.P;
     if (kMk) {
-        const int cur = (op == 2) ? c.cur : n.cur;     // I reads E_conv = T[c.cur]; S / D(a) use the new current
-        Tcur = cur ? a.T1 : a.T0;
-        Tnew = cur ? a.T0 : a.T1;
+        Tcur = c.cur ? a.T1 : a.T0;                  // E(z) at a step start, E_conv afterwards
+        Tnew = c.cur ? a.T0 : a.T1;                  // receives E_fd
+        const long long psz = (1ll << (a.log2N1 + a.log2N2)) * a.ngroups;
+        Pcur = a.P + (c.pcur ? psz : 0);
+        Palt = a.P + (c.pcur ? 0 : psz);
     }
 
     // ---- inverse column transform: G -> time samples in registers -------------------------
@@ -593,54 +702,25 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
 #pragma unroll
         for (int idx = 0; idx < 16; ++idx) a.T0[g.rowbase + g.time_off(idx)] = v[idx];
     } else if (kMk) {
-        T *shT = (T *)ctx.lds;                       // scratch: norms  [2][16][half]
-        cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));   // scratch: rotations [16][half] (disjoint)
-        const T c8g = (T)a.k.c8g, shz = (T)(a.k.sgn * c.hz);
-        if (op == 0 || op == 3) {                    // both need |Ex|^2 + |Ey|^2 of the registers
-            T mine[16], oth[16], ang[16];
-#pragma unroll
-            for (int idx = 0; idx < 16; ++idx) mine[idx] = norm2(v[idx]);
-            if (do_inv) ctx.sync();
-            pair_swap(ctx, g, mine, oth, shT);
-            if (op == 0) {                                               // S: Pch, max phi (channels.py:388-395)
-                double m = -INFINITY;
-#pragma unroll
-                for (int idx = 0; idx < 16; ++idx) {
-                    const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
-                    const T pw = ax + ay;
-                    if (g.pol == 0) a.P[g.pbase + g.time_off(idx)] = pw;
-                    const T phi = c8g * (pw + ax + ay) / (T)2;
-                    m = (double)phi > m ? (double)phi : m;
-                }
-                if (a.k.adaptive) {
-                    m = block_max(ctx, m, red);
-                    if (ctx.tid == 0) a.pmax[ctx.bid] = m;
-                }
-            } else {                                                     // D(a): next iterate (channels.py:436, 414-417)
-#pragma unroll
-                for (int idx = 0; idx < 16; ++idx) {
-                    const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
-                    const T pw = a.P[g.pbase + g.time_off(idx)];
-                    ang[idx] = shz * (c8g * (pw + ax + ay) / (T)2);
-                }
-                cx<T> rot[16];
-                pair_cis(ctx, g, npol, ang, rot, shC);
-#pragma unroll
-                for (int idx = 0; idx < 16; ++idx) v[idx] = a.Ehd[g.rowbase + g.time_off(idx)] * rot[idx];
-            }
-            ctx.sync();                              // scratch reads done before the FFT reuses the LDS
+        const T shz = (T)(a.k.sgn * c.hz);
+        if (op == 0) {                               // S (non-speculative): Pch into the current buffer
+            mk_step_start(ctx, g, a, v, Pcur, false);
+        } else if (op == 3) {                        // D(a) (non-speculative)
+            mk_next_iterate(ctx, g, a, v, Pcur, shz, false);
         } else if (op == 1) {                                            // H: E_hd, first rotation (channels.py:409-417)
+            cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));
+            const T c8g = (T)a.k.c8g;
             T ang[16];
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) {
                 const long long t = g.time_off(idx);
                 a.Ehd[g.rowbase + t] = v[idx];
-                const T pw = a.P[g.pbase + t];
+                const T pw = Pcur[g.pbase + t];
                 ang[idx] = shz * (c8g * (pw + pw) / (T)2);
             }
             cx<T> rot[16];
             ctx.sync();                              // inverse transform's LDS reads are done
-            pair_cis(ctx, g, npol, ang, rot, shC);
+            pair_cis(ctx, g, 2, ang, rot, shC);
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * rot[idx];
             ctx.sync();
@@ -661,6 +741,8 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
                 a.pnum[ctx.bid] = num;
                 a.pden[ctx.bid] = den;
             }
+            if (want == 1) mk_next_iterate(ctx, g, a, v, Pcur, shz, true);      // anticipate: not converged yet
+            else if (want == 2) mk_step_start(ctx, g, a, v, Palt, true);         // anticipate: next step starts from E_fd
         }
     }
 

@@ -140,8 +140,7 @@ struct EmuBackend {
         case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST>(c, a); }); break;
         case CM_NLSE_STEP: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_STEP>(c, a); }); break;
         case CM_NLSE_LAST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST>(c, a); }); break;
-        case CM_MK_A: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK_A>(c, a); }); break;
-        case CM_MK_B: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK_B>(c, a); }); break;
+        case CM_MK: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK>(c, a); }); break;
         case CM_PLAIN_FWD: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD>(c, a); }); break;
         default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV>(c, a); }); break;
         }

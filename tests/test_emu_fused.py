@@ -103,10 +103,23 @@ def test_manakov_vs_oracle_mid_size(N, adaptive):
 
 
 def test_launch_sequence_has_no_host_dependence_on_iteration_count():
-    """The host enqueues [Row, ColA, ColB] triples without reading results inside a chunk:
-    launches >= 3 per (step + iteration), and the surplus (no-op launches after the span
-    finished) stays bounded."""
+    """The host enqueues [Row, Col] pairs without reading results inside a chunk: two launches
+    per (step + iteration) when every continuation was anticipated, two more per miss, and the
+    surplus (no-op launches after the span finished) stays bounded."""
     d, cfg = load_golden("mk_fix_p8_ideal_2span")
     out, info = eb.run("manakovSSF", d["Ei"], cfg)
-    useful = 3 * (info["steps"] + info["iterations"])
+    useful = 2 * (info["steps"] + info["iterations"] + info["spec_misses"])
     assert useful <= info["launches"] <= 1.35 * useful + 64
+
+
+def test_speculation_hits_in_steady_state_and_recovers_from_misses():
+    """The I stage anticipates the continuation from the previous step's iteration count; a
+    wrong guess must only cost time.  Steady iteration counts => (almost) all hits; a case
+    whose counts change between steps => some misses, same results (checked by the golden test)."""
+    d, cfg = load_golden("mk_fix_p8_ideal_2span")          # 3 iterations every step
+    _, info = eb.run("manakovSSF", d["Ei"], cfg)
+    assert info["spec_misses"] <= 2 * 3 + 1                 # only the first step of each span start-up
+    assert info["spec_hits"] >= info["iterations"] - info["spec_misses"] - 4
+    d, cfg = load_golden("mk_fix_p13_ideal_k2")            # 3 <-> 4 iterations
+    _, info = eb.run("manakovSSF", d["Ei"], cfg)
+    assert info["spec_misses"] >= 2 and info["spec_hits"] > info["spec_misses"]
