@@ -80,7 +80,7 @@ template <typename T, class Backend> class FusedCore {
         const int Cc = half / tpf;
         *block = half * npol;
         *grid = groups * (N2 / Cc);
-        *lds = std::max((size_t)npol * Cc * lds_slots_per_fft(1 << sp.l1) * sizeof(C), (size_t)half * npol * 8 + 1024);
+        *lds = std::max((size_t)npol * Cc * lds_slots_per_fft(1 << sp.l1) * sizeof(C), (size_t)half * npol * 16 + 1024);
     }
 
     int init() {
@@ -90,7 +90,7 @@ template <typename T, class Backend> class FusedCore {
         while (nfft % fpw) fpw >>= 1;                          // (nrows need not be a power of two)
         row_block = fpw * tpf2;
         row_grid = (int)(nfft / fpw);
-        row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 8 + 2048);
+        row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 16 + 2048);
         col_geometry(std::max(nrows / 2, 1), 2, &col_block_mk, &col_grid_mk, &col_lds_mk);
         col_geometry(nrows, 1, &col_block_1, &col_grid_1, &col_lds_1);
         npart_max = std::max(col_grid_mk, col_grid_1);
@@ -144,6 +144,8 @@ template <typename T, class Backend> class FusedCore {
         a.log2N1 = sp.l1;
         a.log2N2 = sp.l2;
         a.nfft = (int)((int64_t)nrows << sp.l1);
+        a.stagger = be.row_stagger();
+        a.stagger_mode = be.row_stagger_mode();
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {

@@ -277,6 +277,36 @@ template <bool MAX, class Ctx> SSF_HD double block_reduce(Ctx &ctx, double v, do
     for (int i = 1; i < ng; ++i) s = MAX ? (red[i] > s ? red[i] : s) : s + red[i];
     return s;
 }
+// sum of two values at once (one barrier sequence): results in s0, s1
+template <class Ctx> SSF_HD void block_sum2(Ctx &ctx, double &s0, double &s1, double *red) {
+    ctx.sync();
+    red[2 * ctx.tid] = s0;
+    red[2 * ctx.tid + 1] = s1;
+    ctx.sync();
+    const int nt = ctx.nthreads, ng = nt < 64 ? nt : 64, per = nt / ng;
+    if (ctx.tid < ng) {
+        double a = 0, b = 0;
+        for (int i = 0; i < per; ++i) {
+            a += red[2 * (ctx.tid * per + i)];
+            b += red[2 * (ctx.tid * per + i) + 1];
+        }
+        s0 = a;
+        s1 = b;
+    }
+    ctx.sync();
+    if (ctx.tid < ng) {
+        red[2 * ctx.tid] = s0;
+        red[2 * ctx.tid + 1] = s1;
+    }
+    ctx.sync();
+    double a = 0, b = 0;
+    for (int i = 0; i < ng; ++i) {
+        a += red[2 * i];
+        b += red[2 * i + 1];
+    }
+    s0 = a;
+    s1 = b;
+}
 template <class Ctx> SSF_HD double block_sum(Ctx &ctx, double v, double *red) { return block_reduce<false>(ctx, v, red); }
 template <class Ctx> SSF_HD double block_max(Ctx &ctx, double v, double *red) { return block_reduce<true>(ctx, v, red); }
 // deterministic reduction of a global partial array by the whole block (same order in every block)
@@ -303,6 +333,8 @@ template <typename T> struct RowArgs {
     const double *pmax;       // adaptive: block maxima of phi written by the step-start stage
     const double *pnum, *pden;// convergence partial sums written by the I stage
     int npart;
+    int stagger;              // late start of half of the workgroups, in units of 64 clocks (0 = off)
+    int stagger_mode;         // which half: 0 = upper half of the grid, 1 = odd groups of 8 blocks
 };
 
 // linear operator for the 16 registers of a last-radix-16 butterfly: bins k0 + (N/16) q
@@ -346,14 +378,31 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     cx<T> *lds = (cx<T> *)ctx.lds;
     LinOp *lsh = (LinOp *)ctx.lds;            // only used before the FFT touches the LDS
     LinOp lo;
+    const PassPlan p = make_plan(LG > 0 ? LG : a.log2N2);
+    const int fpw = ctx.nthreads / p.tpf;                  // row transforms per workgroup
+    const int f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
+    const long long rr = (long long)ctx.bid * fpw + f;     // global row-transform index (grid is exact)
+    cx<T> *g = a.G + (rr << a.log2N2);
+    cx<T> v[16];
+    // The row is fetched before the control block is evaluated: the loads do not depend on the
+    // decision, and their latency hides the reduction below (a launch that turns out to have
+    // nothing to do just drops them).  Half of the workgroups may start late (a.stagger) so that
+    // one co-resident workgroup computes while the other one is still waiting for HBM.
+    if (a.stagger > 0 && (a.stagger_mode ? ((ctx.bid >> 3) & 1) : (ctx.bid >= (ctx.nblocks >> 1)))) ctx.sleep(a.stagger);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = g[b + p.tpf * q];
     if (a.use_ctrl) {
         const Ctrl c = *a.cin;
         Ctrl n = c;
         double *red = (double *)(ctx.lds) + 64;
         bool act = c.state == ST_AFTER_S || c.state == ST_ROW_ITER;
         if (c.state == ST_NEED_D) {           // convergence decision (channels.py:424-434), same in every block
-            const double num = global_sum(ctx, a.pnum, a.npart, red);
-            const double den = global_sum(ctx, a.pden, a.npart, red);
+            double num = 0, den = 0;
+            for (int i = ctx.tid; i < a.npart; i += ctx.nthreads) {
+                num += a.pnum[i];
+                den += a.pden[i];
+            }
+            block_sum2(ctx, num, den, red);
             const double lim = sqrt(num) / sqrt(den);                     // channels.py:517-519
             const bool conv = lim < a.k.tol, last = c.it == a.k.maxIter - 1;
             const bool lead = ctx.bid == 0 && ctx.tid == 0;
@@ -425,17 +474,10 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     } else {
         lo = *a.lin;
     }
-    const PassPlan p = make_plan(LG > 0 ? LG : a.log2N2);
-    const int fpw = ctx.nthreads / p.tpf;                  // row transforms per workgroup
-    const int f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
-    const long long rr = (long long)ctx.bid * fpw + f;     // global row-transform index
-    if (rr >= a.nfft) return;                              // (grid is exact; kept for safety)
     const int N1 = 1 << a.log2N1, log2N = a.log2N1 + a.log2N2;
     const int k1 = (int)(rr & (N1 - 1));
-    cx<T> *g = a.G + (rr << a.log2N2);
     cx<T> *l = lds + (size_t)f * lds_slots_per_fft(p.L);
-    cx<T> v[16];
-    // load natural n2 = b + tpf*q, times W_N^{n2 k1}
+    // natural n2 = b + tpf*q, times W_N^{n2 k1}
     {
         const long long N = 1ll << log2N;
         const cx<T> w0 = cis2pi<T>(-scale_pow2((double)(((long long)k1 * b) & (N - 1)), log2N));
@@ -443,7 +485,7 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
         cx<T> w[16];
         powers16(ws, w);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = g[b + p.tpf * q] * (w0 * w[q]);
+        for (int q = 0; q < 16; ++q) v[q] = v[q] * (w0 * w[q]);
     }
     fft_dif<-1>(ctx, p, b, v, l);
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
@@ -735,8 +777,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
                 num += dr * dr + di * di;
                 den += (double)e.re * e.re + (double)e.im * e.im;
             }
-            num = block_sum(ctx, num, red);
-            den = block_sum(ctx, den, red);
+            block_sum2(ctx, num, den, red);
             if (ctx.tid == 0) {
                 a.pnum[ctx.bid] = num;
                 a.pden[ctx.bid] = den;

@@ -26,6 +26,7 @@ struct EmuCtx {
     int tid, bid, nthreads, nblocks;
     char *lds;
     void sync();
+    void sleep(int) {}
 };
 
 struct Fiber {
@@ -124,6 +125,8 @@ struct EmuBackend {
     void d2d(void *d, const void *s, size_t n) { memcpy(d, s, n); }
     void memset(void *d, int v, size_t n) { ::memset(d, v, n); }
     void prepare(size_t, size_t) {}
+    int row_stagger() const { return 0; }
+    int row_stagger_mode() const { return 0; }
     void sync() {}
     bool ok() const { return true; }
     std::string last_error() const { return ""; }
