@@ -11,8 +11,9 @@
 //        -> time-domain work on registers (power, Kerr rotation, norms, E_hd / E_conv I/O)
 //        -> [forward column FFT (DIT, digit-reversed in, natural k1 out) -> G]
 //   row kernel (one contiguous row of N2 per transform):
-//        G * W_N^{n2 k1} -> forward row FFT (DIF) -> * linear operator (from the bin index)
-//        -> inverse row FFT (DIT) -> * conj(W_N^{n2 k1}) / N -> G
+//        G -> forward row FFT (DIF) -> * linear operator / N (from the bin index)
+//        -> inverse row FFT (DIT) -> G
+//   (the inter-pass twiddle W_N^{n2 k1} is applied by the column kernel on its G loads/stores)
 //
 // so FFT . H . IFFT costs two HBM round trips and no transposes.  Reference semantics:
 // optic/models/channels.py:387-441 (Manakov step), :219-229 (NLSE step).
@@ -477,16 +478,6 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     const int N1 = 1 << a.log2N1, log2N = a.log2N1 + a.log2N2;
     const int k1 = (int)(rr & (N1 - 1));
     cx<T> *l = lds + (size_t)f * lds_slots_per_fft(p.L);
-    // natural n2 = b + tpf*q, times W_N^{n2 k1}
-    {
-        const long long N = 1ll << log2N;
-        const cx<T> w0 = cis2pi<T>(-scale_pow2((double)(((long long)k1 * b) & (N - 1)), log2N));
-        const cx<T> ws = cis2pi<T>(-scale_pow2((double)(((long long)k1 * p.tpf) & (N - 1)), log2N));
-        cx<T> w[16];
-        powers16(ws, w);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = v[q] * (w0 * w[q]);
-    }
     fft_dif<-1>(ctx, p, b, v, l);
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
     const int last = p.npass - 1;
@@ -501,15 +492,8 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
         }
     }
     fft_dit<+1>(ctx, p, b, v, l);
-    {
-        const long long N = 1ll << log2N;
-        const cx<T> w0 = cis2pi<T>(scale_pow2((double)(((long long)k1 * b) & (N - 1)), log2N));
-        const cx<T> ws = cis2pi<T>(scale_pow2((double)(((long long)k1 * p.tpf) & (N - 1)), log2N));
-        cx<T> w[16];
-        powers16(ws, w);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) g[b + p.tpf * q] = v[q] * (w0 * w[q]);
-    }
+    for (int q = 0; q < 16; ++q) g[b + p.tpf * q] = v[q];
 }
 
 // --------------------------------------------------------------------------- column kernel
@@ -568,6 +552,19 @@ template <typename T, int LG, class Ctx> struct ColGeom {
         return (long long)rev_pos(p, reg_pos(p, p.npass - 1, b, idx)) * N2 + n2;
     }
 };
+
+// inter-pass twiddle of the N = N1*N2 decomposition, applied on the frequency side of the
+// column kernel (which is HBM-bound and has VALU head-room; the row kernel is VALU-bound):
+// register q holds k1 = b + tpf*q of column n2  ->  v[q] *= cis(SIGN * 2 pi n2 k1 / N)
+template <int SIGN, typename T, class G> SSF_HD void global_twiddle(const G &g, int log2N, cx<T> *v) {
+    const long long N = 1ll << log2N;
+    const cx<T> w0 = cis2pi<T>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.b) & (N - 1)), log2N));
+    const cx<T> ws = cis2pi<T>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.p.tpf) & (N - 1)), log2N));
+    cx<T> w[16];
+    powers16(ws, w);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = v[q] * (w0 * w[q]);
+}
 
 // exchange 16 per-thread values with the partner thread (same column/butterfly, other
 // polarisation) through LDS scratch `sh` (2*16*half values); one barrier inside.
@@ -730,6 +727,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     if (do_inv) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = a.G[g.rowbase + g.freq_off(q)];
+        global_twiddle<+1>(g, a.log2N1 + a.log2N2, v);
         fft_dif<+1>(ctx, p, g.b, v, lds);
     } else {
 #pragma unroll
@@ -791,6 +789,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     if (do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
         fft_dit<-1>(ctx, p, g.b, v, lds);
+        global_twiddle<-1>(g, a.log2N1 + a.log2N2, v);
 #pragma unroll
         for (int q = 0; q < 16; ++q) a.G[g.rowbase + g.freq_off(q)] = v[q];
     }
