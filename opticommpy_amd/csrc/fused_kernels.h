@@ -661,46 +661,61 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     bool do_inv = false, do_fwd = false;
     int op = -1;     // Manakov: 0 = S, 1 = H, 2 = I, 3 = D(a) next iterate
     int want = 0;    // I stage: speculative continuation (0 none, 1 next iterate, 2 next step start)
-    Ctrl c{}, n{};
+    struct { int state, it, cur, pcur, pred_iters; double z, hz; } c{};
     double *red = (double *)ctx.lds;
     if (kMk) {
-        c = *a.cin;
-        n = c;
+        // only scalars are taken from the control block (a private copy of the struct would live
+        // in scratch memory and cost real HBM traffic on every launch)
+        c.state = a.cin->state;
+        c.it = a.cin->it;
+        c.cur = a.cin->cur;
+        c.pcur = a.cin->pcur;
+        c.pred_iters = a.cin->pred_iters;
+        c.z = a.cin->z;
+        c.hz = a.cin->hz;
+        int n_state = c.state, n_it = c.it, n_spec = a.cin->spec, n_hz_valid = a.cin->hz_valid;
+        double n_hz = c.hz;
         if (c.state == ST_NEED_S || c.state == ST_FIX_S) {
             op = 0;
             do_fwd = true;
-            n.state = ST_AFTER_S;
+            n_state = ST_AFTER_S;
             if (c.state == ST_NEED_S) {                                   // span start: nothing decided yet
-                if (a.k.adaptive) n.hz_valid = 0;
-                else {
-                    n.hz = pick_hz(a.k, n.z, 0.0);
-                    n.hz_valid = 0;                                       // the Row derives the operator
-                }
+                if (!a.k.adaptive) n_hz = pick_hz(a.k, c.z, 0.0);
+                n_hz_valid = 0;                                           // the Row derives hz / the operator
             }
         } else if (c.state == ST_NEED_H) {
             op = 1;
             do_inv = do_fwd = true;
-            n.state = ST_ROW_ITER;
-            n.it = 0;
-            n.spec = 0;
+            n_state = ST_ROW_ITER;
+            n_it = 0;
+            n_spec = 0;
         } else if (c.state == ST_NEED_I) {
             op = 2;
             do_inv = true;
-            n.state = ST_NEED_D;
+            n_state = ST_NEED_D;
             const bool more_span = c.z + c.hz < a.k.Lspan;
             if (c.it == a.k.maxIter - 1) want = more_span ? 2 : 0;        // the step ends here for sure
             else if (c.pred_iters > 0) {
                 if (c.it + 1 < c.pred_iters) want = 1;
                 else if (c.it + 1 == c.pred_iters) want = more_span ? 2 : 0;
             }
-            n.spec = want;
+            n_spec = want;
             do_fwd = want != 0;
         } else if (c.state == ST_FIX_A) {
             op = 3;
             do_fwd = true;
-            n.state = ST_ROW_ITER;
+            n_state = ST_ROW_ITER;
         }
-        if (ctx.bid == 0 && ctx.tid == 0) *a.cout = n;
+        if (ctx.bid == 0 && ctx.tid == 0) {                               // forward the control block
+            const unsigned long long *src = (const unsigned long long *)a.cin;
+            unsigned long long *dst = (unsigned long long *)a.cout;
+            for (int i = 0; i < (int)(sizeof(Ctrl) / 8); ++i) dst[i] = src[i];
+            a.cout->state = n_state;
+            a.cout->it = n_it;
+            a.cout->spec = n_spec;
+            a.cout->hz_valid = n_hz_valid;
+            a.cout->hz = n_hz;
+        }
         if (op < 0) return;
     } else {
         do_inv = MODE == CM_NLSE_STEP || MODE == CM_NLSE_LAST || MODE == CM_PLAIN_INV;
