@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--engine", default=os.environ.get("SSF_ENGINE", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=16)
+    ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel HIP-event pass")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +129,7 @@ def main():
     # per-kernel timing pass (HIP events around every launch on the plan stream; separate from the
     # headline run because the events themselves cost a few microseconds per launch)
     kernels = None
-    if rank == 0 and lib.ssf_set_profiling(h, 1) == 0:
+    if rank == 0 and not args.no_kernel_times and lib.ssf_set_profiling(h, 1) == 0:
         nprof = min(args.steps, 200)
         _, stp = run(nprof, soa)
         kt = _lib.KernelTimes()
@@ -175,7 +176,13 @@ def main():
         traffic_file = os.path.join(ROOT, "profiles", "traffic_bytes_per_step.json")
         if os.path.exists(traffic_file):
             try:
-                rec["roofline"]["traffic"] = json.load(open(traffic_file)).get(_lib.ENGINE_NAMES[st.engine])
+                t = json.load(open(traffic_file)).get(_lib.ENGINE_NAMES[st.engine])
+                if t and args.log2n == 20 and args.prec == "c128":
+                    # PMC-measured HBM-side bytes per step (separate rocprofv3 passes, see profiles/), scaled from
+                    # the profiled iteration count to this run's: traffic is linear in (1 + iterations/step)
+                    scale = (1.0 + st.iterations / st.steps) / (1.0 + t["iterations_per_step"])
+                    rec["roofline"]["traffic"] = t["bytes_per_step"] * scale
+                    rec["roofline"]["traffic_source"] = "profiles/traffic_bytes_per_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %d steps at %.2f it/step)" % (t["steps"], t["iterations_per_step"])
             except Exception:
                 pass
         if not args.no_cpu_baseline and world == 1:

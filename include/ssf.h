@@ -144,6 +144,12 @@ int  ssf_execute(ssf_plan *plan, const ssf_params *params, int32_t span_first,
                  int32_t span_last, const void *noise, ssf_stats *stats, ssf_trace *trace);
 int  ssf_download(ssf_plan *plan, void *field_soa);         /* (nrows, N) complex        */
 int  ssf_download_snapshots(ssf_plan *plan, void *snap_soa);/* (n_snapshots, nrows, N)   */
+/* Same transfers in the reference's own array layout: (N, nrows) row-major, i.e. the C-contiguous
+ * numpy field with columns [x0, y0, x1, y1, ...]; the AoS <-> SoA conversion runs on the device
+ * (Ei_[:, 0::2].T / Ech[:, 0::2] = Ech_x.T in the reference, modelsGPU.py:406-407, 506-509).
+ * which = -1: the current field; which >= 0: snapshot number `which`. */
+int  ssf_upload_aos(ssf_plan *plan, const void *field_aos);
+int  ssf_download_aos(ssf_plan *plan, int32_t which, void *field_aos);
 
 /* ---- one-shot: upload + execute all spans + download -------------------------------- */
 int  ssf_run(ssf_plan *plan, const ssf_params *params, const void *field_in_soa,

@@ -168,6 +168,16 @@ struct HipBackend {
         chk(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, pl->stream), "hipMemcpyAsync D2H");
         chk(hipStreamSynchronize(pl->stream), "hipStreamSynchronize");
     }
+    void h2d_big(void *d, const void *h, size_t n) { chk(pl->stager.h2d(d, h, n, pl->stream), "staged H2D"); }
+    void d2h_big(void *h, const void *d, size_t n) { chk(pl->stager.d2h(h, d, n, pl->stream), "staged D2H"); }
+    template <typename C> void aos_to_soa(C *soa, const C *aos, long long N, int nrows) {
+        k_aos_to_soa<C><<<1024, 256, 0, pl->stream>>>(aos, soa, N, nrows);
+        chk(hipStreamSynchronize(pl->stream), "aos_to_soa");
+    }
+    template <typename C> void soa_to_aos(C *aos, const C *soa, long long N, int nrows) {
+        k_soa_to_aos<C><<<1024, 256, 0, pl->stream>>>(soa, aos, N, nrows);
+        chk(hipGetLastError(), "soa_to_aos");
+    }
     void d2d(void *d, const void *s, size_t n) {
         chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, pl->stream), "hipMemcpyAsync D2D");
     }
@@ -236,12 +246,12 @@ template <typename T> class FusedEngine final : public Engine {
         return rc;
     }
     int init() { return ret(core.init()); }
-    int upload(const void *soa) override {
+    int upload(const void *field, bool aos) override {
         be.kt = ssf_kernel_times{};
-        return ret(core.upload(soa));
+        return ret(core.upload(field, aos));
     }
-    int download(void *soa) override { return ret(core.download(soa)); }
-    int download_snapshots(void *soa) override { return ret(core.download_snapshots(soa)); }
+    int download(void *field, int which, bool aos) override { return ret(core.download(field, which, aos)); }
+    int n_snapshots() const override { return (int)core.snaps.size(); }
     int execute(const ssf_params &p, int s0, int s1, const void *noise, ssf_stats *st, ssf_trace *tr) override {
         return ret(core.execute(p, s0, s1, noise, st, tr));
     }

@@ -273,24 +273,27 @@ template <typename T> class RocfftEngine final : public Engine {
         if (ev1) (void)hipEventDestroy(ev1);
     }
 
-    int upload(const void *soa) override {
+    int upload(const void *field, bool aos) override {
         E = bufA;
-        SSF_HIP(pl, hipMemcpyAsync(E, soa, field_bytes, hipMemcpyHostToDevice, pl->stream));
-        SSF_HIP(pl, hipStreamSynchronize(pl->stream));
+        hipError_t e = pl->stager.h2d(aos ? F : E, field, field_bytes, pl->stream);
+        if (e != hipSuccess) return fail(pl, SSF_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+        if (aos) {
+            k_aos_to_soa<C><<<grid_for(N * nrows), kBlock, 0, pl->stream>>>(F, E, N, nrows);
+            SSF_HIP(pl, hipStreamSynchronize(pl->stream));
+        }
         for (C *s : snaps) (void)hipFree(s);
         snaps.clear();
         return SSF_OK;
     }
-    int download(void *soa) override {
-        SSF_HIP(pl, hipMemcpyAsync(soa, E, field_bytes, hipMemcpyDeviceToHost, pl->stream));
-        SSF_HIP(pl, hipStreamSynchronize(pl->stream));
-        return SSF_OK;
-    }
-    int download_snapshots(void *soa) override {
-        for (size_t i = 0; i < snaps.size(); ++i)
-            SSF_HIP(pl, hipMemcpyAsync((char *)soa + i * field_bytes, snaps[i], field_bytes, hipMemcpyDeviceToHost,
-                                       pl->stream));
-        SSF_HIP(pl, hipStreamSynchronize(pl->stream));
+    int n_snapshots() const override { return (int)snaps.size(); }
+    int download(void *field, int which, bool aos) override {
+        const C *src = which < 0 ? E : snaps[(size_t)which];
+        if (aos) {
+            k_soa_to_aos<C><<<grid_for(N * nrows), kBlock, 0, pl->stream>>>(src, F, N, nrows);
+            src = F;
+        }
+        hipError_t e = pl->stager.d2h(field, src, field_bytes, pl->stream);
+        if (e != hipSuccess) return fail(pl, SSF_ERR_HIP, std::string("download: ") + hipGetErrorString(e));
         return SSF_OK;
     }
 

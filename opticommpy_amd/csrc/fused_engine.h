@@ -117,19 +117,21 @@ template <typename T, class Backend> class FusedCore {
 
     C *Tcur() { return cur ? T1 : T0; }
 
-    int upload(const void *soa) {
+    int upload(const void *field, bool aos) {
         cur = 0;
-        be.h2d(T0, soa, field_bytes);
+        be.h2d_big(aos ? G : T0, field, field_bytes);
+        if (aos) be.aos_to_soa(T0, G, N, nrows);
         for (C *s : snaps) be.free(s);
         snaps.clear();
         return be.ok() ? SSF_OK : hiperr();
     }
-    int download(void *soa) {
-        be.d2h(soa, Tcur(), field_bytes);
-        return be.ok() ? SSF_OK : hiperr();
-    }
-    int download_snapshots(void *soa) {
-        for (size_t i = 0; i < snaps.size(); ++i) be.d2h((char *)soa + i * field_bytes, snaps[i], field_bytes);
+    int download(void *field, int which, bool aos) {
+        const C *src = which < 0 ? Tcur() : snaps[(size_t)which];
+        if (aos) {
+            be.soa_to_aos(G, src, N, nrows);
+            src = G;
+        }
+        be.d2h_big(field, src, field_bytes);
         return be.ok() ? SSF_OK : hiperr();
     }
     int hiperr() {

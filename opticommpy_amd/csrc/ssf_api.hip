@@ -79,6 +79,7 @@ int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int
         delete pl;
         return set_err(SSF_ERR_HIP, "hipStreamCreate failed");
     }
+    (void)pl->stager.init();          // falls back to plain copies if pinned memory is unavailable
     int want = engine;
     if (want == SSF_ENGINE_AUTO) want = fused_supports(N, nrows, precision) ? SSF_ENGINE_FUSED : SSF_ENGINE_ROCFFT;
     if (want == SSF_ENGINE_FUSED && !fused_supports(N, nrows, precision)) {
@@ -108,17 +109,19 @@ int ssf_plan_destroy(ssf_plan *plan) {
     return SSF_OK;
 }
 
-int ssf_upload(ssf_plan *plan, const void *field_soa) {
+static int upload_common(ssf_plan *plan, const void *field, bool aos) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
-    if (!field_soa) return fail(plan, SSF_ERR_BAD_ARG, "field is NULL");
+    if (!field) return fail(plan, SSF_ERR_BAD_ARG, "field is NULL");
     SSF_HIP(plan, hipSetDevice(plan->device));
-    int rc = plan->engine->upload(field_soa);
+    int rc = plan->engine->upload(field, aos);
     if (rc) return rc;
     plan->stats = ssf_stats{};
     plan->stats.engine = plan->engine_id;
     plan->has_field = true;
     return SSF_OK;
 }
+int ssf_upload(ssf_plan *plan, const void *field_soa) { return upload_common(plan, field_soa, false); }
+int ssf_upload_aos(ssf_plan *plan, const void *field_aos) { return upload_common(plan, field_aos, true); }
 
 int ssf_execute(ssf_plan *plan, const ssf_params *params, int32_t span_first, int32_t span_last, const void *noise,
                 ssf_stats *stats, ssf_trace *trace) {
@@ -138,19 +141,26 @@ int ssf_execute(ssf_plan *plan, const ssf_params *params, int32_t span_first, in
     return SSF_OK;
 }
 
-int ssf_download(ssf_plan *plan, void *field_soa) {
+static int download_common(ssf_plan *plan, void *dst, int which, bool aos) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
-    if (!field_soa) return fail(plan, SSF_ERR_BAD_ARG, "field is NULL");
-    if (!plan->has_field) return fail(plan, SSF_ERR_STATE, "ssf_download before ssf_upload");
+    if (!dst) return fail(plan, SSF_ERR_BAD_ARG, "destination is NULL");
+    if (!plan->has_field) return fail(plan, SSF_ERR_STATE, "download before ssf_upload");
+    if (which < -1 || which >= plan->engine->n_snapshots()) return fail(plan, SSF_ERR_BAD_ARG, "no such snapshot");
     SSF_HIP(plan, hipSetDevice(plan->device));
-    return plan->engine->download(field_soa);
+    return plan->engine->download(dst, which, aos);
 }
+int ssf_download(ssf_plan *plan, void *field_soa) { return download_common(plan, field_soa, -1, false); }
+int ssf_download_aos(ssf_plan *plan, int32_t which, void *field_aos) { return download_common(plan, field_aos, which, true); }
 
 int ssf_download_snapshots(ssf_plan *plan, void *snap_soa) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     if (!snap_soa) return fail(plan, SSF_ERR_BAD_ARG, "snapshot buffer is NULL");
-    SSF_HIP(plan, hipSetDevice(plan->device));
-    return plan->engine->download_snapshots(snap_soa);
+    const size_t fb = (size_t)plan->N * plan->nrows * (plan->precision == SSF_C128 ? 16 : 8);
+    for (int i = 0; i < plan->engine->n_snapshots(); ++i) {
+        int rc = download_common(plan, (char *)snap_soa + (size_t)i * fb, i, false);
+        if (rc) return rc;
+    }
+    return SSF_OK;
 }
 
 int ssf_run(ssf_plan *plan, const ssf_params *params, const void *in, void *out, void *snaps, const void *noise,

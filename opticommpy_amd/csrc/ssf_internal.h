@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ssf.h"
+#include "ssf_copy.h"
 #include "ssf_derived.h"
 
 namespace ssf {
@@ -38,11 +39,11 @@ struct TraceSink {
 class Engine {
   public:
     virtual ~Engine() {}
-    virtual int upload(const void *soa) = 0;
+    virtual int upload(const void *field, bool aos) = 0;
     virtual int execute(const ssf_params &p, int span_first, int span_last, const void *noise,
                         ssf_stats *stats, ssf_trace *trace) = 0;
-    virtual int download(void *soa) = 0;
-    virtual int download_snapshots(void *soa) = 0;
+    virtual int download(void *field, int which, bool aos) = 0;      // which: -1 current, >= 0 snapshot
+    virtual int n_snapshots() const = 0;
     virtual int linear_channel(double Fs, double Fc, double alpha, double D, double L) = 0;
     virtual int id() const = 0;
     virtual int set_profiling(int) { return SSF_ERR_UNSUPPORTED; }
@@ -62,6 +63,7 @@ struct ssf_plan {
     ssf_stats stats{};
     std::string err;
     bool has_field = false;
+    ssf::Stager stager;
 };
 
 namespace ssf {

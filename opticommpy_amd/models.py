@@ -320,7 +320,8 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
     Nspans = int(np.floor(param.Ltotal / param.Lspan))
     prec = _prec_code(param.prec)
     pl = _get_plan(N, ncols, prec)
-    soa = np.ascontiguousarray(Ei.T, dtype=pl.dtype)            # (2K, N): rows x0, y0, x1, y1, ...
+    # the reference's own layout goes over the bus; the (N, 2K) -> (2K, N) conversion runs on the GPU
+    aos = np.ascontiguousarray(Ei, dtype=pl.dtype)
 
     captured = _captured_spans(save_list, Nspans)
     save_arr = np.array(captured, dtype=np.int32)
@@ -341,7 +342,7 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
             return _span_noise(ncols, N, p_noise, s, True, pl.dtype)
 
     logg.info("Running Manakov SSF model on GPU (HIP, %s)..." % ("forward" if direction > 0 else "DBP"))
-    pl.check(pl.lib.ssf_upload(pl.h, soa.ctypes.data_as(C.c_void_p)))
+    pl.check(pl.lib.ssf_upload_aos(pl.h, aos.ctypes.data_as(C.c_void_p)))
     if param.nlprMethod:
         hint = 1 << 16
     else:
@@ -351,17 +352,20 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
         logg.warning(NONCONV_WARNING.format(param.maxIter))
 
     if save_list:
-        out = np.zeros((N, ncols * len(save_list)), dtype=pl.dtype)
-        if st.n_snapshots:
-            snaps = np.empty((st.n_snapshots, ncols, N), dtype=pl.dtype)
-            pl.check(pl.lib.ssf_download_snapshots(pl.h, snaps.ctypes.data_as(C.c_void_p)))
+        nblk = len(save_list)
+        if nblk == 1 and st.n_snapshots == 1:
+            out = np.empty((N, ncols), dtype=pl.dtype)
+            pl.check(pl.lib.ssf_download_aos(pl.h, 0, out.ctypes.data_as(C.c_void_p)))
+        else:
+            out = np.zeros((N, ncols * nblk), dtype=pl.dtype)
+            tmp = np.empty((N, ncols), dtype=pl.dtype)
             for i in range(st.n_snapshots):
-                out[:, 2 * i: 2 * i + 2] = snaps[i].T
+                pl.check(pl.lib.ssf_download_aos(pl.h, i, tmp.ctypes.data_as(C.c_void_p)))
+                out[:, 2 * i: 2 * i + 2] = tmp
     else:
-        res = np.empty((ncols, N), dtype=pl.dtype)
-        pl.check(pl.lib.ssf_download(pl.h, res.ctypes.data_as(C.c_void_p)))
-        out = Ei.copy()
-        out[:, :] = res.T
+        res = np.empty((N, ncols), dtype=pl.dtype)
+        pl.check(pl.lib.ssf_download_aos(pl.h, -1, res.ctypes.data_as(C.c_void_p)))
+        out = res if (Ei.dtype == pl.dtype) else res.astype(Ei.dtype)     # `Ech = Ei.copy(); Ech[:, 0::2] = ...`
     return (out, param) if param.returnParameters else out
 
 

@@ -123,6 +123,16 @@ struct EmuBackend {
     void h2d(void *d, const void *h, size_t n) { memcpy(d, h, n); }
     void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
     void d2d(void *d, const void *s, size_t n) { memcpy(d, s, n); }
+    void h2d_big(void *d, const void *h, size_t n) { memcpy(d, h, n); }
+    void d2h_big(void *h, const void *d, size_t n) { memcpy(h, d, n); }
+    template <typename C> void aos_to_soa(C *soa, const C *aos, long long N, int nrows) {
+        for (long long n = 0; n < N; ++n)
+            for (int r = 0; r < nrows; ++r) soa[(long long)r * N + n] = aos[n * nrows + r];
+    }
+    template <typename C> void soa_to_aos(C *aos, const C *soa, long long N, int nrows) {
+        for (long long n = 0; n < N; ++n)
+            for (int r = 0; r < nrows; ++r) aos[n * nrows + r] = soa[(long long)r * N + n];
+    }
     void memset(void *d, int v, size_t n) { ::memset(d, v, n); }
     void prepare(size_t, size_t) {}
     int row_stagger() const { return 0; }
@@ -161,7 +171,7 @@ int run_t(int64_t N, int nrows, int prec, const ssf_params *p, const void *in, v
     ssf::fused::FusedCore<T, EmuBackend> core(be, N, nrows, prec);
     int rc = core.init();
     if (rc) return rc;
-    if ((rc = core.upload(in))) return rc;
+    if ((rc = core.upload(in, false))) return rc;
     ssf_stats s{};
     if (tr) tr->count = 0;
     if ((rc = core.execute(*p, 1, p->Nspans, noise, &s, tr))) {
@@ -171,8 +181,10 @@ int run_t(int64_t N, int nrows, int prec, const ssf_params *p, const void *in, v
     s.bytes_algorithmic = (double)s.transforms * 2.0 * sizeof(ssf::fused::cx<T>) * (double)N;
     s.engine = SSF_ENGINE_FUSED;
     if (st) *st = s;
-    if (out && (rc = core.download(out))) return rc;
-    if (snaps && !core.snaps.empty() && (rc = core.download_snapshots(snaps))) return rc;
+    if (out && (rc = core.download(out, -1, false))) return rc;
+    if (snaps)
+        for (size_t i = 0; i < core.snaps.size(); ++i)
+            if ((rc = core.download((char *)snaps + i * core.field_bytes, (int)i, false))) return rc;
     if (launches) *launches = be.launches;
     return SSF_OK;
 }
@@ -184,9 +196,9 @@ int lin_t(int64_t N, int nrows, int prec, double Fs, double Fc, double alpha, do
     ssf::fused::FusedCore<T, EmuBackend> core(be, N, nrows, prec);
     int rc = core.init();
     if (rc) return rc;
-    if ((rc = core.upload(in))) return rc;
+    if ((rc = core.upload(in, false))) return rc;
     if ((rc = core.linear_channel(Fs, Fc, alpha, D, L))) return rc;
-    return core.download(out);
+    return core.download(out, -1, false);
 }
 
 }  // namespace
