@@ -85,6 +85,9 @@ typedef struct {
     int32_t n_save;           /* number of entries of save_spans (0 = final field only)  */
     int32_t reserved;
     const int32_t *save_spans;/* 1-based span indexes to snapshot (reference saveSpanN)  */
+    int64_t rng_seed;         /* amp == EDFA and no host noise given: != 0 -> ASE noise is */
+                              /* generated on the device (Philox4x32-10 keyed by rng_seed, */
+                              /* counter = sample/row/span); 0 -> gain only                */
 } ssf_params;
 
 typedef struct {
@@ -138,7 +141,8 @@ int  ssf_upload(ssf_plan *plan, const void *field_soa);     /* (nrows, N) comple
 /* Propagate spans [span_first, span_last] (1-based, inclusive) of `params`.
  * noise: NULL, or host array (span_last-span_first+1, nrows, N) complex added after
  *        the span gain when amp == SSF_AMP_EDFA (row r of span s at
- *        ((s-span_first)*nrows + r)*N); NULL with EDFA = gain only.
+ *        ((s-span_first)*nrows + r)*N); NULL with EDFA = device-generated noise when
+ *        params->rng_seed != 0, gain only otherwise.
  * stats/trace may be NULL; stats accumulate until ssf_upload resets them. */
 int  ssf_execute(ssf_plan *plan, const ssf_params *params, int32_t span_first,
                  int32_t span_last, const void *noise, ssf_stats *stats, ssf_trace *trace);

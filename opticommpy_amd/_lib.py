@@ -23,7 +23,7 @@ class Params(C.Structure):
                 ("Nspans", C.c_int32), ("maxIter", C.c_int32), ("hz", C.c_double), ("tol", C.c_double),
                 ("nlprMethod", C.c_int32), ("amp", C.c_int32), ("maxNlinPhaseRot", C.c_double),
                 ("NF", C.c_double), ("n_save", C.c_int32), ("reserved", C.c_int32),
-                ("save_spans", C.POINTER(C.c_int32))]
+                ("save_spans", C.POINTER(C.c_int32)), ("rng_seed", C.c_int64)]
 
 
 class Stats(C.Structure):

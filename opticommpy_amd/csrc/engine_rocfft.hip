@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "ssf_internal.h"
+#include "ssf_rng.h"
 
 namespace ssf {
 namespace {
@@ -186,7 +187,8 @@ __global__ void k_finish(const double *a, const double *b, const double *c, int 
 
 // span epilogue: E = E*gain (+ noise)      (channels.py:443-451, devices.py:726)
 template <typename T>
-__global__ void k_amp(typename Cx<T>::type *E, int64_t total, T gain, const typename Cx<T>::type *noise) {
+__global__ void k_amp(typename Cx<T>::type *E, int64_t total, T gain, const typename Cx<T>::type *noise,
+                      double sigma = 0.0, unsigned long long seed = 0, unsigned span = 0, int64_t N = 1) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         auto e = E[i];
         e.x *= gain;
@@ -194,6 +196,12 @@ __global__ void k_amp(typename Cx<T>::type *E, int64_t total, T gain, const type
         if (noise) {
             e.x += noise[i].x;
             e.y += noise[i].y;
+        }
+        if (sigma > 0) {       // device-generated ASE (same generator as the fused engine)
+            double re, im;
+            gauss_pair((unsigned long long)(i % N), (unsigned)(i / N), span, seed, sigma, re, im);
+            e.x += (T)re;
+            e.y += (T)im;
         }
         E[i] = e;
     }
@@ -332,7 +340,7 @@ template <typename T> class RocfftEngine final : public Engine {
             if (p.save_spans[i] == span) return true;
         return false;
     }
-    int amp_fwd(const ssf_params &p, const Derived &d, int span_rel, const void *noise, double ideal_gain) {
+    int amp_fwd(const ssf_params &p, const Derived &d, int span, int span_rel, const void *noise, double ideal_gain) {
         const int64_t total = N * nrows;
         if (p.amp == SSF_AMP_EDFA) {
             const C *nz = nullptr;
@@ -342,7 +350,10 @@ template <typename T> class RocfftEngine final : public Engine {
                                            hipMemcpyHostToDevice, pl->stream));
                 nz = noise_d;
             }
-            k_amp<T><<<grid_for(total), kBlock, 0, pl->stream>>>(E, total, (T)std::sqrt(d.G_lin), nz);
+            const bool dev_noise = !noise && p.rng_seed != 0;
+            k_amp<T><<<grid_for(total), kBlock, 0, pl->stream>>>(E, total, (T)std::sqrt(d.G_lin), nz,
+                                                                  dev_noise ? std::sqrt(d.p_noise / 2) : 0.0,
+                                                                  (unsigned long long)p.rng_seed, (unsigned)span, N);
         } else if (p.amp == SSF_AMP_IDEAL) {
             k_amp<T><<<grid_for(total), kBlock, 0, pl->stream>>>(E, total, (T)ideal_gain, nullptr);
         }
@@ -368,7 +379,7 @@ template <typename T> class RocfftEngine final : public Engine {
             if ((rc = fft(inv, F, other))) return rc;                       // channels.py:232
             k_amp<T><<<grid_for(total), kBlock, 0, pl->stream>>>(other, total, (T)(1.0 / (double)N), nullptr);
             std::swap(E, other);
-            if ((rc = amp_fwd(p, d, span - s0, noise, std::exp(d.alpha_lin / 2 * nsteps * p.hz)))) return rc;
+            if ((rc = amp_fwd(p, d, span, span - s0, noise, std::exp(d.alpha_lin / 2 * nsteps * p.hz)))) return rc;
             if (wants_snapshot(p, span) && (rc = snapshot())) return rc;
             st->steps += nsteps;
             st->transforms += (int64_t)nrows * (2 * (int64_t)nsteps + 2);
@@ -427,7 +438,7 @@ template <typename T> class RocfftEngine final : public Engine {
                 st->transforms += (int64_t)nrows * (2 + 2 * (int64_t)iters);
                 ts.step(hz_, iters, lims.data());
             }
-            if (p.direction >= 0 && (rc = amp_fwd(p, d, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
+            if (p.direction >= 0 && (rc = amp_fwd(p, d, span, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
             if (wants_snapshot(p, span) && (rc = snapshot())) return rc;
         }
         return SSF_OK;

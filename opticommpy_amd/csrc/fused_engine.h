@@ -180,12 +180,16 @@ template <typename T, class Backend> class FusedCore {
         a.npart = col_grid_1;
         be.launch_col(a, col_grid_1, col_block_1, col_lds_1);
     }
-    void launch_amp(C *E, T gain, const C *noise) {
+    void launch_amp(C *E, T gain, const C *noise, double sigma = 0.0, unsigned long long seed = 0, unsigned span = 0) {
         AmpArgs<T> a{};
         a.E = E;
         a.noise = noise;
         a.total = (long long)N * nrows;
+        a.N = N;
         a.gain = gain;
+        a.sigma = sigma;
+        a.seed = seed;
+        a.span = span;
         be.launch_amp(a, 1024, 256);
     }
     int snapshot() {
@@ -200,15 +204,17 @@ template <typename T, class Backend> class FusedCore {
             if (p.save_spans[i] == span) return true;
         return false;
     }
-    int amp_fwd(const ssf_params &p, const Derived &d, int span_rel, const void *noise, double ideal_gain) {
+    int amp_fwd(const ssf_params &p, const Derived &d, int span, int span_rel, const void *noise, double ideal_gain) {
         if (p.amp == SSF_AMP_EDFA) {
             const C *nz = nullptr;
             if (noise) {
                 if (!noise_d && !(noise_d = (C *)be.alloc(field_bytes))) return oom();
-                be.h2d(noise_d, (const char *)noise + (size_t)span_rel * field_bytes, field_bytes);
+                be.h2d_big(noise_d, (const char *)noise + (size_t)span_rel * field_bytes, field_bytes);
                 nz = noise_d;
             }
-            launch_amp(Tcur(), (T)std::sqrt(d.G_lin), nz);
+            const bool dev_noise = !noise && p.rng_seed != 0;                     // devices.py:723-726
+            launch_amp(Tcur(), (T)std::sqrt(d.G_lin), nz, dev_noise ? std::sqrt(d.p_noise / 2) : 0.0,
+                       (unsigned long long)p.rng_seed, (unsigned)span);
         } else if (p.amp == SSF_AMP_IDEAL) {
             launch_amp(Tcur(), (T)ideal_gain, nullptr);
         }
@@ -236,7 +242,7 @@ template <typename T, class Backend> class FusedCore {
                 launch_row_lin(linops + 0);
                 launch_col_plain(CM_NLSE_LAST, E, (T)0);                               // channels.py:232
             }
-            int rc = amp_fwd(p, d, span - s0, noise, std::exp(d.alpha_lin / 2 * nsteps * p.hz));
+            int rc = amp_fwd(p, d, span, span - s0, noise, std::exp(d.alpha_lin / 2 * nsteps * p.hz));
             if (rc) return rc;
             if (wants_snapshot(p, span) && (rc = snapshot())) return rc;
             st->steps += nsteps;
@@ -362,7 +368,7 @@ template <typename T, class Backend> class FusedCore {
             st->spec_hits += c.spec_hit;
             st->spec_misses += c.spec_miss;
             st->transforms += (int64_t)nrows * (2 * c.steps + 2 * c.iterations);
-            if (p.direction >= 0 && (rc = amp_fwd(p, d, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
+            if (p.direction >= 0 && (rc = amp_fwd(p, d, span, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
             if (wants_snapshot(p, span) && (rc = snapshot())) return rc;
         }
         be.sync();

@@ -19,6 +19,7 @@
 // optic/models/channels.py:387-441 (Manakov step), :219-229 (NLSE step).
 #pragma once
 #include "fused_core.h"
+#include "ssf_rng.h"
 
 namespace ssf {
 namespace fused {
@@ -813,14 +814,22 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
 // --------------------------------------------------------------------- elementwise helpers
 template <typename T> struct AmpArgs {
     cx<T> *E;
-    const cx<T> *noise;   // may be null
-    long long total;
+    const cx<T> *noise;   // host-supplied noise (may be null)
+    long long total, N;
     T gain;
+    double sigma;         // > 0: add device-generated ASE, sigma per quadrature
+    unsigned long long seed;
+    unsigned span;
 };
 template <typename T, class Ctx> SSF_HD void amp_body(Ctx &ctx, const AmpArgs<T> &a) {
     for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < a.total; i += (long long)ctx.nblocks * ctx.nthreads) {
         cx<T> e = a.E[i] * a.gain;
         if (a.noise) e = e + a.noise[i];
+        if (a.sigma > 0) {
+            double re, im;
+            gauss_pair((unsigned long long)(i % a.N), (unsigned)(i / a.N), a.span, a.seed, a.sigma, re, im);
+            e = e + mk<T>((T)re, (T)im);
+        }
         a.E[i] = e;
     }
 }

@@ -152,6 +152,16 @@ def _span_noise(nrows, N, p_noise, seed, pairs, dtype):
     return np.ascontiguousarray(gaussianComplexNoise((nrows, N), p_noise, seed).astype(dtype))
 
 
+def _device_seed(seed):
+    """Key of the on-device ASE generator (Philox4x32-10): derived from param.seed when given,
+    fresh entropy otherwise; never 0 (0 means "no device noise" in the ABI)."""
+    if seed is None:
+        v = int.from_bytes(os.urandom(8), "little") >> 1
+    else:
+        v = (int(seed) * 0x9E3779B97F4A7C15 + 0x1234567) & 0x7FFFFFFFFFFFFFFF
+    return v or 1
+
+
 def _captured_spans(save_list, Nspans):
     """Spans that `spanN in saveSpanN` (channels.py:453) would hit, in encounter order."""
     return [s for s in range(1, Nspans + 1) if s in save_list]
@@ -265,10 +275,11 @@ def ssfm(Ei, param=None, _trace=False, _cpu_seed_policy=False):
         assert param.NF >= 3, "The minimal EDFA noise figure is 3 dB"
         _, p_noise = _edfa_noise_power(G, param.NF, param.Fc, Fs)
         seed = param.seed
-
-        def noise_fn(span):
-            s = seed if (seed is None or _cpu_seed_policy) else seed + span        # modelsGPU.py:259-260
-            return _span_noise(1, N, p_noise, s, False, pl.dtype)
+        if _cpu_seed_policy:      # draw-for-draw the CPU reference's numpy stream (golden-vector tests)
+            def noise_fn(span):
+                return _span_noise(1, N, p_noise, seed, False, pl.dtype)
+        else:                     # product path: ASE generated on the device, one stream per span
+            cp.rng_seed = _device_seed(seed)
 
     pl.check(pl.lib.ssf_upload(pl.h, soa.ctypes.data_as(C.c_void_p)))
     nsteps = int(np.floor(param.Lspan / param.hz))
@@ -335,11 +346,14 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
         _, p_noise = _edfa_noise_power(G, param.NF, param.Fc, Fs)
         seed = param.seed
 
-        def noise_fn(span):
-            if _noise is not None:
+        if _noise is not None:        # test hook: caller-supplied noise, (Nspans, 2K, N)
+            def noise_fn(span):
                 return np.ascontiguousarray(_noise[span - 1], dtype=pl.dtype)
-            s = seed if (seed is None or _cpu_seed_policy) else seed + span        # modelsGPU.py:486-487
-            return _span_noise(ncols, N, p_noise, s, True, pl.dtype)
+        elif _cpu_seed_policy:        # draw-for-draw the CPU reference's numpy stream (golden-vector tests)
+            def noise_fn(span):
+                return _span_noise(ncols, N, p_noise, seed, True, pl.dtype)
+        else:                         # product path: ASE generated on the device (Philox, per-span streams;
+            cp.rng_seed = _device_seed(seed)   # x and y rows get independent noise, unlike channels.py:444-445)
 
     logg.info("Running Manakov SSF model on GPU (HIP, %s)..." % ("forward" if direction > 0 else "DBP"))
     pl.check(pl.lib.ssf_upload_aos(pl.h, aos.ctypes.data_as(C.c_void_p)))

@@ -230,6 +230,15 @@ int emu_run(int64_t N, int nrows, int precision, const ssf_params *p, const void
                                  : run_t<float>(N, nrows, precision, p, in, out, snaps, noise, st, tr, launches);
 }
 
+void emu_philox(unsigned long long ctr_lo, unsigned long long ctr_hi, unsigned long long key, unsigned *out) {
+    const ssf::Philox4 r = ssf::philox4x32_10(ctr_lo, ctr_hi, key);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+
+void emu_gauss(long long n, unsigned row, unsigned span, unsigned long long seed, double sigma, double *re, double *im) {
+    for (long long i = 0; i < n; ++i) ssf::gauss_pair((unsigned long long)i, row, span, seed, sigma, re[i], im[i]);
+}
+
 int emu_linear_channel(int64_t N, int nrows, int precision, double Fs, double Fc, double alpha, double D, double L,
                        const void *in, void *out) {
     if (!emu_supported(N, precision)) return SSF_ERR_UNSUPPORTED;

@@ -22,6 +22,8 @@ def load():
                                  C.POINTER(C.c_long)]
         _emu.emu_linear_channel.argtypes = [C.c_int64, C.c_int, C.c_int] + [C.c_double] * 5 + [C.c_void_p, C.c_void_p]
         _emu.emu_supported.argtypes = [C.c_int64, C.c_int]
+        _emu.emu_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+        _emu.emu_gauss.argtypes = [C.c_int64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]
         _emu.emu_split.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return _emu
 
@@ -55,6 +57,7 @@ def run(func, Ei, cfg, noise=None, max_steps=4096):
     p.nlprMethod = int(cfg.get("nlprMethod", True)) if p.model == 1 else 0
     p.maxNlinPhaseRot = cfg.get("maxNlinPhaseRot", 2e-2)
     p.amp, p.NF = _amp(cfg.get("amp", "edfa")), cfg.get("NF", 4.5)
+    p.rng_seed = int(cfg.get("_rng_seed", 0))
     p.n_save = len(save_arr)
     p.save_spans = save_arr.ctypes.data_as(C.POINTER(C.c_int32)) if len(save_arr) else None
     out = np.empty_like(soa)
@@ -90,3 +93,18 @@ def linear_channel(Ei, Fs, Fc, alpha, D, L, dtype=np.complex128):
                                 soa.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert rc == 0, f"emu_linear_channel rc={rc}"
     return out.T.reshape(Ei.shape)
+
+
+def philox(ctr, key):
+    """ctr: 4 x uint32, key: 2 x uint32 -> 4 x uint32 (Philox4x32-10)."""
+    emu = load()
+    out = (C.c_uint32 * 4)()
+    emu.emu_philox(ctr[0] | (ctr[1] << 32), ctr[2] | (ctr[3] << 32), key[0] | (key[1] << 32), out)
+    return [int(x) for x in out]
+
+
+def gauss(n, row, span, seed, sigma):
+    emu = load()
+    re, im = np.empty(n), np.empty(n)
+    emu.emu_gauss(n, row, span, seed, sigma, re.ctypes.data_as(C.c_void_p), im.ctypes.data_as(C.c_void_p))
+    return re + 1j * im

@@ -123,3 +123,36 @@ def test_speculation_hits_in_steady_state_and_recovers_from_misses():
     d, cfg = load_golden("mk_fix_p13_ideal_k2")            # 3 <-> 4 iterations
     _, info = eb.run("manakovSSF", d["Ei"], cfg)
     assert info["spec_misses"] >= 2 and info["spec_hits"] > info["spec_misses"]
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32_10 (Salmon et al., kat_vectors)."""
+    assert eb.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xffffffff
+    assert eb.philox([f, f, f, f], [f, f]) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert eb.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_device_ase_noise_statistics_and_streams():
+    n, sigma = 200000, 0.37
+    a = eb.gauss(n, 0, 1, 1234, sigma)
+    assert abs(a.mean()) < 4 * sigma / np.sqrt(n)
+    assert np.var(a.real) == pytest.approx(sigma ** 2, rel=0.02) and np.var(a.imag) == pytest.approx(sigma ** 2, rel=0.02)
+    assert abs(np.mean(a.real * a.imag)) < 4 * sigma ** 2 / np.sqrt(n)
+    assert abs(np.mean(a[1:] * np.conj(a[:-1]))) < 5 * 2 * sigma ** 2 / np.sqrt(n)      # white
+    assert np.array_equal(a, eb.gauss(n, 0, 1, 1234, sigma))                         # deterministic
+    for other in (eb.gauss(n, 1, 1, 1234, sigma), eb.gauss(n, 0, 2, 1234, sigma), eb.gauss(n, 0, 1, 1235, sigma)):
+        assert abs(np.mean(a * np.conj(other))) < 5 * 2 * sigma ** 2 / np.sqrt(n)    # rows / spans / seeds independent
+    k = np.mean(np.abs(a) ** 4) / np.mean(np.abs(a) ** 2) ** 2
+    assert k == pytest.approx(2.0, rel=0.03)                                         # circular Gaussian
+
+
+def test_edfa_with_device_noise_on_emulated_kernels():
+    d, cfg = load_golden("mk_fix_p8_ideal_2span")
+    cfg = dict(cfg, amp="edfa", NF=5.0, saveSpanN=[])
+    clean, _ = eb.run("manakovSSF", d["Ei"], dict(cfg, _rng_seed=0))                 # gain only
+    noisy, _ = eb.run("manakovSSF", d["Ei"], dict(cfg, _rng_seed=99))
+    _, p_noise = orc.edfa_noise_power(cfg["alpha"] * cfg["Lspan"], 5.0, cfg["Fc"], cfg["Fs"])
+    # two spans: the first span's noise propagates (loss + gain = 1) and the second adds its own
+    assert np.mean(np.abs(noisy - clean) ** 2) == pytest.approx(2 * p_noise, rel=0.15)
