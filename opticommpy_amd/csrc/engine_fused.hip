@@ -15,7 +15,19 @@ using namespace fused;
 struct DevCtx {
     int tid, bid, nthreads, nblocks;
     char *lds;
+    static constexpr bool kWaveOps = true;
     __device__ __forceinline__ void sync() { __syncthreads(); }
+    // all-lanes butterfly over the 64-lane wave (every lane returns the same value)
+    __device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+    __device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        return v;
+    }
     __device__ __forceinline__ void sleep(int units64) {          // ~units64 * 64 clocks
         for (int i = 0; i < units64; i += 64) __builtin_amdgcn_s_sleep(64);
     }

@@ -93,6 +93,18 @@ template <typename T> SSF_HD cx<T> cis2pi(double frac) {
     cis2pi_d(frac, c, s);
     return mk<T>((T)c, (T)s);
 }
+// single precision: frac = m / 2^k with m < 2^24 is exact in float, so sincospif loses nothing
+template <> SSF_HD cx<float> cis2pi<float>(double frac) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float c, s;
+    sincospif(2.0f * (float)frac, &s, &c);
+    return mk<float>(c, s);
+#else
+    double c, s;
+    cis2pi_d(frac, c, s);
+    return mk<float>((float)c, (float)s);
+#endif
+}
 template <typename T> SSF_HD cx<T> cis_t(T a);
 template <> SSF_HD cx<double> cis_t<double>(double a) {
     double s, c;

@@ -7,6 +7,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,8 +26,16 @@ struct Split {
 // (C = 4096/N1 columns x sizeof(complex)); rows are bounded by the 160 KiB LDS.
 inline bool choose_split(int log2N, int precision, Split *s) {
     if (log2N < 8) return false;
+    if (const char *e = std::getenv("SSF_SPLIT_L1")) {        // tuning knob: force log2 N1
+        const int l1 = std::atoi(e);
+        if (l1 >= 4 && log2N - l1 >= 4 && log2N - l1 <= 14) {
+            s->l1 = l1;
+            s->l2 = log2N - l1;
+            return true;
+        }
+    }
     const bool dbl = precision == SSF_C128;
-    const int l1pref = dbl ? 8 : 7, l2max = dbl ? 13 : 14;
+    const int l1pref = 8, l2max = dbl ? 13 : 14;     // (measured: 8 is best for both precisions at 2^20)
     int l1 = std::min(l1pref, log2N / 2);
     int l2 = log2N - l1;
     const int l2soft = l2max - 1;          // prefer two workgroups per CU

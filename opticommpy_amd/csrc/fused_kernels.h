@@ -260,6 +260,18 @@ SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
 // Every thread gets the result; `red` is LDS scratch of nthreads doubles.  Two stages (<= 64
 // partial sums), fixed order: deterministic and identical in every workgroup.
 template <bool MAX, class Ctx> SSF_HD double block_reduce(Ctx &ctx, double v, double *red) {
+    if constexpr (Ctx::kWaveOps) {
+        if (ctx.nthreads >= 64) {             // wave butterfly + one LDS hop (device only; fixed order)
+            v = MAX ? ctx.wave_max(v) : ctx.wave_sum(v);
+            const int w = ctx.tid >> 6, nw = ctx.nthreads >> 6;
+            ctx.sync();
+            if ((ctx.tid & 63) == 0) red[w] = v;
+            ctx.sync();
+            double s = red[0];
+            for (int i = 1; i < nw; ++i) s = MAX ? (red[i] > s ? red[i] : s) : s + red[i];
+            return s;
+        }
+    }
     ctx.sync();
     red[ctx.tid] = v;
     ctx.sync();
@@ -281,6 +293,27 @@ template <bool MAX, class Ctx> SSF_HD double block_reduce(Ctx &ctx, double v, do
 }
 // sum of two values at once (one barrier sequence): results in s0, s1
 template <class Ctx> SSF_HD void block_sum2(Ctx &ctx, double &s0, double &s1, double *red) {
+    if constexpr (Ctx::kWaveOps) {
+        if (ctx.nthreads >= 64) {
+            s0 = ctx.wave_sum(s0);
+            s1 = ctx.wave_sum(s1);
+            const int w = ctx.tid >> 6, nw = ctx.nthreads >> 6;
+            ctx.sync();
+            if ((ctx.tid & 63) == 0) {
+                red[2 * w] = s0;
+                red[2 * w + 1] = s1;
+            }
+            ctx.sync();
+            double a = 0, b = 0;
+            for (int i = 0; i < nw; ++i) {
+                a += red[2 * i];
+                b += red[2 * i + 1];
+            }
+            s0 = a;
+            s1 = b;
+            return;
+        }
+    }
     ctx.sync();
     red[2 * ctx.tid] = s0;
     red[2 * ctx.tid + 1] = s1;

@@ -25,8 +25,11 @@ namespace {
 struct EmuCtx {
     int tid, bid, nthreads, nblocks;
     char *lds;
+    static constexpr bool kWaveOps = false;
     void sync();
     void sleep(int) {}
+    double wave_sum(double v) { return v; }
+    double wave_max(double v) { return v; }
 };
 
 struct Fiber {
