@@ -88,6 +88,16 @@ SSF_HD void cis_rad_d(double a, double &c, double &s) {
     s = std::sin(a);
 #endif
 }
+// sin(d / 2) without the generic sin()'s large-argument machinery
+SSF_HD double sin_half_angle(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double t = d * 0.15915494309189533577;    // d/2 = pi * (d / (2 pi))
+    t -= 2.0 * rint(0.5 * t);                 // sinpi is 2-periodic
+    return sinpi(t);
+#else
+    return std::sin(0.5 * d);
+#endif
+}
 template <typename T> SSF_HD cx<T> cis2pi(double frac) {
     double c, s;
     cis2pi_d(frac, c, s);

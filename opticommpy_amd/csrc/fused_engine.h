@@ -58,7 +58,7 @@ template <typename T, class Backend> class FusedCore {
     Split sp;
     size_t field_bytes;
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
-    T *P = nullptr;
+    T *P = nullptr, *Theta = nullptr;
     Ctrl *ctrl = nullptr;        // [2]
     LinOp *linops = nullptr;     // [2]
     double *part = nullptr;      // 3 * npart_max
@@ -107,9 +107,10 @@ template <typename T, class Backend> class FusedCore {
         for (auto pp : ptrs)
             if (!(*pp = be.alloc(field_bytes))) return oom();
         if (!(P = (T *)be.alloc(2 * sizeof(T) * (size_t)N * (size_t)((nrows + 1) / 2)))) return oom();   // two Pch buffers
+        if (!(Theta = (T *)be.alloc(sizeof(T) * (size_t)N * (size_t)((nrows + 1) / 2)))) return oom();
         if (!(ctrl = (Ctrl *)be.alloc(2 * sizeof(Ctrl)))) return oom();
         if (!(linops = (LinOp *)be.alloc(2 * sizeof(LinOp)))) return oom();
-        if (!(part = (double *)be.alloc(sizeof(double) * 3 * (size_t)npart_max))) return oom();
+        if (!(part = (double *)be.alloc(sizeof(double) * 5 * (size_t)npart_max))) return oom();
         be.prepare(row_lds, std::max(col_lds_mk, col_lds_1));
         return SSF_OK;
     }
@@ -118,7 +119,7 @@ template <typename T, class Backend> class FusedCore {
         return SSF_ERR_OOM;
     }
     ~FusedCore() {
-        for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)ctrl, (void *)linops,
+        for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)Theta, (void *)ctrl, (void *)linops,
                         (void *)part, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
             if (p) be.free(p);
         for (C *s : snaps) be.free(s);
@@ -166,6 +167,7 @@ template <typename T, class Backend> class FusedCore {
         a.T1 = T1;
         a.Ehd = Ehd;
         a.P = P;
+        a.Theta = Theta;
         a.log2N1 = sp.l1;
         a.log2N2 = sp.l2;
         a.npol = npol;
@@ -174,6 +176,8 @@ template <typename T, class Backend> class FusedCore {
         a.pmax = part;
         a.pnum = part + npart_max;
         a.pden = part + 2 * (size_t)npart_max;
+        a.pnum0 = part + 3 * (size_t)npart_max;
+        a.pden0 = part + 4 * (size_t)npart_max;
         return a;
     }
     void launch_row_lin(const LinOp *lin) {
@@ -292,6 +296,8 @@ template <typename T, class Backend> class FusedCore {
         a.pmax = part;
         a.pnum = part + npart_max;
         a.pden = part + 2 * (size_t)npart_max;
+        a.pnum0 = part + 3 * (size_t)npart_max;
+        a.pden0 = part + 4 * (size_t)npart_max;
         a.npart = col_grid_mk;
         be.launch_row(a, row_grid, row_block, row_lds);
         ++seq;
@@ -338,9 +344,7 @@ template <typename T, class Backend> class FusedCore {
         for (int span = s0; span <= s1; ++span) {
             if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))      // equalization.py:1090-1092
                 launch_amp(Tcur(), (T)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);
-            const int pred = c.pred_iters;
             std::memset(&c, 0, sizeof(c));
-            c.pred_iters = pred;
             c.state = ST_NEED_S;
             c.cur = cur;
             c.trace_n = trace_n;
@@ -363,7 +367,7 @@ template <typename T, class Backend> class FusedCore {
                 be.d2h(&c, ctrl + (seq & 1), sizeof(Ctrl));                               // synchronising read
                 if (!be.ok()) return hiperr();
                 if (c.steps > 0) avg_it = (double)c.iterations / (double)c.steps;
-                if (c.state == ST_SPAN_DONE) break;
+                if (c.state == ST_SPAN_DONE && !c.pend0) break;
                 if (++guard > (1 << 22)) {
                     err = "fused engine: span did not terminate";
                     return SSF_ERR_STATE;

@@ -27,17 +27,27 @@ namespace fused {
 // ------------------------------------------------------------------------------- control
 // Launch sequence per span: Col, then [Row, Col] pairs.  Every launch reads the state, does the
 // matching stage (or nothing) and forwards the state; the host never looks inside a chunk.
+//
+// Convergence test without the previous iterate.  The reference compares consecutive iterates
+// after the second linear step, lim = |E_fd(i) - E_fd(i-1)| / |E_fd(i-1)| (channels.py:424,
+// 517-519).  Both iterates are Lin(E_hd * rot), Lin = ifft(fft(.) * linOperator) with
+// |linOperator| = exp(-alpha hz/4) on every bin, so by Parseval
+//     lim_i = sqrt(sum |E_hd|^2 |rot_i - rot_{i-1}|^2) / sqrt(sum |E_hd|^2),   i >= 1,
+// which the column stage that BUILDS iterate i can evaluate from E_hd and the two phase arrays
+// (|rot_i - rot_{i-1}|^2 = 4 sin^2((theta_i - theta_{i-1})/2)) -- one whole iteration before
+// E_fd(i) exists.  The pipeline therefore knows in advance which iterate is the last one: no
+// iterate is ever written to or re-read from HBM just for the test, only the final one is stored.
+// lim_0 (against the field at the step start, channels.py:381-382) is evaluated directly; if it
+// ever signals convergence the iterate is rebuilt as final (ST_REDO0).
 enum {
-    ST_NEED_S = 0,     // Col: step start on T[cur]: Pch, forward column FFT            -> AFTER_S
-    ST_AFTER_S = 1,    // Row: (adaptive step size,) first half linear step             -> NEED_H
-    ST_NEED_H = 2,     // Col: E_hd out, first rotation, forward column FFT             -> ROW_ITER
-    ST_ROW_ITER = 3,   // Row: second linear step of the current iterate                -> NEED_I
-    ST_NEED_I = 4,     // Col: E_fd -> T[cur^1], convergence partial sums, anticipated continuation -> NEED_D
-    ST_NEED_D = 5,     // Row: convergence decision; if the anticipation was right carry on with the
-                       //      linear step (-> NEED_I | NEED_H), else -> FIX_A | FIX_S | SPAN_DONE
+    ST_NEED_S = 0,     // Col: span start: Pch of T[cur], forward column FFT                      -> AFTER_S
+    ST_AFTER_S = 1,    // Row: new step: step size / operator, first half linear step             -> NEED_H
+    ST_NEED_H = 2,     // Col: E_hd out, first rotation, forward column FFT                       -> ROW_ITER
+    ST_ROW_ITER = 3,   // Row: evaluate pending convergence sums, second linear step of iterate it -> NEED_I
+    ST_NEED_I = 4,     // Col: E_fd(it).  Not final: next iterate + sums of lim_{it+1}            -> ROW_ITER
+                       //      final: field out, next step's Pch + forward FFT         -> AFTER_S | SPAN_DONE
     ST_SPAN_DONE = 6,
-    ST_FIX_A = 7,      // Col: next iterate that was not anticipated                    -> ROW_ITER
-    ST_FIX_S = 8       // Col: step start that was not anticipated                      -> AFTER_S
+    ST_REDO0 = 7       // Col: rebuild iterate 0 as the final one (lim_0 < tol)                   -> ROW_ITER
 };
 
 struct LinOp {          // exp(argLimOp * hz/2) / N evaluated from the bin index (row kernel)
@@ -48,12 +58,14 @@ struct LinOp {          // exp(argLimOp * hz/2) / N evaluated from the bin index
 
 struct Ctrl {           // device-resident step state, double-buffered by launch parity
     int state, it, cur, hz_valid;
-    int pred_iters;     // iterations of the previous step (0 = unknown): drives the speculation
-    int spec;           // what ColA's I stage already did beyond E_fd: 0 nothing, 1 next iterate, 2 next step start
-    int pcur, pad_;     // which of the two Pch buffers holds the current step's power
+    int final_;         // the I stage of iterate `it` is the last one of this step
+    int pend0, pendn;   // partial sums of lim_0 / lim_it are waiting for the next Row launch
+    int cap0;           // iterate 0 ended the step only because maxIter == 1 (lim_0 decides non-convergence)
+    int pcur, redo_;    // current Pch buffer; iterate 0 is being rebuilt as final
+    long long pend0_idx;// trace row lim_0 belongs to
     double z, hz;
     long long steps, iterations, nonconv, trace_n;
-    long long spec_hit, spec_miss;
+    long long spec_hit, spec_miss;   // iterations decided in advance / iterates rebuilt
     LinOp lin;
 };
 
@@ -366,7 +378,8 @@ template <typename T> struct RowArgs {
     Ctrl *cout;               // ctrl[(seq + 1) & 1]
     MkConst k;
     const double *pmax;       // adaptive: block maxima of phi written by the step-start stage
-    const double *pnum, *pden;// convergence partial sums written by the I stage
+    const double *pnum, *pden;   // partial sums of lim_it written by the I stage
+    const double *pnum0, *pden0; // partial sums of lim_0
     int npart;
     int stagger;              // late start of half of the workgroups, in units of 64 clocks (0 = off)
     int stagger_mode;         // which half: 0 = upper half of the grid, 1 = odd groups of 8 blocks
@@ -430,62 +443,47 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
         const Ctrl c = *a.cin;
         Ctrl n = c;
         double *red = (double *)(ctx.lds) + 64;
+        const bool lead = ctx.bid == 0 && ctx.tid == 0;
         bool act = c.state == ST_AFTER_S || c.state == ST_ROW_ITER;
-        if (c.state == ST_NEED_D) {           // convergence decision (channels.py:424-434), same in every block
-            double num = 0, den = 0;
+        if (c.pend0 || c.pendn) {             // convergence sums left by the last column stage; every
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;   // block reduces them in the same order
             for (int i = ctx.tid; i < a.npart; i += ctx.nthreads) {
-                num += a.pnum[i];
-                den += a.pden[i];
-            }
-            block_sum2(ctx, num, den, red);
-            const double lim = sqrt(num) / sqrt(den);                     // channels.py:517-519
-            const bool conv = lim < a.k.tol, last = c.it == a.k.maxIter - 1;
-            const bool lead = ctx.bid == 0 && ctx.tid == 0;
-            if (lead && c.trace_n < a.k.trace_cap && a.k.tr_lim)
-                a.k.tr_lim[c.trace_n * a.k.maxIter + c.it] = lim;
-            n.cur = c.cur ^ 1;                                            // E_conv = E_fd
-            n.spec = 0;
-            if (conv || last) {                                           // the step is over
-                if (lead && c.trace_n < a.k.trace_cap) {
-                    if (a.k.tr_hz) a.k.tr_hz[c.trace_n] = c.hz;
-                    if (a.k.tr_it) a.k.tr_it[c.trace_n] = c.it + 1;
+                if (c.pend0) {
+                    s0 += a.pnum0[i];
+                    s1 += a.pden0[i];
                 }
-                n.trace_n = c.trace_n + 1;
-                n.steps = c.steps + 1;
-                n.iterations = c.iterations + c.it + 1;
-                if (!conv) n.nonconv = c.nonconv + 1;
-                n.z = c.z + c.hz;
-                n.pred_iters = c.it + 1;
-                n.it = 0;
-                if (!(n.z < a.k.Lspan)) n.state = ST_SPAN_DONE;
-                else {
-                    if (a.k.adaptive) n.hz_valid = 0;             // hz_valid == 0: (hz and) operator to be derived
-                    else {
-                        n.hz = pick_hz(a.k, n.z, 0.0);
-                        if (n.hz != c.hz) n.hz_valid = 0;
-                    }
-                    if (c.spec == 2) {                                    // the step start is already in G
-                        n.pcur = c.pcur ^ 1;
-                        n.spec_hit = c.spec_hit + 1;
-                        n.state = ST_AFTER_S;
-                        act = true;
-                    } else {
-                        n.spec_miss = c.spec_miss + 1;
-                        n.state = ST_FIX_S;
-                    }
-                }
-            } else {
-                n.it = c.it + 1;
-                if (c.spec == 1) {                                        // the next iterate is already in G
-                    n.spec_hit = c.spec_hit + 1;
-                    n.state = ST_ROW_ITER;
-                    act = true;
-                } else {
-                    n.spec_miss = c.spec_miss + 1;
-                    n.state = ST_FIX_A;
+                if (c.pendn) {
+                    s2 += a.pnum[i];
+                    s3 += a.pden[i];
                 }
             }
+            if (c.pend0) block_sum2(ctx, s0, s1, red);
+            if (c.pendn) block_sum2(ctx, s2, s3, red);
             ctx.sync();
+            bool redo = false;
+            if (c.pend0) {                                                // lim_0 (channels.py:424, 517-519)
+                const double lim0 = sqrt(s0) / sqrt(s1);
+                if (lead && c.pend0_idx < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[c.pend0_idx * a.k.maxIter] = lim0;
+                n.pend0 = 0;
+                if (c.cap0) {
+                    if (!(lim0 < a.k.tol)) n.nonconv = c.nonconv + 1;
+                    n.cap0 = 0;
+                } else if (c.pendn && lim0 < a.k.tol) redo = true;        // converged at iterate 0 after all
+            }
+            if (c.pendn) {                                                // lim_it, known before iterate it exists
+                n.pendn = 0;
+                if (redo) {
+                    n.state = ST_REDO0;
+                    act = false;
+                } else {
+                    const double lim = sqrt(s2) / sqrt(s3);
+                    if (lead && c.trace_n < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[c.trace_n * a.k.maxIter + c.it] = lim;
+                    const bool conv = lim < a.k.tol;
+                    n.final_ = conv || c.it == a.k.maxIter - 1;           // channels.py:429-434
+                    if (n.final_ && !conv) n.nonconv = n.nonconv + 1;
+                    n.spec_hit = c.spec_hit + 1;
+                }
+            }
         }
         if (act && !n.hz_valid) {             // new step size: every block derives the same hz / operator
             double mx = 0.0;
@@ -502,8 +500,8 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
             n.hz_valid = 1;
             ctx.sync();
         }
-        if (act) n.state = n.state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
-        if (ctx.bid == 0 && ctx.tid == 0) *a.cout = n;
+        if (act) n.state = c.state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
+        if (lead) *a.cout = n;
         if (!act) return;
         lo = n.lin;
     } else {
@@ -544,14 +542,15 @@ template <typename T> struct ColArgs {
     cx<T> *G;                 // (nrows, N1, N2)
     cx<T> *T0, *T1;           // time-domain fields, (nrows, N); Manakov: E(z)/E_conv ping-pong
     cx<T> *Ehd;               // (nrows, N)
-    T *P;                     // (K, N)
+    T *P;                     // (2, K, N): Pch of the current / next step
+    T *Theta;                 // (K, N): phase shz * phi of the latest rotation
     int log2N1, log2N2, npol, mode;
     int ngroups;              // Manakov: polarisation pairs K (P holds 2 x K x N values: two buffers)
     T g_hz;                   // NLSE: gamma * hz
     const Ctrl *cin;
     Ctrl *cout;
     MkConst k;
-    double *pmax, *pnum, *pden;
+    double *pmax, *pnum, *pden, *pnum0, *pden0;
     int npart;                // number of column workgroups (partials per array)
 };
 
@@ -658,44 +657,55 @@ SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T>
     }
     ctx.sync();                                  // scratch reads done before the FFT reuses the LDS
 }
-// next iterate (channels.py:436, 414-417): v holds E_conv (the latest E_fd); returns E_hd * rot
+// next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
+// accumulates the sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the header note)
 template <typename T, class Ctx, class G>
-SSF_HD void mk_next_iterate(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, const T *Pbuf, T shz, bool lds_busy) {
+SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, const T *Pbuf, T shz, bool first,
+                       double &num, double &den) {
     T *shT = (T *)ctx.lds;
     cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));
     T mine[16], oth[16], ang[16];
 #pragma unroll
     for (int idx = 0; idx < 16; ++idx) mine[idx] = norm2(v[idx]);
-    if (lds_busy) ctx.sync();
+    ctx.sync();
     pair_swap(ctx, g, mine, oth, shT);
     const T c8g = (T)a.k.c8g;
 #pragma unroll
     for (int idx = 0; idx < 16; ++idx) {
+        const long long t = g.time_off(idx);
         const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
-        const T pw = Pbuf[g.pbase + g.time_off(idx)];
+        const T pw = Pbuf[g.pbase + t];
         ang[idx] = shz * (c8g * (pw + ax + ay) / (T)2);
+        const T prev = first ? shz * (c8g * (pw + pw) / (T)2) : a.Theta[g.pbase + t];
+        // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2); kept in `mine` (its norms are spent)
+        const double s = sin_half_angle((double)ang[idx] - (double)prev);
+        mine[idx] = (T)(4.0 * s * s);
     }
     cx<T> rot[16];
-    pair_cis(ctx, g, 2, ang, rot, shC);
+    pair_cis(ctx, g, 2, ang, rot, shC);      // (barrier inside: both partners have read the old phases)
+    if (g.pol == 0) {
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) v[idx] = a.Ehd[g.rowbase + g.time_off(idx)] * rot[idx];
+        for (int idx = 0; idx < 16; ++idx) a.Theta[g.pbase + g.time_off(idx)] = ang[idx];
+    }
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) {
+        const cx<T> e = a.Ehd[g.rowbase + g.time_off(idx)];
+        const double w = (double)norm2(e);
+        num += w * (double)mine[idx];
+        den += w;
+        v[idx] = e * rot[idx];
+    }
     ctx.sync();
 }
 
-// MODE is one of CM_*; the Manakov modes pick their operation from the Ctrl state.
-//
-// Speculation: the I stage (ColA) already knows E_fd in registers.  If the previous step took
-// more iterations than done so far it goes straight on to the next iterate (spec 1); if this is
-// the iteration the previous step converged at, it starts the next step (spec 2: Pch into the
-// alternate buffer + forward transform).  The D stage (ColB) then only validates: when the
-// guess was right it touches no field data; otherwise it redoes the right thing as before.
+// MODE is one of CM_*; the Manakov mode picks its stage from the Ctrl state.
 template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
     constexpr bool kMk = MODE == CM_MK;
     // ---- what does this launch do? ------------------------------------------------------
     bool do_inv = false, do_fwd = false;
-    int op = -1;     // Manakov: 0 = S, 1 = H, 2 = I, 3 = D(a) next iterate
-    int want = 0;    // I stage: speculative continuation (0 none, 1 next iterate, 2 next step start)
-    struct { int state, it, cur, pcur, pred_iters; double z, hz; } c{};
+    int op = -1;     // Manakov: 0 = S (span start), 1 = H, 2 = I, 3 = rebuild iterate 0
+    bool final_ = false, more = false;
+    struct { int state, it, cur, pcur; double z, hz; } c{};
     double *red = (double *)ctx.lds;
     if (kMk) {
         // only scalars are taken from the control block (a private copy of the struct would live
@@ -704,51 +714,82 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
         c.it = a.cin->it;
         c.cur = a.cin->cur;
         c.pcur = a.cin->pcur;
-        c.pred_iters = a.cin->pred_iters;
         c.z = a.cin->z;
         c.hz = a.cin->hz;
-        int n_state = c.state, n_it = c.it, n_spec = a.cin->spec, n_hz_valid = a.cin->hz_valid;
-        double n_hz = c.hz;
-        if (c.state == ST_NEED_S || c.state == ST_FIX_S) {
+        final_ = a.cin->final_ != 0;
+        if (c.state == ST_NEED_S) {
             op = 0;
             do_fwd = true;
-            n_state = ST_AFTER_S;
-            if (c.state == ST_NEED_S) {                                   // span start: nothing decided yet
-                if (!a.k.adaptive) n_hz = pick_hz(a.k, c.z, 0.0);
-                n_hz_valid = 0;                                           // the Row derives hz / the operator
-            }
         } else if (c.state == ST_NEED_H) {
             op = 1;
             do_inv = do_fwd = true;
-            n_state = ST_ROW_ITER;
-            n_it = 0;
-            n_spec = 0;
         } else if (c.state == ST_NEED_I) {
             op = 2;
             do_inv = true;
-            n_state = ST_NEED_D;
-            const bool more_span = c.z + c.hz < a.k.Lspan;
-            if (c.it == a.k.maxIter - 1) want = more_span ? 2 : 0;        // the step ends here for sure
-            else if (c.pred_iters > 0) {
-                if (c.it + 1 < c.pred_iters) want = 1;
-                else if (c.it + 1 == c.pred_iters) want = more_span ? 2 : 0;
-            }
-            n_spec = want;
-            do_fwd = want != 0;
-        } else if (c.state == ST_FIX_A) {
+            more = c.z + c.hz < a.k.Lspan;                                // channels.py:441, 387
+            do_fwd = final_ ? more : true;
+        } else if (c.state == ST_REDO0) {
             op = 3;
             do_fwd = true;
-            n_state = ST_ROW_ITER;
         }
         if (ctx.bid == 0 && ctx.tid == 0) {                               // forward the control block
             const unsigned long long *src = (const unsigned long long *)a.cin;
             unsigned long long *dst = (unsigned long long *)a.cout;
             for (int i = 0; i < (int)(sizeof(Ctrl) / 8); ++i) dst[i] = src[i];
-            a.cout->state = n_state;
-            a.cout->it = n_it;
-            a.cout->spec = n_spec;
-            a.cout->hz_valid = n_hz_valid;
-            a.cout->hz = n_hz;
+            Ctrl *n = a.cout;
+            if (op == 0) {
+                n->state = ST_AFTER_S;
+                n->hz_valid = 0;
+            } else if (op == 1) {
+                n->state = ST_ROW_ITER;
+                n->it = 0;
+                n->final_ = a.k.maxIter == 1;
+                n->pend0 = n->pendn = 0;
+            } else if (op == 3) {
+                n->state = ST_ROW_ITER;
+                n->it = 0;
+                n->final_ = 1;
+                n->redo_ = 1;
+                n->pend0 = n->pendn = 0;
+                n->spec_miss = a.cin->spec_miss + 1;
+            } else if (op == 2 && !final_) {
+                n->state = ST_ROW_ITER;
+                n->it = c.it + 1;
+                n->pendn = 1;
+                if (c.it == 0) {
+                    n->pend0 = 1;
+                    n->pend0_idx = a.cin->trace_n;
+                }
+            } else if (op == 2) {                                         // the step ends here
+                const long long tn = a.cin->trace_n;
+                if (tn < a.k.trace_cap) {
+                    if (a.k.tr_hz) a.k.tr_hz[tn] = c.hz;
+                    if (a.k.tr_it) a.k.tr_it[tn] = c.it + 1;
+                }
+                n->trace_n = tn + 1;
+                n->steps = a.cin->steps + 1;
+                n->iterations = a.cin->iterations + c.it + 1;
+                n->z = c.z + c.hz;
+                n->cur = c.cur ^ 1;
+                n->it = 0;
+                n->final_ = 0;
+                if (c.it == 0) {
+                    n->pend0 = 1;
+                    n->pend0_idx = tn;
+                    n->cap0 = a.cin->redo_ ? 0 : 1;
+                }
+                n->redo_ = 0;
+                if (more) {
+                    n->state = ST_AFTER_S;
+                    n->pcur = c.pcur ^ 1;
+                    if (a.k.adaptive) n->hz_valid = 0;
+                    else {
+                        const double hz = pick_hz(a.k, c.z + c.hz, 0.0);
+                        if (hz != c.hz) n->hz_valid = 0;
+                        n->hz = hz;
+                    }
+                } else n->state = ST_SPAN_DONE;
+            }
         }
         if (op < 0) return;
     } else {
@@ -761,12 +802,12 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     cx<T> *lds = (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_slots_per_fft(p.L);
     cx<T> v[16];
 
-    // buffers by role (Manakov): the field at the step start / last iterate, and the next iterate
+    // buffers by role (Manakov)
     cx<T> *Tcur = a.T0, *Tnew = a.T1;
     T *Pcur = a.P, *Palt = a.P;
     if (kMk) {
-        Tcur = c.cur ? a.T1 : a.T0;                  // E(z) at a step start, E_conv afterwards
-        Tnew = c.cur ? a.T0 : a.T1;                  // receives E_fd
+        Tcur = c.cur ? a.T1 : a.T0;                  // field at the step start
+        Tnew = c.cur ? a.T0 : a.T1;                  // receives the field at the step end
         const long long psz = (1ll << (a.log2N1 + a.log2N2)) * a.ngroups;
         Pcur = a.P + (c.pcur ? psz : 0);
         Palt = a.P + (c.pcur ? 0 : psz);
@@ -778,7 +819,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
         for (int q = 0; q < 16; ++q) v[q] = a.G[g.rowbase + g.freq_off(q)];
         global_twiddle<+1>(g, a.log2N1 + a.log2N2, v);
         fft_dif<+1>(ctx, p, g.b, v, lds);
-    } else {
+    } else if (!(kMk && op == 3)) {
 #pragma unroll
         for (int idx = 0; idx < 16; ++idx) v[idx] = Tcur[g.rowbase + g.time_off(idx)];
     }
@@ -791,19 +832,17 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
 #pragma unroll
         for (int idx = 0; idx < 16; ++idx) a.T0[g.rowbase + g.time_off(idx)] = v[idx];
     } else if (kMk) {
-        const T shz = (T)(a.k.sgn * c.hz);
-        if (op == 0) {                               // S (non-speculative): Pch into the current buffer
+        const T shz = (T)(a.k.sgn * c.hz), c8g = (T)a.k.c8g;
+        cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));
+        if (op == 0) {                               // span start: Pch into the current buffer
             mk_step_start(ctx, g, a, v, Pcur, false);
-        } else if (op == 3) {                        // D(a) (non-speculative)
-            mk_next_iterate(ctx, g, a, v, Pcur, shz, false);
-        } else if (op == 1) {                                            // H: E_hd, first rotation (channels.py:409-417)
-            cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));
-            const T c8g = (T)a.k.c8g;
+        } else if (op == 1 || op == 3) {             // H (channels.py:409-417) | rebuild of iterate 0
             T ang[16];
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) {
                 const long long t = g.time_off(idx);
-                a.Ehd[g.rowbase + t] = v[idx];
+                if (op == 1) a.Ehd[g.rowbase + t] = v[idx];
+                else v[idx] = a.Ehd[g.rowbase + t];
                 const T pw = Pcur[g.pbase + t];
                 ang[idx] = shz * (c8g * (pw + pw) / (T)2);
             }
@@ -813,24 +852,40 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * rot[idx];
             ctx.sync();
-        } else if (op == 2) {                                            // I: E_fd out, convergence sums
-            double num = 0, den = 0;
+        } else {                                     // I: iterate `it` is in registers
+            double n0 = 0, d0 = 0, n1 = 0, d1 = 0;
+            if (c.it == 0) {                         // lim_0 against the field at the step start
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) {
-                const long long t = g.time_off(idx);
-                const cx<T> e = Tcur[g.rowbase + t];
-                Tnew[g.rowbase + t] = v[idx];
-                const double dr = (double)v[idx].re - (double)e.re, di = (double)v[idx].im - (double)e.im;
-                num += dr * dr + di * di;
-                den += (double)e.re * e.re + (double)e.im * e.im;
+                for (int idx = 0; idx < 16; ++idx) {
+                    const cx<T> e = Tcur[g.rowbase + g.time_off(idx)];
+                    const double dr = (double)v[idx].re - (double)e.re, di = (double)v[idx].im - (double)e.im;
+                    n0 += dr * dr + di * di;
+                    d0 += (double)e.re * e.re + (double)e.im * e.im;
+                }
             }
-            block_sum2(ctx, num, den, red);
-            if (ctx.tid == 0) {
-                a.pnum[ctx.bid] = num;
-                a.pden[ctx.bid] = den;
+            if (final_) {                            // the field after this step (channels.py:438-439)
+#pragma unroll
+                for (int idx = 0; idx < 16; ++idx) Tnew[g.rowbase + g.time_off(idx)] = v[idx];
+            } else {
+                mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1);
             }
-            if (want == 1) mk_next_iterate(ctx, g, a, v, Pcur, shz, true);      // anticipate: not converged yet
-            else if (want == 2) mk_step_start(ctx, g, a, v, Palt, true);         // anticipate: next step starts from E_fd
+            if (c.it == 0) {
+                block_sum2(ctx, n0, d0, red);
+                if (ctx.tid == 0) {
+                    a.pnum0[ctx.bid] = n0;
+                    a.pden0[ctx.bid] = d0;
+                }
+            }
+            if (!final_) {
+                block_sum2(ctx, n1, d1, red);
+                if (ctx.tid == 0) {
+                    a.pnum[ctx.bid] = n1;
+                    a.pden[ctx.bid] = d1;
+                }
+                ctx.sync();
+            } else if (more) {
+                mk_step_start(ctx, g, a, v, Palt, true);     // next step: Pch + forward transform
+            }
         }
     }
 

@@ -104,25 +104,51 @@ def test_manakov_vs_oracle_mid_size(N, adaptive):
 
 def test_launch_sequence_has_no_host_dependence_on_iteration_count():
     """The host enqueues [Row, Col] pairs without reading results inside a chunk: two launches
-    per (step + iteration) when every continuation was anticipated, two more per miss, and the
-    surplus (no-op launches after the span finished) stays bounded."""
+    per (step + iteration), two more per rebuilt iterate, and the surplus (no-op launches after
+    the span finished) stays bounded."""
     d, cfg = load_golden("mk_fix_p8_ideal_2span")
     out, info = eb.run("manakovSSF", d["Ei"], cfg)
     useful = 2 * (info["steps"] + info["iterations"] + info["spec_misses"])
     assert useful <= info["launches"] <= 1.35 * useful + 64
 
 
-def test_speculation_hits_in_steady_state_and_recovers_from_misses():
-    """The I stage anticipates the continuation from the previous step's iteration count; a
-    wrong guess must only cost time.  Steady iteration counts => (almost) all hits; a case
-    whose counts change between steps => some misses, same results (checked by the golden test)."""
-    d, cfg = load_golden("mk_fix_p8_ideal_2span")          # 3 iterations every step
-    _, info = eb.run("manakovSSF", d["Ei"], cfg)
-    assert info["spec_misses"] <= 2 * 3 + 1                 # only the first step of each span start-up
-    assert info["spec_hits"] >= info["iterations"] - info["spec_misses"] - 4
-    d, cfg = load_golden("mk_fix_p13_ideal_k2")            # 3 <-> 4 iterations
-    _, info = eb.run("manakovSSF", d["Ei"], cfg)
-    assert info["spec_misses"] >= 2 and info["spec_hits"] > info["spec_misses"]
+def test_convergence_is_decided_one_iteration_ahead():
+    """lim_i (i >= 1) is evaluated by the stage that builds iterate i (Parseval form), so every
+    iteration after the first of a step is decided in advance and nothing is rebuilt."""
+    for name in ("mk_fix_p8_ideal_2span", "mk_fix_p13_ideal_k2", "dbp_adp_ideal"):
+        d, cfg = load_golden(name)
+        _, info = eb.run(cfg["func"], d["Ei"], cfg)
+        assert info["spec_hits"] == info["iterations"] - info["steps"]
+        assert info["spec_misses"] == 0
+
+
+def test_convergence_at_iterate_zero_rebuilds_it_as_final():
+    """A field that barely changes over a step converges at iterate 0 (lim_0 < tol): the pipeline
+    has already moved on, notices it one launch later and rebuilds iterate 0 as the final one."""
+    E = synth_field(1024, 2, 41, -10.0)
+    cfg = dict(func="manakovSSF", alpha=0.0, D=1e-5, gamma=1e-6, Fc=193.1e12, Fs=64e9, maxIter=10, tol=1e-5,
+               prgsBar=False, Ltotal=0.4, Lspan=0.2, hz=0.05, nlprMethod=False, amp=None, saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+    assert set(tr["iters"]) == {1}
+    out, info = eb.run("manakovSSF", E, cfg)
+    assert rel_l2(out.T, ref) <= TOL_C128
+    assert list(info["iters"]) == tr["iters"] and info["spec_misses"] == info["steps"]
+    np.testing.assert_allclose(np.concatenate(info["lims"]), np.concatenate(tr["lims"]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("maxIter", [1, 2])
+def test_iteration_cap(maxIter):
+    """maxIter = 1: the only iterate is final by the cap and lim_0 alone decides the warning count."""
+    E = synth_field(1024, 2, 42, 10.0)
+    cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=maxIter, tol=1e-5,
+               prgsBar=False, Ltotal=2, Lspan=1, hz=0.25, nlprMethod=False, amp="ideal", saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+    out, info = eb.run("manakovSSF", E, cfg)
+    assert rel_l2(out.T, ref) <= TOL_C128
+    assert list(info["iters"]) == tr["iters"] and info["nonconverged_steps"] == tr["nonconverged"] == len(tr["iters"])
+    np.testing.assert_allclose(np.concatenate(info["lims"]), np.concatenate(tr["lims"]), rtol=1e-6)
 
 
 def test_philox_known_answers():
