@@ -664,7 +664,7 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
                        double &num, double &den) {
     T *shT = (T *)ctx.lds;
     cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));
-    T mine[16], oth[16], ang[16];
+    T mine[16], oth[16];                       // norms, then reused: mine -> |d rot|^2, oth -> new phase
 #pragma unroll
     for (int idx = 0; idx < 16; ++idx) mine[idx] = norm2(v[idx]);
     ctx.sync();
@@ -675,20 +675,21 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
         const long long t = g.time_off(idx);
         const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
         const T pw = Pbuf[g.pbase + t];
-        ang[idx] = shz * (c8g * (pw + ax + ay) / (T)2);
+        const T ang = shz * (c8g * (pw + ax + ay) / (T)2);
         const T prev = first ? shz * (c8g * (pw + pw) / (T)2) : a.Theta[g.pbase + t];
-        // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2); kept in `mine` (its norms are spent)
-        const double s = sin_half_angle((double)ang[idx] - (double)prev);
+        // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2)
+        const double s = sin_half_angle((double)ang - (double)prev);
         mine[idx] = (T)(4.0 * s * s);
+        oth[idx] = ang;
     }
     cx<T> rot[16];
-    pair_cis(ctx, g, 2, ang, rot, shC);      // (barrier inside: both partners have read the old phases)
+    pair_cis(ctx, g, 2, oth, rot, shC);      // (barrier inside: both partners have read the old phases)
     if (g.pol == 0) {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) a.Theta[g.pbase + g.time_off(idx)] = ang[idx];
+        for (int idx = 0; idx < 16; ++idx) a.Theta[g.pbase + g.time_off(idx)] = oth[idx];
     }
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) {
+    for (int idx = 0; idx < 16; ++idx) {       // (fetching E_hd any earlier costs 64 registers at the peak: spills)
         const cx<T> e = a.Ehd[g.rowbase + g.time_off(idx)];
         const double w = (double)norm2(e);
         num += w * (double)mine[idx];
