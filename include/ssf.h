@@ -21,6 +21,8 @@
  *   ssf_mgpu_run                         (no reference equivalent) independent fields
  *                                        sharded over the GPUs of one node, SURVEY.md 8e
  *   ssf_linear_channel                   linearFiberChannel               channels.py:30-109
+ *   ssf_overlap_save                     blockwiseFFTConv as used by edc  optic/dsp/core.py:973-1046,
+ *                                                                          optic/dsp/equalization.py:113-117
  *   ssf_set_profiling / ssf_get_kernel_times   time.time() pairs around calls in
  *                                        examples/benchmarck_GPU_processing.ipynb:389-395
  *
@@ -185,6 +187,15 @@ int  ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out);
 /* ---- linear channel (gamma = 0 closed form): one FFT . H . IFFT over the whole length */
 int  ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, double D,
                         double L, const void *field_in_soa, void *field_out_soa);
+
+/* ---- overlap-save FFT convolution: the engine of edc -------------------------------------- */
+/* Replaces blockwiseFFTConv(x, h, NFFT, freqDomainFilter=True) as edc calls it, once per mode
+ * (optic/dsp/equalization.py:113-117, optic/dsp/core.py:973-1046), for all modes at once.
+ * sig_in / sig_out: (sigLen, nrows) row-major complex (the reference's sigIn layout).
+ * Hfft: nfft complex values = fft(zero-padded impulse response) (core.py:1020); nfft = 2^m,
+ * 16 <= nfft <= 8192 (SSF_C128) / 16384 (SSF_C64), K = filter length <= nfft. */
+int  ssf_overlap_save(int device, int64_t sigLen, int32_t nrows, int32_t precision, int32_t nfft,
+                      int32_t K, const void *Hfft, const void *sig_in, void *sig_out);
 
 #ifdef __cplusplus
 }

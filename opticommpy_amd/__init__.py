@@ -9,9 +9,9 @@ library or without a GPU every propagation call raises.
 """
 from .utils import parameters  # noqa: F401
 from .models import (  # noqa: F401
-    checkGPU, edfa, linearFiberChannel, manakovDBP, manakovSSF, setPowerforParSSFM, ssfm,
+    checkGPU, edc, edfa, linearFiberChannel, manakovDBP, manakovSSF, setPowerforParSSFM, ssfm,
     last_run, set_device, set_engine,
 )
 
-__all__ = ["parameters", "ssfm", "manakovSSF", "manakovDBP", "edfa", "linearFiberChannel",
+__all__ = ["parameters", "ssfm", "manakovSSF", "manakovDBP", "edfa", "edc", "linearFiberChannel",
            "setPowerforParSSFM", "checkGPU", "last_run", "set_device", "set_engine"]

@@ -55,6 +55,11 @@ template <typename T> __global__ void __launch_bounds__(256) k_amp(const AmpArgs
     amp_body<T>(ctx, a);
 }
 
+template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT) k_ols(const OlsArgs<T> a) {
+    SSF_DEV_CTX();
+    ols_body<T>(ctx, a);
+}
+
 template <typename T> using RowFn = void (*)(const RowArgs<T>);
 template <typename T> using ColFn = void (*)(const ColArgs<T>);
 
@@ -282,6 +287,80 @@ template <typename T> class FusedEngine final : public Engine {
 };
 
 }  // namespace
+
+namespace {
+template <typename T>
+int overlap_save_t(int64_t sigLen, int nrows, int lg, int K, const void *Hfft, const void *in, void *out, std::string *err) {
+    using Cc = cx<T>;
+    const int nfft = 1 << lg, d = nfft - K + 1, discard = K - 1, D = (K - 1) / 2;
+    const long long numBlocks = (sigLen + K - 1 + d - 1) / d;                       // core.py:1023-1025
+    const size_t sig_bytes = sizeof(Cc) * (size_t)sigLen * (size_t)nrows;
+    hipStream_t st = nullptr;
+    Cc *din = nullptr, *dout = nullptr, *dH = nullptr;
+    auto fail_ = [&](const char *what, hipError_t e) {
+        *err = std::string(what) + ": " + hipGetErrorString(e);
+        if (din) (void)hipFree(din);
+        if (dout) (void)hipFree(dout);
+        if (dH) (void)hipFree(dH);
+        if (st) (void)hipStreamDestroy(st);
+        return e == hipErrorOutOfMemory ? SSF_ERR_OOM : SSF_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail_("hipStreamCreate", e);
+    if ((e = hipMalloc(&din, sig_bytes)) != hipSuccess) return fail_("hipMalloc", e);
+    if ((e = hipMalloc(&dout, sig_bytes)) != hipSuccess) return fail_("hipMalloc", e);
+    if ((e = hipMalloc(&dH, sizeof(Cc) * (size_t)nfft)) != hipSuccess) return fail_("hipMalloc", e);
+    std::vector<Cc> Hs((size_t)nfft);                                                // fold the 1/NFFT of the ifft into H
+    for (int i = 0; i < nfft; ++i) {
+        Hs[(size_t)i].re = ((const Cc *)Hfft)[i].re / (T)nfft;
+        Hs[(size_t)i].im = ((const Cc *)Hfft)[i].im / (T)nfft;
+    }
+    Stager stg;
+    (void)stg.init();
+    if ((e = stg.h2d(din, in, sig_bytes, st)) != hipSuccess) return fail_("upload", e);
+    if ((e = hipMemcpyAsync(dH, Hs.data(), sizeof(Cc) * (size_t)nfft, hipMemcpyHostToDevice, st)) != hipSuccess) return fail_("upload H", e);
+    OlsArgs<T> a{};
+    a.in = din;
+    a.out = dout;
+    a.H = dH;
+    a.sigLen = sigLen;
+    a.njobs = numBlocks * nrows;
+    a.nrows = nrows;
+    a.log2nfft = lg;
+    a.d = d;
+    a.discard = discard;
+    a.D = D;
+    const int tpf = nfft / 16;
+    const int block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
+    const long long grid = (a.njobs + fpw - 1) / fpw;
+    const size_t lds = (size_t)fpw * lds_slots_per_fft(nfft) * sizeof(Cc);
+    if (block <= 256) {
+        (void)hipFuncSetAttribute((const void *)k_ols<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        k_ols<T, 256><<<(unsigned)grid, block, lds, st>>>(a);
+    } else {
+        (void)hipFuncSetAttribute((const void *)k_ols<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        k_ols<T, 1024><<<(unsigned)grid, block, lds, st>>>(a);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return fail_("launch k_ols", e);
+    if ((e = stg.d2h(out, dout, sig_bytes, st)) != hipSuccess) return fail_("download", e);
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    (void)hipFree(dH);
+    (void)hipStreamDestroy(st);
+    return SSF_OK;
+}
+}  // namespace
+
+int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int log2nfft, int K, const void *Hfft,
+                       const void *in, void *out, std::string *err) {
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        *err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return SSF_ERR_HIP;
+    }
+    return precision == SSF_C128 ? overlap_save_t<double>(sigLen, nrows, log2nfft, K, Hfft, in, out, err)
+                                 : overlap_save_t<float>(sigLen, nrows, log2nfft, K, Hfft, in, out, err);
+}
 
 bool fused_supports(int64_t N, int nrows, int precision) {
     if (N < 256 || (N & (N - 1)) || nrows < 1) return false;

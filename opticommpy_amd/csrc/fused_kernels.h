@@ -923,5 +923,45 @@ template <typename T, class Ctx> SSF_HD void amp_body(Ctx &ctx, const AmpArgs<T>
     }
 }
 
+// ------------------------------------------------------------------- overlap-save convolution
+// One block of the overlap-and-save FFT convolution of optic/dsp/core.py:1032-1041 per transform:
+//   X = fft(xpad[blk*d : blk*d + NFFT]);  y_blk = ifft(X * H);  y[blk*d : (blk+1)*d] = y_blk[discard:]
+// followed by out = y[D : D + sigLen] (core.py:1043-1046), all fused: the padded signal and y are
+// never materialised, the block is transformed in LDS with the same DIF/DIT pair as the row kernel.
+template <typename T> struct OlsArgs {
+    const cx<T> *in;      // (sigLen, nrows) row-major, as the reference's sigIn
+    cx<T> *out;           // (sigLen, nrows)
+    const cx<T> *H;       // NFFT values: fft(zero-padded impulse response) / NFFT
+    long long sigLen, njobs;   // njobs = numBlocks * nrows
+    int nrows, log2nfft, d, discard, D;
+};
+template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T> &a) {
+    const PassPlan p = make_plan(a.log2nfft);
+    const int fpw = ctx.nthreads / p.tpf;
+    const int f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
+    const long long job = (long long)ctx.bid * fpw + f;
+    const bool live = job < a.njobs;                     // idle threads still take part in the barriers
+    const long long blk = live ? job / a.nrows : 0;
+    const int m = live ? (int)(job - blk * a.nrows) : 0;
+    cx<T> *l = (cx<T> *)ctx.lds + (size_t)f * lds_slots_per_fft(p.L);
+    cx<T> v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const long long i = blk * a.d + (b + p.tpf * q) - a.discard;      // index into the unpadded signal
+        v[q] = (live && i >= 0 && i < a.sigLen) ? a.in[i * a.nrows + m] : mk<T>((T)0, (T)0);
+    }
+    fft_dif<-1>(ctx, p, b, v, l);
+    const int last = p.npass - 1;
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * a.H[rev_pos(p, reg_pos(p, last, b, idx))];
+    fft_dit<+1>(ctx, p, b, v, l);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int pos = b + p.tpf * q;
+        const long long n = blk * a.d + pos - a.discard - a.D;
+        if (live && pos >= a.discard && n >= 0 && n < a.sigLen) a.out[n * a.nrows + m] = v[q];
+    }
+}
+
 }  // namespace fused
 }  // namespace ssf

@@ -195,6 +195,25 @@ int ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, doubl
     return ssf_download(plan, out);
 }
 
+int ssf_overlap_save(int device, int64_t sigLen, int32_t nrows, int32_t precision, int32_t nfft, int32_t K,
+                     const void *Hfft, const void *sig_in, void *sig_out) {
+    if (sigLen < 1 || nrows < 1 || !Hfft || !sig_in || !sig_out) return set_err(SSF_ERR_BAD_ARG, "ssf_overlap_save: bad argument");
+    if (precision != SSF_C64 && precision != SSF_C128) return set_err(SSF_ERR_BAD_ARG, "bad precision");
+    int lg = 0;
+    while ((1 << lg) < nfft) ++lg;
+    const int lgmax = precision == SSF_C128 ? 13 : 14;
+    if ((1 << lg) != nfft || lg < 4 || lg > lgmax)
+        return set_err(SSF_ERR_UNSUPPORTED, "ssf_overlap_save: nfft must be a power of two in [16, 8192 (c128) / 16384 (c64)]");
+    if (K < 1 || K > nfft) return set_err(SSF_ERR_BAD_ARG, "FFT size is smaller than filter length");   // core.py:1012
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_err(SSF_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return set_err(SSF_ERR_NO_DEVICE, "device index out of range");
+    std::string err;
+    int rc = fused_overlap_save(device, sigLen, nrows, precision, lg, K, Hfft, sig_in, sig_out, &err);
+    if (rc) set_err(rc, err);
+    return rc;
+}
+
 int ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_t N, int32_t rows_per_unit,
                  int32_t precision, int32_t engine, const ssf_params *params, const void *fields_in,
                  void *fields_out, ssf_stats *stats) {

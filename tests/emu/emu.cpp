@@ -242,6 +242,32 @@ void emu_gauss(long long n, unsigned row, unsigned span, unsigned long long seed
     for (long long i = 0; i < n; ++i) ssf::gauss_pair((unsigned long long)i, row, span, seed, sigma, re[i], im[i]);
 }
 
+int emu_overlap_save(int64_t sigLen, int nrows, int lg, int K, const void *Hfft, const void *in, void *out) {
+    using namespace ssf::fused;
+    using Cc = cx<double>;
+    const int nfft = 1 << lg, d = nfft - K + 1;
+    std::vector<Cc> Hs((size_t)nfft);
+    for (int i = 0; i < nfft; ++i) {
+        Hs[(size_t)i].re = ((const Cc *)Hfft)[i].re / nfft;
+        Hs[(size_t)i].im = ((const Cc *)Hfft)[i].im / nfft;
+    }
+    OlsArgs<double> a{};
+    a.in = (const Cc *)in;
+    a.out = (Cc *)out;
+    a.H = Hs.data();
+    a.sigLen = sigLen;
+    a.njobs = ((sigLen + K - 1 + d - 1) / d) * nrows;
+    a.nrows = nrows;
+    a.log2nfft = lg;
+    a.d = d;
+    a.discard = K - 1;
+    a.D = (K - 1) / 2;
+    const int tpf = nfft / 16, block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
+    const long long grid = (a.njobs + fpw - 1) / fpw;
+    run_grid((int)grid, block, (size_t)fpw * lds_slots_per_fft(nfft) * sizeof(Cc), [&](EmuCtx &c) { ols_body<double>(c, a); });
+    return 0;
+}
+
 int emu_linear_channel(int64_t N, int nrows, int precision, double Fs, double Fc, double alpha, double D, double L,
                        const void *in, void *out) {
     if (!emu_supported(N, precision)) return SSF_ERR_UNSUPPORTED;

@@ -12,6 +12,8 @@ ALL = golden_names()
 
 def _run(cfg, Ei, trace):
     p = make_param(orc.parameters, cfg)
+    if cfg["func"] == "edc":
+        return orc.edc(Ei, p), p
     fn = {"ssfm": orc.ssfm, "manakovSSF": orc.manakovSSF, "manakovDBP": orc.manakovDBP}[cfg["func"]]
     return fn(Ei, p, trace=trace), p
 

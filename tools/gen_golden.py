@@ -254,6 +254,19 @@ def main():
     rt = np.linalg.norm(back - E8) / np.linalg.norm(E8)
     print(f"round trip rel-L2 = {rt:.2e}")
 
+    # ---------------- edc (overlap-save chromatic dispersion compensation) ----------------
+    from optic.dsp.equalization import edc as ref_edc
+    rng = np.random.default_rng(50)
+    sig = (rng.normal(size=(4096, 2)) + 1j * rng.normal(size=(4096, 2))) / np.sqrt(2)
+    for name, x, kw in (
+            ("edc_2mode_default", sig, dict(L=50, D=16, Fc=193.1e12, Fs=64e9, Rs=32e9)),
+            ("edc_1d_long_link", sig[:3000, 0].copy(), dict(L=800, D=17, Fc=193.1e12, Fs=64e9, Rs=32e9)),
+            ("edc_given_nfft", sig, dict(L=100, D=16, Fc=193.1e12, Fs=64e9, Rs=32e9, NfilterCoeffs=45, Nfft=256)),
+            ("edc_real_input", sig[:2048].real.copy(), dict(L=20, D=16, Fc=193.1e12, Fs=64e9, Rs=32e9))):
+        out = ref_edc(x, mk_param(**kw))
+        save(name, Ei=x, out=out, cfg=cfg_json("edc", kw))
+        print(f"{name:24s} in {x.dtype}{x.shape} out {out.dtype}{out.shape}")
+
 
 if __name__ == "__main__":
     main()
