@@ -28,9 +28,6 @@ struct DevCtx {
         for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
         return v;
     }
-    __device__ __forceinline__ void sleep(int units64) {          // ~units64 * 64 clocks
-        for (int i = 0; i < units64; i += 64) __builtin_amdgcn_s_sleep(64);
-    }
 };
 
 #define SSF_DEV_CTX()                                                         \
@@ -109,9 +106,7 @@ struct HipBackend {
     std::string where;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
-    int row_occ = 2, stagger = 0, stagger_mode = 0;
-    int row_stagger() const { return stagger; }
-    int row_stagger_mode() const { return stagger_mode; }
+    int row_occ = 2;
     // optional per-launch event timing (ssf_set_profiling)
     bool profiling = false;
     struct Stamp { hipEvent_t a, b; int cat; };
@@ -150,8 +145,6 @@ struct HipBackend {
     }
     explicit HipBackend(ssf_plan *p) : pl(p) {
         if (const char *s = getenv("SSF_FUSED_ROW_OCC")) row_occ = atoi(s) == 1 ? 1 : 2;
-        if (const char *s = getenv("SSF_ROW_STAGGER")) stagger = atoi(s);
-        if (const char *s = getenv("SSF_ROW_STAGGER_MODE")) stagger_mode = atoi(s);
         chk(hipEventCreate(&ev0), "hipEventCreate");
         chk(hipEventCreate(&ev1), "hipEventCreate");
     }

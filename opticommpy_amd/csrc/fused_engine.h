@@ -165,8 +165,6 @@ template <typename T, class Backend> class FusedCore {
         a.log2N1 = sp.l1;
         a.log2N2 = sp.l2;
         a.nfft = (int)((int64_t)nrows << sp.l1);
-        a.stagger = be.row_stagger();
-        a.stagger_mode = be.row_stagger_mode();
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {

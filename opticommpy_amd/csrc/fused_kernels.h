@@ -381,8 +381,6 @@ template <typename T> struct RowArgs {
     const double *pnum, *pden;   // partial sums of lim_it written by the I stage
     const double *pnum0, *pden0; // partial sums of lim_0
     int npart;
-    int stagger;              // late start of half of the workgroups, in units of 64 clocks (0 = off)
-    int stagger_mode;         // which half: 0 = upper half of the grid, 1 = odd groups of 8 blocks
 };
 
 // linear operator for the 16 registers of a last-radix-16 butterfly: bins k0 + (N/16) q
@@ -434,9 +432,8 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     cx<T> v[16];
     // The row is fetched before the control block is evaluated: the loads do not depend on the
     // decision, and their latency hides the reduction below (a launch that turns out to have
-    // nothing to do just drops them).  Half of the workgroups may start late (a.stagger) so that
-    // one co-resident workgroup computes while the other one is still waiting for HBM.
-    if (a.stagger > 0 && (a.stagger_mode ? ((ctx.bid >> 3) & 1) : (ctx.bid >= (ctx.nblocks >> 1)))) ctx.sleep(a.stagger);
+    // nothing to do just drops them).  (Starting half of the workgroups late, so that co-resident
+    // workgroups are out of phase, was measured and does not help.)
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = g[b + p.tpf * q];
     if (a.use_ctrl) {

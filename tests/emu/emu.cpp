@@ -27,7 +27,6 @@ struct EmuCtx {
     char *lds;
     static constexpr bool kWaveOps = false;
     void sync();
-    void sleep(int) {}
     double wave_sum(double v) { return v; }
     double wave_max(double v) { return v; }
 };
@@ -138,8 +137,6 @@ struct EmuBackend {
     }
     void memset(void *d, int v, size_t n) { ::memset(d, v, n); }
     void prepare(size_t, size_t) {}
-    int row_stagger() const { return 0; }
-    int row_stagger_mode() const { return 0; }
     void sync() {}
     bool ok() const { return true; }
     std::string last_error() const { return ""; }
