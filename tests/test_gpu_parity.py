@@ -312,3 +312,24 @@ def test_kernel_profiling_api():
     pl.lib.ssf_set_profiling(pl.h, 0)
     steps, iters = models.last_run["steps"], models.last_run["iterations"]
     assert kt.row_n >= steps + iters and kt.colA_n >= steps + iters and kt.row_ms > 0 and kt.colA_ms > 0
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_reference_defaults_end_to_end(engine):
+    """A notebook-style call with nothing but Fs set: 5 x 80 km, adaptive step, amp='edfa' (ASE
+    generated on the device), default saveSpanN -> one (N, 2) snapshot; seeded runs repeat."""
+    N = 1 << 13
+    _select(engine, N)
+    E = synth_field(N, 2, 80, 0.0)
+    outs = []
+    for seed in (11, 11, 12):
+        p = oa.parameters()
+        p.Fs, p.seed, p.prgsBar = 512e9, seed, False
+        out = oa.manakovSSF(E, p)
+        assert out.shape == (N, 2) and out.dtype == np.complex128 and np.all(np.isfinite(out.view(float)))
+        assert p.amp == "edfa" and p.Ltotal == 400 and p.saveSpanN == [5] and p.nlprMethod is True
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
+    # span loss is compensated by the EDFA gain: output power = input power + 5 spans of ASE
+    _, p_noise = orc.edfa_noise_power(0.2 * 80, 4.5, 193.1e12, 512e9)
+    assert orc.signalPower(outs[0]) == pytest.approx(orc.signalPower(E) + 2 * 5 * p_noise, rel=0.05)
