@@ -104,6 +104,21 @@ def test_manakov_vs_oracle_mid_size(N, adaptive):
     np.testing.assert_allclose(info["hz"], tr["hz"], rtol=1e-9)
 
 
+def test_headline_geometry_on_emulated_kernels():
+    """N = 2^20 (N1 = 256 columns x N2 = 4096 rows, three radix-16 passes, LDS twiddle tables incl.
+    the two-level W_4096 form): one linear channel and two Manakov steps of BASELINE config 2."""
+    E = synth_field(1 << 20, 2, 2, 8.4)
+    p = orc.parameters()
+    p.Fs, p.L, p.alpha, p.D, p.Fc = 512e9, 2.0, 0.2, 16, 193.1e12
+    assert rel_l2(eb.linear_channel(E, 512e9, 193.1e12, 0.2, 16, 2.0), orc.linearFiberChannel(E, p)) < 1e-14
+    cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5,
+               prgsBar=False, Ltotal=0.16, Lspan=0.16, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+    out, info = eb.run("manakovSSF", E, cfg)
+    assert rel_l2(out.T, ref) <= TOL_C128 and list(info["iters"]) == tr["iters"]
+
+
 def test_launch_sequence_has_no_host_dependence_on_iteration_count():
     """The host enqueues [Row, Col] pairs without reading results inside a chunk: two launches
     per (step + iteration), two more per rebuilt iterate, and the surplus (no-op launches after
