@@ -208,34 +208,30 @@ struct HipBackend {
         col_lds_max = col_lds;
     }
     template <typename T> void launch_row(const RowArgs<T> &a, int grid, int block, size_t lds) {
-        static thread_local const void *armed[64];
-        static thread_local int narmed = 0;
         RowFn<T> f = pick_row<T>(a.log2N2, block, row_occ);
-        arm((const void *)f, row_lds_max, armed, narmed);
+        arm((const void *)f);
         stamp_begin(0);
         f<<<grid, block, lds, pl->stream>>>(a);
         stamp_end();
         chk(hipGetLastError(), "launch k_row");
     }
     template <typename T> void launch_col(const ColArgs<T> &a, int grid, int block, size_t lds) {
-        static thread_local const void *armed[64];
-        static thread_local int narmed = 0;
         ColFn<T> f = pick_col<T>(a.log2N1, a.mode);
-        arm((const void *)f, col_lds_max, armed, narmed);
+        arm((const void *)f);
         stamp_begin(a.mode == CM_MK ? 1 : 3);
         f<<<grid, block, lds, pl->stream>>>(a);
         stamp_end();
         chk(hipGetLastError(), "launch k_col");
     }
-    // raise the dynamic-LDS cap of a kernel the first time this (thread, device) uses it
-    void arm(const void *f, size_t bytes, const void **armed, int &narmed) {
-        const size_t want = bytes > 160 * 1024 ? 160 * 1024 : bytes;
-        for (int i = 0; i < narmed; ++i)
-            if (armed[i] == f) return;
+    // raise the dynamic-LDS cap of a kernel the first time THIS backend (= this plan, hence this
+    // device) launches it; the attribute is per device, so the record must not be shared
+    std::vector<const void *> armed;
+    void arm(const void *f) {
+        for (const void *g : armed)
+            if (g == f) return;
         chk(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        (void)want;
-        if (narmed < 64) armed[narmed++] = f;
+        armed.push_back(f);
     }
     template <typename T> void launch_amp(const AmpArgs<T> &a, int grid, int block) {
         k_amp<T><<<grid, block, 0, pl->stream>>>(a);
