@@ -223,3 +223,34 @@ def test_edc_inverts_the_linear_channel():
     mid = slice(2000, -2000)
     res = min(rel_l2(np.roll(back, k, axis=0)[mid], E[mid]) for k in range(-4, 5))
     assert res ** 2 < 0.02 and res < rel_l2(disp[mid], E[mid]) / 10
+
+
+@pytest.mark.parametrize("case", ["hz_longer_than_span", "all_zero_field", "min_length", "three_pairs"])
+def test_edge_cases_on_emulated_kernels(case):
+    import logging
+    logging.disable(logging.WARNING)
+    try:
+        N, ncols = 1024, 2
+        kw = dict(Ltotal=2, Lspan=1, hz=0.25, saveSpanN=[])
+        if case == "hz_longer_than_span":
+            kw = dict(Ltotal=4, Lspan=2, hz=5.0, saveSpanN=[])
+        elif case == "all_zero_field":         # lim = 0/0 = nan never passes: maxIter iterations, warnings
+            kw = dict(Ltotal=1, Lspan=1, hz=0.5, maxIter=3, saveSpanN=[])
+        elif case == "min_length":
+            N = 256
+        elif case == "three_pairs":
+            ncols = 6
+        E = synth_field(N, ncols, 90, 6.0) if case != "all_zero_field" else np.zeros((N, 2), complex)
+        cfg = dict(dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5,
+                        prgsBar=False, nlprMethod=False, amp="ideal"), **kw)
+        tr = {}
+        with np.errstate(all="ignore"):
+            ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+        out, info = eb.run("manakovSSF", E, cfg)
+        if case == "all_zero_field":
+            assert np.all(out == 0) and info["nonconverged_steps"] == tr["nonconverged"] == info["steps"]
+        else:
+            assert rel_l2(out.T, ref) <= TOL_C128
+        assert list(info["iters"]) == tr["iters"]
+    finally:
+        logging.disable(logging.NOTSET)

@@ -333,3 +333,44 @@ def test_reference_defaults_end_to_end(engine):
     # span loss is compensated by the EDFA gain: output power = input power + 5 spans of ASE
     _, p_noise = orc.edfa_noise_power(0.2 * 80, 4.5, 193.1e12, 512e9)
     assert orc.signalPower(outs[0]) == pytest.approx(orc.signalPower(E) + 2 * 5 * p_noise, rel=0.05)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("case", ["no_span", "hz_longer_than_span", "all_zero_field", "min_length", "three_pairs",
+                                  "odd_tiny_length"])
+def test_edge_cases_vs_oracle(engine, case):
+    import logging
+    logging.disable(logging.WARNING)
+    try:
+        N, ncols, kw = 1024, 2, {}
+        if case == "no_span":                      # Ltotal < Lspan: zero spans, nothing propagates
+            kw = dict(Ltotal=5, Lspan=10, saveSpanN=[])
+        elif case == "hz_longer_than_span":        # one shortened step per span (channels.py:398-400)
+            kw = dict(Ltotal=4, Lspan=2, hz=5.0, saveSpanN=[1, 2])
+        elif case == "all_zero_field":             # lim = 0/0 = nan never passes: maxIter iterations, warnings
+            kw = dict(Ltotal=1, Lspan=1, hz=0.5, maxIter=3, saveSpanN=[])
+        elif case == "min_length":
+            N = 256
+            kw = dict(Ltotal=2, Lspan=1, hz=0.25, saveSpanN=[])
+        elif case == "three_pairs":
+            ncols = 6
+            kw = dict(Ltotal=2, Lspan=1, hz=0.25, saveSpanN=[])
+        else:
+            N = 97
+            kw = dict(Ltotal=2, Lspan=1, hz=0.25, saveSpanN=[])
+        _select(engine, N)
+        E = synth_field(N, ncols, 90, 6.0) if case != "all_zero_field" else np.zeros((N, 2), complex)
+        cfg = _mk_cfg(nlprMethod=False, amp="ideal", **kw)
+        tr = {}
+        ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+        out, _, run = _run_hip(cfg, E)
+        assert out.shape == ref.shape and out.dtype == ref.dtype
+        if case == "all_zero_field":
+            assert np.all(out == 0) and run["nonconverged_steps"] == tr["nonconverged"] == run["steps"]
+        elif case == "no_span":
+            assert np.array_equal(out, E) and run["steps"] == 0
+        else:
+            assert rel_l2(out, ref) <= TOL_C128
+        assert run["steps"] == tr.get("steps", 0) and list(run["iters"]) == tr.get("iters", [])
+    finally:
+        logging.disable(logging.NOTSET)
