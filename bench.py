@@ -138,7 +138,7 @@ def main():
         bytes_per_launch = 2 * (16 if args.prec == "c128" else 8) * N * 2       # one transform-equivalent per row
         kernels = {}
         for name, ms, n in (("row (decision + FFT.H.IFFT of rows)", kt.row_ms, kt.row_n),
-                            ("col (S | H | I+anticipated continuation)", kt.colA_ms, kt.colA_n)):
+                            ("col (Manakov column stage: S | H | I)", kt.col_ms, kt.col_n)):
             if n:
                 avg_us = ms / n * 1e3
                 kernels[name] = {"launches": int(n), "avg_us": avg_us}

@@ -101,8 +101,10 @@ typedef struct {
     double  bytes_algorithmic;   /* transforms * 2 * sizeof(complex) * N      */
     int32_t engine;              /* SSF_ENGINE_* actually used                           */
     int32_t n_snapshots;         /* snapshots captured so far                            */
-    int64_t spec_hits;           /* fused engine: iterations whose continuation was      */
-    int64_t spec_misses;         /*   anticipated correctly / had to be redone           */
+    int64_t decided_ahead;       /* fused engine: iterations whose convergence test was  */
+                                 /*   evaluated one iteration in advance (all but the    */
+                                 /*   first of every step)                               */
+    int64_t rebuilt_iterates;    /* fused engine: iterates rebuilt as final (lim_0<tol)  */
 } ssf_stats;
 
 /* Optional per-step trace (for parity checks of the data-dependent control flow).
@@ -173,13 +175,13 @@ int  ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_
 /* ---- per-kernel timing (measurement aid; fused engine only) ------------------------------ */
 /* With profiling enabled every kernel launch of ssf_execute is bracketed by HIP events on the
  * plan's stream (costs a few microseconds per launch: do not enable for the headline timing).
- * Totals accumulate until ssf_upload.  Kernel classes of the fused Manakov pipeline:
- *   row  = FFT_rows . H . IFFT_rows        (one transform-equivalent per row per launch)
- *   colA = inverse/forward column FFTs around E_hd / E_fd work (never idle in steady state)
- *   colB = step-start / decision stage     (idle once per step)                            */
+ * Totals accumulate until ssf_upload.  Kernel classes of the fused pipeline:
+ *   row   = (convergence decision,) FFT_rows . H . IFFT_rows   (one transform-equivalent per row)
+ *   col   = Manakov column stage: inverse/forward column FFTs around the time-domain work
+ *   other = scalar-NLSE / linear-channel column stages                                      */
 typedef struct {
-    double  row_ms, colA_ms, colB_ms, other_ms;
-    int64_t row_n, colA_n, colB_n, other_n;
+    double  row_ms, col_ms, other_ms;
+    int64_t row_n, col_n, other_n;
 } ssf_kernel_times;
 int  ssf_set_profiling(ssf_plan *plan, int32_t enable);
 int  ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out);

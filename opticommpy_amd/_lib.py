@@ -30,7 +30,7 @@ class Stats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("iterations", C.c_int64), ("transforms", C.c_int64),
                 ("nonconverged_steps", C.c_int64), ("device_ms", C.c_double),
                 ("bytes_algorithmic", C.c_double), ("engine", C.c_int32), ("n_snapshots", C.c_int32),
-                ("spec_hits", C.c_int64), ("spec_misses", C.c_int64)]
+                ("decided_ahead", C.c_int64), ("rebuilt_iterates", C.c_int64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
@@ -44,8 +44,8 @@ class Trace(C.Structure):
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("row_ms", C.c_double), ("colA_ms", C.c_double), ("colB_ms", C.c_double), ("other_ms", C.c_double),
-                ("row_n", C.c_int64), ("colA_n", C.c_int64), ("colB_n", C.c_int64), ("other_n", C.c_int64)]
+    _fields_ = [("row_ms", C.c_double), ("col_ms", C.c_double), ("other_ms", C.c_double),
+                ("row_n", C.c_int64), ("col_n", C.c_int64), ("other_n", C.c_int64)]
 
 
 class DeviceInfo(C.Structure):

@@ -133,8 +133,8 @@ struct HipBackend {
         for (auto &s : stamps) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-                double *t = s.cat == 0 ? &kt.row_ms : s.cat == 1 ? &kt.colA_ms : s.cat == 2 ? &kt.colB_ms : &kt.other_ms;
-                int64_t *n = s.cat == 0 ? &kt.row_n : s.cat == 1 ? &kt.colA_n : s.cat == 2 ? &kt.colB_n : &kt.other_n;
+                double *t = s.cat == 0 ? &kt.row_ms : s.cat == 1 ? &kt.col_ms : &kt.other_ms;
+                int64_t *n = s.cat == 0 ? &kt.row_n : s.cat == 1 ? &kt.col_n : &kt.other_n;
                 *t += ms;
                 *n += 1;
             }

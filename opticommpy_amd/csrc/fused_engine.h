@@ -385,8 +385,8 @@ template <typename T, class Backend> class FusedCore {
             st->steps += c.steps;
             st->iterations += c.iterations;
             st->nonconverged_steps += c.nonconv;
-            st->spec_hits += c.spec_hit;
-            st->spec_misses += c.spec_miss;
+            st->decided_ahead += c.n_ahead;
+            st->rebuilt_iterates += c.n_rebuilt;
             st->transforms += (int64_t)nrows * (2 * c.steps + 2 * c.iterations);
             if (p.direction >= 0 && (rc = amp_fwd(p, d, span, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
             if (wants_snapshot(p, span) && (rc = snapshot())) return rc;

@@ -8,7 +8,7 @@
 //
 //   column kernel (C columns x N1 per workgroup, both polarisations of a pair):
 //        [G -> inverse column FFT (DIF, natural k1 in, digit-reversed n1 in registers)]
-//        -> time-domain work on registers (power, Kerr rotation, norms, E_hd / E_conv I/O)
+//        -> time-domain work on registers (power, Kerr rotation, convergence sums, E_hd / field I/O)
 //        -> [forward column FFT (DIT, digit-reversed in, natural k1 out) -> G]
 //   row kernel (one contiguous row of N2 per transform):
 //        G -> forward row FFT (DIF) -> * linear operator / N (from the bin index)
@@ -65,7 +65,7 @@ struct Ctrl {           // device-resident step state, double-buffered by launch
     long long pend0_idx;// trace row lim_0 belongs to
     double z, hz;
     long long steps, iterations, nonconv, trace_n;
-    long long spec_hit, spec_miss;   // iterations decided in advance / iterates rebuilt
+    long long n_ahead, n_rebuilt;   // iterations decided in advance / iterates rebuilt
     LinOp lin;
 };
 
@@ -478,7 +478,7 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
                     const bool conv = lim < a.k.tol;
                     n.final_ = conv || c.it == a.k.maxIter - 1;           // channels.py:429-434
                     if (n.final_ && !conv) n.nonconv = n.nonconv + 1;
-                    n.spec_hit = c.spec_hit + 1;
+                    n.n_ahead = c.n_ahead + 1;
                 }
             }
         }
@@ -530,14 +530,14 @@ enum {
     CM_NLSE_FIRST = 0,   // time -> forward -> G
     CM_NLSE_STEP = 1,    // G -> inverse -> E *= exp(j g_hz |E|^2) -> forward -> G
     CM_NLSE_LAST = 2,    // G -> inverse -> time
-    CM_MK = 3,           // Manakov column stage picked by the Ctrl state (S | H | I | unanticipated next iterate)
+    CM_MK = 3,           // Manakov column stage picked by the Ctrl state (S | H | I | rebuild of iterate 0)
     CM_PLAIN_FWD = 5,    // time -> forward -> G            (linear channel)
     CM_PLAIN_INV = 6     // G -> inverse -> time            (linear channel)
 };
 
 template <typename T> struct ColArgs {
     cx<T> *G;                 // (nrows, N1, N2)
-    cx<T> *T0, *T1;           // time-domain fields, (nrows, N); Manakov: E(z)/E_conv ping-pong
+    cx<T> *T0, *T1;           // time-domain fields, (nrows, N); Manakov: field at the step start / end (ping-pong)
     cx<T> *Ehd;               // (nrows, N)
     T *P;                     // (2, K, N): Pch of the current / next step
     T *Theta;                 // (K, N): phase shz * phi of the latest rotation
@@ -749,7 +749,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
                 n->final_ = 1;
                 n->redo_ = 1;
                 n->pend0 = n->pendn = 0;
-                n->spec_miss = a.cin->spec_miss + 1;
+                n->n_rebuilt = a.cin->n_rebuilt + 1;
             } else if (op == 2 && !final_) {
                 n->state = ST_ROW_ITER;
                 n->it = c.it + 1;

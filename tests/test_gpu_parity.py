@@ -311,7 +311,7 @@ def test_kernel_profiling_api():
     assert pl.lib.ssf_get_kernel_times(pl.h, C.byref(kt)) == 0
     pl.lib.ssf_set_profiling(pl.h, 0)
     steps, iters = models.last_run["steps"], models.last_run["iterations"]
-    assert kt.row_n >= steps + iters and kt.colA_n >= steps + iters and kt.row_ms > 0 and kt.colA_ms > 0
+    assert kt.row_n >= steps + iters and kt.col_n >= steps + iters and kt.row_ms > 0 and kt.col_ms > 0
 
 
 @pytest.mark.parametrize("engine", ENGINES)
