@@ -12,11 +12,35 @@ namespace {
 
 using namespace fused;
 
+// Phase timing (diagnostic builds only, make PHASE=1): mark(i) drains the memory counters and
+// stores the 100 MHz wall clock for the lead thread of every workgroup; the product build
+// compiles mark() to nothing.
+#ifdef SSF_PHASE_TIMING
+__device__ unsigned long long g_marks[2][4096][8];
+#endif
+
 struct DevCtx {
     int tid, bid, nthreads, nblocks;
     char *lds;
     static constexpr bool kWaveOps = true;
+#ifdef SSF_PHASE_TIMING
+    int kind;
+    unsigned long long t0 = 0;
+    __device__ __forceinline__ void mark(int i) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long now = wall_clock64();
+        if (i == 0) t0 = now;                       // kept in a register: a launch that returns early
+        else if (tid == 0 && bid < 4096) {          // (nothing to do) leaves the previous record intact
+            g_marks[kind][bid][i] = now;
+            if (i == 1) g_marks[kind][bid][0] = t0;
+        }
+    }
+#else
+    __device__ __forceinline__ void mark(int) {}
+#endif
     __device__ __forceinline__ void sync() { __syncthreads(); }
+    // keeps the instruction scheduler from moving memory operations across this point
+    __device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
     // all-lanes butterfly over the 64-lane wave (every lane returns the same value)
     __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -30,30 +54,35 @@ struct DevCtx {
     }
 };
 
-#define SSF_DEV_CTX()                                                         \
+#ifdef SSF_PHASE_TIMING
+#define SSF_CTX_KIND(k) , k
+#else
+#define SSF_CTX_KIND(k)
+#endif
+#define SSF_DEV_CTX(k)                                                        \
     extern __shared__ __attribute__((aligned(16))) char ssf_smem[];           \
-    DevCtx ctx{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, ssf_smem}
+    DevCtx ctx{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, ssf_smem SSF_CTX_KIND(k)}
 
 // OCC = minimum waves per SIMD the register allocator must leave room for: 1 = up to 512
 // registers per lane and no spills (one 256-thread workgroup per CU), 2 = 256 registers
 // (two workgroups per CU).  LG = compile-time log2 of the transform length (0 = runtime).
 template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds__(MAXT, OCC) k_row(const RowArgs<T> a) {
-    SSF_DEV_CTX();
+    SSF_DEV_CTX(0);
     row_body<T, LG>(ctx, a);
 }
 // Manakov column kernels run 512 threads (x half | y half); the single-row modes run 256
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs<T> a) {
-    SSF_DEV_CTX();
+    SSF_DEV_CTX(1);
     col_body<T, LG, MODE>(ctx, a);
 }
 template <typename T> __global__ void __launch_bounds__(256) k_amp(const AmpArgs<T> a) {
-    SSF_DEV_CTX();
+    SSF_DEV_CTX(1);
     amp_body<T>(ctx, a);
 }
 
 template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT) k_ols(const OlsArgs<T> a) {
-    SSF_DEV_CTX();
+    SSF_DEV_CTX(1);
     ols_body<T>(ctx, a);
 }
 
@@ -379,3 +408,9 @@ Engine *make_fused_engine(ssf_plan *plan) {
 }
 
 }  // namespace ssf
+
+#ifdef SSF_PHASE_TIMING
+extern "C" int ssf_debug_marks(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssf::g_marks), sizeof(unsigned long long) * 2 * 4096 * 8);
+}
+#endif

@@ -438,84 +438,130 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     const long long rr = (long long)ctx.bid * fpw + f;     // global row-transform index (grid is exact)
     cx<T> *g = a.G + (rr << a.log2N2);
     cx<T> v[16];
-    // The row is fetched before the control block is evaluated: the loads do not depend on the
-    // decision, and their latency hides the reduction below (a launch that turns out to have
-    // nothing to do just drops them).  (Starting half of the workgroups late, so that co-resident
-    // workgroups are out of phase, was measured and does not help.)
+    ctx.mark(0);
+    // Issue order matters (vmcnt retires in order): first the convergence sums the last column
+    // stage may have left (fetched unconditionally, they are only used if the control block says
+    // they are pending), then the row itself.  The control block (scalar loads) and the
+    // reduction of the sums are then evaluated while the row is still in flight; a launch that
+    // turns out to have nothing to do just drops the row.  (Fetching the sums after the row
+    // makes the decision wait for the row: +2.5 us per launch.  Starting half of the workgroups
+    // late, so that co-resident workgroups are out of phase, was measured and does not help.)
+    double part[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (a.use_ctrl) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = ctx.tid + u * ctx.nthreads;
+            if (i < a.npart) {
+                part[u][0] = a.pnum0[i];
+                part[u][1] = a.pden0[i];
+                part[u][2] = a.pnum[i];
+                part[u][3] = a.pden[i];
+            }
+        }
+        ctx.issue_fence();
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = g[b + p.tpf * q];
     if (a.use_ctrl) {
-        const Ctrl c = *a.cin;
-        Ctrl n = c;
+        ctx.issue_fence();
+        // Only the fields used here are read (scalar loads); the lead thread forwards the block
+        // word by word and patches what changed.  A private copy of the whole struct makes the
+        // compiler fetch the pass-through fields with a vector load, and waiting for that one
+        // means waiting for the row (in-order vmcnt).
+        const Ctrl &c = *a.cin;
+        const int c_state = c.state, c_it = c.it, c_pend0 = c.pend0, c_pendn = c.pendn, c_cap0 = c.cap0;
+        int n_state = c_state, n_final = c.final_, n_cap0 = c_cap0, n_hzv = c.hz_valid;
+        int add_nonconv = 0, add_ahead = 0;
+        double n_hz = c.hz;
         double *red = (double *)(ctx.lds) + 64;
         const bool lead = ctx.bid == 0 && ctx.tid == 0;
-        bool act = c.state == ST_AFTER_S || c.state == ST_ROW_ITER;
-        if (c.pend0 || c.pendn) {             // convergence sums left by the last column stage; every
-            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;   // block reduces them in the same order
-            for (int i = ctx.tid; i < a.npart; i += ctx.nthreads) {
-                if (c.pend0) {
-                    s0 += a.pnum0[i];
-                    s1 += a.pden0[i];
-                }
-                if (c.pendn) {
-                    s2 += a.pnum[i];
-                    s3 += a.pden[i];
-                }
+        bool act = c_state == ST_AFTER_S || c_state == ST_ROW_ITER;
+        if (c_pend0 || c_pendn) {             // every block reduces the sums in the same order
+            double s0 = part[0][0] + part[1][0], s1 = part[0][1] + part[1][1];
+            double s2 = part[0][2] + part[1][2], s3 = part[0][3] + part[1][3];
+            for (int i = ctx.tid + 2 * ctx.nthreads; i < a.npart; i += ctx.nthreads) {
+                s0 += a.pnum0[i];
+                s1 += a.pden0[i];
+                s2 += a.pnum[i];
+                s3 += a.pden[i];
             }
-            if (c.pend0) block_sum2(ctx, s0, s1, red);
-            if (c.pendn) block_sum2(ctx, s2, s3, red);
+            if (c_pend0) block_sum2(ctx, s0, s1, red);
+            if (c_pendn) block_sum2(ctx, s2, s3, red);
             ctx.sync();
             bool redo = false;
-            if (c.pend0) {                                                // lim_0 (channels.py:424, 517-519)
+            if (c_pend0) {                                                // lim_0 (channels.py:424, 517-519)
                 const double lim0 = sqrt(s0) / sqrt(s1);
-                if (lead && c.pend0_idx < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[c.pend0_idx * a.k.maxIter] = lim0;
-                n.pend0 = 0;
-                if (c.cap0) {
-                    if (!(lim0 < a.k.tol)) n.nonconv = c.nonconv + 1;
-                    n.cap0 = 0;
-                } else if (c.pendn && lim0 < a.k.tol) redo = true;        // converged at iterate 0 after all
+                if (lead) {
+                    const long long idx = c.pend0_idx;
+                    if (idx < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[idx * a.k.maxIter] = lim0;
+                }
+                if (c_cap0) {
+                    if (!(lim0 < a.k.tol)) add_nonconv = 1;
+                    n_cap0 = 0;
+                } else if (c_pendn && lim0 < a.k.tol) redo = true;        // converged at iterate 0 after all
             }
-            if (c.pendn) {                                                // lim_it, known before iterate it exists
-                n.pendn = 0;
+            if (c_pendn) {                                                // lim_it, known before iterate it exists
                 if (redo) {
-                    n.state = ST_REDO0;
+                    n_state = ST_REDO0;
                     act = false;
                 } else {
                     const double lim = sqrt(s2) / sqrt(s3);
-                    if (lead && c.trace_n < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[c.trace_n * a.k.maxIter + c.it] = lim;
+                    if (lead) {
+                        const long long tn = c.trace_n;
+                        if (tn < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[tn * a.k.maxIter + c_it] = lim;
+                    }
                     const bool conv = lim < a.k.tol;
-                    n.final_ = conv || c.it == a.k.maxIter - 1;           // channels.py:429-434
-                    if (n.final_ && !conv) n.nonconv = n.nonconv + 1;
-                    n.n_ahead = c.n_ahead + 1;
+                    n_final = conv || c_it == a.k.maxIter - 1;            // channels.py:429-434
+                    if (n_final && !conv) add_nonconv += 1;
+                    add_ahead = 1;
                 }
             }
         }
-        if (act && !n.hz_valid) {             // new step size: every block derives the same hz / operator
+        const bool new_lin = act && !n_hzv;
+        if (new_lin) {                        // new step size: every block derives the same hz / operator
             double mx = 0.0;
             if (a.k.adaptive) mx = global_max(ctx, a.pmax, a.npart, red);
             ctx.sync();
             if (ctx.tid == 0) {
-                const double hz = pick_hz(a.k, n.z, mx);
+                const double hz = pick_hz(a.k, c.z, mx);
                 lsh[0] = make_linop(hz / 2, a.k.lin_a, a.k.lin_b, a.k.w2, a.k.invN, a.k.log2N);
                 ((double *)(lsh + 1))[0] = hz;
             }
             ctx.sync();
-            n.hz = ((double *)(lsh + 1))[0];
-            n.lin = lsh[0];
-            n.hz_valid = 1;
+            n_hz = ((double *)(lsh + 1))[0];
+            lo = lsh[0];
+            n_hzv = 1;
             ctx.sync();
+        } else if (act) {
+            lo = c.lin;
         }
-        if (act) n.state = c.state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
-        if (lead) *a.cout = n;
+        if (act) n_state = c_state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
+        if (lead) {
+            const unsigned long long *src = (const unsigned long long *)a.cin;
+            unsigned long long *dst = (unsigned long long *)a.cout;
+            for (int i = 0; i < (int)(sizeof(Ctrl) / 8); ++i) dst[i] = src[i];
+            Ctrl *n = a.cout;
+            n->state = n_state;
+            n->final_ = n_final;
+            n->pend0 = 0;
+            n->pendn = 0;
+            n->cap0 = n_cap0;
+            n->hz_valid = n_hzv;
+            n->hz = n_hz;
+            n->nonconv = c.nonconv + add_nonconv;
+            n->n_ahead = c.n_ahead + add_ahead;
+            if (new_lin) n->lin = lo;
+        }
         if (!act) return;
-        lo = n.lin;
     } else {
         lo = *a.lin;
     }
     const int N1 = 1 << a.log2N1, log2N = a.log2N1 + a.log2N2;
     const int k1 = (int)(rr & (N1 - 1));
     cx<T> *l = lds + (size_t)f * lds_slots_per_fft(p.L);
+    ctx.mark(1);
     fft_dif<-1>(ctx, p, b, v, l);
+    ctx.mark(2);
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
     const int last = p.npass - 1;
     if (p.lg(last) == 4) {
@@ -528,9 +574,12 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
             v[idx] = v[idx] * lin_at<T>(lo, k, log2N);
         }
     }
+    ctx.mark(3);
     fft_dit<+1>(ctx, p, b, v, l);
+    ctx.mark(4);
 #pragma unroll
     for (int q = 0; q < 16; ++q) g[b + p.tpf * q] = v[q];
+    ctx.mark(5);
 }
 
 // --------------------------------------------------------------------------- column kernel
@@ -716,6 +765,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     bool final_ = false, more = false;
     struct { int state, it, cur, pcur; double z, hz; } c{};
     double *red = (double *)ctx.lds;
+    ctx.mark(0);
     if (kMk) {
         // only scalars are taken from the control block (a private copy of the struct would live
         // in scratch memory and cost real HBM traffic on every launch)
@@ -826,8 +876,10 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     if (do_inv) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = a.G[g.rowbase + g.freq_off(q)];
+        ctx.mark(1);
         global_twiddle<+1>(g, a.log2N1 + a.log2N2, v);
         fft_dif<+1>(ctx, p, g.b, v, lds);
+        ctx.mark(2);
     } else if (!(kMk && op == 3)) {
 #pragma unroll
         for (int idx = 0; idx < 16; ++idx) v[idx] = Tcur[g.rowbase + g.time_off(idx)];
@@ -899,12 +951,15 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     }
 
     // ---- forward column transform: registers -> G -------------------------------------------
+    ctx.mark(3);
     if (do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
         fft_dit<-1>(ctx, p, g.b, v, lds);
         global_twiddle<-1>(g, a.log2N1 + a.log2N2, v);
+        ctx.mark(4);
 #pragma unroll
         for (int q = 0; q < 16; ++q) a.G[g.rowbase + g.freq_off(q)] = v[q];
+        ctx.mark(5);
     }
 }
 

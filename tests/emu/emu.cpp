@@ -27,6 +27,8 @@ struct EmuCtx {
     char *lds;
     static constexpr bool kWaveOps = false;
     void sync();
+    void mark(int) {}
+    void issue_fence() {}
     double wave_sum(double v) { return v; }
     double wave_max(double v) { return v; }
 };

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""In-kernel phase timing of the fused engine (diagnostic build: make -C opticommpy_amd/csrc phase).
+Runs config-2-like steps with libssf_hip_phase.so, then prints, for the last row launch and the
+last column launch, when each phase ended (µs after the first workgroup entered), as
+min / median / max over the workgroups.  mark() drains vmcnt/lgkmcnt, so phases do not overlap as
+they do in the product build: this shows where the time goes, not the product kernel's duration.
+    SSF_LIB=opticommpy_amd/libssf_hip_phase.so python tools/phase_timing.py [log2N] [c64]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("SSF_LIB", os.path.join(ROOT, "opticommpy_amd", "libssf_hip_phase.so"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import opticommpy_amd as oa  # noqa: E402
+from helpers import synth_field  # noqa: E402
+from opticommpy_amd import _lib, models  # noqa: E402
+
+ROW = ["entry", "loads+ctrl done", "fwd FFT", "x lin", "inv FFT", "stores done"]
+COL = ["entry", "G loads done", "inv FFT", "time-domain work", "fwd FFT", "stores done"]
+
+
+def main():
+    lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    prec = np.complex64 if len(sys.argv) > 2 and sys.argv[2] == "c64" else np.complex128
+    E = synth_field(1 << lg, 2, 2, 8.4).astype(prec)
+    p = oa.parameters()
+    for k, v in dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, Ltotal=4.0, Lspan=4.0, hz=0.08, maxIter=10,
+                     tol=1e-5, nlprMethod=False, amp="ideal", prgsBar=False, prec=prec, saveSpanN=[]).items():
+        setattr(p, k, v)
+    models.manakovSSF(E, p)
+    print(models.last_run["engine"], models.last_run["steps"], "steps", models.last_run["device_ms"], "ms")
+    lib = _lib.load()
+    buf = np.zeros((2, 4096, 8), dtype=np.uint64)
+    lib.ssf_debug_marks.argtypes = [C.c_void_p]
+    rc = lib.ssf_debug_marks(buf.ctypes.data_as(C.c_void_p))
+    assert rc == 0, rc
+    for kind, names in ((0, ROW), (1, COL)):
+        m = buf[kind].astype(np.int64)
+        used = m[:, 0] > 0
+        m = m[used][:, : len(names)]
+        t0 = m[:, 0].min()
+        us = (m - t0) / 100.0                 # 100 MHz wall clock
+        print(f"{'row' if kind == 0 else 'col'} kernel: {used.sum()} workgroups")
+        for i, n in enumerate(names):
+            col = us[:, i]
+            col = col[m[:, i] > 0]
+            if len(col):
+                print(f"   {n:20s} min {col.min():7.2f}  med {np.median(col):7.2f}  max {col.max():7.2f} us")
+        d = np.diff(us, axis=1)
+        print("   per-phase median durations:", " | ".join(f"{names[i + 1]} {np.median(d[:, i]):.2f}" for i in range(len(names) - 1)))
+
+
+if __name__ == "__main__":
+    main()
