@@ -16,7 +16,7 @@ using namespace fused;
 // stores the 100 MHz wall clock for the lead thread of every workgroup; the product build
 // compiles mark() to nothing.
 #ifdef SSF_PHASE_TIMING
-__device__ unsigned long long g_marks[2][4096][8];
+__device__ unsigned long long g_marks[4][4096][8];
 #endif
 
 struct DevCtx {
@@ -25,18 +25,22 @@ struct DevCtx {
     static constexpr bool kWaveOps = true;
 #ifdef SSF_PHASE_TIMING
     int kind;
-    unsigned long long t0 = 0;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // stamps stay in registers; flush(set) stores the complete record of this launch, so a
+    // launch of another kind (early return, no forward transform) never mixes into it
     __device__ __forceinline__ void mark(int i) {
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        const unsigned long long now = wall_clock64();
-        if (i == 0) t0 = now;                       // kept in a register: a launch that returns early
-        else if (tid == 0 && bid < 4096) {          // (nothing to do) leaves the previous record intact
-            g_marks[kind][bid][i] = now;
-            if (i == 1) g_marks[kind][bid][0] = t0;
-        }
+        ts[i] = wall_clock64();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void flush(int set) {
+        if (tid == 0 && bid < 4096)
+            for (int i = 0; i < 8; ++i) g_marks[kind + 2 * set][bid][i] = ts[i];
     }
 #else
     __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(int) {}
 #endif
     __device__ __forceinline__ void sync() { __syncthreads(); }
     // keeps the instruction scheduler from moving memory operations across this point
@@ -411,6 +415,6 @@ Engine *make_fused_engine(ssf_plan *plan) {
 
 #ifdef SSF_PHASE_TIMING
 extern "C" int ssf_debug_marks(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssf::g_marks), sizeof(unsigned long long) * 2 * 4096 * 8);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssf::g_marks), sizeof(unsigned long long) * 4 * 4096 * 8);
 }
 #endif

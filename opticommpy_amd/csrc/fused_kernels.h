@@ -580,6 +580,7 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
 #pragma unroll
     for (int q = 0; q < 16; ++q) g[b + p.tpf * q] = v[q];
     ctx.mark(5);
+    ctx.flush(0);
 }
 
 // --------------------------------------------------------------------------- column kernel
@@ -667,25 +668,34 @@ template <typename V, class Ctx, class G> SSF_HD void pair_swap(Ctx &ctx, const 
     for (int idx = 0; idx < 16; ++idx) other[idx] = sh[(size_t)((g.pol ^ 1) * 16 + idx) * g.half + g.t];
 }
 
-// rot[idx] = cis(ang[idx]) for all 16 registers; with a polarisation pair each partner
-// evaluates 8 of the 16 sincos and they swap through LDS scratch `sh` (16*half complex).
+// The two threads of a polarisation pair hold the same 16 time samples (x row | y row).  Every
+// per-sample quantity that is common to both polarisations (phase, rotation, |d rot|^2) is
+// evaluated once, by the sample's owner: the x thread owns registers 0-7, the y thread 8-15.
+// own_idx(j) = register of this thread's j-th owned sample, oth_idx(j) = the partner's.
+template <class G> SSF_HD int own_idx(const G &g, int j) { return g.pol ? j + 8 : j; }
+template <class G> SSF_HD int oth_idx(const G &g, int j) { return g.pol ? j : j + 8; }
+template <class G> SSF_HD long long own_time_off(const G &g, int j) { return g.pol ? g.time_off(j + 8) : g.time_off(j); }
+// pick, for register idx (compile-time), the owner's or the partner's value
+template <typename V, class G> SSF_HD V pick16(const G &g, int idx, const V *own, const V *oth) {
+    return ((idx >> 3) == g.pol) ? own[idx & 7] : oth[idx & 7];
+}
+
+// rot[idx] = cis(ang) for all 16 registers from the 8 phases this thread owns; the partners
+// swap their halves through LDS scratch `sh` (16*half complex).  One barrier inside; the caller
+// guarantees `sh` is free on entry.
 template <typename T, class Ctx, class G>
-SSF_HD void pair_cis(Ctx &ctx, const G &g, int npol, const T *ang, cx<T> *rot, cx<T> *sh) {
-    if (npol == 2) {
+SSF_HD void pair_cis(Ctx &ctx, const G &g, const T *ang_own, cx<T> *rot, cx<T> *sh) {
+    cx<T> own[8], oth[8];
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx)
-            if ((idx >> 3) == g.pol) {
-                rot[idx] = cis_t<T>(ang[idx]);
-                sh[(size_t)idx * g.half + g.t] = rot[idx];
-            }
-        ctx.sync();
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx)
-            if ((idx >> 3) != g.pol) rot[idx] = sh[(size_t)idx * g.half + g.t];
-    } else {
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx) rot[idx] = cis_t<T>(ang[idx]);
+    for (int j = 0; j < 8; ++j) {
+        own[j] = cis_t<T>(ang_own[j]);
+        sh[(size_t)own_idx(g, j) * g.half + g.t] = own[j];
     }
+    ctx.sync();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) oth[j] = sh[(size_t)oth_idx(g, j) * g.half + g.t];
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) rot[idx] = pick16(g, idx, own, oth);
 }
 
 // ---- Manakov time-domain building blocks (registers v = this thread's 16 samples of its row) ----
@@ -715,43 +725,65 @@ SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T>
     ctx.sync();                                  // scratch reads done before the FFT reuses the LDS
 }
 // next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
-// accumulates the sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the header note)
+// accumulates the sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the header note).
+// Once the powers are taken the iterate itself is dead, so E_hd is fetched into its registers
+// right away and arrives while the phases are evaluated (the stage used to wait for it afterwards:
+// 13 us of a 29 us launch in the phase timing).
 template <typename T, class Ctx, class G>
 SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, const T *Pbuf, T shz, bool first,
                        double &num, double &den) {
-    T *shT = (T *)ctx.lds;
-    cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));
-    T mine[16], oth[16];                       // norms, then reused: mine -> |d rot|^2, oth -> new phase
+    T *shN = (T *)ctx.lds;                                   // 16*half powers for the owners
+    cx<T> *shC = (cx<T> *)(shN + 16 * (size_t)g.half);       // 16*half rotations
+    T *shD = (T *)(shC + 16 * (size_t)g.half);               // 16*half |d rot|^2
+    T nown[8], noth[8];
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) mine[idx] = norm2(v[idx]);
+    for (int j = 0; j < 8; ++j) {
+        const T lo = norm2(v[j]), hi = norm2(v[j + 8]);
+        nown[j] = g.pol ? hi : lo;
+        noth[j] = g.pol ? lo : hi;                           // goes to the partner, who owns that sample
+    }
+    ctx.sync();                                              // the inverse transform's LDS reads are done
+#pragma unroll
+    for (int j = 0; j < 8; ++j) shN[(size_t)oth_idx(g, j) * g.half + g.t] = noth[j];
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) v[idx] = a.Ehd[g.rowbase + g.time_off(idx)];
+    ctx.issue_fence();
     ctx.sync();
-    pair_swap(ctx, g, mine, oth, shT);
-    const T c8g = (T)a.k.c8g;
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) {
-        const long long t = g.time_off(idx);
-        const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
+    for (int j = 0; j < 8; ++j) noth[j] = shN[(size_t)own_idx(g, j) * g.half + g.t];
+    ctx.mark(6);
+    const T c8g = (T)a.k.c8g;
+    cx<T> rown[8], roth[8];
+    T down[8], doth[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long t = own_time_off(g, j);
+        const T ax = g.pol ? noth[j] : nown[j], ay = g.pol ? nown[j] : noth[j];
         const T pw = Pbuf[g.pbase + t];
         const T ang = shz * (c8g * (pw + ax + ay) / (T)2);
         const T prev = first ? shz * (c8g * (pw + pw) / (T)2) : a.Theta[g.pbase + t];
         // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2)
         const double s = sin_half_angle((double)ang - (double)prev);
-        mine[idx] = (T)(4.0 * s * s);
-        oth[idx] = ang;
+        down[j] = (T)(4.0 * s * s);
+        rown[j] = cis_t<T>(ang);
+        a.Theta[g.pbase + t] = ang;                          // read and written by the owner only
+        shC[(size_t)own_idx(g, j) * g.half + g.t] = rown[j];
+        shD[(size_t)own_idx(g, j) * g.half + g.t] = down[j];
     }
-    cx<T> rot[16];
-    pair_cis(ctx, g, 2, oth, rot, shC);      // (barrier inside: both partners have read the old phases)
-    if (g.pol == 0) {
+    ctx.mark(7);
+    ctx.sync();
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) a.Theta[g.pbase + g.time_off(idx)] = oth[idx];
+    for (int j = 0; j < 8; ++j) {
+        roth[j] = shC[(size_t)oth_idx(g, j) * g.half + g.t];
+        doth[j] = shD[(size_t)oth_idx(g, j) * g.half + g.t];
     }
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) {       // (fetching E_hd any earlier costs 64 registers at the peak: spills)
-        const cx<T> e = a.Ehd[g.rowbase + g.time_off(idx)];
+    for (int idx = 0; idx < 16; ++idx) {
+        const cx<T> e = v[idx];
         const double w = (double)norm2(e);
-        num += w * (double)mine[idx];
+        num += w * (double)pick16(g, idx, down, doth);
         den += w;
-        v[idx] = e * rot[idx];
+        v[idx] = e * pick16(g, idx, rown, roth);
     }
     ctx.sync();
 }
@@ -898,18 +930,21 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
         if (op == 0) {                               // span start: Pch into the current buffer
             mk_step_start(ctx, g, a, v, Pcur, false);
         } else if (op == 1 || op == 3) {             // H (channels.py:409-417) | rebuild of iterate 0
-            T ang[16];
+            T ang[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const T pw = Pcur[g.pbase + own_time_off(g, j)];
+                ang[j] = shz * (c8g * (pw + pw) / (T)2);
+            }
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) {
                 const long long t = g.time_off(idx);
                 if (op == 1) a.Ehd[g.rowbase + t] = v[idx];
                 else v[idx] = a.Ehd[g.rowbase + t];
-                const T pw = Pcur[g.pbase + t];
-                ang[idx] = shz * (c8g * (pw + pw) / (T)2);
             }
             cx<T> rot[16];
             ctx.sync();                              // inverse transform's LDS reads are done
-            pair_cis(ctx, g, 2, ang, rot, shC);
+            pair_cis(ctx, g, ang, rot, shC);
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * rot[idx];
             ctx.sync();
@@ -960,6 +995,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
 #pragma unroll
         for (int q = 0; q < 16; ++q) a.G[g.rowbase + g.freq_off(q)] = v[q];
         ctx.mark(5);
+        ctx.flush(do_inv ? 0 : 1);
     }
 }
 

@@ -28,6 +28,7 @@ struct EmuCtx {
     static constexpr bool kWaveOps = false;
     void sync();
     void mark(int) {}
+    void flush(int) {}
     void issue_fence() {}
     double wave_sum(double v) { return v; }
     double wave_max(double v) { return v; }

@@ -34,12 +34,15 @@ def main():
     models.manakovSSF(E, p)
     print(models.last_run["engine"], models.last_run["steps"], "steps", models.last_run["device_ms"], "ms")
     lib = _lib.load()
-    buf = np.zeros((2, 4096, 8), dtype=np.uint64)
+    buf = np.zeros((4, 4096, 8), dtype=np.uint64)
     lib.ssf_debug_marks.argtypes = [C.c_void_p]
     rc = lib.ssf_debug_marks(buf.ctypes.data_as(C.c_void_p))
     assert rc == 0, rc
     for kind, names in ((0, ROW), (1, COL)):
         m = buf[kind].astype(np.int64)
+        if kind == 1 and (m[:, 6] > 0).any():             # column kernel: two extra stamps inside the I stage
+            m = m[:, [0, 1, 2, 6, 7, 3, 4, 5]]
+            names = names[:3] + ["I: E_hd in, powers swapped", "I: phases done"] + names[3:]
         used = m[:, 0] > 0
         m = m[used][:, : len(names)]
         t0 = m[:, 0].min()
@@ -50,6 +53,14 @@ def main():
             col = col[m[:, i] > 0]
             if len(col):
                 print(f"   {n:20s} min {col.min():7.2f}  med {np.median(col):7.2f}  max {col.max():7.2f} us")
+        G = int(os.environ.get("PHASE_GROUPS", "1"))
+        if G > 1:                                         # experiment: statistics per workgroup class
+            bids = np.nonzero(used)[0]
+            mode = int(os.environ.get("PHASE_GROUP_MODE", "0"))
+            grp = bids % G if mode == 0 else (bids // 8) % G if mode == 1 else bids // ((used.sum() + G - 1) // G)
+            for gi in range(G):
+                sel = grp == gi
+                print(f"   group {gi}: " + " | ".join(f"{names[i]} {np.median(us[sel, i]):.2f}" for i in range(len(names))))
         d = np.diff(us, axis=1)
         print("   per-phase median durations:", " | ".join(f"{names[i + 1]} {np.median(d[:, i]):.2f}" for i in range(len(names) - 1)))
 
