@@ -171,6 +171,15 @@ def main():
                          "device_ms_per_step": st.device_ms / st.steps,
                          "kernels": kernels},
         }
+        # measured memory ceiling on this box: a kernel with the row stage's memory shape and no arithmetic
+        # (32 MiB in + 32 MiB out per launch at N = 2^20 c128), SURVEY.md 8d
+        probe = C.c_double(0.0)
+        probe_bytes = max(65536, (2 * s * N) // 65536 * 65536)
+        if lib.ssf_device_copy_bandwidth(local_rank, probe_bytes, 50, C.byref(probe)) == 0:
+            rec["roofline"]["measured_copy_GBs"] = probe.value
+            rec["roofline"]["frac_of_measured_copy"] = achieved / probe.value
+            rec["roofline"]["measured_copy_note"] = ("burst copy kernel, %d MiB read + %d MiB written per launch, "
+                                                     "no arithmetic" % (probe_bytes >> 20, probe_bytes >> 20))
         if dist is not None:
             rec["rank_checksums"] = checksums
         traffic_file = os.path.join(ROOT, "profiles", "traffic_bytes_per_step.json")

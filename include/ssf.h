@@ -23,6 +23,7 @@
  *   ssf_linear_channel                   linearFiberChannel               channels.py:30-109
  *   ssf_overlap_save                     blockwiseFFTConv as used by edc  optic/dsp/core.py:973-1046,
  *                                                                          optic/dsp/equalization.py:113-117
+ *   ssf_device_copy_bandwidth            (no reference equivalent) measured memory ceiling
  *   ssf_set_profiling / ssf_get_kernel_times   time.time() pairs around calls in
  *                                        examples/benchmarck_GPU_processing.ipynb:389-395
  *
@@ -185,6 +186,13 @@ typedef struct {
 } ssf_kernel_times;
 int  ssf_set_profiling(ssf_plan *plan, int32_t enable);
 int  ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out);
+
+/* ---- measured memory ceiling ("also report against an empirically measured
+ * device-copy bandwidth from the same run").  Launches a kernel with the memory shape of the
+ * fused row stage and no arithmetic: every 256-thread workgroup fetches 16 x 16 B per thread
+ * in one burst and stores them again, `bytes` in and `bytes` out per launch, ping-ponging between
+ * two buffers.  *gbs = (read + written bytes) / average launch time.  No reference equivalent. */
+int  ssf_device_copy_bandwidth(int device, int64_t bytes, int32_t launches, double *gbs);
 
 /* ---- linear channel (gamma = 0 closed form): one FFT . H . IFFT over the whole length */
 int  ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, double D,

@@ -76,6 +76,7 @@ SYMBOLS = {
     "ssf_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "ssf_overlap_save": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "ssf_device_copy_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     "ssf_linear_channel": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p, C.c_void_p]),
 }

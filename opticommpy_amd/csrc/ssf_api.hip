@@ -187,6 +187,48 @@ int ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out) {
     return rc ? fail(plan, rc, "per-kernel profiling is only available on the fused engine") : SSF_OK;
 }
 
+namespace {
+// memory shape of the fused row stage, no arithmetic (see include/ssf.h)
+__global__ void __launch_bounds__(256) k_burst_copy(const double2 *__restrict__ a, double2 *__restrict__ b) {
+    const double2 *g = a + (size_t)blockIdx.x * 4096;
+    double2 *o = b + (size_t)blockIdx.x * 4096;
+    double2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = g[threadIdx.x + 256 * q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) o[threadIdx.x + 256 * q] = v[q];
+}
+}  // namespace
+
+int ssf_device_copy_bandwidth(int device, int64_t bytes, int32_t launches, double *gbs) {
+    if (!gbs || bytes < 65536 || bytes % 65536 || launches < 1) return set_err(SSF_ERR_BAD_ARG, "ssf_device_copy_bandwidth: bytes must be a positive multiple of 64 KiB");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return set_err(SSF_ERR_BAD_ARG, "no such device");
+    if (hipSetDevice(device) != hipSuccess) return set_err(SSF_ERR_HIP, "hipSetDevice failed");
+    double2 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = SSF_OK;
+    float ms = 0;
+    const unsigned nwg = (unsigned)(bytes / 65536);
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) rc = set_err(SSF_ERR_OOM, "hipMalloc failed");
+    if (!rc && (hipMemset(a, 0, bytes) != hipSuccess || hipMemset(b, 0, bytes) != hipSuccess)) rc = set_err(SSF_ERR_HIP, "hipMemset failed");
+    if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = set_err(SSF_ERR_HIP, "hipEventCreate failed");
+    if (!rc) {
+        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(k_burst_copy, dim3(nwg), dim3(256), 0, 0, i & 1 ? b : a, i & 1 ? a : b);
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_burst_copy, dim3(nwg), dim3(256), 0, 0, i & 1 ? b : a, i & 1 ? a : b);
+        (void)hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess)
+            rc = set_err(SSF_ERR_HIP, "copy probe failed");
+        else *gbs = 2.0 * (double)bytes * launches / ((double)ms * 1e-3) / 1e9;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return rc;
+}
+
 int ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, double D, double L, const void *in,
                        void *out) {
     int rc = ssf_upload(plan, in);

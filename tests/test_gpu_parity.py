@@ -318,6 +318,18 @@ def test_single_process_multi_device_entry_point():
         assert stats[u]["steps"] == tr["steps"] and stats[u]["iterations"] == tr["iterations"]
 
 
+def test_measured_copy_ceiling_probe():
+    """ssf_device_copy_bandwidth: plausible (between 1 and 12 TB/s for 32 MiB in + out), bad sizes refused."""
+    import ctypes as C
+    from opticommpy_amd import _lib
+    lib = _lib.load()
+    g = C.c_double(0.0)
+    assert lib.ssf_device_copy_bandwidth(0, 32 << 20, 20, C.byref(g)) == 0
+    assert 1000.0 < g.value < 12000.0
+    assert lib.ssf_device_copy_bandwidth(0, 1000, 20, C.byref(g)) == -1
+    assert lib.ssf_device_copy_bandwidth(99, 32 << 20, 20, C.byref(g)) == -1
+
+
 def test_kernel_profiling_api():
     import ctypes as C
     from opticommpy_amd import _lib
