@@ -84,3 +84,37 @@ def parity_gate(func, Ei, cfg, base_tol):
     if sens > 1e-6:
         return None
     return max(base_tol, 30 * sens)
+
+
+def _bag(cls, d):
+    p = cls()
+    for k, v in d.items():
+        setattr(p, k, v)
+    return p
+
+
+def rx_call(mod, params_cls, d, cfg):
+    """Run one receiver-side golden case (tests/golden/rx_*.npz) on `mod`, which exports the
+    reference's function names (oracle.rx_oracle or opticommpy_amd)."""
+    f = cfg["func"]
+    kw = {k: v for k, v in cfg.items() if k != "func"}
+    Ei = d["Ei"].copy()
+    if f == "firFilter":
+        return mod.firFilter(d["h"], Ei)
+    if f == "decimate":
+        return mod.decimate(Ei, _bag(params_cls, kw))
+    if f == "delaySignal":
+        return mod.delaySignal(Ei, kw["delay"], kw["Fs"])
+    if f == "iqMixing":
+        return mod.iqMixing(Ei, _bag(params_cls, kw))
+    if f == "photodiode":
+        return mod.photodiode(Ei, _bag(params_cls, kw))
+    if f == "balancedPD":
+        return mod.balancedPD(Ei[:, 0].copy(), Ei[:, 1].copy(), _bag(params_cls, kw))
+    if f == "opticalHybrid2x4":
+        return mod.opticalHybrid2x4(Ei, d["Elo"])
+    if f == "coherentReceiver":
+        return mod.coherentReceiver(Ei, d["Elo"], _bag(params_cls, kw["fe"]), _bag(params_cls, kw["pd"]))
+    if f == "pdmCoherentReceiver":
+        return mod.pdmCoherentReceiver(Ei, d["Elo"], _bag(params_cls, kw["fe"]), _bag(params_cls, kw["pd"]))
+    raise KeyError(f)

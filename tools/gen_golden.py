@@ -15,7 +15,7 @@ Output: tests/golden/<case>.npz, each holding
     margin    min |lim - tol| / tol over the run           (Manakov/DBP only)
     extra_*   case-specific extras (e.g. linear-channel output, edfa noise)
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx]
 """
 import json
 import os
@@ -266,7 +266,93 @@ def main():
         out = ref_edc(x, mk_param(**kw))
         save(name, Ei=x, out=out, cfg=cfg_json("edc", kw))
         print(f"{name:24s} in {x.dtype}{x.shape} out {out.dtype}{out.shape}")
+    rx_vectors()
+
+
+def rx_vectors():
+    """receiver front-end, FIR filtering, decimation"""
+    import optic.dsp.core as ref_core
+    import optic.models.devices as ref_dev
+    rng = np.random.default_rng(60)
+    x2 = (rng.normal(size=(3000, 2)) + 1j * rng.normal(size=(3000, 2))) / np.sqrt(2)
+    xr = rng.normal(size=2048)
+    h255 = ref_core.lowPassFIR(30e9, 128e9, 255, "rect")
+    hg = ref_core.lowPassFIR(20e9, 128e9, 64, "gauss")          # even tap count
+    t = np.arange(-64, 65) / 16.0
+    hrrc = ref_core.rrcFilterTaps(t, 0.1, 1.0)
+    hcx = (rng.normal(size=33) + 1j * rng.normal(size=33)) / 8
+    for name, h, x in (("rx_fir_lp255_2mode", h255, x2), ("rx_fir_gauss64_real1d", hg, xr),
+                       ("rx_fir_rrc129_1d", hrrc, x2[:, 0].copy()), ("rx_fir_complex_taps", hcx, x2),
+                       ("rx_fir_taps_longer_than_signal", h255, x2[:100, 0].copy())):
+        out = ref_core.firFilter(h, x)
+        save(name, h=h, Ei=x, out=out, cfg=cfg_json("firFilter", {}))
+        print(f"{name:32s} in {x.dtype}{x.shape} taps {len(h)} out {out.dtype}{out.shape}")
+    save("rx_lowpassfir", rect=h255, gauss=hg, cfg=cfg_json("lowPassFIR", dict(rect=[30e9, 128e9, 255], gauss=[20e9, 128e9, 64])))
+
+    # decimate: 16 -> 2 samples per symbol, 2 modes, and a 1-D real signal 8 -> 1
+    sps = 16
+    sym = rng.choice([-3.0, -1.0, 1.0, 3.0], size=(256, 2)) + 1j * rng.choice([-3.0, -1.0, 1.0, 3.0], size=(256, 2))
+    up = np.zeros((256 * sps, 2), dtype=complex)
+    up[5::sps] = sym                                               # sampling phase 5
+    pulse = ref_core.rrcFilterTaps(np.arange(-8 * sps, 8 * sps + 1) / sps, 0.2, 1.0)
+    shaped = ref_core.firFilter(pulse / np.max(np.abs(pulse)), up)
+    for name, x, kw in (("rx_decimate_16to2", shaped, dict(SpSin=16, SpSout=2)),
+                        ("rx_decimate_8to1_real1d", shaped[::2, 0].real.copy(), dict(SpSin=8, SpSout=1))):
+        out = ref_core.decimate(x, mk_param(**kw))
+        save(name, Ei=x, out=out, cfg=cfg_json("decimate", kw))
+        print(f"{name:32s} in {x.dtype}{x.shape} out {out.dtype}{out.shape}")
+
+    # delaySignal / iqMixing
+    xs = x2[:2500, 0].copy()
+    for name, kw in (("rx_delay_frac", dict(delay=0.37 / 128e9, Fs=128e9)), ("rx_delay_neg3p2", dict(delay=-3.2 / 128e9, Fs=128e9)),
+                     ("rx_delay_zero", dict(delay=0.0, Fs=128e9))):
+        out = ref_core.delaySignal(xs, kw["delay"], kw["Fs"])
+        save(name, Ei=xs, out=out, cfg=cfg_json("delaySignal", kw))
+    for name, kw in (("rx_iqmix_imbalance", dict(ampImb=1.5, phaseImb=0.2, timeSkew=0.0, Fs=128e9)),
+                     ("rx_iqmix_skew", dict(ampImb=0.0, phaseImb=0.0, timeSkew=2.5e-12, Fs=128e9))):
+        out = ref_core.iqMixing(xs, mk_param(**kw))
+        save(name, Ei=xs, out=out, cfg=cfg_json("iqMixing", kw))
+
+    # photodiode / balancedPD / hybrid / coherent receivers: deterministic settings (no shot / thermal noise)
+    Es = synth_field(4096, 2, 61, 0.0)
+    Fs = 128e9
+    tt = np.arange(4096) / Fs
+    Elo = np.sqrt(10e-3) * np.exp(1j * (2 * np.pi * 150e6 * tt + 0.3))
+    pd_quiet = dict(Fs=Fs, B=30e9, shotNoise=False, thermalNoise=False)
+    for name, kw in (("rx_pd_ideal", dict(ideal=True)), ("rx_pd_bandlimited", dict(pd_quiet)),
+                     ("rx_pd_saturating_gauss", dict(pd_quiet, currentSaturation=True, IpdSat=8e-4, fType="gauss", N=128, R=0.8))):
+        out = ref_dev.photodiode(Es[:, 0].copy(), mk_param(**kw))
+        save(name, Ei=Es[:, 0], out=out, cfg=cfg_json("photodiode", kw))
+    out = ref_dev.photodiode(Es.copy(), mk_param(**pd_quiet))
+    save("rx_pd_two_modes", Ei=Es, out=out, cfg=cfg_json("photodiode", pd_quiet))
+    out = ref_dev.balancedPD(Es[:, 0].copy(), Es[:, 1].copy(), mk_param(**pd_quiet))
+    save("rx_bpd_bandlimited", Ei=Es, out=out, cfg=cfg_json("balancedPD", pd_quiet))
+    out = ref_dev.opticalHybrid2x4(Es[:, 0].copy(), Elo)
+    save("rx_hybrid", Ei=Es[:, 0], Elo=Elo, out=out, cfg=cfg_json("opticalHybrid2x4", {}))
+    fe1 = dict(Fs=Fs, ampImb=0.5, phaseImb=0.05, timeSkew=1e-12)
+    out = ref_dev.coherentReceiver(Es[:, 0].copy(), Elo, mk_param(**fe1), mk_param(**pd_quiet))
+    save("rx_coh_single_pol", Ei=Es[:, 0], Elo=Elo, out=out, cfg=cfg_json("coherentReceiver", dict(fe=fe1, pd=pd_quiet)))
+    for name, fe, pd in (
+            ("rx_pdm_default_pd_ideal", dict(Fs=Fs), dict(ideal=True)),
+            ("rx_pdm_bandlimited", dict(Fs=Fs), pd_quiet),
+            ("rx_pdm_impaired", dict(Fs=Fs, polRotation=0.4, pdl=1.2, polDelay=3e-12, ampImbX=0.8, phaseImbX=0.1,
+                                     timeSkewX=2e-12, ampImbY=-0.5, phaseImbY=-0.07, timeSkewY=-1e-12),
+             dict(pd_quiet, R=0.9, N=201))):
+        out = ref_dev.pdmCoherentReceiver(Es.copy(), Elo, mk_param(**fe), mk_param(**pd))
+        save(name, Ei=Es, Elo=Elo, out=out, cfg=cfg_json("pdmCoherentReceiver", dict(fe=fe, pd=pd)))
+        print(f"{name:32s} out {out.dtype}{out.shape}")
+    # seeded noise: the reference's own draw order (np.random.seed(seed); shot normals; thermal normals per photodiode)
+    pdn = dict(Fs=Fs, B=30e9, seed=11)
+    out = ref_dev.photodiode(Es[:, 0].copy(), mk_param(**pdn))
+    np.random.seed(11)
+    u_shot = np.random.normal(0, 1, 4096)
+    u_th = np.random.normal(0, 1, 4096)
+    save("rx_pd_noise_seed11", Ei=Es[:, 0], out=out, extra_shot=u_shot, extra_thermal=u_th, cfg=cfg_json("photodiode", pdn))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rx":      # only the receiver-side vectors
+        os.makedirs(OUT, exist_ok=True)
+        rx_vectors()
+    else:
+        main()
