@@ -23,6 +23,7 @@
  *   ssf_linear_channel                   linearFiberChannel               channels.py:30-109
  *   ssf_overlap_save                     blockwiseFFTConv as used by edc  optic/dsp/core.py:973-1046,
  *                                                                          optic/dsp/equalization.py:113-117
+ *   ssf_fir_filter / ssf_delay_signal / ssf_decimate / ssf_rx_run   receiver side, see below
  *   ssf_device_copy_bandwidth            (no reference equivalent) measured memory ceiling
  *   ssf_set_profiling / ssf_get_kernel_times   time.time() pairs around calls in
  *                                        examples/benchmarck_GPU_processing.ipynb:389-395
@@ -206,6 +207,55 @@ int  ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, doub
  * 16 <= nfft <= 8192 (SSF_C128) / 16384 (SSF_C64), K = filter length <= nfft. */
 int  ssf_overlap_save(int device, int64_t sigLen, int32_t nrows, int32_t precision, int32_t nfft,
                       int32_t K, const void *Hfft, const void *sig_in, void *sig_out);
+
+/* ---- receiver side of the channel: FIR filtering, fractional delay,
+ * decimation and the coherent front-end.  All arrays are host buffers, complex128 interleaved,
+ * (samples, columns) row-major exactly as the reference passes them; every call uploads its
+ * inputs once, keeps all intermediate stages in device memory and downloads the result.
+ *
+ *   ssf_fir_filter       firFilter            optic/dsp/core.py:87-125 (GPU twin optic/dsp/coreGPU.py:27-78)
+ *   ssf_delay_signal     delaySignal          optic/dsp/core.py:880-922
+ *   ssf_decimate         decimate             optic/dsp/core.py:435-491
+ *   ssf_rx_run           photodiode / balancedPD / coherentReceiver / pdmCoherentReceiver / iqMixing
+ *                                             optic/models/devices.py:289-668, optic/dsp/core.py:925-970 */
+
+/* 'same'-mode convolution of every column with `ntaps` complex taps (1 <= ntaps <= 4096) */
+int  ssf_fir_filter(int device, int64_t sigLen, int32_t ncols, int32_t ntaps, const void *taps,
+                    const void *sig_in, void *sig_out);
+/* one column delayed by `delay` seconds (NFFT = 1024 as the reference's default) */
+int  ssf_delay_signal(int device, int64_t N, double delay, double Fs, const void *sig_in, void *sig_out);
+/* maximum-variance sampling phase per column, then every decFactor-th sample; N % SpSin == 0,
+ * ncols <= 8; sig_out: (ceil(N / decFactor), ncols); sampDelay (may be NULL): ncols phases */
+int  ssf_decimate(int device, int64_t N, int32_t ncols, int32_t SpSin, int32_t decFactor,
+                  const void *sig_in, void *sig_out, int32_t *sampDelay);
+
+typedef struct {
+    double  Fs;
+    /* pdmCoherentReceiver: paramFE.polRotation / pdl / polDelay (devices.py:649-662) */
+    double  polRotation, pdl, polDelay;
+    /* iqMixing per polarisation: index 0 = X or the only polarisation, 1 = Y (core.py:925-970) */
+    double  ampImb[2], phaseImb[2], timeSkew[2];
+    /* photodiode (devices.py:289-399); defaults are applied by the caller */
+    double  R, Tc, Id, RL, B, IpdSat;
+    int32_t N;                    /* filter taps (an even value is incremented, devices.py:361-365) */
+    int32_t fType;                /* 0 'rect', 1 'gauss' */
+    int32_t ideal, shotNoise, thermalNoise, currentSaturation, bandwidthLimitation;
+    int32_t pad_;
+    int64_t rng_seed;             /* device noise streams (Philox4x32-10), one per photodiode */
+} ssf_rx_params;
+
+enum ssf_rx_mode {
+    SSF_RX_PHOTODIODE   = 0,      /* in0 (N, nmodes) field          -> out (N,) float64            */
+    SSF_RX_BALANCED_PD  = 1,      /* in0 (N, 2) = [E1, E2]          -> out (N,) float64            */
+    SSF_RX_COHERENT     = 2,      /* in0 (N,) signal, lo (N,)       -> out (N,) complex128         */
+    SSF_RX_PDM_COHERENT = 3,      /* in0 (N, 2) signal, lo (N,)     -> out (N, 2) complex128       */
+    SSF_RX_IQ_MIXING    = 4       /* in0 (N,) complex               -> out (N,) complex128         */
+};
+/* unit_normals: NULL = noise drawn on the device; otherwise [(pd * 2 + kind) * N + n] standard
+ * normals, kind 0 = shot / 1 = thermal, pd = photodiode slot: photodiode 0; balanced pair 0, 1;
+ * coherent receiver per polarisation p: 4p + {0: I+, 1: I-, 2: Q+, 3: Q-} (devices.py:562-563) */
+int  ssf_rx_run(int device, int32_t mode, int64_t N, int32_t nmodes, const ssf_rx_params *params,
+                const void *in0, const void *lo, const double *unit_normals, void *out);
 
 #ifdef __cplusplus
 }

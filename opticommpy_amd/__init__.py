@@ -13,5 +13,11 @@ from .models import (  # noqa: F401
     last_run, set_device, set_engine,
 )
 
-__all__ = ["parameters", "ssfm", "manakovSSF", "manakovDBP", "edfa", "edc", "linearFiberChannel",
+from .rx import (  # noqa: F401
+    balancedPD, coherentReceiver, decimate, delaySignal, firFilter, iqMixing, lowPassFIR, opticalHybrid2x4, pbs,
+    pdmCoherentReceiver, photodiode,
+)
+
+__all__ = ["firFilter", "lowPassFIR", "decimate", "delaySignal", "iqMixing", "pbs", "photodiode", "balancedPD",
+           "opticalHybrid2x4", "coherentReceiver", "pdmCoherentReceiver", "parameters", "ssfm", "manakovSSF", "manakovDBP", "edfa", "edc", "linearFiberChannel",
            "setPowerforParSSFM", "checkGPU", "last_run", "set_device", "set_engine"]

@@ -48,6 +48,16 @@ class KernelTimes(C.Structure):
                 ("row_n", C.c_int64), ("col_n", C.c_int64), ("other_n", C.c_int64)]
 
 
+class RxParams(C.Structure):
+    """ssf_rx_params (include/ssf.h)."""
+    _fields_ = [("Fs", C.c_double), ("polRotation", C.c_double), ("pdl", C.c_double), ("polDelay", C.c_double),
+                ("ampImb", C.c_double * 2), ("phaseImb", C.c_double * 2), ("timeSkew", C.c_double * 2),
+                ("R", C.c_double), ("Tc", C.c_double), ("Id", C.c_double), ("RL", C.c_double), ("B", C.c_double),
+                ("IpdSat", C.c_double), ("N", C.c_int32), ("fType", C.c_int32), ("ideal", C.c_int32),
+                ("shotNoise", C.c_int32), ("thermalNoise", C.c_int32), ("currentSaturation", C.c_int32),
+                ("bandwidthLimitation", C.c_int32), ("pad_", C.c_int32), ("rng_seed", C.c_int64)]
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int32),
                 ("reserved", C.c_int32), ("total_mem_bytes", C.c_int64), ("lds_per_block_bytes", C.c_int64)]
@@ -76,6 +86,12 @@ SYMBOLS = {
     "ssf_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "ssf_overlap_save": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "ssf_fir_filter": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ssf_delay_signal": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "ssf_decimate": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_int32)]),
+    "ssf_rx_run": (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_int32, C.POINTER(RxParams), C.c_void_p, C.c_void_p,
+                             C.POINTER(C.c_double), C.c_void_p]),
     "ssf_device_copy_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     "ssf_linear_channel": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p, C.c_void_p]),

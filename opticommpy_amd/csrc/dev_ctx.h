@@ -1,0 +1,28 @@
+// Execution context handed to the kernel bodies on the GPU (the CPU tests hand them the fiber
+// emulator's context instead).  HIP only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ssf {
+
+struct DevCtxCore {
+    int tid, bid, nthreads, nblocks;
+    char *lds;
+    static constexpr bool kWaveOps = true;
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    // keeps the instruction scheduler from moving memory operations across this point
+    __device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
+    // all-lanes butterfly over the 64-lane wave (every lane returns the same value)
+    __device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+    __device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        return v;
+    }
+};
+
+}  // namespace ssf

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "dev_ctx.h"
 #include "fused_engine.h"
 #include "ssf_internal.h"
 
@@ -19,10 +20,7 @@ using namespace fused;
 __device__ unsigned long long g_marks[4][4096][8];
 #endif
 
-struct DevCtx {
-    int tid, bid, nthreads, nblocks;
-    char *lds;
-    static constexpr bool kWaveOps = true;
+struct DevCtx : DevCtxCore {
 #ifdef SSF_PHASE_TIMING
     int kind;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -42,20 +40,6 @@ struct DevCtx {
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void flush(int) {}
 #endif
-    __device__ __forceinline__ void sync() { __syncthreads(); }
-    // keeps the instruction scheduler from moving memory operations across this point
-    __device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
-    // all-lanes butterfly over the 64-lane wave (every lane returns the same value)
-    __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
-    }
-    __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-        return v;
-    }
 };
 
 #ifdef SSF_PHASE_TIMING
@@ -65,7 +49,7 @@ struct DevCtx {
 #endif
 #define SSF_DEV_CTX(k)                                                        \
     extern __shared__ __attribute__((aligned(16))) char ssf_smem[];           \
-    DevCtx ctx{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, ssf_smem SSF_CTX_KIND(k)}
+    DevCtx ctx{{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, ssf_smem} SSF_CTX_KIND(k)}
 
 // OCC = minimum waves per SIMD the register allocator must leave room for: 1 = up to 512
 // registers per lane and no spills (one 256-thread workgroup per CU), 2 = 256 registers
@@ -352,6 +336,7 @@ int overlap_save_t(int64_t sigLen, int nrows, int lg, int K, const void *Hfft, c
     a.d = d;
     a.discard = discard;
     a.D = D;
+    ols_defaults(a);
     const int tpf = nfft / 16;
     const int block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
     const long long grid = (a.njobs + fpw - 1) / fpw;

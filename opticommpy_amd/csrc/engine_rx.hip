@@ -1,0 +1,236 @@
+// engine_rx.hip -- HIP backend of the receiver front-end pipeline: __global__ wrappers around the
+// bodies of rx_kernels.h / ols_body and the Backend that RxCore (rx_pipeline.h) drives.  One
+// stream per call; stages are enqueued back to back and nothing is read back between them (the
+// decimator's sampling-phase decision is the one exception: 8 x SpSin doubles).
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dev_ctx.h"
+#include "rx_pipeline.h"
+#include "ssf_copy.h"
+#include "ssf_internal.h"
+
+namespace ssf {
+namespace {
+
+using namespace rx;
+
+struct RxCtx : DevCtxCore {
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(int) {}
+};
+#define SSF_RX_CTX()                                                          \
+    extern __shared__ __attribute__((aligned(16))) char ssf_smem[];           \
+    RxCtx ctx{{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, ssf_smem}}
+
+template <int MAXT> __global__ void __launch_bounds__(MAXT) k_rx_ols(const fused::OlsArgs<double> a) {
+    SSF_RX_CTX();
+    fused::ols_body<double>(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_pbs(const PbsArgs a) {
+    SSF_RX_CTX();
+    pbs_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_front(const FrontArgs a) {
+    SSF_RX_CTX();
+    front_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_iqmix(const IqMixArgs a) {
+    SSF_RX_CTX();
+    iqmix_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_combine(const CombineArgs a) {
+    SSF_RX_CTX();
+    combine_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_dec_var(const DecVarArgs a) {
+    SSF_RX_CTX();
+    dec_var_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_dec_gather(const DecGatherArgs a) {
+    SSF_RX_CTX();
+    dec_gather_body(ctx, a);
+}
+
+struct HipRxBackend {
+    hipStream_t st = nullptr;
+    hipError_t first_err = hipSuccess;
+    std::string where;
+    Stager stg;
+    bool armed = false;
+    void chk(hipError_t e, const char *what) {
+        if (e != hipSuccess && first_err == hipSuccess) {
+            first_err = e;
+            where = what;
+        }
+    }
+    int open(int device) {
+        chk(hipSetDevice(device), "hipSetDevice");
+        chk(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+        if (ok()) chk(stg.init(), "pinned staging buffers");
+        return ok() ? SSF_OK : SSF_ERR_HIP;
+    }
+    ~HipRxBackend() {
+        if (st) (void)hipStreamDestroy(st);
+    }
+    bool ok() const { return first_err == hipSuccess; }
+    bool oom() const { return first_err == hipErrorOutOfMemory; }
+    std::string last_error() const { return where + ": " + hipGetErrorString(first_err); }
+    void *alloc(size_t n) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            chk(e, "hipMalloc");
+            return nullptr;
+        }
+        return p;
+    }
+    void free(void *p) { (void)hipFree(p); }
+    void h2d(void *d, const void *h, size_t n) {      // small, pageable source: synchronous copy
+        chk(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D");
+    }
+    void d2h(void *h, const void *d, size_t n) { chk(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+    void h2d_big(void *d, const void *h, size_t n) { chk(stg.h2d(d, h, n, st), "staged upload"); }
+    void d2h_big(void *h, const void *d, size_t n) { chk(stg.d2h(h, d, n, st), "staged download"); }
+    void sync() { chk(hipStreamSynchronize(st), "hipStreamSynchronize"); }
+    static unsigned ew_grid(long long n) {
+        const long long g = (n + 255) / 256;
+        return (unsigned)(g < 1 ? 1 : g > 4096 ? 4096 : g);
+    }
+    void launch_ols(const fused::OlsArgs<double> &a) {
+        const int nfft = 1 << a.log2nfft, tpf = nfft / 16;
+        const int block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
+        const long long grid = (a.njobs + fpw - 1) / fpw;
+        const size_t lds = (size_t)fpw * fused::lds_slots_per_fft(nfft) * sizeof(Cd);
+        if (!armed) {
+            chk(hipFuncSetAttribute((const void *)k_rx_ols<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
+            chk(hipFuncSetAttribute((const void *)k_rx_ols<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
+            armed = true;
+        }
+        if (block <= 256) k_rx_ols<256><<<(unsigned)grid, block, lds, st>>>(a);
+        else k_rx_ols<1024><<<(unsigned)grid, block, lds, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_ols");
+    }
+    void launch_pbs(const PbsArgs &a) {
+        k_rx_pbs<<<ew_grid(a.N), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_pbs");
+    }
+    void launch_front(const FrontArgs &a) {
+        k_rx_front<<<ew_grid(a.N), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_front");
+    }
+    void launch_iqmix(const IqMixArgs &a) {
+        k_rx_iqmix<<<ew_grid(a.N), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_iqmix");
+    }
+    void launch_combine(const CombineArgs &a) {
+        k_rx_combine<<<ew_grid(a.N), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_combine");
+    }
+    void launch_dec_var(const DecVarArgs &a) {
+        k_rx_dec_var<<<(unsigned)(a.ncols * a.sps), 256, 4096, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_dec_var");
+    }
+    void launch_dec_gather(const DecGatherArgs &a) {
+        k_rx_dec_gather<<<ew_grid(a.Nout * a.ncols), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_dec_gather");
+    }
+};
+
+// One backend per (host thread, device), kept between calls: the stream, the pinned staging buffers
+// and a small pool of device blocks (hipMalloc / hipHostMalloc per call cost more than the kernels of
+// a 2^20-sample receiver).  The pool keeps at most kPoolBytes; larger working sets are freed on return.
+struct Pooled : HipRxBackend {
+    struct Block {
+        void *p;
+        size_t n;
+        bool used;
+    };
+    std::vector<Block> blocks;
+    static constexpr size_t kPoolBytes = (size_t)2 << 30;
+    void *alloc(size_t n) {
+        Block *best = nullptr;
+        for (auto &b : blocks)
+            if (!b.used && b.n >= n && b.n <= 2 * n + (1u << 20) && (!best || b.n < best->n)) best = &b;
+        if (best) {
+            best->used = true;
+            return best->p;
+        }
+        void *p = HipRxBackend::alloc(n);
+        if (!p) {                                   // out of memory: drop the idle blocks and try once more
+            trim(0);
+            first_err = hipSuccess;
+            p = HipRxBackend::alloc(n);
+        }
+        if (p) blocks.push_back(Block{p, n, true});
+        return p;
+    }
+    void free(void *p) {
+        for (auto &b : blocks)
+            if (b.p == p) b.used = false;
+    }
+    void trim(size_t keep) {
+        size_t total = 0;
+        for (auto &b : blocks) total += b.n;
+        for (size_t i = 0; i < blocks.size() && total > keep;) {
+            if (!blocks[i].used) {
+                total -= blocks[i].n;
+                (void)hipFree(blocks[i].p);
+                blocks.erase(blocks.begin() + (long)i);
+            } else ++i;
+        }
+    }
+    ~Pooled() { trim(0); }
+};
+
+Pooled *backend_for(int device, std::string *err) {
+    thread_local std::vector<std::pair<int, Pooled *>> cache;
+    for (auto &c : cache)
+        if (c.first == device) {
+            (void)hipSetDevice(device);
+            c.second->first_err = hipSuccess;
+            return c.second;
+        }
+    Pooled *be = new Pooled();
+    if (be->open(device) != SSF_OK) {
+        *err = be->last_error();
+        delete be;
+        return nullptr;
+    }
+    cache.emplace_back(device, be);
+    return be;
+}
+
+template <class F> int with_core(int device, std::string *err, F &&f) {
+    Pooled *be = backend_for(device, err);
+    if (!be) return SSF_ERR_HIP;
+    int rc;
+    {
+        RxCore<Pooled> core(*be);
+        rc = f(core);
+        if (rc != SSF_OK) *err = core.err;
+    }
+    if (rc == SSF_ERR_HIP && be->oom()) rc = SSF_ERR_OOM;
+    be->trim(Pooled::kPoolBytes);
+    return rc;
+}
+
+}  // namespace
+
+int rx_run(int device, int mode, int64_t N, int nmodes, const ssf_rx_params *p, const void *in0, const void *lo,
+           const double *un, void *out, std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.run(mode, N, nmodes, *p, in0, lo, un, out); });
+}
+int rx_fir(int device, int64_t sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out, std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.fir(sigLen, ncols, ntaps, taps, in, out); });
+}
+int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, void *out, std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.delay(N, delay, Fs, in, out); });
+}
+int rx_decimate(int device, int64_t N, int ncols, int SpSin, int decFactor, const void *in, void *out, int32_t *sampDelay,
+                std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.decimate(N, ncols, SpSin, decFactor, in, out, sampDelay); });
+}
+
+}  // namespace ssf

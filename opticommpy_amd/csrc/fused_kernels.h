@@ -1028,12 +1028,25 @@ template <typename T, class Ctx> SSF_HD void amp_body(Ctx &ctx, const AmpArgs<T>
 // followed by out = y[D : D + sigLen] (core.py:1043-1046), all fused: the padded signal and y are
 // never materialised, the block is transformed in LDS with the same DIF/DIT pair as the row kernel.
 template <typename T> struct OlsArgs {
-    const cx<T> *in;      // (sigLen, nrows) row-major, as the reference's sigIn
-    cx<T> *out;           // (sigLen, nrows)
-    const cx<T> *H;       // NFFT values: fft(zero-padded impulse response) / NFFT
+    const cx<T> *in;      // (inLen, in_ld) row-major, as the reference's sigIn; this launch filters columns [0, nrows)
+    cx<T> *out;           // (keep, out_ld)
+    const cx<T> *H;       // NFFT values per filter: fft(zero-padded impulse response) / NFFT
     long long sigLen, njobs;   // njobs = numBlocks * nrows
     int nrows, log2nfft, d, discard, D;
+    // extensions used by the receiver pipeline (all neutral when zero-initialised through ols_defaults):
+    long long inLen;      // samples actually present in `in` (the rest of sigLen is the reference's zero padding)
+    long long keep;       // only outputs n < keep are stored
+    int in_ld, out_ld;    // leading dimensions (columns per sample) of in / out
+    int Hstride;          // 0: one filter for all columns; NFFT: column m uses H + m * NFFT
+    int roll;             // np.roll(y, -roll) before the [:keep] cut (optic/dsp/core.py:920-922)
 };
+template <typename T> SSF_HD void ols_defaults(OlsArgs<T> &a) {
+    a.inLen = a.sigLen;
+    a.keep = a.sigLen;
+    a.in_ld = a.out_ld = a.nrows;
+    a.Hstride = 0;
+    a.roll = 0;
+}
 template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T> &a) {
     const PassPlan p = make_plan(a.log2nfft);
     const int fpw = ctx.nthreads / p.tpf;
@@ -1043,22 +1056,27 @@ template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T>
     const long long blk = live ? job / a.nrows : 0;
     const int m = live ? (int)(job - blk * a.nrows) : 0;
     cx<T> *l = (cx<T> *)ctx.lds + (size_t)f * lds_slots_per_fft(p.L);
+    const cx<T> *H = a.H + (size_t)m * a.Hstride;
     cx<T> v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const long long i = blk * a.d + (b + p.tpf * q) - a.discard;      // index into the unpadded signal
-        v[q] = (live && i >= 0 && i < a.sigLen) ? a.in[i * a.nrows + m] : mk<T>((T)0, (T)0);
+        v[q] = (live && i >= 0 && i < a.inLen) ? a.in[i * a.in_ld + m] : mk<T>((T)0, (T)0);
     }
     fft_dif<-1>(ctx, p, b, v, l);
     const int last = p.npass - 1;
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * a.H[rev_pos(p, reg_pos(p, last, b, idx))];
+    for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * H[rev_pos(p, reg_pos(p, last, b, idx))];
     fft_dit<+1>(ctx, p, b, v, l);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int pos = b + p.tpf * q;
-        const long long n = blk * a.d + pos - a.discard - a.D;
-        if (live && pos >= a.discard && n >= 0 && n < a.sigLen) a.out[n * a.nrows + m] = v[q];
+        long long n = blk * a.d + pos - a.discard - a.D;
+        if (live && pos >= a.discard && n >= 0 && n < a.sigLen) {
+            n -= a.roll;
+            if (n < 0) n += a.sigLen;
+            if (n < a.keep) a.out[n * a.out_ld + m] = v[q];
+        }
     }
 }
 

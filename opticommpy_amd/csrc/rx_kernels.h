@@ -1,0 +1,209 @@
+// Device bodies of the coherent receiver front-end.  Same convention as
+// fused_kernels.h: every body is a template over a Ctx (HIP: DevCtx, tests: the CPU fiber
+// emulator), so the code that runs on the GPU is the code the CPU tests execute.
+//
+// Reference (file:line under the reference checkout):
+//   pbs                  optic/models/devices.py:223-260
+//   opticalHybrid2x4     optic/models/devices.py:462-500
+//   photodiode           optic/models/devices.py:289-399
+//   balancedPD           optic/models/devices.py:402-459
+//   coherentReceiver     optic/models/devices.py:503-571
+//   pdmCoherentReceiver  optic/models/devices.py:574-668
+//   iqMixing             optic/dsp/core.py:925-970
+// The FIR / fractional-delay filters between these stages are overlap-save launches (ols_body).
+#pragma once
+#include "fused_kernels.h"
+#include "ssf_rng.h"
+
+namespace ssf {
+namespace rx {
+
+using fused::cx;
+using fused::mk;
+typedef cx<double> Cd;
+
+// ---- polarisation beam splitter: (N, 2) field -> rotated (N, 2) field, E @ [[c, -s], [s, c]]
+struct PbsArgs {
+    const Cd *in;      // (N, 2)
+    Cd *out;           // (N, 2)
+    long long N;
+    double c, s;
+};
+template <class Ctx> SSF_HD void pbs_body(Ctx &ctx, const PbsArgs &a) {
+    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
+        const Cd e0 = a.in[2 * n], e1 = a.in[2 * n + 1];
+        a.out[2 * n] = mk<double>(e0.re * a.c + e1.re * a.s, e0.im * a.c + e1.im * a.s);
+        a.out[2 * n + 1] = mk<double>(e1.re * a.c - e0.re * a.s, e1.im * a.c - e0.im * a.s);
+    }
+}
+
+// ---- photodiode model shared by every detection mode (devices.py:352-399, without the filter)
+struct PdModel {
+    double R, IpdSat;
+    double shot_k;       // Fs * q:            Is = sqrt(shot_k * (ipd + Id)) * u    (devices.py:381-383)
+    double Id;
+    double thermal_sigma;// sqrt(Fs * 2 kB T / RL)                                   (devices.py:387-390)
+    int saturate, shot, thermal;   // all 0 for the ideal model
+    unsigned long long seed;       // device noise (Philox), used when `un` is null
+    const double *un;    // host-supplied unit normals, [(pd * 2 + kind) * N + n], or null
+};
+SSF_HD double pd_current_pw(const PdModel &m, double pw, long long n, long long N, int pd) {
+    double i = m.R * pw;
+    if (m.saturate && i > m.IpdSat) i = m.IpdSat;
+    if (m.shot || m.thermal) {
+        double us, ut;
+        if (m.un) {
+            us = m.un[(size_t)(pd * 2) * N + n];
+            ut = m.un[(size_t)(pd * 2 + 1) * N + n];
+        } else {
+            gauss_pair((unsigned long long)n, (unsigned)pd, 0x5044u, m.seed, 1.0, us, ut);   // one Philox draw: two normals
+        }
+        if (m.shot) i += sqrt(m.shot_k * (i + m.Id)) * us;
+        if (m.thermal) i += m.thermal_sigma * ut;
+    }
+    return i;
+}
+
+SSF_HD double pd_current(const PdModel &m, Cd e, long long n, long long N, int pd) {
+    return pd_current_pw(m, e.re * e.re + e.im * e.im, n, N, pd);
+}
+
+enum { RX_PHOTODIODE = 0, RX_BALANCED = 1, RX_COHERENT = 2, RX_PDM = 3 };
+
+// ---- detection stage.  Output s: (N, nout) complex, before the photodiodes' low-pass filter
+//   RX_PHOTODIODE  in0 = (N, nm) field; out (N, 1): R * sum_modes |E|^2 (+ noise), imaginary part 0
+//   RX_BALANCED    in0 = (N, 2): columns E1, E2; out (N, 1): i1 - i2
+//   RX_COHERENT    in0 = (N, 1) signal, lo = (N,); out (N, 1): sI + j sQ
+//   RX_PDM         in0 = (N, 2) signal after the PBS (and PDL), lo = (N,); out (N, 2)
+// Subtracting before the (linear, common) filter instead of after it is exact.
+struct FrontArgs {
+    const Cd *in0;
+    const Cd *lo;
+    Cd *out;
+    long long N;
+    int mode, nm;
+    double es_scale[2];       // PDL (devices.py:660-662)
+    double lo_scale[2];       // LO split by the PBS at pi/4 (devices.py:653): cos, -sin
+    PdModel pd;
+};
+template <class Ctx> SSF_HD void front_body(Ctx &ctx, const FrontArgs &a) {
+    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
+        if (a.mode == RX_PHOTODIODE) {
+            double i = 0;
+            if (a.nm == 1) {
+                i = pd_current(a.pd, a.in0[n], n, a.N, 0);
+            } else {                            // devices.py:356-359: one photocurrent from the summed mode powers
+                double pw = 0;
+                for (int k = 0; k < a.nm; ++k) {
+                    const Cd e = a.in0[n * a.nm + k];
+                    pw += e.re * e.re + e.im * e.im;
+                }
+                i = pd_current_pw(a.pd, pw, n, a.N, 0);
+            }
+            a.out[n] = mk<double>(i, 0.0);
+        } else if (a.mode == RX_BALANCED) {
+            const double i1 = pd_current(a.pd, a.in0[2 * n], n, a.N, 0);
+            const double i2 = pd_current(a.pd, a.in0[2 * n + 1], n, a.N, 1);
+            a.out[n] = mk<double>(i1 - i2, 0.0);
+        } else {
+            const int nm = a.mode == RX_PDM ? 2 : 1;
+            for (int p = 0; p < nm; ++p) {
+                Cd es = a.in0[n * nm + p], lo = a.lo[n];
+                es = mk<double>(es.re * a.es_scale[p], es.im * a.es_scale[p]);
+                lo = mk<double>(lo.re * a.lo_scale[p], lo.im * a.lo_scale[p]);
+                // 2x4 90-degree hybrid, T @ [Es, 0, 0, Elo] (devices.py:487-499)
+                const Cd e0 = mk<double>(0.5 * es.re - 0.5 * lo.re, 0.5 * es.im - 0.5 * lo.im);      //  Es/2 -  Elo/2
+                const Cd e1 = mk<double>(-0.5 * es.im - 0.5 * lo.im, 0.5 * es.re + 0.5 * lo.re);     // jEs/2 + jElo/2
+                const Cd e2 = mk<double>(-0.5 * es.im - 0.5 * lo.re, 0.5 * es.re - 0.5 * lo.im);     // jEs/2 -  Elo/2
+                const Cd e3 = mk<double>(-0.5 * es.re - 0.5 * lo.im, -0.5 * es.im + 0.5 * lo.re);    // -Es/2 + jElo/2
+                // balanced pairs (devices.py:562-563); photodiode slots: I pair = (e1, e0), Q pair = (e2, e3)
+                const int base = 4 * p;
+                const double sI = pd_current(a.pd, e1, n, a.N, base) - pd_current(a.pd, e0, n, a.N, base + 1);
+                const double sQ = pd_current(a.pd, e2, n, a.N, base + 2) - pd_current(a.pd, e3, n, a.N, base + 3);
+                a.out[n * nm + p] = mk<double>(sI, sQ);
+            }
+        }
+    }
+}
+
+// ---- IQ imbalance (core.py:952-960): s' = k1 s + k2 conj(s); real and imaginary parts go to
+// separate columns because each gets its own skew filter afterwards (core.py:963-966)
+struct IqMixArgs {
+    const Cd *in;      // (N, nm)
+    Cd *out;           // (N, 2 nm): column 2p = Re s'_p, 2p + 1 = Im s'_p (imaginary parts 0)
+    long long N;
+    int nm;
+    Cd k1[2], k2[2];
+};
+template <class Ctx> SSF_HD void iqmix_body(Ctx &ctx, const IqMixArgs &a) {
+    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
+        for (int p = 0; p < a.nm; ++p) {
+            const Cd s = a.in[n * a.nm + p];
+            const Cd t = a.k1[p] * s + a.k2[p] * fused::conj(s);
+            a.out[(n * a.nm + p) * 2] = mk<double>(t.re, 0.0);
+            a.out[(n * a.nm + p) * 2 + 1] = mk<double>(t.im, 0.0);
+        }
+    }
+}
+
+// ---- S_p = Re(column 2p) + j Re(column 2p + 1)   (core.py:965-968)
+struct CombineArgs {
+    const Cd *in;      // (N, 2 nm)
+    Cd *out;           // (N, nm)
+    long long N;
+    int nm;
+};
+template <class Ctx> SSF_HD void combine_body(Ctx &ctx, const CombineArgs &a) {
+    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads)
+        for (int p = 0; p < a.nm; ++p)
+            a.out[n * a.nm + p] = mk<double>(a.in[(n * a.nm + p) * 2].re, a.in[(n * a.nm + p) * 2 + 1].re);
+}
+
+// ---- decimate (optic/dsp/core.py:435-491)
+// variance of every sampling phase of every column: var[col * sps + ph] = np.var(x[ph::sps, col])
+struct DecVarArgs {
+    const Cd *in;      // (N, ncols)
+    double *var;       // (ncols, sps)
+    long long N;
+    int ncols, sps;
+};
+template <class Ctx> SSF_HD void dec_var_body(Ctx &ctx, const DecVarArgs &a) {
+    double *red = (double *)ctx.lds;
+    const int col = ctx.bid / a.sps, ph = ctx.bid % a.sps;
+    const long long M = a.N / a.sps;
+    double sr = 0, si = 0;
+    for (long long m = ctx.tid; m < M; m += ctx.nthreads) {
+        const Cd e = a.in[(m * a.sps + ph) * a.ncols + col];
+        sr += e.re;
+        si += e.im;
+    }
+    fused::block_sum2(ctx, sr, si, red);
+    const double mr = sr / (double)M, mi = si / (double)M;
+    ctx.sync();
+    double v = 0, unused = 0;
+    for (long long m = ctx.tid; m < M; m += ctx.nthreads) {
+        const Cd e = a.in[(m * a.sps + ph) * a.ncols + col];
+        v += (e.re - mr) * (e.re - mr) + (e.im - mi) * (e.im - mi);
+    }
+    fused::block_sum2(ctx, v, unused, red);
+    if (ctx.tid == 0) a.var[col * a.sps + ph] = v / (double)M;
+}
+// out[j, col] = x[(j * dec + delay[col]) mod N, col]
+struct DecGatherArgs {
+    const Cd *in;      // (N, ncols)
+    Cd *out;           // (Nout, ncols)
+    long long N, Nout;
+    int ncols, dec;
+    int delay[8];
+};
+template <class Ctx> SSF_HD void dec_gather_body(Ctx &ctx, const DecGatherArgs &a) {
+    const long long total = a.Nout * a.ncols;
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < total; i += (long long)ctx.nblocks * ctx.nthreads) {
+        const long long j = i / a.ncols;
+        const int col = (int)(i - j * a.ncols);
+        a.out[i] = a.in[((j * a.dec + a.delay[col]) % a.N) * a.ncols + col];
+    }
+}
+
+}  // namespace rx
+}  // namespace ssf

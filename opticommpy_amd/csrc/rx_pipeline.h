@@ -1,0 +1,373 @@
+// Host-side sequencing of the receiver front-end stages (Backend = HIP or the CPU emulator).
+// Everything between the upload of the inputs and the download of the result stays in device
+// memory: PBS -> [polarisation delay] -> hybrid + photodiodes -> [low-pass FIR] -> IQ imbalance ->
+// skew filters -> result.  Filters are derived here from the raw parameters with the same
+// formulas as the reference, so the host wrapper and the library cannot drift.
+//
+// Reference: optic/models/devices.py:289-668, optic/dsp/core.py:352-392 (lowPassFIR),
+// 880-922 (delaySignal), 925-970 (iqMixing), 973-1046 (blockwiseFFTConv).
+#pragma once
+#include <cmath>
+#include <complex>
+#include <string>
+#include <vector>
+
+#include "fused_kernels.h"
+#include "rx_kernels.h"
+#include "ssf.h"
+
+namespace ssf {
+namespace rx {
+
+typedef std::complex<double> zc;
+constexpr double kPi = 3.14159265358979323846;
+
+// in-place radix-2 FFT (n = power of two), sign = -1 forward / +1 inverse (unscaled)
+inline void host_fft(std::vector<zc> &a, int sign) {
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double ang = sign * 2.0 * kPi * (double)k / (double)len;
+                const zc w(std::cos(ang), std::sin(ang));
+                const zc u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+// optic/dsp/core.py:352-392
+inline std::vector<double> low_pass_fir(double fc, double fs, int N, int gauss) {
+    std::vector<double> h((size_t)N);
+    const double fu = fc / fs, d = (N - 1) / 2.0;
+    double sum = 0;
+    for (int n = 0; n < N; ++n) {
+        const double x = n - d;
+        if (!gauss) {
+            const double t = kPi * 2 * fu * x;                       // np.sinc(y) = sin(pi y) / (pi y)
+            h[(size_t)n] = (2 * fu) * (t == 0.0 ? 1.0 : std::sin(t) / t);
+        } else {
+            const double a = kPi * fu * x;
+            h[(size_t)n] = std::sqrt(2 * kPi / std::log(2.0)) * fu * std::exp(-(2 / std::log(2.0)) * a * a);
+        }
+        sum += h[(size_t)n];
+    }
+    for (auto &v : h) v /= sum;
+    return h;
+}
+
+// H = fft(zero-padded taps) / nfft: what ols_body multiplies with (the 1/nfft of the inverse transform folded in)
+inline std::vector<zc> ols_filter_from_taps(const zc *taps, int K, int nfft) {
+    std::vector<zc> h((size_t)nfft, zc(0, 0));
+    for (int i = 0; i < K; ++i) h[(size_t)i] = taps[i];
+    host_fft(h, -1);
+    for (auto &v : h) v /= (double)nfft;
+    return h;
+}
+
+// delaySignal's filter (core.py:909-916 + blockwiseFFTConv's freqDomainFilter branch, core.py:1015-1020):
+// K = nfft/2 frequency samples exp(-j 2 pi f delay) -> centred impulse response -> zero-padded -> fft
+inline std::vector<zc> ols_filter_from_delay(double delay, double Fs, int nfft) {
+    const int K = nfft / 2;
+    std::vector<zc> Hk((size_t)K);
+    for (int i = 0; i < K; ++i) {
+        const int kk = i < (K + 1) / 2 ? i : i - K;                  // np.fft.fftfreq(K, 1 / Fs)
+        const double f = (double)kk / ((double)K * (1.0 / Fs));
+        const double ang = -2.0 * kPi * f * delay;
+        Hk[(size_t)i] = zc(std::cos(ang), std::sin(ang));
+    }
+    host_fft(Hk, +1);                                                // ifft (scaled below)
+    std::vector<zc> taps((size_t)K);
+    for (int i = 0; i < K; ++i) taps[(size_t)((i + K / 2) % K)] = Hk[(size_t)i] / (double)K;   // fftshift (K even)
+    return ols_filter_from_taps(taps.data(), K, nfft);
+}
+
+struct OlsGeom {
+    int nfft, lg, K, d, discard, D;
+    long long numBlocks;
+};
+inline OlsGeom ols_geometry(long long sigLen, int K, int nfft) {
+    OlsGeom g;
+    g.nfft = nfft;
+    g.lg = 0;
+    while ((1 << g.lg) < nfft) ++g.lg;
+    g.K = K;
+    g.d = nfft - K + 1;
+    g.discard = K - 1;
+    g.D = (K - 1) / 2;
+    g.numBlocks = (sigLen + K - 1 + g.d - 1) / g.d;                  // core.py:1023-1025
+    return g;
+}
+// transform size for a K-tap 'same' filter: the block advance nfft - K + 1 should be most of the block
+inline int fir_nfft(int K) {
+    int nfft = 256;
+    while (nfft < 8 * K && nfft < 4096) nfft <<= 1;
+    while (nfft < K) nfft <<= 1;
+    return nfft;
+}
+constexpr int kMaxNfft = 8192;            // c128 rows of the LDS transform (engine_fused.hip: k_ols)
+
+template <class Backend> struct RxCore {
+    Backend &be;
+    std::string err;
+    std::vector<void *> owned;
+    explicit RxCore(Backend &b) : be(b) {}
+    ~RxCore() {
+        for (void *p : owned) be.free(p);
+    }
+    Cd *dalloc(size_t n) {
+        void *p = be.alloc(sizeof(Cd) * (n ? n : 1));
+        if (p) owned.push_back(p);
+        return (Cd *)p;
+    }
+    int fail(int rc, const std::string &m) {
+        err = m;
+        return rc;
+    }
+    Cd *upload_filter(const std::vector<zc> &H) {
+        Cd *d = dalloc(H.size());
+        if (d) be.h2d(d, H.data(), sizeof(Cd) * H.size());
+        return d;
+    }
+
+    // y[:keep] = roll(blockwiseFFTConv(in zero-extended to sigLen, filter), -roll) for `ncols` columns
+    int ols(const Cd *in, int in_ld, long long inLen, long long sigLen, Cd *out, int out_ld, long long keep, int ncols,
+            const Cd *H, int Hstride, int K, int nfft, int roll) {
+        const OlsGeom g = ols_geometry(sigLen, K, nfft);
+        fused::OlsArgs<double> a{};
+        a.in = in;
+        a.out = out;
+        a.H = H;
+        a.sigLen = sigLen;
+        a.njobs = g.numBlocks * ncols;
+        a.nrows = ncols;
+        a.log2nfft = g.lg;
+        a.d = g.d;
+        a.discard = g.discard;
+        a.D = g.D;
+        a.inLen = inLen;
+        a.keep = keep;
+        a.in_ld = in_ld;
+        a.out_ld = out_ld;
+        a.Hstride = Hstride;
+        a.roll = roll;
+        be.launch_ols(a);
+        return SSF_OK;
+    }
+
+    // delaySignal on columns [c0, c0 + 2) of a (N, ld) array with delays (dl[0], dl[1]) of equal magnitude
+    int delay_pair(const Cd *in, Cd *out, int ld, long long N, const double *dl, int ncols, double Fs) {
+        const int nfft = 1024;
+        const long long padLen = (long long)std::ceil(std::fabs(dl[0] * Fs));
+        std::vector<zc> H;
+        for (int c = 0; c < ncols; ++c) {
+            const std::vector<zc> h = ols_filter_from_delay(dl[c], Fs, nfft);
+            H.insert(H.end(), h.begin(), h.end());
+        }
+        Cd *dH = upload_filter(H);
+        if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
+        return ols(in, ld, N, N + padLen, out, ld, N, ncols, dH, nfft, nfft / 2, nfft, 1);
+    }
+
+    // run one of the ssf_rx_mode pipelines; in0 / lo / un / out are HOST pointers
+    int run(int mode, long long N, int nmodes, const ssf_rx_params &p, const void *in0, const void *lo, const double *un,
+            void *out) {
+        const bool coherent = mode == SSF_RX_COHERENT || mode == SSF_RX_PDM_COHERENT;
+        const bool iq_only = mode == SSF_RX_IQ_MIXING;
+        const int nin = mode == SSF_RX_PHOTODIODE ? nmodes : mode == SSF_RX_BALANCED_PD ? 2 : mode == SSF_RX_PDM_COHERENT ? 2 : 1;
+        const int nm = mode == SSF_RX_PDM_COHERENT ? 2 : 1;          // columns of the detected signal
+        const int npd = mode == SSF_RX_PHOTODIODE ? 1 : mode == SSF_RX_BALANCED_PD ? 2 : 4 * nm;
+        if (N < 1 || nin < 1) return fail(SSF_ERR_BAD_ARG, "bad size");
+        if (!iq_only && !(p.R > 0)) return fail(SSF_ERR_BAD_ARG, "PD responsivity should be a positive scalar");
+        const bool quiet = p.ideal != 0;
+        const bool noisy = !iq_only && !quiet && (p.shotNoise || p.thermalNoise);
+        const bool lowpass = !iq_only && !quiet && p.bandwidthLimitation;
+        if (!iq_only && !quiet && !(p.Fs >= 2 * p.B)) return fail(SSF_ERR_BAD_ARG, "Sampling frequency Fs needs to be at least twice of B.");
+        int ntaps = p.N;
+        if (ntaps % 2 == 0) ++ntaps;                                 // devices.py:361-365
+        if (lowpass && (ntaps < 1 || ntaps > kMaxNfft / 2)) return fail(SSF_ERR_UNSUPPORTED, "photodiode filter: 1 <= N <= 4096 taps");
+
+        Cd *a = dalloc((size_t)N * nin), *b = dalloc((size_t)N * (coherent || iq_only ? 2 * nm : 1) + 16);
+        Cd *dlo = coherent ? dalloc((size_t)N) : nullptr;
+        double *dun = nullptr;
+        if (!a || !b || (coherent && !dlo)) return fail(SSF_ERR_OOM, "out of device memory");
+        be.h2d_big(a, in0, sizeof(Cd) * (size_t)N * nin);
+        if (coherent) be.h2d_big(dlo, lo, sizeof(Cd) * (size_t)N);
+        if (noisy && un) {
+            dun = (double *)be.alloc(sizeof(double) * (size_t)N * npd * 2);
+            if (!dun) return fail(SSF_ERR_OOM, "out of device memory");
+            owned.push_back(dun);
+            be.h2d_big(dun, un, sizeof(double) * (size_t)N * npd * 2);
+        }
+        Cd *s = a;                                                   // detected signal (N, nm)
+        if (!iq_only) {
+            Cd *field = a;
+            if (mode == SSF_RX_PDM_COHERENT) {
+                PbsArgs pa{a, b, N, std::cos(p.polRotation), std::sin(p.polRotation)};
+                be.launch_pbs(pa);
+                field = b;
+                if (p.polDelay != 0) {                               // devices.py:656-658
+                    const double dl[2] = {-p.polDelay / 2, p.polDelay / 2};
+                    int rc = delay_pair(b, a, 2, N, dl, 2, p.Fs);
+                    if (rc) return rc;
+                    field = a;
+                }
+            }
+            Cd *det = field == a ? b : a;
+            FrontArgs fa{};
+            fa.in0 = field;
+            fa.lo = dlo;
+            fa.out = det;
+            fa.N = N;
+            fa.mode = mode == SSF_RX_PHOTODIODE ? RX_PHOTODIODE : mode == SSF_RX_BALANCED_PD ? RX_BALANCED
+                      : mode == SSF_RX_COHERENT ? RX_COHERENT : RX_PDM;
+            fa.nm = nin;
+            fa.es_scale[0] = fa.es_scale[1] = 1.0;
+            fa.lo_scale[0] = fa.lo_scale[1] = 1.0;
+            if (mode == SSF_RX_PDM_COHERENT) {
+                if (p.pdl != 0) {
+                    fa.es_scale[0] = std::pow(10.0, -(p.pdl / 2) / 20);
+                    fa.es_scale[1] = std::pow(10.0, (p.pdl / 2) / 20);
+                }
+                fa.lo_scale[0] = std::cos(kPi / 4);
+                fa.lo_scale[1] = -std::sin(kPi / 4);
+            }
+            const double q = 1.602176634e-19, kB = 1.380649e-23;     // scipy.constants (CODATA 2018, exact)
+            fa.pd.R = p.R;
+            fa.pd.IpdSat = p.IpdSat;
+            fa.pd.saturate = !quiet && p.currentSaturation;
+            fa.pd.shot = !quiet && p.shotNoise;
+            fa.pd.thermal = !quiet && p.thermalNoise;
+            fa.pd.shot_k = p.Fs * q;
+            fa.pd.Id = p.Id;
+            fa.pd.thermal_sigma = std::sqrt(p.Fs * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
+            fa.pd.seed = (unsigned long long)p.rng_seed;
+            fa.pd.un = dun;
+            be.launch_front(fa);
+            s = det;
+            if (lowpass) {
+                const std::vector<double> h = low_pass_fir(p.B, p.Fs, ntaps, p.fType);
+                std::vector<zc> hz(h.begin(), h.end());
+                const int nfft = fir_nfft(ntaps);
+                Cd *dH = upload_filter(ols_filter_from_taps(hz.data(), ntaps, nfft));
+                if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
+                Cd *flt = s == a ? b : a;
+                int rc = ols(s, nm, N, N, flt, nm, N, nm, dH, 0, ntaps, nfft, 0);
+                if (rc) return rc;
+                s = flt;
+            }
+        }
+        if (coherent || iq_only) {                                   // iqMixing (devices.py:568, core.py:925-970)
+            Cd *cols = dalloc((size_t)N * 2 * nm), *dly = dalloc((size_t)N * 2 * nm);
+            if (!cols || !dly) return fail(SSF_ERR_OOM, "out of device memory");
+            IqMixArgs ia{};
+            ia.in = s;
+            ia.out = cols;
+            ia.N = N;
+            ia.nm = nm;
+            for (int k = 0; k < nm; ++k) {
+                const double amp = std::pow(10.0, p.ampImb[k] / 20) - 1, ph = p.phaseImb[k];
+                const zc ep(std::cos(ph / 2), std::sin(ph / 2)), em(std::cos(ph / 2), -std::sin(ph / 2));
+                const zc k1 = (1 - amp) * ep / 2.0 + (1 + amp) * em / 2.0, k2 = (1 - amp) * em / 2.0 - (1 + amp) * ep / 2.0;
+                ia.k1[k] = mk<double>(k1.real(), k1.imag());
+                ia.k2[k] = mk<double>(k2.real(), k2.imag());
+            }
+            be.launch_iqmix(ia);
+            for (int k = 0; k < nm; ++k) {                           // sI delayed by -skew/2, sQ by +skew/2
+                const double dl[2] = {-p.timeSkew[k] / 2, p.timeSkew[k] / 2};
+                int rc = delay_pair(cols + 2 * k, dly + 2 * k, 2 * nm, N, dl, 2, p.Fs);
+                if (rc) return rc;
+            }
+            CombineArgs ca{dly, cols, N, nm};                        // (cols is free again: reuse it for the result)
+            be.launch_combine(ca);
+            s = cols;
+        }
+        be.sync();
+        if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
+        if (coherent || iq_only) {
+            be.d2h_big(out, s, sizeof(Cd) * (size_t)N * nm);
+        } else {                                                     // real photocurrent: (N,) doubles
+            std::vector<Cd> tmp((size_t)N);
+            be.d2h_big(tmp.data(), s, sizeof(Cd) * (size_t)N);
+            double *o = (double *)out;
+            for (long long n = 0; n < N; ++n) o[n] = tmp[(size_t)n].re;
+        }
+        if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
+        return SSF_OK;
+    }
+
+    // firFilter (core.py:87-125): 'same'-mode convolution of every column with the taps
+    int fir(long long sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out) {
+        if (sigLen < 1 || ncols < 1 || ntaps < 1) return fail(SSF_ERR_BAD_ARG, "bad size");
+        if (ntaps > kMaxNfft / 2) return fail(SSF_ERR_UNSUPPORTED, "firFilter: at most 4096 taps");
+        const int nfft = fir_nfft(ntaps);
+        Cd *a = dalloc((size_t)sigLen * ncols), *b = dalloc((size_t)sigLen * ncols);
+        Cd *dH = upload_filter(ols_filter_from_taps((const zc *)taps, ntaps, nfft));
+        if (!a || !b || !dH) return fail(SSF_ERR_OOM, "out of device memory");
+        be.h2d_big(a, in, sizeof(Cd) * (size_t)sigLen * ncols);
+        int rc = ols(a, ncols, sigLen, sigLen, b, ncols, sigLen, ncols, dH, 0, ntaps, nfft, 0);
+        if (rc) return rc;
+        be.sync();
+        be.d2h_big(out, b, sizeof(Cd) * (size_t)sigLen * ncols);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+
+    // decimate (core.py:435-491); sampDelay_out[ncols] receives the chosen sampling phases
+    int decimate(long long N, int ncols, int SpSin, int decFactor, const void *in, void *out, int *sampDelay_out) {
+        if (N < 1 || ncols < 1 || ncols > 8 || SpSin < 1 || decFactor < 1) return fail(SSF_ERR_BAD_ARG, "decimate: 1 <= columns <= 8, SpSin >= 1, decFactor >= 1");
+        if (N % SpSin) return fail(SSF_ERR_BAD_ARG, "cannot reshape array: length is not a multiple of SpSin");   // core.py:477
+        const long long Nout = (N + decFactor - 1) / decFactor;
+        Cd *a = dalloc((size_t)N * ncols), *b = dalloc((size_t)Nout * ncols);
+        double *dvar = (double *)be.alloc(sizeof(double) * (size_t)ncols * SpSin);
+        if (dvar) owned.push_back(dvar);
+        if (!a || !b || !dvar) return fail(SSF_ERR_OOM, "out of device memory");
+        be.h2d_big(a, in, sizeof(Cd) * (size_t)N * ncols);
+        DecVarArgs va{a, dvar, N, ncols, SpSin};
+        be.launch_dec_var(va);
+        std::vector<double> var((size_t)ncols * SpSin);
+        be.sync();
+        be.d2h(var.data(), dvar, sizeof(double) * var.size());
+        DecGatherArgs ga{};
+        ga.in = a;
+        ga.out = b;
+        ga.N = N;
+        ga.Nout = Nout;
+        ga.ncols = ncols;
+        ga.dec = decFactor;
+        for (int c = 0; c < ncols; ++c) {                            // first index of the maximum (core.py:478)
+            int best = 0;
+            for (int ph = 1; ph < SpSin; ++ph)
+                if (var[(size_t)c * SpSin + ph] > var[(size_t)c * SpSin + best]) best = ph;
+            ga.delay[c] = best;
+            if (sampDelay_out) sampDelay_out[c] = best;
+        }
+        be.launch_dec_gather(ga);
+        be.sync();
+        be.d2h_big(out, b, sizeof(Cd) * (size_t)Nout * ncols);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+
+    // delaySignal (core.py:880-922) of one column
+    int delay(long long N, double delay_s, double Fs, const void *in, void *out) {
+        if (N < 1 || !(Fs > 0)) return fail(SSF_ERR_BAD_ARG, "bad size");
+        Cd *a = dalloc((size_t)N), *b = dalloc((size_t)N);
+        if (!a || !b) return fail(SSF_ERR_OOM, "out of device memory");
+        be.h2d_big(a, in, sizeof(Cd) * (size_t)N);
+        const double dl[1] = {delay_s};
+        int rc = delay_pair(a, b, 1, N, dl, 1, Fs);
+        if (rc) return rc;
+        be.sync();
+        be.d2h_big(out, b, sizeof(Cd) * (size_t)N);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+};
+
+}  // namespace rx
+}  // namespace ssf

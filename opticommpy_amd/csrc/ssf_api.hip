@@ -296,4 +296,48 @@ int ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_t
     return SSF_OK;
 }
 
+// ---- receiver side (engine_rx.hip) -----------------------------------------------------------
+static int rx_check_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_err(SSF_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return set_err(SSF_ERR_NO_DEVICE, "device index out of range");
+    return SSF_OK;
+}
+
+int ssf_fir_filter(int device, int64_t sigLen, int32_t ncols, int32_t ntaps, const void *taps, const void *in, void *out) {
+    if (!taps || !in || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_fir_filter: NULL argument");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::rx_fir(device, sigLen, ncols, ntaps, taps, in, out, &err);
+    return rc ? set_err(rc, "ssf_fir_filter: " + err) : SSF_OK;
+}
+
+int ssf_delay_signal(int device, int64_t N, double delay, double Fs, const void *in, void *out) {
+    if (!in || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_delay_signal: NULL argument");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::rx_delay(device, N, delay, Fs, in, out, &err);
+    return rc ? set_err(rc, "ssf_delay_signal: " + err) : SSF_OK;
+}
+
+int ssf_decimate(int device, int64_t N, int32_t ncols, int32_t SpSin, int32_t decFactor, const void *in, void *out,
+                 int32_t *sampDelay) {
+    if (!in || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_decimate: NULL argument");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::rx_decimate(device, N, ncols, SpSin, decFactor, in, out, sampDelay, &err);
+    return rc ? set_err(rc, "ssf_decimate: " + err) : SSF_OK;
+}
+
+int ssf_rx_run(int device, int32_t mode, int64_t N, int32_t nmodes, const ssf_rx_params *params, const void *in0,
+               const void *lo, const double *unit_normals, void *out) {
+    if (!params || !in0 || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_rx_run: NULL argument");
+    if (mode < SSF_RX_PHOTODIODE || mode > SSF_RX_IQ_MIXING) return set_err(SSF_ERR_BAD_ARG, "ssf_rx_run: unknown mode");
+    if ((mode == SSF_RX_COHERENT || mode == SSF_RX_PDM_COHERENT) && !lo) return set_err(SSF_ERR_BAD_ARG, "ssf_rx_run: the LO field is NULL");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::rx_run(device, mode, N, nmodes, params, in0, lo, unit_normals, out, &err);
+    return rc ? set_err(rc, "ssf_rx_run: " + err) : SSF_OK;
+}
+
 }  // extern "C"

@@ -76,6 +76,14 @@ bool fused_supports(int64_t N, int nrows, int precision);
 int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int log2nfft, int K, const void *Hfft,
                         const void *in, void *out, std::string *err);
 
+// receiver front-end (engine_rx.hip)
+int rx_run(int device, int mode, int64_t N, int nmodes, const ssf_rx_params *p, const void *in0, const void *lo,
+           const double *un, void *out, std::string *err);
+int rx_fir(int device, int64_t sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out, std::string *err);
+int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, void *out, std::string *err);
+int rx_decimate(int device, int64_t N, int ncols, int SpSin, int decFactor, const void *in, void *out, int32_t *sampDelay,
+                std::string *err);
+
 inline int fail(ssf_plan *p, int code, const std::string &msg) {
     if (p) p->err = msg;
     return code;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "fused_engine.h"
+#include "rx_pipeline.h"
 
 namespace {
 
@@ -165,6 +166,23 @@ struct EmuBackend {
         ++launches;
         run_grid(std::min(grid, 8), block, 64, [&](EmuCtx &c) { ssf::fused::amp_body<T>(c, a); });
     }
+    // receiver pipeline (rx_pipeline.h)
+    void launch_ols(const ssf::fused::OlsArgs<double> &a) {
+        ++launches;
+        const int nfft = 1 << a.log2nfft, tpf = nfft / 16, block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
+        const long long grid = (a.njobs + fpw - 1) / fpw;
+        run_grid((int)grid, block, (size_t)fpw * ssf::fused::lds_slots_per_fft(nfft) * sizeof(ssf::fused::cx<double>),
+                 [&](EmuCtx &c) { ssf::fused::ols_body<double>(c, a); });
+    }
+    static int ew_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>(3, (n + 63) / 64)); }
+    void launch_pbs(const ssf::rx::PbsArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::pbs_body(c, a); }); }
+    void launch_front(const ssf::rx::FrontArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::front_body(c, a); }); }
+    void launch_iqmix(const ssf::rx::IqMixArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::iqmix_body(c, a); }); }
+    void launch_combine(const ssf::rx::CombineArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::combine_body(c, a); }); }
+    void launch_dec_var(const ssf::rx::DecVarArgs &a) { run_grid(a.ncols * a.sps, 64, 4096, [&](EmuCtx &c) { ssf::rx::dec_var_body(c, a); }); }
+    void launch_dec_gather(const ssf::rx::DecGatherArgs &a) {
+        run_grid(ew_grid(a.Nout * a.ncols), 64, 64, [&](EmuCtx &c) { ssf::rx::dec_gather_body(c, a); });
+    }
 };
 
 template <typename T>
@@ -262,10 +280,34 @@ int emu_overlap_save(int64_t sigLen, int nrows, int lg, int K, const void *Hfft,
     a.d = d;
     a.discard = K - 1;
     a.D = (K - 1) / 2;
+    ols_defaults(a);
     const int tpf = nfft / 16, block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
     const long long grid = (a.njobs + fpw - 1) / fpw;
     run_grid((int)grid, block, (size_t)fpw * lds_slots_per_fft(nfft) * sizeof(Cc), [&](EmuCtx &c) { ols_body<double>(c, a); });
     return 0;
+}
+
+int emu_rx_run(int mode, int64_t N, int nmodes, const ssf_rx_params *p, const void *in0, const void *lo, const double *un, void *out) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    int rc = core.run(mode, N, nmodes, *p, in0, lo, un, out);
+    if (rc) fprintf(stderr, "emu: %s\n", core.err.c_str());
+    return rc;
+}
+int emu_fir(int64_t sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    return core.fir(sigLen, ncols, ntaps, taps, in, out);
+}
+int emu_delay(int64_t N, double delay, double Fs, const void *in, void *out) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    return core.delay(N, delay, Fs, in, out);
+}
+int emu_decimate(int64_t N, int ncols, int SpSin, int dec, const void *in, void *out, int32_t *sd) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    return core.decimate(N, ncols, SpSin, dec, in, out, sd);
 }
 
 int emu_linear_channel(int64_t N, int nrows, int precision, double Fs, double Fc, double alpha, double D, double L,

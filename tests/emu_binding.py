@@ -129,3 +129,50 @@ def edc(sigIn, param):
     res = out if np.iscomplexobj(sigIn) else out.real
     res = res.astype(sigIn.dtype, copy=False)
     return res.flatten() if one_d else res
+
+
+class EmuRxBackend:
+    """Drop-in for opticommpy_amd.rx._backend: the receiver pipeline (rx_pipeline.h + rx_kernels.h) on the
+    CPU emulator instead of the GPU.  Same marshalling code (opticommpy_amd/rx.py) in front of it."""
+
+    def __init__(self):
+        e = load()
+        e.emu_fir.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        e.emu_delay.argtypes = [C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        e.emu_decimate.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        e.emu_rx_run.argtypes = [C.c_int, C.c_int64, C.c_int, C.POINTER(_lib.RxParams), C.c_void_p, C.c_void_p,
+                                 C.POINTER(C.c_double), C.c_void_p]
+        self.e = e
+
+    @staticmethod
+    def _check(rc):
+        if rc == -1:
+            raise ValueError("bad argument")
+        if rc == -6:
+            raise RuntimeError("unsupported")
+        assert rc == 0, f"emulator rc={rc}"
+
+    def fir(self, x, taps):
+        out = np.empty_like(x)
+        self._check(self.e.emu_fir(x.shape[0], x.shape[1], len(taps), taps.ctypes.data_as(C.c_void_p),
+                                   x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def delay(self, x, delay, Fs):
+        out = np.empty_like(x)
+        self._check(self.e.emu_delay(x.shape[0], float(delay), float(Fs), x.ctypes.data_as(C.c_void_p),
+                                     out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def decimate(self, x, SpSin, dec):
+        out = np.empty(((x.shape[0] + dec - 1) // dec, x.shape[1]), dtype=np.complex128)
+        sd = (C.c_int32 * x.shape[1])()
+        self._check(self.e.emu_decimate(x.shape[0], x.shape[1], int(SpSin), int(dec), x.ctypes.data_as(C.c_void_p),
+                                        out.ctypes.data_as(C.c_void_p), sd))
+        return out, list(sd)
+
+    def rx(self, mode, N, nmodes, p, in0, lo, un, out):
+        self._check(self.e.emu_rx_run(mode, N, nmodes, C.byref(p), in0.ctypes.data_as(C.c_void_p),
+                                      lo.ctypes.data_as(C.c_void_p) if lo is not None else None,
+                                      un.ctypes.data_as(C.POINTER(C.c_double)) if un is not None else None,
+                                      out.ctypes.data_as(C.c_void_p)))

@@ -1,0 +1,117 @@
+"""Receiver front-end on the CPU emulator: the kernel bodies of rx_kernels.h / ols_body and the stage
+sequencing of rx_pipeline.h are the ones the GPU runs; the host marshalling is opticommpy_amd/rx.py
+itself with its backend swapped.  Checked against the reference-generated vectors (tests/golden/rx_*)
+and the receiver oracle."""
+import numpy as np
+import pytest
+
+import emu_binding as eb
+import opticommpy_amd as oa
+from helpers import golden_names, load_golden, rel_l2, rx_call
+from opticommpy_amd import rx as rxmod
+from oracle import rx_oracle as orx
+from oracle.ssf_oracle import parameters as oparams
+
+RX = [n for n in golden_names("rx_") if n not in ("rx_lowpassfir", "rx_pd_noise_seed11")]
+TOL = 1e-12                      # complex128 arithmetic in a different operation order (FFT sizes, fused subtraction)
+
+
+@pytest.fixture(autouse=True)
+def emu_backend(monkeypatch):
+    monkeypatch.setattr(rxmod, "_backend", eb.EmuRxBackend())
+
+
+@pytest.mark.parametrize("name", RX)
+def test_rx_golden_vectors_on_emulated_kernels(name):
+    d, cfg = load_golden(name)
+    out = rx_call(oa, oa.parameters, d, cfg)
+    ref = d["out"]
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    if cfg["func"] in ("decimate", "opticalHybrid2x4"):
+        assert np.array_equal(out, ref)                                    # pure selection / host glue
+    else:
+        scale = np.max(np.abs(ref))
+        assert np.max(np.abs(out - ref)) <= TOL * max(scale, 1e-300), np.max(np.abs(out - ref)) / scale
+
+
+def test_lowpassfir_matches_reference_vectors():
+    d, cfg = load_golden("rx_lowpassfir")
+    assert np.array_equal(oa.lowPassFIR(*cfg["rect"], "rect"), d["rect"])
+    assert np.array_equal(oa.lowPassFIR(*cfg["gauss"], "gauss"), d["gauss"])
+
+
+def test_photodiode_with_supplied_noise_matches_seeded_reference_run():
+    d, cfg = load_golden("rx_pd_noise_seed11")
+    p = oa.parameters()
+    for k, v in cfg.items():
+        if k != "func":
+            setattr(p, k, v)
+    un = np.stack([d["extra_shot"], d["extra_thermal"]])[None]             # (1 photodiode, 2 kinds, N)
+    out = oa.photodiode(d["Ei"].copy(), p, _unit_normals=un)
+    assert np.max(np.abs(out - d["out"])) <= 1e-12 * np.max(np.abs(d["out"]))
+
+
+def test_device_noise_statistics():
+    """Philox noise of a photodiode: variance of shot + thermal terms as devices.py:381-390 defines them."""
+    N = 1 << 14
+    E = np.full(N, np.sqrt(1e-3), dtype=complex)
+    p = oa.parameters()
+    p.Fs, p.B, p.bandwidthLimitation, p.seed = 128e9, 30e9, False, 7
+    i = oa.photodiode(E, p)
+    q, kB = 1.602176634e-19, 1.380649e-23
+    var = p.Fs * q * (1e-3 + 5e-9) + p.Fs * 2 * kB * 298.15 / 50
+    assert np.mean(i) == pytest.approx(1e-3, rel=2e-3)
+    assert np.var(i) == pytest.approx(var, rel=0.05)
+    p.seed = 8
+    assert not np.array_equal(i, oa.photodiode(E, p))                      # another seed, another stream
+    p.seed = 7
+    assert np.array_equal(i, oa.photodiode(E, p))                          # same seed, same stream
+
+
+def test_pdm_receiver_against_oracle_on_a_longer_field_with_noise_arrays():
+    """All stages at once (PBS, polarisation delay, PDL, hybrid, 8 noisy photodiodes, low-pass, IQ
+    imbalance, skew) with host-supplied unit normals, against the oracle fed with the same normals."""
+    rng = np.random.default_rng(5)
+    N = 6000
+    Es = (rng.normal(size=(N, 2)) + 1j * rng.normal(size=(N, 2))) * 0.02
+    Elo = np.sqrt(8e-3) * np.exp(1j * 2 * np.pi * 2e8 * np.arange(N) / 96e9)
+    fe = dict(Fs=96e9, polRotation=-0.3, pdl=0.7, polDelay=-4e-12, ampImbX=0.3, phaseImbX=-0.1, timeSkewX=1e-12,
+              ampImbY=0.1, phaseImbY=0.05, timeSkewY=0.0)
+    pd = dict(Fs=96e9, B=25e9, N=101, currentSaturation=True, IpdSat=6e-3)
+    un = rng.normal(size=(8, 2, N))
+
+    def bag(cls, kw):
+        o = cls()
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+    out = oa.pdmCoherentReceiver(Es, Elo, bag(oa.parameters, fe), bag(oa.parameters, pd), _unit_normals=un)
+    # oracle noise layout: ((I pair: (PD1, PD2)), (Q pair: (PD1, PD2))) per polarisation, each PD = (shot, thermal)
+    def pd_noise(slot):
+        return un[slot][0], un[slot][1]
+
+    def pol(b):
+        return (pd_noise(b), pd_noise(b + 1)), (pd_noise(b + 2), pd_noise(b + 3))
+    ref = orx.pdmCoherentReceiver(Es, Elo, bag(oparams, fe), bag(oparams, pd), noise=(pol(0), pol(4)))
+    assert rel_l2(out, ref) <= 1e-12
+
+
+def test_error_conventions():
+    p = oa.parameters()
+    with pytest.raises(AttributeError):
+        oa.pdmCoherentReceiver(np.zeros((16, 2), complex), np.zeros(16, complex), p)          # no Fs
+    p.Fs = 64e9
+    with pytest.raises(AssertionError):
+        oa.pdmCoherentReceiver(np.zeros((16, 2), complex), np.zeros(15, complex), p)
+    pd = oa.parameters()
+    pd.Fs, pd.B = 40e9, 30e9
+    with pytest.raises(AssertionError):
+        oa.photodiode(np.zeros(16, complex), pd)                                              # Fs < 2 B
+    pd = oa.parameters()
+    pd.R, pd.ideal = -1, True
+    with pytest.raises(AssertionError):
+        oa.photodiode(np.zeros(16, complex), pd)
+    dp = oa.parameters()
+    dp.SpSin, dp.SpSout = 16, 2
+    with pytest.raises(ValueError):
+        oa.decimate(np.zeros(100), dp)                                                        # 100 % 16 != 0
