@@ -24,6 +24,7 @@
  *   ssf_overlap_save                     blockwiseFFTConv as used by edc  optic/dsp/core.py:973-1046,
  *                                                                          optic/dsp/equalization.py:113-117
  *   ssf_fir_filter / ssf_delay_signal / ssf_decimate / ssf_rx_run   receiver side, see below
+ *   ssf_device_malloc / ssf_device_free / ssf_device_memcpy         device-resident arrays, see below
  *   ssf_device_copy_bandwidth            (no reference equivalent) measured memory ceiling
  *   ssf_set_profiling / ssf_get_kernel_times   time.time() pairs around calls in
  *                                        examples/benchmarck_GPU_processing.ipynb:389-395
@@ -207,6 +208,19 @@ int  ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, doub
  * 16 <= nfft <= 8192 (SSF_C128) / 16384 (SSF_C64), K = filter length <= nfft. */
 int  ssf_overlap_save(int device, int64_t sigLen, int32_t nrows, int32_t precision, int32_t nfft,
                       int32_t K, const void *Hfft, const void *sig_in, void *sig_out);
+
+/* ---- device-resident arrays: chaining calls without crossing PCIe -----------------------------
+ * The reference's cupy twin converts to numpy at every function boundary (cp.asnumpy,
+ * optic/models/modelsGPU.py:271, 501-509; optic/dsp/coreGPU.py:72), so a channel -> receiver -> DBP
+ * chain crosses the bus five times.  Here every `const void *` / `void *` array argument of this ABI
+ * (fields, signals, LO, noise, snapshots; NOT the small filter / parameter arrays: Hfft, taps,
+ * save_spans, trace) may also be a device pointer obtained from ssf_device_malloc on the same
+ * device: the library recognises it (hipPointerGetAttributes) and copies device to device.
+ * Layouts and sizes are unchanged.  ssf_device_memcpy copies between any two host / device
+ * buffers and is synchronous at return. */
+int  ssf_device_malloc(int device, int64_t bytes, void **ptr);
+int  ssf_device_free(int device, void *ptr);
+int  ssf_device_memcpy(int device, void *dst, const void *src, int64_t bytes);
 
 /* ---- receiver side of the channel: FIR filtering, fractional delay,
  * decimation and the coherent front-end.  All arrays are host buffers, complex128 interleaved,

@@ -13,11 +13,12 @@ from .models import (  # noqa: F401
     last_run, set_device, set_engine,
 )
 
+from .device import DeviceArray, to_device  # noqa: F401
 from .rx import (  # noqa: F401
     balancedPD, coherentReceiver, decimate, delaySignal, firFilter, iqMixing, lowPassFIR, opticalHybrid2x4, pbs,
     pdmCoherentReceiver, photodiode,
 )
 
-__all__ = ["firFilter", "lowPassFIR", "decimate", "delaySignal", "iqMixing", "pbs", "photodiode", "balancedPD",
+__all__ = ["DeviceArray", "to_device", "firFilter", "lowPassFIR", "decimate", "delaySignal", "iqMixing", "pbs", "photodiode", "balancedPD",
            "opticalHybrid2x4", "coherentReceiver", "pdmCoherentReceiver", "parameters", "ssfm", "manakovSSF", "manakovDBP", "edfa", "edc", "linearFiberChannel",
            "setPowerforParSSFM", "checkGPU", "last_run", "set_device", "set_engine"]

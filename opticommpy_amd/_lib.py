@@ -86,6 +86,9 @@ SYMBOLS = {
     "ssf_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "ssf_overlap_save": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "ssf_device_malloc": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "ssf_device_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "ssf_device_memcpy": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     "ssf_fir_filter": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ssf_delay_signal": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "ssf_decimate": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -347,7 +347,7 @@ template <typename T> class RocfftEngine final : public Engine {
             if (noise) {
                 if (!noise_d) SSF_HIP(pl, hipMalloc(&noise_d, field_bytes));
                 SSF_HIP(pl, hipMemcpyAsync(noise_d, (const char *)noise + (size_t)span_rel * field_bytes, field_bytes,
-                                           hipMemcpyHostToDevice, pl->stream));
+                                           hipMemcpyDefault, pl->stream));
                 nz = noise_d;
             }
             const bool dev_noise = !noise && p.rng_seed != 0;

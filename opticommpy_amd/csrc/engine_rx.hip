@@ -44,9 +44,13 @@ __global__ void __launch_bounds__(256) k_rx_combine(const CombineArgs a) {
     SSF_RX_CTX();
     combine_body(ctx, a);
 }
-__global__ void __launch_bounds__(256) k_rx_dec_var(const DecVarArgs a) {
+__global__ void __launch_bounds__(256) k_rx_real_part(const RealPartArgs a) {
     SSF_RX_CTX();
-    dec_var_body(ctx, a);
+    real_part_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_dec_sum(const DecSumArgs a) {
+    SSF_RX_CTX();
+    dec_sum_body(ctx, a);
 }
 __global__ void __launch_bounds__(256) k_rx_dec_gather(const DecGatherArgs a) {
     SSF_RX_CTX();
@@ -128,9 +132,13 @@ struct HipRxBackend {
         k_rx_combine<<<ew_grid(a.N), 256, 0, st>>>(a);
         chk(hipGetLastError(), "launch k_rx_combine");
     }
-    void launch_dec_var(const DecVarArgs &a) {
-        k_rx_dec_var<<<(unsigned)(a.ncols * a.sps), 256, 4096, st>>>(a);
-        chk(hipGetLastError(), "launch k_rx_dec_var");
+    void launch_real_part(const RealPartArgs &a) {
+        k_rx_real_part<<<ew_grid(a.N), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_real_part");
+    }
+    void launch_dec_sum(const DecSumArgs &a, int nblocks, int nthreads) {
+        k_rx_dec_sum<<<(unsigned)nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_dec_sum");
     }
     void launch_dec_gather(const DecGatherArgs &a) {
         k_rx_dec_gather<<<ew_grid(a.Nout * a.ncols), 256, 0, st>>>(a);

@@ -159,34 +159,54 @@ template <class Ctx> SSF_HD void combine_body(Ctx &ctx, const CombineArgs &a) {
             a.out[n * a.nm + p] = mk<double>(a.in[(n * a.nm + p) * 2].re, a.in[(n * a.nm + p) * 2 + 1].re);
 }
 
-// ---- decimate (optic/dsp/core.py:435-491)
-// variance of every sampling phase of every column: var[col * sps + ph] = np.var(x[ph::sps, col])
-struct DecVarArgs {
-    const Cd *in;      // (N, ncols)
-    double *var;       // (ncols, sps)
+// ---- real part of a complex column as a float64 array (photocurrents: `return ipd.real`, devices.py:399)
+struct RealPartArgs {
+    const Cd *in;
+    double *out;
     long long N;
-    int ncols, sps;
 };
-template <class Ctx> SSF_HD void dec_var_body(Ctx &ctx, const DecVarArgs &a) {
-    double *red = (double *)ctx.lds;
-    const int col = ctx.bid / a.sps, ph = ctx.bid % a.sps;
-    const long long M = a.N / a.sps;
-    double sr = 0, si = 0;
-    for (long long m = ctx.tid; m < M; m += ctx.nthreads) {
-        const Cd e = a.in[(m * a.sps + ph) * a.ncols + col];
-        sr += e.re;
-        si += e.im;
+template <class Ctx> SSF_HD void real_part_body(Ctx &ctx, const RealPartArgs &a) {
+    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) a.out[n] = a.in[n].re;
+}
+
+// ---- decimate (optic/dsp/core.py:435-491)
+// np.var(x[ph::sps, col]) for every sampling phase of every column, in two passes like numpy
+// (mean, then mean |x - mean|^2).  The (N, ncols) array is read as one flat stream: with a thread
+// count that is a multiple of nclass = sps * ncols every thread only ever sees one (phase, column)
+// class, so the per-class sums are plain register accumulations; each workgroup leaves its partial
+// sums (fixed order, deterministic) and the host adds the few hundred partials.
+struct DecSumArgs {
+    const Cd *in;        // (N, ncols)
+    const Cd *mean;      // nclass means for pass 2, null for pass 1
+    double *part;        // (nblocks, nclass, 2): pass 1 sum re / sum im, pass 2 sum |x - mean|^2 / unused
+    long long total;     // N * ncols
+    int nclass;
+};
+template <class Ctx> SSF_HD void dec_sum_body(Ctx &ctx, const DecSumArgs &a) {
+    double *red = (double *)ctx.lds;               // nthreads x 2 doubles
+    const int cls = ctx.tid % a.nclass;
+    const Cd m = a.mean ? a.mean[cls] : mk<double>(0.0, 0.0);
+    double s0 = 0, s1 = 0;
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < a.total; i += (long long)ctx.nblocks * ctx.nthreads) {
+        const Cd e = a.in[i];
+        if (a.mean) s0 += (e.re - m.re) * (e.re - m.re) + (e.im - m.im) * (e.im - m.im);
+        else {
+            s0 += e.re;
+            s1 += e.im;
+        }
     }
-    fused::block_sum2(ctx, sr, si, red);
-    const double mr = sr / (double)M, mi = si / (double)M;
+    red[2 * ctx.tid] = s0;
+    red[2 * ctx.tid + 1] = s1;
     ctx.sync();
-    double v = 0, unused = 0;
-    for (long long m = ctx.tid; m < M; m += ctx.nthreads) {
-        const Cd e = a.in[(m * a.sps + ph) * a.ncols + col];
-        v += (e.re - mr) * (e.re - mr) + (e.im - mi) * (e.im - mi);
+    if (ctx.tid < a.nclass) {                      // threads of one class are tid, tid + nclass, ...
+        double t0 = 0, t1 = 0;
+        for (int t = ctx.tid; t < ctx.nthreads; t += a.nclass) {
+            t0 += red[2 * t];
+            t1 += red[2 * t + 1];
+        }
+        a.part[((size_t)ctx.bid * a.nclass + ctx.tid) * 2] = t0;
+        a.part[((size_t)ctx.bid * a.nclass + ctx.tid) * 2 + 1] = t1;
     }
-    fused::block_sum2(ctx, v, unused, red);
-    if (ctx.tid == 0) a.var[col * a.sps + ph] = v / (double)M;
 }
 // out[j, col] = x[(j * dec + delay[col]) mod N, col]
 struct DecGatherArgs {

@@ -7,6 +7,7 @@
 // Reference: optic/models/devices.py:289-668, optic/dsp/core.py:352-392 (lowPassFIR),
 // 880-922 (delaySignal), 925-970 (iqMixing), 973-1046 (blockwiseFFTConv).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <string>
@@ -74,8 +75,7 @@ inline std::vector<zc> ols_filter_from_taps(const zc *taps, int K, int nfft) {
 
 // delaySignal's filter (core.py:909-916 + blockwiseFFTConv's freqDomainFilter branch, core.py:1015-1020):
 // K = nfft/2 frequency samples exp(-j 2 pi f delay) -> centred impulse response -> zero-padded -> fft
-inline std::vector<zc> ols_filter_from_delay(double delay, double Fs, int nfft) {
-    const int K = nfft / 2;
+inline std::vector<zc> ols_filter_from_delay(double delay, double Fs, int K, int nfft) {
     std::vector<zc> Hk((size_t)K);
     for (int i = 0; i < K; ++i) {
         const int kk = i < (K + 1) / 2 ? i : i - K;                  // np.fft.fftfreq(K, 1 / Fs)
@@ -164,16 +164,19 @@ template <class Backend> struct RxCore {
 
     // delaySignal on columns [c0, c0 + 2) of a (N, ld) array with delays (dl[0], dl[1]) of equal magnitude
     int delay_pair(const Cd *in, Cd *out, int ld, long long N, const double *dl, int ncols, double Fs) {
-        const int nfft = 1024;
+        // the reference's filter: NFFT = 1024 -> a 512-tap impulse response (core.py:880, 909-916).  The block
+        // size of the overlap-save evaluation does not change the convolution, so larger blocks are
+        // used here (4096: 87 % of every transform is output, 50 % with 1024)
+        const int K = 512, nfft = 4096;
         const long long padLen = (long long)std::ceil(std::fabs(dl[0] * Fs));
         std::vector<zc> H;
         for (int c = 0; c < ncols; ++c) {
-            const std::vector<zc> h = ols_filter_from_delay(dl[c], Fs, nfft);
+            const std::vector<zc> h = ols_filter_from_delay(dl[c], Fs, K, nfft);
             H.insert(H.end(), h.begin(), h.end());
         }
         Cd *dH = upload_filter(H);
         if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
-        return ols(in, ld, N, N + padLen, out, ld, N, ncols, dH, nfft, nfft / 2, nfft, 1);
+        return ols(in, ld, N, N + padLen, out, ld, N, ncols, dH, nfft, K, nfft, 1);
     }
 
     // run one of the ssf_rx_mode pipelines; in0 / lo / un / out are HOST pointers
@@ -293,11 +296,12 @@ template <class Backend> struct RxCore {
         if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
         if (coherent || iq_only) {
             be.d2h_big(out, s, sizeof(Cd) * (size_t)N * nm);
-        } else {                                                     // real photocurrent: (N,) doubles
-            std::vector<Cd> tmp((size_t)N);
-            be.d2h_big(tmp.data(), s, sizeof(Cd) * (size_t)N);
-            double *o = (double *)out;
-            for (long long n = 0; n < N; ++n) o[n] = tmp[(size_t)n].re;
+        } else {                                                     // real photocurrent: (N,) float64
+            double *re = (double *)(s == a ? b : a);                 // (the other buffer holds >= N complex values)
+            RealPartArgs ra{s, re, N};
+            be.launch_real_part(ra);
+            be.sync();
+            be.d2h_big(out, re, sizeof(double) * (size_t)N);
         }
         if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
         return SSF_OK;
@@ -324,16 +328,42 @@ template <class Backend> struct RxCore {
         if (N < 1 || ncols < 1 || ncols > 8 || SpSin < 1 || decFactor < 1) return fail(SSF_ERR_BAD_ARG, "decimate: 1 <= columns <= 8, SpSin >= 1, decFactor >= 1");
         if (N % SpSin) return fail(SSF_ERR_BAD_ARG, "cannot reshape array: length is not a multiple of SpSin");   // core.py:477
         const long long Nout = (N + decFactor - 1) / decFactor;
-        Cd *a = dalloc((size_t)N * ncols), *b = dalloc((size_t)Nout * ncols);
-        double *dvar = (double *)be.alloc(sizeof(double) * (size_t)ncols * SpSin);
-        if (dvar) owned.push_back(dvar);
-        if (!a || !b || !dvar) return fail(SSF_ERR_OOM, "out of device memory");
+        const int nclass = SpSin * ncols;
+        if (nclass > 256) return fail(SSF_ERR_UNSUPPORTED, "decimate: SpSin * columns <= 256");
+        const int nthreads = 256 / nclass * nclass;                  // every thread keeps one (phase, column) class
+        // the grid stride must keep the class too: nblocks * nthreads is a multiple of nclass by construction
+        const int nblocks = (int)std::max<long long>(1, std::min<long long>(512, (N * ncols + 4 * nthreads - 1) / (4 * nthreads)));
+        Cd *a = dalloc((size_t)N * ncols), *b = dalloc((size_t)Nout * ncols), *dmean = dalloc((size_t)nclass);
+        double *dpart = (double *)be.alloc(sizeof(double) * 2 * (size_t)nblocks * nclass);
+        if (dpart) owned.push_back(dpart);
+        if (!a || !b || !dmean || !dpart) return fail(SSF_ERR_OOM, "out of device memory");
         be.h2d_big(a, in, sizeof(Cd) * (size_t)N * ncols);
-        DecVarArgs va{a, dvar, N, ncols, SpSin};
-        be.launch_dec_var(va);
-        std::vector<double> var((size_t)ncols * SpSin);
+        std::vector<double> part(2 * (size_t)nblocks * nclass);
+        std::vector<zc> mean((size_t)nclass);
+        std::vector<double> var((size_t)nclass);
+        const double M = (double)(N / SpSin);
+        DecSumArgs sa{a, nullptr, dpart, N * ncols, nclass};
+        be.launch_dec_sum(sa, nblocks, nthreads);
         be.sync();
-        be.d2h(var.data(), dvar, sizeof(double) * var.size());
+        be.d2h(part.data(), dpart, sizeof(double) * part.size());
+        for (int c = 0; c < nclass; ++c) {
+            double sr = 0, si = 0;
+            for (int w = 0; w < nblocks; ++w) {
+                sr += part[((size_t)w * nclass + c) * 2];
+                si += part[((size_t)w * nclass + c) * 2 + 1];
+            }
+            mean[(size_t)c] = zc(sr / M, si / M);
+        }
+        be.h2d(dmean, mean.data(), sizeof(Cd) * (size_t)nclass);
+        sa.mean = dmean;
+        be.launch_dec_sum(sa, nblocks, nthreads);
+        be.sync();
+        be.d2h(part.data(), dpart, sizeof(double) * part.size());
+        for (int c = 0; c < nclass; ++c) {                           // flat index i = n * ncols + col: class = (n % SpSin) * ncols + col
+            double s = 0;
+            for (int w = 0; w < nblocks; ++w) s += part[((size_t)w * nclass + c) * 2];
+            var[(size_t)c] = s / M;
+        }
         DecGatherArgs ga{};
         ga.in = a;
         ga.out = b;
@@ -344,7 +374,7 @@ template <class Backend> struct RxCore {
         for (int c = 0; c < ncols; ++c) {                            // first index of the maximum (core.py:478)
             int best = 0;
             for (int ph = 1; ph < SpSin; ++ph)
-                if (var[(size_t)c * SpSin + ph] > var[(size_t)c * SpSin + best]) best = ph;
+                if (var[(size_t)ph * ncols + c] > var[(size_t)best * ncols + c]) best = ph;
             ga.delay[c] = best;
             if (sampDelay_out) sampDelay_out[c] = best;
         }

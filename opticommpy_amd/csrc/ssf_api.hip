@@ -296,6 +296,31 @@ int ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_t
     return SSF_OK;
 }
 
+// ---- device-resident arrays ------------------------------------------------------------------
+int ssf_device_malloc(int device, int64_t bytes, void **ptr) {
+    if (!ptr || bytes < 1) return set_err(SSF_ERR_BAD_ARG, "ssf_device_malloc: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return set_err(SSF_ERR_NO_DEVICE, "device index out of range");
+    if (hipSetDevice(device) != hipSuccess) return set_err(SSF_ERR_HIP, "hipSetDevice failed");
+    hipError_t e = hipMalloc(ptr, (size_t)bytes);
+    if (e != hipSuccess) return set_err(e == hipErrorOutOfMemory ? SSF_ERR_OOM : SSF_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return SSF_OK;
+}
+
+int ssf_device_free(int device, void *ptr) {
+    if (!ptr) return SSF_OK;
+    if (hipSetDevice(device) != hipSuccess) return set_err(SSF_ERR_HIP, "hipSetDevice failed");
+    hipError_t e = hipFree(ptr);
+    return e == hipSuccess ? SSF_OK : set_err(SSF_ERR_HIP, std::string("hipFree: ") + hipGetErrorString(e));
+}
+
+int ssf_device_memcpy(int device, void *dst, const void *src, int64_t bytes) {
+    if (!dst || !src || bytes < 0) return set_err(SSF_ERR_BAD_ARG, "ssf_device_memcpy: bad argument");
+    if (hipSetDevice(device) != hipSuccess) return set_err(SSF_ERR_HIP, "hipSetDevice failed");
+    hipError_t e = hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault);
+    return e == hipSuccess ? SSF_OK : set_err(SSF_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+}
+
 // ---- receiver side (engine_rx.hip) -----------------------------------------------------------
 static int rx_check_device(int device) {
     int ndev = 0;

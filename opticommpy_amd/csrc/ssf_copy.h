@@ -27,6 +27,17 @@ template <typename C> __global__ void k_soa_to_aos(const C *soa, C *aos, long lo
     }
 }
 
+// true if p points into device memory (a buffer of ssf_device_malloc, or any other HIP allocation): the
+// "host" pointers of the C ABI may be device pointers, in which case transfers become device copies
+inline bool on_device(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();               // plain pageable host memory is not known to the runtime
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
 class Stager {
     static constexpr size_t kChunk = 8u << 20;
     void *pin[2] = {nullptr, nullptr};
@@ -52,6 +63,10 @@ class Stager {
     }
     // synchronous at return
     hipError_t h2d(void *dev, const void *host, size_t n, hipStream_t s) {
+        if (on_device(host)) {                  // device-resident input: no staging, no PCIe
+            hipError_t e = hipMemcpyAsync(dev, host, n, hipMemcpyDeviceToDevice, s);
+            return e != hipSuccess ? e : hipStreamSynchronize(s);
+        }
         if (!ok_ || n < (1u << 20)) {
             hipError_t e = hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, s);
             return e != hipSuccess ? e : hipStreamSynchronize(s);
@@ -72,6 +87,10 @@ class Stager {
         return hipStreamSynchronize(s);
     }
     hipError_t d2h(void *host, const void *dev, size_t n, hipStream_t s) {
+        if (on_device(host)) {
+            hipError_t e = hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToDevice, s);
+            return e != hipSuccess ? e : hipStreamSynchronize(s);
+        }
         if (!ok_ || n < (1u << 20)) {
             hipError_t e = hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, s);
             return e != hipSuccess ? e : hipStreamSynchronize(s);

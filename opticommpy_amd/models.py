@@ -18,6 +18,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _lib
+from . import device as _dev
 from .utils import parameters
 
 _H_PLANCK = 6.62607015e-34          # scipy.constants.h (devices.py:721)
@@ -255,13 +256,15 @@ def ssfm(Ei, param=None, _trace=False, _cpu_seed_policy=False):
     param.saveSpanN = getattr(param, "saveSpanN", [param.Ltotal // param.Lspan])
     param.returnParameters = getattr(param, "returnParameters", False)
 
-    Ei = np.asarray(Ei)
+    on_dev = _dev.is_device(Ei)
+    if not on_dev:
+        Ei = np.asarray(Ei)
     N = len(Ei)
     E = Ei.reshape(N)                                   # raises like the reference for ncols > 1
     Nspans = int(np.floor(param.Ltotal / param.Lspan))
     prec = _prec_code(param.prec)
     pl = _get_plan(N, 1, prec)
-    soa = np.ascontiguousarray(E.reshape(1, N), dtype=pl.dtype)
+    in_ptr, _keep = _dev.arg(E, pl.dtype)               # a single row: SoA and the reference's layout coincide
 
     save_list = list(param.saveSpanN) if param.saveSpanN is not None else []
     captured = _captured_spans(save_list, Nspans)
@@ -281,11 +284,19 @@ def ssfm(Ei, param=None, _trace=False, _cpu_seed_policy=False):
         else:                     # product path: ASE generated on the device, one stream per span
             cp.rng_seed = _device_seed(seed)
 
-    pl.check(pl.lib.ssf_upload(pl.h, soa.ctypes.data_as(C.c_void_p)))
+    pl.check(pl.lib.ssf_upload(pl.h, in_ptr))
     nsteps = int(np.floor(param.Lspan / param.hz))
     st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, nsteps + 1)
 
-    if save_list:
+    if on_dev:                                          # device in -> device out (one field: last saved span / final)
+        if len(save_list) > 1:
+            raise NotImplementedError("device-resident ssfm returns one field: set param.saveSpanN to one span or []")
+        out = _dev.empty(True, (N,), pl.dtype)
+        if save_list and not st.n_snapshots:
+            out.set(np.zeros(N, dtype=pl.dtype))
+        else:
+            pl.check(pl.lib.ssf_download(pl.h, out.ptr) if not save_list else pl.lib.ssf_download_snapshots(pl.h, out.ptr))
+    elif save_list:
         out = np.zeros((N, len(save_list)), dtype=pl.dtype)
         if st.n_snapshots:
             snaps = np.empty((st.n_snapshots, 1, N), dtype=pl.dtype)
@@ -318,7 +329,9 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
     param.saveSpanN = getattr(param, "saveSpanN", [param.Ltotal // param.Lspan])
     param.returnParameters = getattr(param, "returnParameters", False)
 
-    Ei = np.asarray(Ei)
+    on_dev = _dev.is_device(Ei)
+    if not on_dev:
+        Ei = np.asarray(Ei)
     if Ei.ndim != 2 or Ei.shape[1] % 2 or Ei.shape[1] == 0:
         raise IndexError("manakov models need a 2-D field of shape (N, 2K): columns [x0, y0, x1, y1, ...]")
     N, ncols = Ei.shape
@@ -332,7 +345,7 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
     prec = _prec_code(param.prec)
     pl = _get_plan(N, ncols, prec)
     # the reference's own layout goes over the bus; the (N, 2K) -> (2K, N) conversion runs on the GPU
-    aos = np.ascontiguousarray(Ei, dtype=pl.dtype)
+    in_ptr, _keep = _dev.arg(Ei, pl.dtype)
 
     captured = _captured_spans(save_list, Nspans)
     save_arr = np.array(captured, dtype=np.int32)
@@ -356,7 +369,7 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
             cp.rng_seed = _device_seed(seed)   # x and y rows get independent noise, unlike channels.py:444-445)
 
     logg.info("Running Manakov SSF model on GPU (HIP, %s)..." % ("forward" if direction > 0 else "DBP"))
-    pl.check(pl.lib.ssf_upload_aos(pl.h, aos.ctypes.data_as(C.c_void_p)))
+    pl.check(pl.lib.ssf_upload_aos(pl.h, in_ptr))
     if param.nlprMethod:
         hint = 1 << 16
     else:
@@ -365,7 +378,15 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
     for _ in range(int(st.nonconverged_steps)):
         logg.warning(NONCONV_WARNING.format(param.maxIter))
 
-    if save_list:
+    if on_dev:                                          # device in -> device out
+        if len(save_list) > 1:
+            raise NotImplementedError("device-resident runs return one field: set param.saveSpanN to one span or []")
+        out = _dev.empty(True, (N, ncols), pl.dtype)
+        if save_list and not st.n_snapshots:
+            out.set(np.zeros((N, ncols), dtype=pl.dtype))
+        else:
+            pl.check(pl.lib.ssf_download_aos(pl.h, 0 if save_list else -1, out.ptr))
+    elif save_list:
         nblk = len(save_list)
         if nblk == 1 and st.n_snapshots == 1:
             out = np.empty((N, ncols), dtype=pl.dtype)
@@ -476,7 +497,9 @@ def edc(sigIn, param):
     filtered and stitched in one HIP launch.  Parameters: L [50], D [16], Fc [193.1e12], Fs
     (mandatory), Rs [32e9], NfilterCoeffs [None], Nfft [None] (must be a power of two >= 16)."""
     Fs = _require_fs(param)
-    sigIn = np.asarray(sigIn)
+    on_dev = _dev.is_device(sigIn)
+    if not on_dev:
+        sigIn = np.asarray(sigIn)
     one_d = sigIn.ndim == 1
     sig2 = sigIn.reshape(sigIn.size, 1) if one_d else sigIn
     K, Nfft, Hf = _edc_filter(param, Fs)
@@ -487,13 +510,14 @@ def edc(sigIn, param):
     # core.py:1015-1020: centred impulse response, zero-padded to the FFT size, back to frequency
     h = np.pad(np.fft.fftshift(np.fft.ifft(Hf)), (0, Nfft - K), mode="constant")
     H = np.ascontiguousarray(np.fft.fft(h), dtype=np.complex128)
-    x = np.ascontiguousarray(sig2, dtype=np.complex128)
-    out = np.empty_like(x)
+    in_ptr, _keep = _dev.arg(sig2, np.complex128)
+    out = _dev.empty(on_dev, sig2.shape, np.complex128)
     lib = _lib.load()
-    rc = lib.ssf_overlap_save(_state["device"], x.shape[0], x.shape[1], _lib.SSF_C128, int(Nfft), int(K),
-                              H.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
-                              out.ctypes.data_as(C.c_void_p))
+    rc = lib.ssf_overlap_save(_state["device"], sig2.shape[0], sig2.shape[1], _lib.SSF_C128, int(Nfft), int(K),
+                              H.ctypes.data_as(C.c_void_p), in_ptr, _dev.out_ptr(out))
     _lib.raise_for(lib, None, rc)
+    if on_dev:
+        return out.reshape(-1) if one_d else out
     res = out if np.iscomplexobj(sigIn) else out.real        # core.py:1043-1046
     res = res.astype(sigIn.dtype, copy=False)                # sigOut = np.zeros(sigIn.shape, dtype=sigIn.dtype)
     return res.flatten() if one_d else res

@@ -25,57 +25,42 @@ import logging as logg
 import numpy as np
 
 from . import _lib
+from . import device as _device
 from .utils import parameters
 
 _MODE = {"photodiode": 0, "balancedPD": 1, "coherentReceiver": 2, "pdmCoherentReceiver": 3, "iqMixing": 4}
 
 
 class _HipBackend:
-    """Calls into libssf_hip.so (tests swap in the CPU emulator of the same kernels)."""
+    """Calls into libssf_hip.so (tests swap in the CPU emulator of the same kernels).  All array
+    arguments are raw pointers: host (numpy) or device (DeviceArray) memory alike."""
 
     def _dev(self):
         from .models import _state
         return _state["device"]
 
-    def fir(self, x, taps):
+    def fir(self, N, ncols, ntaps, taps, x, out):
         lib = _lib.load()
-        out = np.empty_like(x)
-        rc = lib.ssf_fir_filter(self._dev(), x.shape[0], x.shape[1], len(taps), taps.ctypes.data_as(C.c_void_p),
-                                x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
-        _lib.raise_for(lib, None, rc)
-        return out
+        _lib.raise_for(lib, None, lib.ssf_fir_filter(self._dev(), N, ncols, ntaps, taps, x, out))
 
-    def delay(self, x, delay, Fs):
+    def delay(self, N, delay, Fs, x, out):
         lib = _lib.load()
-        out = np.empty_like(x)
-        rc = lib.ssf_delay_signal(self._dev(), x.shape[0], float(delay), float(Fs), x.ctypes.data_as(C.c_void_p),
-                                  out.ctypes.data_as(C.c_void_p))
-        _lib.raise_for(lib, None, rc)
-        return out
+        _lib.raise_for(lib, None, lib.ssf_delay_signal(self._dev(), N, float(delay), float(Fs), x, out))
 
-    def decimate(self, x, SpSin, dec):
+    def decimate(self, N, ncols, SpSin, dec, x, out):
         lib = _lib.load()
-        out = np.empty(((x.shape[0] + dec - 1) // dec, x.shape[1]), dtype=np.complex128)
-        sd = (C.c_int32 * x.shape[1])()
-        rc = lib.ssf_decimate(self._dev(), x.shape[0], x.shape[1], int(SpSin), int(dec), x.ctypes.data_as(C.c_void_p),
-                              out.ctypes.data_as(C.c_void_p), sd)
-        _lib.raise_for(lib, None, rc)
-        return out, list(sd)
+        sd = (C.c_int32 * ncols)()
+        _lib.raise_for(lib, None, lib.ssf_decimate(self._dev(), N, ncols, int(SpSin), int(dec), x, out, sd))
+        return list(sd)
 
     def rx(self, mode, N, nmodes, p, in0, lo, un, out):
         lib = _lib.load()
-        rc = lib.ssf_rx_run(self._dev(), mode, N, nmodes, C.byref(p), in0.ctypes.data_as(C.c_void_p),
-                            lo.ctypes.data_as(C.c_void_p) if lo is not None else None,
-                            un.ctypes.data_as(C.POINTER(C.c_double)) if un is not None else None,
-                            out.ctypes.data_as(C.c_void_p))
-        _lib.raise_for(lib, None, rc)
+        _lib.raise_for(lib, None, lib.ssf_rx_run(self._dev(), mode, N, nmodes, C.byref(p), in0, lo,
+                                                 C.cast(un, C.POINTER(C.c_double)) if un is not None else None, out))
 
 
 _backend = _HipBackend()
-
-
-def _c128(x):
-    return np.ascontiguousarray(x, dtype=np.complex128)
+_dev = _device
 
 
 def _fs(param, default=None):
@@ -86,6 +71,10 @@ def _fs(param, default=None):
             return default
         logg.error("Simulation sampling frequency (Fs) not provided.")
         raise AttributeError("Simulation sampling frequency (Fs) not provided: set param.Fs") from None
+
+
+def _is_complex(x):
+    return x.dtype.kind == "c"
 
 
 # ------------------------------------------------------------------------------------ filters
@@ -106,15 +95,21 @@ def lowPassFIR(fc, fs, N, typeF="rect"):
 def firFilter(h, x, prec=None):
     """FIR filtering with the filter delay compensated: 'same'-mode convolution of every column of x
     with h (optic/dsp/core.py:87-125; ``prec`` as in the cupy twin optic/dsp/coreGPU.py:27-78).  One
-    overlap-save launch for all columns; at most 4096 taps."""
-    x = np.asarray(x)
-    h = np.asarray(h)
+    overlap-save launch for all columns; at most 4096 taps.  A complex128 DeviceArray stays on the device."""
+    on_dev = _dev.is_device(x)
+    if not on_dev:
+        x = np.asarray(x)
+    taps = np.ascontiguousarray(h, dtype=np.complex128)
     input1D = x.ndim == 1
     x2 = x.reshape(len(x), 1) if input1D else x
-    y = _backend.fir(_c128(x2), _c128(h))
+    xp, _keep = _dev.arg(x2, np.complex128)
+    y = _dev.empty(on_dev, x2.shape, np.complex128)
+    _backend.fir(x2.shape[0], x2.shape[1], len(taps), taps.ctypes.data_as(C.c_void_p), xp, _dev.out_ptr(y))
+    if on_dev:
+        return y.reshape(-1) if input1D else y
     if prec is not None:
         y = y.astype(prec)
-    elif np.iscomplexobj(x2):
+    elif _is_complex(x2):
         y = y.astype(x2.dtype, copy=False)
     else:                                          # y = x.copy(); y[:, n] = ... keeps x's dtype (core.py:115-119)
         y = y.real.astype(x2.dtype if x2.dtype.kind == "f" else np.float64)
@@ -122,26 +117,39 @@ def firFilter(h, x, prec=None):
 
 
 def delaySignal(sig, delay, Fs=1, NFFT=1024):
-    """Fractional delay by FFT overlap-save filtering (optic/dsp/core.py:880-922); NFFT is fixed to the
-    reference's default 1024."""
+    """Fractional delay by FFT overlap-save filtering (optic/dsp/core.py:880-922) with the reference's
+    default NFFT = 1024, i.e. a 512-tap delay filter."""
     if NFFT != 1024:
         raise ValueError("delaySignal on the GPU uses NFFT = 1024 (the reference's default)")
-    sig = np.asarray(sig)
-    out = _backend.delay(_c128(sig.reshape(-1, 1)), delay, Fs).reshape(-1)
-    return out if np.iscomplexobj(sig) else out.real      # core.py:1043-1046
+    on_dev = _dev.is_device(sig)
+    if not on_dev:
+        sig = np.asarray(sig)
+    s1 = sig.reshape(-1)
+    xp, _keep = _dev.arg(s1, np.complex128)
+    out = _dev.empty(on_dev, s1.shape, np.complex128)
+    _backend.delay(s1.shape[0], delay, Fs, xp, _dev.out_ptr(out))
+    if on_dev:
+        return out
+    return out if _is_complex(sig) else out.real          # core.py:1043-1046
 
 
 def decimate(sigIn, param):
     """Maximum-variance sampling phase per column, then every ``SpSin / SpSout``-th sample
     (optic/dsp/core.py:435-491)."""
-    sigIn = np.asarray(sigIn)
+    on_dev = _dev.is_device(sigIn)
+    if not on_dev:
+        sigIn = np.asarray(sigIn)
     input1D = sigIn.ndim == 1
     x2 = sigIn.reshape(len(sigIn), 1) if input1D else sigIn
     decFactor = int(param.SpSin / param.SpSout)
     if x2.shape[0] % param.SpSin:
         raise ValueError(f"cannot reshape array of size {x2.shape[0]} into shape ({param.SpSin})")
-    out, _ = _backend.decimate(_c128(x2), int(param.SpSin), decFactor)
-    if not np.iscomplexobj(sigIn):
+    xp, _keep = _dev.arg(x2, np.complex128)
+    out = _dev.empty(on_dev, ((x2.shape[0] + decFactor - 1) // decFactor, x2.shape[1]), np.complex128)
+    _backend.decimate(x2.shape[0], x2.shape[1], int(param.SpSin), decFactor, xp, _dev.out_ptr(out))
+    if on_dev:
+        return out.reshape(-1) if input1D else out
+    if not _is_complex(sigIn):
         out = out.real
     out = out.astype(sigIn.dtype, copy=False)
     return out.flatten() if input1D else out
@@ -200,35 +208,39 @@ def _pd_fields(p, paramPD, seed_offset=0):
     return p
 
 
+def _rx(mode, N, nmodes, p, in0, lo, un, out_shape, out_dtype, npd):
+    """Marshal one ssf_rx_run call: device arrays stay on the device, numpy arrays are converted."""
+    on_dev = _dev.is_device(in0)
+    ip, _k0 = _dev.arg(in0, np.complex128)
+    lp, _k1 = (None, None) if lo is None else _dev.arg(lo, np.complex128)
+    up, _k2 = (None, None)
+    if un is not None:
+        if not _dev.is_device(un):
+            un = np.ascontiguousarray(un, dtype=np.float64)
+        assert tuple(un.shape) == (npd, 2, N), f"_unit_normals must have shape ({npd}, 2, {N})"
+        up, _k2 = _dev.arg(un, np.float64)
+    out = _dev.empty(on_dev, out_shape, out_dtype)
+    _backend.rx(mode, N, nmodes, p, ip, lp, up, _dev.out_ptr(out))
+    return out
+
+
 def photodiode(E, param=None, _unit_normals=None):
     """Pin photodiode (optic/models/devices.py:289-399): R |E|^2 (summed over modes), optional
     saturation, shot / thermal noise and the low-pass frequency response."""
-    E = np.asarray(E)
+    if not _dev.is_device(E):
+        E = np.asarray(E)
     E2 = E.reshape(len(E), 1) if E.ndim == 1 else E
     p = _pd_fields(_lib.RxParams(), param)
-    out = np.empty(E2.shape[0], dtype=np.float64)
-    _backend.rx(_MODE["photodiode"], E2.shape[0], E2.shape[1], p, _c128(E2), None, _normals(_unit_normals, 1, len(out)), out)
-    return out
+    return _rx(_MODE["photodiode"], E2.shape[0], E2.shape[1], p, E2, None, _unit_normals, (E2.shape[0],), np.float64, 1)
 
 
 def balancedPD(E1, E2, param=None, _unit_normals=None):
     """Balanced photodiode pair (optic/models/devices.py:402-459): i(E1) - i(E2)."""
     assert E1.shape == E2.shape, "E1 and E2 need to have the same shape"
     if np.asarray(E1).ndim != 1:
-        raise ValueError("balancedPD on the GPU takes (N,) fields")
+        raise ValueError("balancedPD on the GPU takes (N,) host fields")
     p = _pd_fields(_lib.RxParams(), param)
-    out = np.empty(len(E1), dtype=np.float64)
-    _backend.rx(_MODE["balancedPD"], len(E1), 2, p, _c128(np.stack([E1, E2], axis=1)), None,
-                _normals(_unit_normals, 2, len(out)), out)
-    return out
-
-
-def _normals(un, npd, N):
-    if un is None:
-        return None
-    un = np.ascontiguousarray(un, dtype=np.float64)
-    assert un.shape == (npd, 2, N), f"_unit_normals must have shape ({npd}, 2, {N})"
-    return un
+    return _rx(_MODE["balancedPD"], len(E1), 2, p, np.stack([E1, E2], axis=1), None, _unit_normals, (len(E1),), np.float64, 2)
 
 
 def _iq_fields(p, k, par):
@@ -246,10 +258,9 @@ def iqMixing(sig, param):
         raise AttributeError("Sampling frequency not provided: set param.Fs")
     p.Fs = Fs
     _iq_fields(p, 0, param)
-    sig = np.asarray(sig)
-    out = np.empty(len(sig), dtype=np.complex128)
-    _backend.rx(_MODE["iqMixing"], len(sig), 1, p, _c128(sig), None, None, out)
-    return out
+    if not _dev.is_device(sig):
+        sig = np.asarray(sig)
+    return _rx(_MODE["iqMixing"], len(sig), 1, p, sig.reshape(-1), None, None, (len(sig),), np.complex128, 0)
 
 
 def coherentReceiver(Es, Elo, paramFE=None, paramPD=None, _unit_normals=None):
@@ -265,17 +276,16 @@ def coherentReceiver(Es, Elo, paramFE=None, paramPD=None, _unit_normals=None):
     p = _pd_fields(_lib.RxParams(), paramPD)
     p.Fs = Fs
     _iq_fields(p, 0, paramFE)
-    out = np.empty(len(Es), dtype=np.complex128)
-    _backend.rx(_MODE["coherentReceiver"], len(Es), 1, p, _c128(Es), _c128(Elo), _normals(_unit_normals, 4, len(Es)), out)
-    return out
+    return _rx(_MODE["coherentReceiver"], len(Es), 1, p, Es, Elo, _unit_normals, (len(Es),), np.complex128, 4)
 
 
 def pdmCoherentReceiver(Es, Elo, paramFE, paramPD=None, _unit_normals=None):
     """Polarisation-multiplexed coherent front-end (optic/models/devices.py:574-668).  paramFE: Fs,
     polRotation, pdl, polDelay, phaseImbX/Y, ampImbX/Y, timeSkewX/Y; paramPD: see photodiode.
-    Returns the (N, 2) down-converted signal."""
+    Returns the (N, 2) down-converted signal (a DeviceArray when Es is one)."""
     assert len(Es) == len(Elo), "Es and Elo need to have the same length"
-    Es = np.asarray(Es)
+    if not _dev.is_device(Es):
+        Es = np.asarray(Es)
     if Es.ndim != 2 or Es.shape[1] != 2:
         raise ValueError("Es must be a (N, 2) polarisation-multiplexed field")
     Fs = _fs(paramFE)
@@ -291,7 +301,5 @@ def pdmCoherentReceiver(Es, Elo, paramFE, paramPD=None, _unit_normals=None):
         p.ampImb[k] = getattr(paramFE, "ampImb" + s, 0)
         p.phaseImb[k] = getattr(paramFE, "phaseImb" + s, 0)
         p.timeSkew[k] = getattr(paramFE, "timeSkew" + s, 0)
-    out = np.empty((len(Es), 2), dtype=np.complex128)
-    _backend.rx(_MODE["pdmCoherentReceiver"], len(Es), 2, p, _c128(Es), _c128(np.asarray(Elo).reshape(-1)),
-                _normals(_unit_normals, 8, len(Es)), out)
-    return out
+    lo = Elo if _dev.is_device(Elo) else np.asarray(Elo).reshape(-1)
+    return _rx(_MODE["pdmCoherentReceiver"], len(Es), 2, p, Es, lo.reshape(-1), _unit_normals, (len(Es), 2), np.complex128, 8)

@@ -179,7 +179,10 @@ struct EmuBackend {
     void launch_front(const ssf::rx::FrontArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::front_body(c, a); }); }
     void launch_iqmix(const ssf::rx::IqMixArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::iqmix_body(c, a); }); }
     void launch_combine(const ssf::rx::CombineArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::combine_body(c, a); }); }
-    void launch_dec_var(const ssf::rx::DecVarArgs &a) { run_grid(a.ncols * a.sps, 64, 4096, [&](EmuCtx &c) { ssf::rx::dec_var_body(c, a); }); }
+    void launch_real_part(const ssf::rx::RealPartArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::real_part_body(c, a); }); }
+    void launch_dec_sum(const ssf::rx::DecSumArgs &a, int nblocks, int nthreads) {
+        run_grid(nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, [&](EmuCtx &c) { ssf::rx::dec_sum_body(c, a); });
+    }
     void launch_dec_gather(const ssf::rx::DecGatherArgs &a) {
         run_grid(ew_grid(a.Nout * a.ncols), 64, 64, [&](EmuCtx &c) { ssf::rx::dec_gather_body(c, a); });
     }

@@ -152,27 +152,17 @@ class EmuRxBackend:
             raise RuntimeError("unsupported")
         assert rc == 0, f"emulator rc={rc}"
 
-    def fir(self, x, taps):
-        out = np.empty_like(x)
-        self._check(self.e.emu_fir(x.shape[0], x.shape[1], len(taps), taps.ctypes.data_as(C.c_void_p),
-                                   x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
-        return out
+    def fir(self, N, ncols, ntaps, taps, x, out):
+        self._check(self.e.emu_fir(N, ncols, ntaps, taps, x, out))
 
-    def delay(self, x, delay, Fs):
-        out = np.empty_like(x)
-        self._check(self.e.emu_delay(x.shape[0], float(delay), float(Fs), x.ctypes.data_as(C.c_void_p),
-                                     out.ctypes.data_as(C.c_void_p)))
-        return out
+    def delay(self, N, delay, Fs, x, out):
+        self._check(self.e.emu_delay(N, float(delay), float(Fs), x, out))
 
-    def decimate(self, x, SpSin, dec):
-        out = np.empty(((x.shape[0] + dec - 1) // dec, x.shape[1]), dtype=np.complex128)
-        sd = (C.c_int32 * x.shape[1])()
-        self._check(self.e.emu_decimate(x.shape[0], x.shape[1], int(SpSin), int(dec), x.ctypes.data_as(C.c_void_p),
-                                        out.ctypes.data_as(C.c_void_p), sd))
-        return out, list(sd)
+    def decimate(self, N, ncols, SpSin, dec, x, out):
+        sd = (C.c_int32 * ncols)()
+        self._check(self.e.emu_decimate(N, ncols, int(SpSin), int(dec), x, out, sd))
+        return list(sd)
 
     def rx(self, mode, N, nmodes, p, in0, lo, un, out):
-        self._check(self.e.emu_rx_run(mode, N, nmodes, C.byref(p), in0.ctypes.data_as(C.c_void_p),
-                                      lo.ctypes.data_as(C.c_void_p) if lo is not None else None,
-                                      un.ctypes.data_as(C.POINTER(C.c_double)) if un is not None else None,
-                                      out.ctypes.data_as(C.c_void_p)))
+        self._check(self.e.emu_rx_run(mode, N, nmodes, C.byref(p), in0, lo,
+                                      C.cast(un, C.POINTER(C.c_double)) if un is not None else None, out))

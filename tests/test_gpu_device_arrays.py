@@ -1,0 +1,95 @@
+"""Device-resident arrays (opticommpy_amd.DeviceArray): every function that accepts one must give the
+result of the numpy call bit for bit, and a channel -> receiver -> DSP chain must run without host
+round trips (run with -m gpu)."""
+import time
+
+import numpy as np
+import pytest
+
+import opticommpy_amd as oa
+from helpers import synth_field
+
+pytestmark = pytest.mark.gpu
+
+
+def bag(**kw):
+    p = oa.parameters()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def test_round_trip_reshape_and_dtype_checks():
+    x = (np.arange(24.0) + 1j).reshape(12, 2)
+    d = oa.to_device(x)
+    assert d.shape == (12, 2) and d.dtype == np.complex128 and len(d) == 12 and d.ndim == 2
+    assert np.array_equal(d.get(), x) and np.array_equal(np.asarray(d), x)
+    assert np.array_equal(d.reshape(-1).get(), x.reshape(-1))
+    assert np.array_equal(d.copy().get(), x)
+    with pytest.raises(ValueError):
+        d.reshape(5, 5)
+    with pytest.raises(TypeError):
+        oa.firFilter(np.ones(3), oa.to_device(x.astype(np.complex64)))          # no hidden conversions on the device
+
+
+def test_every_entry_point_matches_its_numpy_call():
+    N = 1 << 14
+    E = synth_field(N, 2, 4, 6.0)
+    ch = dict(Fs=512e9, Ltotal=4, Lspan=2, hz=0.25, alpha=0.2, D=16, gamma=1.3, amp="ideal", nlprMethod=False,
+              prgsBar=False, maxIter=10, tol=1e-5)
+    for save in ([], [2]):
+        a = oa.manakovSSF(E, bag(saveSpanN=save, **ch))
+        b = oa.manakovSSF(oa.to_device(E), bag(saveSpanN=save, **ch))
+        assert isinstance(b, oa.DeviceArray) and np.array_equal(a, b.get())
+    a = oa.manakovDBP(E, bag(saveSpanN=[], **ch))
+    assert np.array_equal(a, oa.manakovDBP(oa.to_device(E), bag(saveSpanN=[], **ch)).get())
+    s = dict(Fs=512e9, Ltotal=4, Lspan=2, hz=0.5, amp=None, prgsBar=False)
+    a = oa.ssfm(E[:, 0].copy(), bag(**s))
+    assert np.array_equal(a, oa.ssfm(oa.to_device(E[:, 0].copy()), bag(**s)).get())
+    with pytest.raises(NotImplementedError):
+        oa.manakovSSF(oa.to_device(E), bag(saveSpanN=[1, 2], **ch))
+    Elo = np.full(N, np.sqrt(5e-3), dtype=complex)
+    fe, pd = bag(Fs=512e9, polRotation=0.3, timeSkewX=1e-13), bag(Fs=512e9, B=100e9, seed=3)
+    a = oa.pdmCoherentReceiver(E, Elo, fe, pd)
+    b = oa.pdmCoherentReceiver(oa.to_device(E), oa.to_device(Elo), fe, pd)
+    c = oa.pdmCoherentReceiver(oa.to_device(E), Elo, fe, pd)                    # mixed: host LO
+    assert np.array_equal(a, b.get()) and np.array_equal(a, c.get())
+    h = oa.lowPassFIR(60e9, 512e9, 127)
+    assert np.array_equal(oa.firFilter(h, a), oa.firFilter(h, b).get())
+    e = bag(Fs=512e9, L=4, D=16, Fc=193.1e12, Rs=32e9)
+    assert np.array_equal(oa.edc(a, e), oa.edc(b, e).get())
+    dp = bag(SpSin=16, SpSout=2)
+    assert np.array_equal(oa.decimate(a, dp), oa.decimate(b, dp).get())
+    assert np.array_equal(oa.delaySignal(a[:, 0].copy(), 1e-12, 512e9), oa.delaySignal(oa.to_device(a[:, 0].copy()), 1e-12, 512e9).get())
+    assert np.array_equal(oa.photodiode(E, pd), oa.photodiode(oa.to_device(E), pd).get())
+    assert np.array_equal(oa.iqMixing(a[:, 0].copy(), bag(Fs=512e9, ampImb=1.0)), oa.iqMixing(oa.to_device(a[:, 0].copy()), bag(Fs=512e9, ampImb=1.0)).get())
+
+
+def test_chain_on_the_device_equals_chain_through_the_host(capsys):
+    N = 1 << 20
+    E = synth_field(N, 2, 5, 6.0)
+    Elo = np.full(N, np.sqrt(5e-3), dtype=complex)
+    ch = bag(Fs=512e9, Ltotal=8, Lspan=8, hz=0.08, alpha=0.2, D=16, gamma=1.3, amp="ideal", nlprMethod=False, prgsBar=False,
+             saveSpanN=[])
+    fe, pd = bag(Fs=512e9), bag(Fs=512e9, B=100e9, seed=3)
+    e, dp = bag(Fs=512e9, L=8, D=16, Fc=193.1e12, Rs=32e9), bag(SpSin=16, SpSout=2)
+
+    def host():
+        x = oa.manakovSSF(E, ch)
+        x = oa.pdmCoherentReceiver(x, Elo, fe, pd)
+        x = oa.edc(x, e)
+        return oa.decimate(x, dp)
+
+    def dev():
+        x = oa.manakovSSF(oa.to_device(E), ch)
+        x = oa.pdmCoherentReceiver(x, Elo_d, fe, pd)
+        x = oa.edc(x, e)
+        return oa.decimate(x, dp).get()
+    Elo_d = oa.to_device(Elo)
+    a, b = host(), dev()
+    assert np.array_equal(a, b)
+    t0 = time.perf_counter(); host(); th = time.perf_counter() - t0
+    t0 = time.perf_counter(); dev(); td = time.perf_counter() - t0
+    with capsys.disabled():
+        print(f"\n[chain] 100-step channel + PDM receiver + EDC + decimate at N=2^20: through the host {th*1e3:.1f} ms, "
+              f"device-resident {td*1e3:.1f} ms")
