@@ -1,0 +1,43 @@
+"""Pin the transmitter oracle (oracle/tx_oracle.py) bit-for-bit against golden vectors produced by
+importing the reference (tools/gen_golden.py tx -> tests/golden/tx_*.npz)."""
+import numpy as np
+import pytest
+
+from helpers import golden_names, load_golden, make_param
+from oracle import tx_oracle as tx
+from oracle.ssf_oracle import parameters
+
+WDM = golden_names("tx_wdm_")
+
+
+def test_gray_maps():
+    d, _ = load_golden("tx_gray_maps")
+    for name, (M, t) in dict(qam4=(4, "qam"), qam16=(16, "qam"), qam64=(64, "qam"), psk8=(8, "psk"), pam4=(4, "pam")).items():
+        out = tx.grayMapping(M, t)
+        assert out.dtype == d[name].dtype and np.array_equal(out, d[name]), name
+
+
+def test_pulse_shapes():
+    d, _ = load_golden("tx_pulses")
+    for name, kw in (("rrc", dict(pulseType="rrc", SpS=16, nFilterTaps=1024, rollOff=0.01)),
+                     ("rrc_odd", dict(pulseType="rrc", SpS=8, nFilterTaps=513, rollOff=0.25)),
+                     ("rc", dict(pulseType="rc", SpS=4, nFilterTaps=64, rollOff=0.5)),
+                     ("nrz", dict(pulseType="nrz", SpS=16)), ("rect", dict(pulseType="rect", SpS=8))):
+        assert np.array_equal(tx.pulseShape(make_param(parameters, kw)), d[name]), name
+
+
+def test_iqm_and_phase_noise():
+    d, _ = load_golden("tx_iqm")
+    assert np.array_equal(tx.iqm(d["lo"], d["u"]), d["out"])
+    assert np.array_equal(tx.iqm(1.0, d["u"]), d["out_scalar_lo"])
+    d, cfg = load_golden("tx_phase_noise")
+    assert np.array_equal(tx.phaseNoise(cfg["lw"], cfg["N"], cfg["Ts"], seed=cfg["seed"]), d["out"])
+
+
+@pytest.mark.parametrize("name", WDM)
+def test_simple_wdm_tx_bit_for_bit(name):
+    d, cfg = load_golden(name)
+    sig, symb, par = tx.simpleWDMTx(make_param(parameters, cfg))
+    assert sig.shape == d["out"].shape and np.array_equal(sig, d["out"]), np.max(np.abs(sig - d["out"]))
+    assert np.array_equal(symb, d["symb"])
+    assert np.array_equal(par.wdmFreqGrid, d["freqGrid"]) and np.array_equal(par.pmf, d["pmf"])

@@ -15,7 +15,7 @@ Output: tests/golden/<case>.npz, each holding
     margin    min |lim - tol| / tol over the run           (Manakov/DBP only)
     extra_*   case-specific extras (e.g. linear-channel output, edfa noise)
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|tx]
 """
 import json
 import os
@@ -267,6 +267,7 @@ def main():
         save(name, Ei=x, out=out, cfg=cfg_json("edc", kw))
         print(f"{name:24s} in {x.dtype}{x.shape} out {out.dtype}{out.shape}")
     rx_vectors()
+    tx_vectors()
 
 
 def rx_vectors():
@@ -350,8 +351,46 @@ def rx_vectors():
     save("rx_pd_noise_seed11", Ei=Es[:, 0], out=out, extra_shot=u_shot, extra_thermal=u_th, cfg=cfg_json("photodiode", pdn))
 
 
+def tx_vectors():
+    """WDM transmitter"""
+    import optic.comm.modulation as ref_mod
+    import optic.dsp.core as ref_core
+    import optic.models.devices as ref_dev
+    import optic.models.tx as ref_tx
+    save("tx_gray_maps", qam4=ref_mod.grayMapping(4, "qam"), qam16=ref_mod.grayMapping(16, "qam"),
+         qam64=ref_mod.grayMapping(64, "qam"), psk8=ref_mod.grayMapping(8, "psk"), pam4=ref_mod.grayMapping(4, "pam"),
+         cfg=cfg_json("grayMapping", {}))
+    pulses = {}
+    for name, kw in (("rrc", dict(pulseType="rrc", SpS=16, nFilterTaps=1024, rollOff=0.01)),
+                     ("rrc_odd", dict(pulseType="rrc", SpS=8, nFilterTaps=513, rollOff=0.25)),
+                     ("rc", dict(pulseType="rc", SpS=4, nFilterTaps=64, rollOff=0.5)),
+                     ("nrz", dict(pulseType="nrz", SpS=16)), ("rect", dict(pulseType="rect", SpS=8))):
+        pulses[name] = ref_core.pulseShape(mk_param(**kw))
+    save("tx_pulses", cfg=cfg_json("pulseShape", {}), **pulses)
+    rng = np.random.default_rng(70)
+    u = (rng.normal(size=2000) + 1j * rng.normal(size=2000)) * 0.4
+    lo = np.exp(1j * rng.normal(size=2000) * 0.1)
+    save("tx_iqm", u=u, lo=lo, out=ref_dev.iqm(lo, u), out_scalar_lo=ref_dev.iqm(1.0, u), cfg=cfg_json("iqm", {}))
+    save("tx_phase_noise", out=ref_core.phaseNoise(100e3, 3000, 1 / 512e9, seed=5), cfg=cfg_json("phaseNoise", dict(lw=100e3, N=3000, Ts=1 / 512e9, seed=5)))
+    for name, kw in (
+            ("tx_wdm_qam16_5ch_1pol", dict(M=16, nBits=2048, SpS=16, nChannels=5, nPolModes=1, seed=123, prgsBar=False)),
+            ("tx_wdm_qam64_4ch_2pol_linewidth", dict(M=64, nBits=3072, SpS=8, nChannels=4, nPolModes=2, seed=7, laserLinewidth=100e3,
+                                                     powerPerChannel=[-3, -1.5, 0, 1], pulseRollOff=0.1, nFilterTaps=513,
+                                                     wdmGridSpacing=37.5e9, prgsBar=False)),
+            ("tx_wdm_shaped_nrz_2pol", dict(M=16, nBits=1024, SpS=16, nChannels=1, nPolModes=2, seed=3, pulseType="nrz",
+                                            probDist="maxwell-boltzmann", shapingFactor=0.05, mzmScale=0.25, prgsBar=False)),
+            ("tx_wdm_psk_3ch", dict(M=8, constType="psk", nBits=1536, SpS=4, nChannels=3, nPolModes=1, seed=11, Rs=10e9,
+                                    wdmGridSpacing=12.5e9, nFilterTaps=128, pulseRollOff=0.2, prgsBar=False))):
+        sig, symb, par = ref_tx.simpleWDMTx(mk_param(**kw))
+        save(name, out=sig, symb=symb, freqGrid=par.wdmFreqGrid, pmf=par.pmf, cfg=cfg_json("simpleWDMTx", kw))
+        print(f"{name:36s} sig {sig.dtype}{sig.shape} symb {symb.shape}")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "rx":      # only the receiver-side vectors
+    if len(sys.argv) > 1 and sys.argv[1] == "tx":      # only the transmitter vectors
+        os.makedirs(OUT, exist_ok=True)
+        tx_vectors()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rx":    # only the receiver-side vectors
         os.makedirs(OUT, exist_ok=True)
         rx_vectors()
     else:
