@@ -25,6 +25,7 @@
  *                                                                          optic/dsp/equalization.py:113-117
  *   ssf_fir_filter / ssf_delay_signal / ssf_decimate / ssf_rx_run   receiver side, see below
  *   ssf_device_malloc / ssf_device_free / ssf_device_memcpy         device-resident arrays, see below
+ *   ssf_wdm_tx                           simpleWDMTx signal path          optic/models/tx.py:178-217
  *   ssf_device_copy_bandwidth            (no reference equivalent) measured memory ceiling
  *   ssf_set_profiling / ssf_get_kernel_times   time.time() pairs around calls in
  *                                        examples/benchmarck_GPU_processing.ipynb:389-395
@@ -270,6 +271,26 @@ enum ssf_rx_mode {
  * coherent receiver per polarisation p: 4p + {0: I+, 1: I-, 2: Q+, 3: Q-} (devices.py:562-563) */
 int  ssf_rx_run(int device, int32_t mode, int64_t N, int32_t nmodes, const ssf_rx_params *params,
                 const void *in0, const void *lo, const double *unit_normals, void *out);
+
+/* ---- WDM transmitter: the signal path of simpleWDMTx, optic/models/tx.py:178-217.
+ * For every channel and polarisation: zero-stuffing to SpS samples per symbol + pulse-shaping FIR
+ * ('same' mode, one overlap-save launch), normalisation to unit peak, IQ modulator with the
+ * reference's default bias and extinction (optic/models/devices.py:147-220), power normalisation to
+ * amp^2, frequency shift to the channel's grid position, accumulation into the WDM field.  Symbol
+ * sources, constellations, pulse taps and the LO phase-noise random walk are the caller's (they are
+ * host-side numpy draws in the reference: optic/comm/sources.py:137-212, optic/dsp/core.py:792-826).
+ *   symbols   (nChannels, nPolModes, nSymbols) complex128
+ *   taps      ntaps float64 (<= 4096)
+ *   phi       (nChannels, N) float64 LO phase per channel, or NULL for an ideal laser; N = nSymbols * SpS
+ *   amp       nChannels: sqrt(Pch / nPolModes);   deltaF: nChannels grid offsets [Hz]
+ *   sig_out   (N, nPolModes) complex128 (host or device);  power_out (may be NULL): nChannels * nPolModes */
+typedef struct {
+    double  Fs, mzmScale;
+    int64_t nSymbols;
+    int32_t SpS, nChannels, nPolModes, ntaps;
+} ssf_tx_params;
+int  ssf_wdm_tx(int device, const ssf_tx_params *params, const void *symbols, const double *taps, const double *phi,
+                const double *amp, const double *deltaF, void *sig_out, double *power_out);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,8 @@ from .rx import (  # noqa: F401
     pdmCoherentReceiver, photodiode,
 )
 
-__all__ = ["DeviceArray", "to_device", "firFilter", "lowPassFIR", "decimate", "delaySignal", "iqMixing", "pbs", "photodiode", "balancedPD",
+from .wdm_tx import grayMapping, phaseNoise, pulseShape, simpleWDMTx  # noqa: F401
+
+__all__ = ["simpleWDMTx", "pulseShape", "phaseNoise", "grayMapping", "DeviceArray", "to_device", "firFilter", "lowPassFIR", "decimate", "delaySignal", "iqMixing", "pbs", "photodiode", "balancedPD",
            "opticalHybrid2x4", "coherentReceiver", "pdmCoherentReceiver", "parameters", "ssfm", "manakovSSF", "manakovDBP", "edfa", "edc", "linearFiberChannel",
            "setPowerforParSSFM", "checkGPU", "last_run", "set_device", "set_engine"]

@@ -58,6 +58,12 @@ class RxParams(C.Structure):
                 ("bandwidthLimitation", C.c_int32), ("pad_", C.c_int32), ("rng_seed", C.c_int64)]
 
 
+class TxParams(C.Structure):
+    """ssf_tx_params (include/ssf.h)."""
+    _fields_ = [("Fs", C.c_double), ("mzmScale", C.c_double), ("nSymbols", C.c_int64), ("SpS", C.c_int32),
+                ("nChannels", C.c_int32), ("nPolModes", C.c_int32), ("ntaps", C.c_int32)]
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int32),
                 ("reserved", C.c_int32), ("total_mem_bytes", C.c_int64), ("lds_per_block_bytes", C.c_int64)]
@@ -95,6 +101,8 @@ SYMBOLS = {
                                C.POINTER(C.c_int32)]),
     "ssf_rx_run": (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_int32, C.POINTER(RxParams), C.c_void_p, C.c_void_p,
                              C.POINTER(C.c_double), C.c_void_p]),
+    "ssf_wdm_tx": (C.c_int, [C.c_int, C.POINTER(TxParams), C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_double)]),
     "ssf_device_copy_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     "ssf_linear_channel": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p, C.c_void_p]),

@@ -44,6 +44,18 @@ __global__ void __launch_bounds__(256) k_rx_combine(const CombineArgs a) {
     SSF_RX_CTX();
     combine_body(ctx, a);
 }
+__global__ void __launch_bounds__(256) k_tx_absmax(const AbsMaxArgs a) {
+    SSF_RX_CTX();
+    absmax_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_tx_iqm(const IqmArgs a) {
+    SSF_RX_CTX();
+    iqm_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_tx_shift_add(const ShiftAddArgs a) {
+    SSF_RX_CTX();
+    shift_add_body(ctx, a);
+}
 __global__ void __launch_bounds__(256) k_rx_real_part(const RealPartArgs a) {
     SSF_RX_CTX();
     real_part_body(ctx, a);
@@ -131,6 +143,19 @@ struct HipRxBackend {
     void launch_combine(const CombineArgs &a) {
         k_rx_combine<<<ew_grid(a.N), 256, 0, st>>>(a);
         chk(hipGetLastError(), "launch k_rx_combine");
+    }
+    void memset(void *d, int v, size_t n) { chk(hipMemsetAsync(d, v, n, st), "hipMemsetAsync"); }
+    void launch_absmax(const AbsMaxArgs &a, int nblocks) {
+        k_tx_absmax<<<(unsigned)nblocks, 256, 4096, st>>>(a);
+        chk(hipGetLastError(), "launch k_tx_absmax");
+    }
+    void launch_iqm(const IqmArgs &a, int nblocks) {
+        k_tx_iqm<<<(unsigned)nblocks, 256, 4096, st>>>(a);
+        chk(hipGetLastError(), "launch k_tx_iqm");
+    }
+    void launch_shift_add(const ShiftAddArgs &a) {
+        k_tx_shift_add<<<ew_grid(a.N), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_tx_shift_add");
     }
     void launch_real_part(const RealPartArgs &a) {
         k_rx_real_part<<<ew_grid(a.N), 256, 0, st>>>(a);
@@ -235,6 +260,10 @@ int rx_fir(int device, int64_t sigLen, int ncols, int ntaps, const void *taps, c
 }
 int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, void *out, std::string *err) {
     return with_core(device, err, [&](RxCore<Pooled> &c) { return c.delay(N, delay, Fs, in, out); });
+}
+int tx_wdm(int device, const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
+           const double *deltaF, void *out, double *power_out, std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.wdm_tx(*p, symbols, taps, phi, amp, deltaF, out, power_out); });
 }
 int rx_decimate(int device, int64_t N, int ncols, int SpSin, int decFactor, const void *in, void *out, int32_t *sampDelay,
                 std::string *err) {

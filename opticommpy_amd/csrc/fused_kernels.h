@@ -1039,6 +1039,7 @@ template <typename T> struct OlsArgs {
     int in_ld, out_ld;    // leading dimensions (columns per sample) of in / out
     int Hstride;          // 0: one filter for all columns; NFFT: column m uses H + m * NFFT
     int roll;             // np.roll(y, -roll) before the [:keep] cut (optic/dsp/core.py:920-922)
+    int in_up;            // > 1: `in` holds every in_up-th sample, the others are zero (upsample, core.py:395-432)
 };
 template <typename T> SSF_HD void ols_defaults(OlsArgs<T> &a) {
     a.inLen = a.sigLen;
@@ -1046,6 +1047,7 @@ template <typename T> SSF_HD void ols_defaults(OlsArgs<T> &a) {
     a.in_ld = a.out_ld = a.nrows;
     a.Hstride = 0;
     a.roll = 0;
+    a.in_up = 1;
 }
 template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T> &a) {
     const PassPlan p = make_plan(a.log2nfft);
@@ -1061,7 +1063,13 @@ template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T>
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const long long i = blk * a.d + (b + p.tpf * q) - a.discard;      // index into the unpadded signal
-        v[q] = (live && i >= 0 && i < a.inLen) ? a.in[i * a.in_ld + m] : mk<T>((T)0, (T)0);
+        bool have = live && i >= 0 && i < a.inLen;
+        long long src = i;
+        if (a.in_up > 1) {                                                // zero-stuffed input, never materialised
+            src = i / a.in_up;
+            have = have && src * a.in_up == i;
+        }
+        v[q] = have ? a.in[src * a.in_ld + m] : mk<T>((T)0, (T)0);
     }
     fft_dif<-1>(ctx, p, b, v, l);
     const int last = p.npass - 1;

@@ -169,6 +169,92 @@ template <class Ctx> SSF_HD void real_part_body(Ctx &ctx, const RealPartArgs &a)
     for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) a.out[n] = a.in[n].re;
 }
 
+// =====================================================================================================
+// WDM transmitter (optic/models/tx.py:42-228): after the pulse-shaping filter
+// (an overlap-save launch on the zero-stuffed symbols) each (channel, polarisation) needs
+//   max |x|                       -> absmax_body      sigTx / np.max(np.abs(sigTx))        (tx.py:204)
+//   IQ modulator + mean power     -> iqm_body         iqm(sigLO, mzmScale * sigTx)         (tx.py:211-214)
+//   normalise, shift, accumulate  -> shift_add_body   sqrt(P) * pnorm(.), freqShift, +=    (tx.py:215-217)
+// Block partials are reduced on the host (a few hundred doubles, fixed order).
+struct AbsMaxArgs {
+    const Cd *in;
+    double *part;      // nblocks
+    long long N;
+};
+template <class Ctx> SSF_HD void absmax_body(Ctx &ctx, const AbsMaxArgs &a) {
+    double m = 0;
+    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
+        const double v = a.in[n].re * a.in[n].re + a.in[n].im * a.in[n].im;
+        m = v > m ? v : m;
+    }
+    m = fused::block_max(ctx, m, (double *)ctx.lds);
+    if (ctx.tid == 0) a.part[ctx.bid] = sqrt(m);
+}
+
+// IQ modulator with the reference's default bias / extinction (devices.py:147-220 -> core.py:1076-1140):
+//   MZM(E, u, Vb) = sqrt(1 + g) E/2 cis(pi (u + Vb) / (2 Vpi)) + sqrt(1 - g) E/2 cis(-pi (u + Vb) / (2 Vpi))
+//   Eo = MZM(Ei / sqrt2, Re u, VbI) + MZM(Ei / sqrt2, Im u, VbQ) cis(pi Vphi / Vpi)
+struct IqmArgs {
+    const Cd *sig;       // pulse-shaped signal
+    const double *phi;   // LO phase noise (N) or null: Ei = exp(j phi)
+    Cd *out;
+    double *part;        // nblocks partial sums of |Eo|^2
+    long long N;
+    double u_scale;      // mzmScale / max|sig|   (applied as (sig / max) * mzmScale, see body)
+    double inv_max, mzmScale;
+    double Vpi, VbI, VbQ, sp, sm;   // sp = sqrt(1 + gamma), sm = sqrt(1 - gamma)
+    Cd rotQ;             // cis(pi Vphi / Vpi)
+};
+SSF_HD Cd mzm_out(Cd e, double u, double Vb, double Vpi, double sp, double sm) {
+    const double ang = ((u + Vb) / 2 / Vpi) * 3.14159265358979323846;
+    double c, s, c2, s2;
+    fused::cis_rad_d(ang, c, s);
+    fused::cis_rad_d(-(u + Vb) / 2 / Vpi * 3.14159265358979323846, c2, s2);
+    const Cd h = mk<double>(e.re / 2, e.im / 2);
+    const Cd a = h * mk<double>(c, s), b = h * mk<double>(c2, s2);
+    return mk<double>(sp * a.re + sm * b.re, sp * a.im + sm * b.im);
+}
+template <class Ctx> SSF_HD void iqm_body(Ctx &ctx, const IqmArgs &a) {
+    double acc = 0, unused = 0;
+    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
+        Cd ei = mk<double>(1.0, 0.0);
+        if (a.phi) {
+            double c, s;
+            fused::sincos_d(a.phi[n], s, c);                 // a random walk: arbitrary magnitude, full-range sincos
+            ei = mk<double>(c, s);
+        }
+        const Cd u = mk<double>(a.mzmScale * (a.sig[n].re * a.inv_max), a.mzmScale * (a.sig[n].im * a.inv_max));
+        const Cd e = mk<double>(ei.re / 1.4142135623730951, ei.im / 1.4142135623730951);
+        const Cd eI = mzm_out(e, u.re, a.VbI, a.Vpi, a.sp, a.sm);
+        const Cd eQ = mzm_out(e, u.im, a.VbQ, a.Vpi, a.sp, a.sm);
+        const Cd eo = eI + eQ * a.rotQ;
+        a.out[n] = eo;
+        acc += eo.re * eo.re + eo.im * eo.im;
+    }
+    fused::block_sum2(ctx, acc, unused, (double *)ctx.lds);
+    if (ctx.tid == 0) a.part[ctx.bid] = acc;
+}
+
+// acc[n, mode] += amp * (x[n] / rms) * exp(j w t_n),  t_n = n * (1 / Fs), w = 2 pi deltaF  (core.py:1050-1073)
+struct ShiftAddArgs {
+    const Cd *in;
+    Cd *acc;             // (N, npol)
+    long long N;
+    int npol, mode;
+    double inv_rms, amp, w, Ts;
+};
+template <class Ctx> SSF_HD void shift_add_body(Ctx &ctx, const ShiftAddArgs &a) {
+    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
+        const double t = (double)n * a.Ts;
+        double c, s;
+        fused::sincos_d(a.w * t, s, c);                      // |w t| reaches 1e6 rad: the argument is exact as the
+        const Cd x = mk<double>(a.amp * (a.in[n].re * a.inv_rms), a.amp * (a.in[n].im * a.inv_rms));   // reference rounds it
+        const Cd y = x * mk<double>(c, s);
+        Cd &d = a.acc[n * a.npol + a.mode];
+        d = mk<double>(d.re + y.re, d.im + y.im);
+    }
+}
+
 // ---- decimate (optic/dsp/core.py:435-491)
 // np.var(x[ph::sps, col]) for every sampling phase of every column, in two passes like numpy
 // (mean, then mean |x - mean|^2).  The (N, ncols) array is read as one flat stream: with a thread

@@ -139,7 +139,7 @@ template <class Backend> struct RxCore {
 
     // y[:keep] = roll(blockwiseFFTConv(in zero-extended to sigLen, filter), -roll) for `ncols` columns
     int ols(const Cd *in, int in_ld, long long inLen, long long sigLen, Cd *out, int out_ld, long long keep, int ncols,
-            const Cd *H, int Hstride, int K, int nfft, int roll) {
+            const Cd *H, int Hstride, int K, int nfft, int roll, int in_up = 1) {
         const OlsGeom g = ols_geometry(sigLen, K, nfft);
         fused::OlsArgs<double> a{};
         a.in = in;
@@ -158,6 +158,7 @@ template <class Backend> struct RxCore {
         a.out_ld = out_ld;
         a.Hstride = Hstride;
         a.roll = roll;
+        a.in_up = in_up;
         be.launch_ols(a);
         return SSF_OK;
     }
@@ -320,6 +321,72 @@ template <class Backend> struct RxCore {
         if (rc) return rc;
         be.sync();
         be.d2h_big(out, b, sizeof(Cd) * (size_t)sigLen * ncols);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+
+    // simpleWDMTx's signal path (tx.py:178-217) for all channels and polarisations; symbols (nCh, nPol, nSymbols),
+    // taps (ntaps real), phi (nCh, N) or null, amp[nCh] = sqrt(Pch / nPol), deltaF[nCh]; out (N, nPol), N = nSymbols * SpS
+    int wdm_tx(const ssf_tx_params &p, const void *symbols, const double *taps, const double *phi, const double *amp,
+               const double *deltaF, void *out, double *power_out) {
+        const long long nS = p.nSymbols, N = nS * p.SpS;
+        const int nCh = p.nChannels, nPol = p.nPolModes, K = p.ntaps;
+        if (nS < 1 || p.SpS < 1 || nCh < 1 || nPol < 1 || K < 1 || !(p.Fs > 0)) return fail(SSF_ERR_BAD_ARG, "ssf_wdm_tx: bad size");
+        if (K > kMaxNfft / 2) return fail(SSF_ERR_UNSUPPORTED, "ssf_wdm_tx: at most 4096 pulse-shaping taps");
+        const int nfft = fir_nfft(K), nblocks = 256;
+        std::vector<zc> tz((size_t)K);
+        for (int i = 0; i < K; ++i) tz[(size_t)i] = zc(taps[i], 0.0);
+        Cd *dH = upload_filter(ols_filter_from_taps(tz.data(), K, nfft));
+        Cd *dsym = dalloc((size_t)nCh * nPol * nS), *sig = dalloc((size_t)N), *mod = dalloc((size_t)N), *acc = dalloc((size_t)N * nPol);
+        double *dpart = (double *)be.alloc(sizeof(double) * nblocks), *dphi = nullptr;
+        if (dpart) owned.push_back(dpart);
+        if (!dH || !dsym || !sig || !mod || !acc || !dpart) return fail(SSF_ERR_OOM, "out of device memory");
+        if (phi) {
+            dphi = (double *)be.alloc(sizeof(double) * (size_t)N);
+            if (!dphi) return fail(SSF_ERR_OOM, "out of device memory");
+            owned.push_back(dphi);
+        }
+        be.h2d_big(dsym, symbols, sizeof(Cd) * (size_t)nCh * nPol * nS);
+        be.memset(acc, 0, sizeof(Cd) * (size_t)N * nPol);
+        std::vector<double> part((size_t)nblocks);
+        const double erLin = std::pow(10.0, 60.0 / 10), gamma = 2 * std::sqrt(erLin) / (erLin + 1);   // devices.py:185-188 defaults
+        for (int ch = 0; ch < nCh; ++ch) {
+            if (phi) be.h2d_big(dphi, phi + (size_t)ch * N, sizeof(double) * (size_t)N);
+            for (int mode = 0; mode < nPol; ++mode) {
+                const Cd *sym = dsym + ((size_t)ch * nPol + mode) * nS;
+                int rc = ols(sym, 1, N, N, sig, 1, N, 1, dH, 0, K, nfft, 0, p.SpS);
+                if (rc) return rc;
+                AbsMaxArgs ma{sig, dpart, N};
+                be.launch_absmax(ma, nblocks);
+                be.sync();
+                be.d2h(part.data(), dpart, sizeof(double) * nblocks);
+                double mx = 0;
+                for (double v : part) mx = v > mx ? v : mx;
+                IqmArgs ia{};
+                ia.sig = sig;
+                ia.phi = dphi;
+                ia.out = mod;
+                ia.part = dpart;
+                ia.N = N;
+                ia.inv_max = 1.0 / mx;
+                ia.mzmScale = p.mzmScale;
+                ia.Vpi = 2;
+                ia.VbI = ia.VbQ = -2;
+                ia.sp = std::sqrt(1 + gamma);
+                ia.sm = std::sqrt(1 - gamma);
+                ia.rotQ = mk<double>(std::cos(kPi * 1 / 2), std::sin(kPi * 1 / 2));
+                be.launch_iqm(ia, nblocks);
+                be.sync();
+                be.d2h(part.data(), dpart, sizeof(double) * nblocks);
+                double pw = 0;
+                for (double v : part) pw += v;
+                const double mean = pw / (double)N;
+                ShiftAddArgs sa{mod, acc, N, nPol, mode, 1.0 / std::sqrt(mean), amp[ch], 2 * kPi * deltaF[ch], 1.0 / p.Fs};
+                be.launch_shift_add(sa);
+                if (power_out) power_out[(size_t)ch * nPol + mode] = amp[ch] * amp[ch];   // signalPower(sqrt(P) pnorm(x)) = P
+            }
+        }
+        be.sync();
+        be.d2h_big(out, acc, sizeof(Cd) * (size_t)N * nPol);
         return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
     }
 

@@ -365,4 +365,13 @@ int ssf_rx_run(int device, int32_t mode, int64_t N, int32_t nmodes, const ssf_rx
     return rc ? set_err(rc, "ssf_rx_run: " + err) : SSF_OK;
 }
 
+int ssf_wdm_tx(int device, const ssf_tx_params *params, const void *symbols, const double *taps, const double *phi,
+               const double *amp, const double *deltaF, void *sig_out, double *power_out) {
+    if (!params || !symbols || !taps || !amp || !deltaF || !sig_out) return set_err(SSF_ERR_BAD_ARG, "ssf_wdm_tx: NULL argument");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::tx_wdm(device, params, symbols, taps, phi, amp, deltaF, sig_out, power_out, &err);
+    return rc ? set_err(rc, "ssf_wdm_tx: " + err) : SSF_OK;
+}
+
 }  // extern "C"

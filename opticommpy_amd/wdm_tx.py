@@ -1,0 +1,197 @@
+"""WDM transmitter on the GPU: ``simpleWDMTx`` with the reference's parameters
+and return values (optic/models/tx.py:42-228), signal path on the device through ``ssf_wdm_tx``.
+
+Split of the work:
+  host (numpy, a few thousand values, and it has to be numpy: these are the reference's seeded
+  ``np.random`` draws) -- constellation and its pmf, the symbol sequences of every channel and
+  polarisation, the pulse-shaping taps, the LO phase-noise random walk, the WDM grid;
+  device -- everything that touches the N = nSymbols * SpS samples: zero-stuffing + pulse-shaping FIR,
+  peak normalisation, IQ modulator, power normalisation, frequency shift, accumulation of the
+  channels.  ``device_output=True`` returns the field as a DeviceArray, ready for ``manakovSSF``.
+
+With a seed the result equals the reference's to rounding (same draws, same arithmetic); without one
+both draw fresh entropy."""
+import ctypes as C
+import logging as logg
+
+import numpy as np
+
+from . import _lib
+from . import device as _dev
+from .utils import parameters
+
+_DEFAULTS = (("M", 16), ("constType", "qam"), ("Rs", 32e9), ("SpS", 16), ("probDist", "uniform"), ("shapingFactor", 0),
+             ("seed", None), ("nBits", 60000), ("pulseType", "rrc"), ("nFilterTaps", 1024), ("pulseRollOff", 0.01),
+             ("mzmScale", 0.5), ("powerPerChannel", -3), ("nChannels", 5), ("Fc", 193.1e12), ("laserLinewidth", 0),
+             ("wdmGridSpacing", 50e9), ("nPolModes", 1), ("prgsBar", True))
+
+
+class _HipBackend:
+    def wdm_tx(self, p, symbols, taps, phi, amp, deltaF, out_ptr, power):
+        from .models import _state
+        lib = _lib.load()
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None   # noqa: E731
+        _lib.raise_for(lib, None, lib.ssf_wdm_tx(_state["device"], C.byref(p), symbols.ctypes.data_as(C.c_void_p), dp(taps),
+                                                 dp(phi), dp(amp), dp(deltaF), out_ptr, dp(power)))
+
+
+_backend = _HipBackend()
+
+
+# ------------------------------------------------------------------ constellations (optic/comm/modulation.py:35-198)
+def _constellation(M, constType):
+    """Constellation in the reference's own point order (qamConst / pskConst / pamConst)."""
+    if constType == "qam":
+        side = int(np.sqrt(M))
+        if side * side != M:
+            raise ValueError("square QAM needs M = 4, 16, 64, ...")
+        levels = np.arange(-(side - 1), side, 2)
+        grid = levels[None, :] + 1j * levels[::-1, None]            # rows: imaginary part from +L down to -L
+        grid[1::2] = grid[1::2, ::-1]                               # boustrophedon rows
+        return grid
+    if constType == "psk":
+        return np.exp(1j * np.arange(0, 2 * np.pi, 2 * np.pi / M))
+    if constType == "pam":
+        return np.arange(-(M - 1), M, 2)
+    raise ValueError("constType must be 'qam', 'psk' or 'pam'")
+
+
+def grayMapping(M, constType):
+    """Constellation sorted by the integer value of each point's Gray label (modulation.py:64-118)."""
+    const = np.asarray(_constellation(M, constType)).reshape(M)
+    labels = np.arange(M) ^ (np.arange(M) >> 1)                    # grayCode(log2 M), as integers
+    dtype = np.float32 if constType == "pam" else np.complex64     # the reference stores the table in single precision
+    return const.astype(dtype)[np.argsort(labels, kind="stable")]
+
+
+def _symbol_source(nSymbols, M, constType, dist, shapingFactor, seed):
+    """optic/comm/sources.py:137-212: unit-energy constellation, np.random.choice under np.random.seed."""
+    if seed is not None:
+        np.random.seed(seed)
+    const = np.asarray(_constellation(M, constType))
+    if dist == "uniform":
+        px = np.ones(M) / M
+    else:
+        px = np.exp(-shapingFactor * np.abs(const) ** 2)
+        px = (px / np.sum(px)).flatten()
+    const = const / np.sqrt(np.sum(px * np.abs(const.flatten()) ** 2))
+    return np.random.choice(const.flatten(), nSymbols, p=px)
+
+
+# ------------------------------------------------------------------ pulse shapes (optic/dsp/core.py:129-270)
+def _rrc(t, alpha):
+    h = np.empty(len(t))
+    for i, ti in enumerate(t):                                     # a few hundred taps: scalar code keeps the
+        if ti == 0:                                                # reference's branch structure and rounding
+            h[i] = 1 + alpha * (4 / np.pi - 1)
+        elif abs(ti) == 1 / (4 * alpha):
+            h[i] = (alpha / np.sqrt(2)) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * alpha)) + (1 - 2 / np.pi) * np.cos(np.pi / (4 * alpha)))
+        else:
+            t1, t2 = np.pi * ti / 1, 4 * alpha * ti / 1
+            h[i] = (1 / 1) * (np.sin(t1 * (1 - alpha)) + 4 * alpha * ti / 1 * np.cos(t1 * (1 + alpha))) / (np.pi * ti * (1 - t2**2))
+    return h
+
+
+def _rc(t, alpha):
+    h = np.empty(len(t))
+    for i, ti in enumerate(t):
+        if abs(ti) == 1 / (2 * alpha):
+            h[i] = np.pi / 4 * np.sinc(1 / (2 * alpha))
+        else:
+            h[i] = np.sinc(ti) * np.cos(np.pi * alpha * ti) / (1 - 4 * alpha**2 * ti**2)
+    return h
+
+
+def pulseShape(param):
+    """Pulse-shaping filter taps, normalised to unit sum (optic/dsp/core.py:217-270): 'rect', 'nrz', 'rrc', 'rc'."""
+    kind = getattr(param, "pulseType", "rrc")
+    SpS = getattr(param, "SpS", 2)
+    n = getattr(param, "nFilterTaps", 256)
+    ro = getattr(param, "rollOff", 0.1)
+    if kind == "rect":
+        h = np.concatenate((np.zeros(int(SpS / 2)), np.ones(SpS), np.zeros(int(SpS / 2))))
+    elif kind == "nrz":
+        t = np.linspace(-2, 2, SpS)
+        h = np.convolve(np.ones(SpS), 2 / np.sqrt(np.pi) * np.exp(-(t**2)), mode="full")
+    elif kind in ("rrc", "rc"):
+        t = np.linspace(-n // 2, n // 2, n) * (1 / SpS)
+        h = _rrc(t, ro) if kind == "rrc" else _rc(t, ro)
+    else:
+        raise ValueError("pulseType must be 'rect', 'nrz', 'rrc' or 'rc'")
+    return h / np.sum(h)
+
+
+def phaseNoise(lw, Nsamples, Ts, seed=None):
+    """Laser phase-noise random walk (optic/dsp/core.py:792-826): the same draws, accumulated in order."""
+    if seed is not None:
+        np.random.seed(seed)
+    steps = np.random.normal(0, np.sqrt(2 * np.pi * lw * Ts), max(Nsamples - 1, 0))
+    return np.concatenate(([0.0], np.cumsum(steps)))[:Nsamples]
+
+
+# ------------------------------------------------------------------ simpleWDMTx
+def simpleWDMTx(param, device_output=False):
+    """Simple WDM transmitter (optic/models/tx.py:42-228).  Parameters (defaults): M [16], constType ['qam'], Rs
+    [32e9], SpS [16], probDist ['uniform'], shapingFactor [0], seed [None], nBits [60000], pulseType ['rrc'],
+    nFilterTaps [1024], pulseRollOff [0.01], mzmScale [0.5], powerPerChannel [-3 dBm, scalar or list], nChannels [5],
+    Fc [193.1e12], laserLinewidth [0], wdmGridSpacing [50e9], nPolModes [1], prgsBar [True].
+
+    Returns (sigTxWDM (N, nPolModes), symbTxWDM (nSymbols, nPolModes, nChannels), param) with param.pmf and
+    param.wdmFreqGrid set; ``device_output=True`` leaves sigTxWDM in HBM (DeviceArray)."""
+    for k, d in _DEFAULTS:
+        setattr(param, k, getattr(param, k, d))
+    Fs = 1 / ((1 / param.Rs) / param.SpS)
+    bits = int(np.log2(param.M))
+    nSymbols = int(param.nBits / np.log2(param.M))
+    constSymb = grayMapping(param.M, param.constType)
+    if param.probDist == "uniform":
+        px = np.ones(param.M) / param.M
+    elif param.probDist == "maxwell-boltzmann":
+        px = np.exp(-param.shapingFactor * np.abs(constSymb) ** 2)
+        px = px / np.sum(px)
+    else:
+        raise ValueError("Invalid probability distribution.")
+    param.pmf = px
+    pp = parameters()
+    pp.pulseType, pp.nFilterTaps, pp.rollOff, pp.SpS = param.pulseType, param.nFilterTaps, param.pulseRollOff, param.SpS
+    pulse = np.ascontiguousarray(pulseShape(pp), dtype=np.float64)
+    nCh, nPol = int(param.nChannels), int(param.nPolModes)
+    freqGrid = np.arange(-np.floor(nCh / 2), np.floor(nCh / 2) + 1, 1) * param.wdmGridSpacing
+    if nCh % 2 == 0:
+        freqGrid += param.wdmGridSpacing / 2
+    if type(param.powerPerChannel) == list:
+        assert len(param.powerPerChannel) == nCh, "list length of power per channel does not match number of channels."
+        Pch = 10 ** (np.array(param.powerPerChannel) / 10) * 1e-3
+    else:
+        Pch = 10 ** (param.powerPerChannel / 10) * 1e-3 * np.ones(nCh)
+    N = int(nSymbols * param.SpS)
+    if nSymbols != param.nBits // bits:
+        raise ValueError("nBits must give the same symbol count for the source and the time axis")   # tx.py:112, 125
+
+    symbols = np.empty((nCh, nPol, nSymbols), dtype=np.complex128)
+    phi = np.empty((nCh, N)) if param.laserLinewidth else None
+    seed = param.seed
+    for ch in range(nCh):                                          # the reference's draw order (tx.py:184-210)
+        logg.info("channel %d\t fc : %3.4f THz" % (ch, (param.Fc + freqGrid[ch]) / 1e12))
+        for mode in range(nPol):
+            logg.info("  mode #%d\t power: %.2f dBm" % (mode, 10 * np.log10((Pch[ch] / nPol) / 1e-3)))
+            symbols[ch, mode] = _symbol_source(nSymbols, param.M, param.constType, param.probDist, param.shapingFactor, seed)
+            if param.seed is not None:
+                seed += 1
+            if mode == 0:
+                pn = phaseNoise(param.laserLinewidth, N, 1 / Fs, seed=param.seed)      # drawn even when the linewidth is 0
+                if phi is not None:
+                    phi[ch] = pn
+
+    p = _lib.TxParams(Fs=Fs, mzmScale=float(param.mzmScale), nSymbols=nSymbols, SpS=int(param.SpS), nChannels=nCh,
+                      nPolModes=nPol, ntaps=len(pulse))
+    amp = np.sqrt(Pch / nPol).astype(np.float64)
+    power = np.zeros(nCh * nPol)
+    sig = _dev.empty(device_output, (N, nPol), np.complex128)
+    _backend.wdm_tx(p, symbols, pulse, phi, amp, np.ascontiguousarray(freqGrid, dtype=np.float64), _dev.out_ptr(sig), power)
+    for ch in range(nCh):
+        logg.info("channel %d\t power: %.2f dBm\n" % (ch, 10 * np.log10(np.sum(power[ch * nPol:(ch + 1) * nPol]) / 1e-3)))
+    logg.info("total WDM signal power: %.2f dBm" % (10 * np.log10(np.sum(power) / 1e-3)))
+    param.wdmFreqGrid = freqGrid
+    symbTxWDM = np.ascontiguousarray(np.transpose(symbols, (2, 1, 0)))           # (nSymbols, nPolModes, nChannels)
+    return sig, symbTxWDM, param

@@ -179,6 +179,9 @@ struct EmuBackend {
     void launch_front(const ssf::rx::FrontArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::front_body(c, a); }); }
     void launch_iqmix(const ssf::rx::IqMixArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::iqmix_body(c, a); }); }
     void launch_combine(const ssf::rx::CombineArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::combine_body(c, a); }); }
+    void launch_absmax(const ssf::rx::AbsMaxArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::absmax_body(c, a); }); }
+    void launch_iqm(const ssf::rx::IqmArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::iqm_body(c, a); }); }
+    void launch_shift_add(const ssf::rx::ShiftAddArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::shift_add_body(c, a); }); }
     void launch_real_part(const ssf::rx::RealPartArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::real_part_body(c, a); }); }
     void launch_dec_sum(const ssf::rx::DecSumArgs &a, int nblocks, int nthreads) {
         run_grid(nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, [&](EmuCtx &c) { ssf::rx::dec_sum_body(c, a); });
@@ -306,6 +309,14 @@ int emu_delay(int64_t N, double delay, double Fs, const void *in, void *out) {
     EmuBackend be;
     ssf::rx::RxCore<EmuBackend> core(be);
     return core.delay(N, delay, Fs, in, out);
+}
+int emu_wdm_tx(const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
+               const double *deltaF, void *out, double *power_out) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    int rc = core.wdm_tx(*p, symbols, taps, phi, amp, deltaF, out, power_out);
+    if (rc) fprintf(stderr, "emu: %s\n", core.err.c_str());
+    return rc;
 }
 int emu_decimate(int64_t N, int ncols, int SpSin, int dec, const void *in, void *out, int32_t *sd) {
     EmuBackend be;

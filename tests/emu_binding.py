@@ -166,3 +166,17 @@ class EmuRxBackend:
     def rx(self, mode, N, nmodes, p, in0, lo, un, out):
         self._check(self.e.emu_rx_run(mode, N, nmodes, C.byref(p), in0, lo,
                                       C.cast(un, C.POINTER(C.c_double)) if un is not None else None, out))
+
+
+class EmuTxBackend:
+    """Drop-in for opticommpy_amd.wdm_tx._backend (the transmitter's signal path on the CPU emulator)."""
+
+    def __init__(self):
+        e = load()
+        e.emu_wdm_tx.argtypes = [C.POINTER(_lib.TxParams), C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.c_void_p, C.POINTER(C.c_double)]
+        self.e = e
+
+    def wdm_tx(self, p, symbols, taps, phi, amp, deltaF, out_ptr, power):
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None   # noqa: E731
+        rc = self.e.emu_wdm_tx(C.byref(p), symbols.ctypes.data_as(C.c_void_p), dp(taps), dp(phi), dp(amp), dp(deltaF), out_ptr, dp(power))
+        assert rc == 0, f"emulator rc={rc}"
