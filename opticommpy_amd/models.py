@@ -519,6 +519,10 @@ def edc(sigIn, param):
     if on_dev:
         return out.reshape(-1) if one_d else out
     res = out if np.iscomplexobj(sigIn) else out.real        # core.py:1043-1046
+    if np.iscomplexobj(sigIn):
+        for m in range(sig2.shape[1]):                       # ... which looks at the values: a column without any
+            if not np.any(np.iscomplex(sig2[:, m])):         # imaginary part is filtered as a real signal
+                res[:, m] = res[:, m].real
     res = res.astype(sigIn.dtype, copy=False)                # sigOut = np.zeros(sigIn.shape, dtype=sigIn.dtype)
     return res.flatten() if one_d else res
 

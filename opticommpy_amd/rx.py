@@ -130,7 +130,9 @@ def delaySignal(sig, delay, Fs=1, NFFT=1024):
     _backend.delay(s1.shape[0], delay, Fs, xp, _dev.out_ptr(out))
     if on_dev:
         return out
-    return out if _is_complex(sig) else out.real          # core.py:1043-1046
+    # core.py:1043-1046 decides on the values, not the dtype: a complex array whose imaginary parts are all
+    # zero comes back as float64
+    return out if np.any(np.iscomplex(sig)) else out.real
 
 
 def decimate(sigIn, param):

@@ -96,6 +96,37 @@ def test_pdm_receiver_against_oracle_on_a_longer_field_with_noise_arrays():
     assert rel_l2(out, ref) <= 1e-12
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 17])
+def test_tiny_signals(N):
+    """Shorter than every filter involved (31-tap low-pass, 512-tap delay filters)."""
+    rng = np.random.default_rng(N)
+    Es = (rng.normal(size=(N, 2)) + 1j * rng.normal(size=(N, 2))) * 0.02
+    Elo = np.full(N, 0.05 + 0j)
+    fe = dict(Fs=64e9, polDelay=3e-12, timeSkewX=2e-12)
+    pd = dict(Fs=64e9, B=20e9, shotNoise=False, thermalNoise=False, N=31)
+
+    def bag(cls, kw):
+        o = cls()
+        for k_, v in kw.items():
+            setattr(o, k_, v)
+        return o
+    a = oa.pdmCoherentReceiver(Es, Elo, bag(oa.parameters, fe), bag(oa.parameters, pd))
+    b = orx.pdmCoherentReceiver(Es, Elo, bag(oparams, fe), bag(oparams, pd))
+    assert np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
+    x = rng.normal(size=N) + 1j * rng.normal(size=N)
+    for K in (1, 2, 5):
+        h = rng.normal(size=K)
+        assert np.max(np.abs(oa.firFilter(h, x) - orx.firFilter(h, x))) <= 1e-13
+
+
+def test_realness_is_decided_on_values_like_the_reference():
+    """blockwiseFFTConv returns a float array when no sample has an imaginary part, whatever the dtype
+    (optic/dsp/core.py:1043-1046)."""
+    x = np.random.default_rng(3).normal(size=300) + 0j
+    a, b = oa.delaySignal(x, 0.3 / 64e9, 64e9), orx.delaySignal(x, 0.3 / 64e9, 64e9)
+    assert a.dtype == b.dtype == np.float64 and np.max(np.abs(a - b)) <= 1e-13
+
+
 def test_error_conventions():
     p = oa.parameters()
     with pytest.raises(AttributeError):

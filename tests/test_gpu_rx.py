@@ -120,6 +120,16 @@ def test_decimate_large_exact():
     assert np.array_equal(oa.decimate(x, p), orx.decimate(x, bag(oparams, dict(SpSin=sps, SpSout=2))))
 
 
+def test_edc_filters_a_column_without_imaginary_part_as_a_real_signal():
+    """optic/dsp/core.py:1043-1046 looks at the values: such a column comes back with zero imaginary part."""
+    from oracle import ssf_oracle as orc
+    x = np.random.default_rng(1).normal(size=(4096, 2)) + 0j
+    x[:, 1] += 1j * np.random.default_rng(2).normal(size=4096)
+    kw = dict(Fs=64e9, L=20, D=16, Fc=193.1e12, Rs=32e9)
+    a, b = oa.edc(x, bag(oa.parameters, kw)), orc.edc(x, bag(oparams, kw))
+    assert np.all(a[:, 0].imag == 0) and np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
+
+
 def test_error_conventions():
     p = oa.parameters()
     with pytest.raises(AttributeError):
