@@ -726,9 +726,7 @@ SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T>
 }
 // next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
 // accumulates the sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the header note).
-// Once the powers are taken the iterate itself is dead, so E_hd is fetched into its registers
-// right away and arrives while the phases are evaluated (the stage used to wait for it afterwards:
-// 13 us of a 29 us launch in the phase timing).
+// Every phase / rotation / |d rot|^2 is evaluated by the sample's owner and swapped through LDS.
 template <typename T, class Ctx, class G>
 SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, const T *Pbuf, T shz, bool first,
                        double &num, double &den) {
@@ -745,9 +743,6 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     ctx.sync();                                              // the inverse transform's LDS reads are done
 #pragma unroll
     for (int j = 0; j < 8; ++j) shN[(size_t)oth_idx(g, j) * g.half + g.t] = noth[j];
-#pragma unroll
-    for (int idx = 0; idx < 16; ++idx) v[idx] = a.Ehd[g.rowbase + g.time_off(idx)];
-    ctx.issue_fence();
     ctx.sync();
 #pragma unroll
     for (int j = 0; j < 8; ++j) noth[j] = shN[(size_t)own_idx(g, j) * g.half + g.t];
@@ -771,6 +766,11 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
         shD[(size_t)own_idx(g, j) * g.half + g.t] = down[j];
     }
     ctx.mark(7);
+    // E_hd goes into the dead iterate's registers once the phases are done: fetched here, it arrives while
+    // the partners swap their halves (any earlier and 64 more registers are live through the phase
+    // loop: 68 B/lane of scratch, measured as +5 MB of HBM writes per launch)
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) v[idx] = a.Ehd[g.rowbase + g.time_off(idx)];
     ctx.sync();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -23,7 +23,7 @@ def main(fetch_db, write_db, total_steps, engine, out=None):
     total = 0.0
     rows = []
     for name in sorted(set(f) | set(w)):
-        if "k_amp" in name or "copyBuffer" in name or "k_aos" in name or "k_soa" in name:
+        if any(s in name for s in ("k_amp", "copyBuffer", "fillBuffer", "k_aos", "k_soa", "k_burst_copy")):
             cal = (f.get(name, (0, 0)), w.get(name, (0, 0)))
             rows.append((name.split("(")[0][-40:], "calibration/aux", cal))
             continue
