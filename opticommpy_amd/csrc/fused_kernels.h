@@ -627,7 +627,14 @@ template <typename T, int LG, class Ctx> struct ColGeom {
         b = t / C;
         N2 = 1 << a.log2N2;
         const int tpp = N2 / C;                      // tiles per field group
-        const int grp = ctx.bid / tpp, tile = ctx.bid - grp * tpp;
+        const int grp = ctx.bid / tpp;
+        int tile = ctx.bid - grp * tpp;
+        // Workgroups go round-robin over the 8 XCDs (each with its own L2).  Neighbouring tiles share the
+        // 128-B lines of the real-valued P / Theta arrays (C = 8 columns are 64 B), so tiles are dealt out
+        // in contiguous runs per XCD: the second half of such a line is then an L2 hit, not a second fetch
+        // (+1.2 %).  (Laying P / Theta out tile-major instead, one contiguous 16 KiB block per workgroup,
+        // is slower: -1.5 %, the block sits in one memory channel.)
+        if (tpp % 8 == 0) tile = (tile & 7) * (tpp >> 3) + (tile >> 3);
         n2 = tile * C + c;
         const long long N = 1ll << (a.log2N1 + a.log2N2);
         rowbase = (long long)(grp * a.npol + pol) * N;
