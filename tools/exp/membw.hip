@@ -40,6 +40,18 @@ template <int E> __global__ void __launch_bounds__(256) k_burst(const double2 *_
     for (int q = 0; q < E; ++q) o[threadIdx.x + 256 * q] = v[q];
 }
 
+// column-stage shape: a workgroup of 256 threads owns 8 adjacent columns (128 B) of a (256, pitch) array of
+// double2 and reads / writes all 256 rows of them: 16 accesses per thread at a stride of `pitch` elements.
+__global__ void __launch_bounds__(256) k_colshape(const double2 *__restrict__ a, double2 *__restrict__ b, int pitch) {
+    const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;          // 8 columns x 32 rows per pass
+    const size_t col = (size_t)blockIdx.x * 8 + c;
+    double2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = a[(size_t)(r0 + 32 * q) * pitch + col];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[(size_t)(r0 + 32 * q) * pitch + col] = v[q];
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 
 int main() {
@@ -74,6 +86,17 @@ int main() {
             printf("size %5zu MiB grid %5d: copy %7.2f us = %6.0f GB/s (r+w)   read %7.2f us = %6.0f GB/s\n", mib, grid,
                    tc * 1e6, 2.0 * bytes / tc / 1e9, tr * 1e6, bytes / tr / 1e9);
         }
+    }
+    printf("# column-shaped access: 512 workgroups x (8 columns x 256 rows), 16 MiB in + 16 MiB out, row pitch varied\n");
+    for (int pad : {0, 8, 16, 64, 136, 520}) {
+        const int pitch = 4096 + pad, it = 50;
+        for (int w = 0; w < 4; ++w) hipLaunchKernelGGL(k_colshape, dim3(512), dim3(256), 0, 0, w & 1 ? b : a, w & 1 ? a : b, pitch);
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < it; ++i) hipLaunchKernelGGL(k_colshape, dim3(512), dim3(256), 0, 0, i & 1 ? b : a, i & 1 ? a : b, pitch);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        const double t = time_ms(e0, e1) / it * 1e-3;
+        printf("pitch 4096 + %3d elements: %7.2f us  %6.0f GB/s (r+w)\n", pad, t * 1e6, 2.0 * (16 << 20) / t / 1e9);
     }
     printf("# burst kernels (32 MiB in, 32 MiB out per launch, ping-pong a<->b like the row/column stages)\n");
     for (int spin : {0, 100, 200, 400}) {
