@@ -317,8 +317,29 @@ int ssf_device_free(int device, void *ptr) {
 int ssf_device_memcpy(int device, void *dst, const void *src, int64_t bytes) {
     if (!dst || !src || bytes < 0) return set_err(SSF_ERR_BAD_ARG, "ssf_device_memcpy: bad argument");
     if (hipSetDevice(device) != hipSuccess) return set_err(SSF_ERR_HIP, "hipSetDevice failed");
-    hipError_t e = hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault);
-    return e == hipSuccess ? SSF_OK : set_err(SSF_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    const bool dst_dev = ssf::on_device(dst), src_dev = ssf::on_device(src);
+    hipError_t e;
+    if (dst_dev != src_dev && bytes >= (1 << 20)) {
+        // large host <-> device copies of pageable memory go through the pinned double buffer (a plain
+        // hipMemcpy of pageable memory runs at a fraction of the link rate)
+        struct Lane {
+            hipStream_t st = nullptr;
+            ssf::Stager stg;
+            int dev = -1;
+        };
+        thread_local Lane lane;
+        if (lane.dev != device) {
+            if (lane.st) (void)hipStreamDestroy(lane.st);
+            lane.st = nullptr;
+            if (hipStreamCreateWithFlags(&lane.st, hipStreamNonBlocking) != hipSuccess) return set_err(SSF_ERR_HIP, "hipStreamCreate failed");
+            if (lane.dev < 0) (void)lane.stg.init();
+            lane.dev = device;
+        }
+        e = dst_dev ? lane.stg.h2d(dst, src, (size_t)bytes, lane.st) : lane.stg.d2h(dst, src, (size_t)bytes, lane.st);
+    } else {
+        e = hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault);
+    }
+    return e == hipSuccess ? SSF_OK : set_err(SSF_ERR_HIP, std::string("ssf_device_memcpy: ") + hipGetErrorString(e));
 }
 
 // ---- receiver side (engine_rx.hip) -----------------------------------------------------------
