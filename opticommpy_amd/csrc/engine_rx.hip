@@ -258,6 +258,10 @@ int rx_run(int device, int mode, int64_t N, int nmodes, const ssf_rx_params *p, 
 int rx_fir(int device, int64_t sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out, std::string *err) {
     return with_core(device, err, [&](RxCore<Pooled> &c) { return c.fir(sigLen, ncols, ntaps, taps, in, out); });
 }
+int rx_overlap_save(int device, int64_t sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out,
+                    std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.overlap_save(sigLen, ncols, nfft, K, Hfft, in, out); });
+}
 int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, void *out, std::string *err) {
     return with_core(device, err, [&](RxCore<Pooled> &c) { return c.delay(N, delay, Fs, in, out); });
 }

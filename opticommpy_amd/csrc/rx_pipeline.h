@@ -23,9 +23,26 @@ namespace rx {
 typedef std::complex<double> zc;
 constexpr double kPi = 3.14159265358979323846;
 
-// in-place radix-2 FFT (n = power of two), sign = -1 forward / +1 inverse (unscaled)
+// in-place radix-2 FFT (n = power of two), sign = -1 forward / +1 inverse (unscaled).  The n/2 twiddles of
+// a size are computed once per thread (direct cos / sin of every angle, no recurrences) and reused.
+inline const std::vector<zc> &host_twiddles(size_t n) {
+    thread_local std::vector<std::vector<zc>> cache(32);
+    size_t lg = 0;
+    while (((size_t)1 << lg) < n) ++lg;
+    std::vector<zc> &w = cache[lg];
+    if (w.size() != n / 2) {
+        w.resize(n / 2);
+        for (size_t k = 0; k < n / 2; ++k) {
+            const double ang = -2.0 * kPi * (double)k / (double)n;
+            w[k] = zc(std::cos(ang), std::sin(ang));
+        }
+    }
+    return w;
+}
 inline void host_fft(std::vector<zc> &a, int sign) {
     const size_t n = a.size();
+    if (n < 2) return;
+    const std::vector<zc> &w = host_twiddles(n);
     for (size_t i = 1, j = 0; i < n; ++i) {
         size_t bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -33,11 +50,11 @@ inline void host_fft(std::vector<zc> &a, int sign) {
         if (i < j) std::swap(a[i], a[j]);
     }
     for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t step = n / len;
         for (size_t i = 0; i < n; i += len)
             for (size_t k = 0; k < len / 2; ++k) {
-                const double ang = sign * 2.0 * kPi * (double)k / (double)len;
-                const zc w(std::cos(ang), std::sin(ang));
-                const zc u = a[i + k], v = a[i + k + len / 2] * w;
+                const zc t = sign < 0 ? w[k * step] : std::conj(w[k * step]);
+                const zc u = a[i + k], v = a[i + k + len / 2] * t;
                 a[i + k] = u + v;
                 a[i + k + len / 2] = u - v;
             }
@@ -448,6 +465,21 @@ template <class Backend> struct RxCore {
         be.launch_dec_gather(ga);
         be.sync();
         be.d2h_big(out, b, sizeof(Cd) * (size_t)Nout * ncols);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+
+    // blockwiseFFTConv with a caller-supplied frequency response (edc: ssf_overlap_save); Hfft = fft(zero-padded
+    // impulse response), nfft values
+    int overlap_save(long long sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out) {
+        std::vector<zc> H((size_t)nfft);
+        for (int i = 0; i < nfft; ++i) H[(size_t)i] = ((const zc *)Hfft)[i] / (double)nfft;    // the ifft's 1/NFFT folded in
+        Cd *a = dalloc((size_t)sigLen * ncols), *b = dalloc((size_t)sigLen * ncols), *dH = upload_filter(H);
+        if (!a || !b || !dH) return fail(SSF_ERR_OOM, "out of device memory");
+        be.h2d_big(a, in, sizeof(Cd) * (size_t)sigLen * ncols);
+        int rc = ols(a, ncols, sigLen, sigLen, b, ncols, sigLen, ncols, dH, 0, K, nfft, 0);
+        if (rc) return rc;
+        be.sync();
+        be.d2h_big(out, b, sizeof(Cd) * (size_t)sigLen * ncols);
         return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
     }
 

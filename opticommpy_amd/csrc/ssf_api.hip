@@ -251,7 +251,10 @@ int ssf_overlap_save(int device, int64_t sigLen, int32_t nrows, int32_t precisio
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_err(SSF_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return set_err(SSF_ERR_NO_DEVICE, "device index out of range");
     std::string err;
-    int rc = fused_overlap_save(device, sigLen, nrows, precision, lg, K, Hfft, sig_in, sig_out, &err);
+    // complex128 goes through the receiver pipeline's pooled backend (stream, pinned staging and device
+    // blocks are kept between calls); complex64 through the one-shot path of the fused engine
+    int rc = precision == SSF_C128 ? ssf::rx_overlap_save(device, sigLen, nrows, nfft, K, Hfft, sig_in, sig_out, &err)
+                                   : fused_overlap_save(device, sigLen, nrows, precision, lg, K, Hfft, sig_in, sig_out, &err);
     if (rc) set_err(rc, err);
     return rc;
 }

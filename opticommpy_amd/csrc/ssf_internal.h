@@ -80,6 +80,8 @@ int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int
 int rx_run(int device, int mode, int64_t N, int nmodes, const ssf_rx_params *p, const void *in0, const void *lo,
            const double *un, void *out, std::string *err);
 int rx_fir(int device, int64_t sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out, std::string *err);
+int rx_overlap_save(int device, int64_t sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out,
+                    std::string *err);
 int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, void *out, std::string *err);
 int tx_wdm(int device, const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
            const double *deltaF, void *out, double *power_out, std::string *err);

@@ -20,6 +20,23 @@ import numpy as np
 from . import _lib
 
 
+# Freed blocks are kept (by device and size) and handed out again: hipMalloc / hipFree of tens of MiB cost
+# hundreds of microseconds and hipFree synchronises the device.  Capped; release_pool() returns everything.
+_POOL = {}
+_POOL_BYTES = [0]
+_POOL_CAP = 4 << 30
+
+
+def release_pool():
+    """Give the cached device blocks back to the driver."""
+    lib = _lib.load()
+    for (dev, _), ptrs in _POOL.items():
+        for p in ptrs:
+            lib.ssf_device_free(dev, p)
+    _POOL.clear()
+    _POOL_BYTES[0] = 0
+
+
 class DeviceArray:
     """C-contiguous ndarray-like block of HBM on one GPU.  ``get()`` / ``np.asarray`` download it."""
 
@@ -29,8 +46,18 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self.device = _state["device"] if device is None else int(device)
         self._ptr = C.c_void_p()
+        self._alloc = max(self.nbytes, 1)
+        cached = _POOL.get((self.device, self._alloc))
+        if cached:
+            self._ptr = cached.pop()
+            _POOL_BYTES[0] -= self._alloc
+            return
         lib = _lib.load()
-        _lib.raise_for(lib, None, lib.ssf_device_malloc(self.device, max(self.nbytes, 1), C.byref(self._ptr)))
+        rc = lib.ssf_device_malloc(self.device, self._alloc, C.byref(self._ptr))
+        if rc == -3 and _POOL:                      # out of memory: drop the cache and retry once
+            release_pool()
+            rc = lib.ssf_device_malloc(self.device, self._alloc, C.byref(self._ptr))
+        _lib.raise_for(lib, None, rc)
 
     # ---- ndarray-like surface
     @property
@@ -91,7 +118,11 @@ class DeviceArray:
     def __del__(self):
         if getattr(self, "_owner", None) is None and getattr(self, "_ptr", None):
             try:
-                _lib.load().ssf_device_free(self.device, self._ptr)
+                if _POOL_BYTES[0] + self._alloc <= _POOL_CAP:
+                    _POOL.setdefault((self.device, self._alloc), []).append(self._ptr)
+                    _POOL_BYTES[0] += self._alloc
+                else:
+                    _lib.load().ssf_device_free(self.device, self._ptr)
             except Exception:
                 pass
 
