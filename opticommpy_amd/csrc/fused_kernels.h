@@ -85,7 +85,8 @@ SSF_HD LinOp make_linop(double hzh, double lin_a, double lin_b, double w2, doubl
     const double d = (double)(1ll << (log2N - 4));
     for (int m = 0; m < 9; ++m) {
         double s, c;
-        sincos_d(l.cth * d * d * (double)(m * m), s, c);
+        cis_rad_d(l.cth * d * d * (double)(m * m), c, s);     // (not the full-range sincos: nine inlined copies of
+                                                              //  its reduction are a fifth of the row kernel's code)
         l.Cre[m] = c;
         l.Cim[m] = s;
     }
