@@ -59,6 +59,7 @@ template <typename T, class Backend> class FusedCore {
     size_t field_bytes;
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
     T *P = nullptr, *Theta = nullptr;
+    bool lim0_bound = true;       // SSF_LIM0_BOUND=0: always evaluate lim_0 on all samples (A/B runs)
     Ctrl *ctrl = nullptr;        // [2]
     LinOp *linops = nullptr;     // [2]
     double *part = nullptr;      // 3 * npart_max
@@ -102,6 +103,7 @@ template <typename T, class Backend> class FusedCore {
     }
 
     int init() {
+        if (const char *e = std::getenv("SSF_LIM0_BOUND")) lim0_bound = std::atoi(e) != 0;
         const int tpf2 = (1 << sp.l2) / 16;
         const int64_t nfft = (int64_t)nrows << sp.l1;
         int fpw = tpf2 >= 256 ? 1 : 256 / tpf2;               // row transforms per workgroup
@@ -287,6 +289,7 @@ template <typename T, class Backend> class FusedCore {
         k.invN = 1.0 / (double)N;
         k.maxIter = p.maxIter;
         k.adaptive = p.nlprMethod ? 1 : 0;
+        k.exact_lim0 = (p.maxIter == 1 || !lim0_bound) ? 1 : 0;      // (+ whenever a trace is recorded, run_manakov)
         k.log2N = log2N;
         k.trace_cap = tr_cap;
         k.tr_hz = tr_hz;
@@ -345,6 +348,7 @@ template <typename T, class Backend> class FusedCore {
         if (rc) return rc;
         MkConst k = mk_const(p, d);
         if (!trace) k.trace_cap = 0;
+        if (k.trace_cap > 0) k.exact_lim0 = 1;
         Ctrl c{};
         long long trace_n = 0;
         double avg_it = 3.0;

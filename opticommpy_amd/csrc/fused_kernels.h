@@ -38,7 +38,11 @@ namespace fused {
 // E_fd(i) exists.  The pipeline therefore knows in advance which iterate is the last one: no
 // iterate is ever written to or re-read from HBM just for the test, only the final one is stored.
 // lim_0 (against the field at the step start, channels.py:381-382) is evaluated directly; if it
-// ever signals convergence the iterate is rebuilt as final (ST_REDO0).
+// ever signals convergence the iterate is rebuilt as final (ST_REDO0).  Only that decision needs lim_0,
+// and lim_0 is normally orders of magnitude above tol: unless a trace is recorded the numerator is taken
+// over one sample in sixteen (a rigorous lower bound with the exact denominator sum Pch), which spares
+// re-reading the step-start field (32 MiB per step at N = 2^20).  A bound below tol proves nothing: iterate 0
+// is then rebuilt and lim_0 evaluated on all samples (exact0) before anything is decided.
 enum {
     ST_NEED_S = 0,     // Col: span start: Pch of T[cur], forward column FFT                      -> AFTER_S
     ST_AFTER_S = 1,    // Row: new step: step size / operator, first half linear step             -> NEED_H
@@ -62,6 +66,8 @@ struct Ctrl {           // device-resident step state, double-buffered by launch
     int pend0, pendn;   // partial sums of lim_0 / lim_it are waiting for the next Row launch
     int cap0;           // iterate 0 ended the step only because maxIter == 1 (lim_0 decides non-convergence)
     int pcur, redo_;    // current Pch buffer; iterate 0 is being rebuilt as final
+    int bound0;         // the pending lim_0 sums cover a sixteenth of the samples: a lower bound of lim_0
+    int exact0;         // the next I stage of iterate 0 evaluates lim_0 on all samples (bound was inconclusive)
     long long pend0_idx;// trace row lim_0 belongs to
     double z, hz;
     long long steps, iterations, nonconv, trace_n;
@@ -71,7 +77,8 @@ struct Ctrl {           // device-resident step state, double-buffered by launch
 
 struct MkConst {        // per-execute constants (by value)
     double Lspan, hz_fixed, tol, maxRot, c8g, sgn, lin_a, lin_b, w2, invN;
-    int maxIter, adaptive, log2N, pad_;
+    int maxIter, adaptive, log2N;
+    int exact_lim0;     // lim_0 always on all samples (a trace is recorded, or maxIter == 1: lim_0 decides convergence)
     long long trace_cap;
     double *tr_hz;
     int *tr_it;
@@ -470,7 +477,8 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
         // compiler fetch the pass-through fields with a vector load, and waiting for that one
         // means waiting for the row (in-order vmcnt).
         const Ctrl &c = *a.cin;
-        const int c_state = c.state, c_it = c.it, c_pend0 = c.pend0, c_pendn = c.pendn, c_cap0 = c.cap0;
+        const int c_state = c.state, c_it = c.it, c_pend0 = c.pend0, c_pendn = c.pendn, c_cap0 = c.cap0, c_bound0 = c.bound0;
+        int n_exact0 = c.exact0;
         int n_state = c_state, n_final = c.final_, n_cap0 = c_cap0, n_hzv = c.hz_valid;
         int add_nonconv = 0, add_ahead = 0;
         double n_hz = c.hz;
@@ -499,7 +507,10 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
                 if (c_cap0) {
                     if (!(lim0 < a.k.tol)) add_nonconv = 1;
                     n_cap0 = 0;
-                } else if (c_pendn && lim0 < a.k.tol) redo = true;        // converged at iterate 0 after all
+                } else if (c_pendn && lim0 < a.k.tol) {
+                    redo = true;                                          // converged at iterate 0 after all ...
+                    if (c_bound0) n_exact0 = 1;                           // ... or the bound could not exclude it: measure it
+                }
             }
             if (c_pendn) {                                                // lim_it, known before iterate it exists
                 if (redo) {
@@ -547,6 +558,8 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
             n->pend0 = 0;
             n->pendn = 0;
             n->cap0 = n_cap0;
+            n->bound0 = 0;
+            n->exact0 = n_exact0;
             n->hz_valid = n_hzv;
             n->hz = n_hz;
             n->nonconv = c.nonconv + add_nonconv;
@@ -737,7 +750,7 @@ SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T>
 // Every phase / rotation / |d rot|^2 is evaluated by the sample's owner and swapped through LDS.
 template <typename T, class Ctx, class G>
 SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, const T *Pbuf, T shz, bool first,
-                       double &num, double &den) {
+                       double &num, double &den, double &pch_sum) {
     T *shN = (T *)ctx.lds;                                   // 16*half powers for the owners
     cx<T> *shC = (cx<T> *)(shN + 16 * (size_t)g.half);       // 16*half rotations
     T *shD = (T *)(shC + 16 * (size_t)g.half);               // 16*half |d rot|^2
@@ -763,6 +776,7 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
         const long long t = own_time_off(g, j);
         const T ax = g.pol ? noth[j] : nown[j], ay = g.pol ? nown[j] : noth[j];
         const T pw = Pbuf[g.pbase + t];
+        pch_sum += (double)pw;                               // sum |E(step start)|^2 of the owned samples (lim_0 bound)
         const T ang = shz * (c8g * (pw + ax + ay) / (T)2);
         const T prev = first ? shz * (c8g * (pw + pw) / (T)2) : a.Theta[g.pbase + t];
         // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2)
@@ -802,7 +816,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     // ---- what does this launch do? ------------------------------------------------------
     bool do_inv = false, do_fwd = false;
     int op = -1;     // Manakov: 0 = S (span start), 1 = H, 2 = I, 3 = rebuild iterate 0
-    bool final_ = false, more = false;
+    bool final_ = false, more = false, exact0 = true;
     struct { int state, it, cur, pcur; double z, hz; } c{};
     double *red = (double *)ctx.lds;
     ctx.mark(0);
@@ -816,6 +830,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
         c.z = a.cin->z;
         c.hz = a.cin->hz;
         final_ = a.cin->final_ != 0;
+        exact0 = a.k.exact_lim0 || a.cin->exact0 != 0;
         if (c.state == ST_NEED_S) {
             op = 0;
             do_fwd = true;
@@ -847,8 +862,8 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
             } else if (op == 3) {
                 n->state = ST_ROW_ITER;
                 n->it = 0;
-                n->final_ = 1;
-                n->redo_ = 1;
+                n->final_ = a.cin->exact0 ? 0 : 1;                        // (exact0: rebuilt to measure lim_0, not as final)
+                n->redo_ = a.cin->exact0 ? 0 : 1;
                 n->pend0 = n->pendn = 0;
                 n->n_rebuilt = a.cin->n_rebuilt + 1;
             } else if (op == 2 && !final_) {
@@ -858,6 +873,8 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
                 if (c.it == 0) {
                     n->pend0 = 1;
                     n->pend0_idx = a.cin->trace_n;
+                    n->bound0 = exact0 ? 0 : 1;
+                    n->exact0 = 0;
                 }
             } else if (op == 2) {                                         // the step ends here
                 const long long tn = a.cin->trace_n;
@@ -876,6 +893,8 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
                     n->pend0 = 1;
                     n->pend0_idx = tn;
                     n->cap0 = a.cin->redo_ ? 0 : 1;
+                    n->bound0 = exact0 ? 0 : 1;      // (only recorded in a trace, and a trace makes it exact)
+                    n->exact0 = 0;
                 }
                 n->redo_ = 0;
                 if (more) {
@@ -957,21 +976,24 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
             for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * rot[idx];
             ctx.sync();
         } else {                                     // I: iterate `it` is in registers
-            double n0 = 0, d0 = 0, n1 = 0, d1 = 0;
+            double n0 = 0, d0 = 0, n1 = 0, d1 = 0, psum = 0;
             if (c.it == 0) {                         // lim_0 against the field at the step start
 #pragma unroll
                 for (int idx = 0; idx < 16; ++idx) {
-                    const cx<T> e = Tcur[g.rowbase + g.time_off(idx)];
-                    const double dr = (double)v[idx].re - (double)e.re, di = (double)v[idx].im - (double)e.im;
-                    n0 += dr * dr + di * di;
-                    d0 += (double)e.re * e.re + (double)e.im * e.im;
+                    if (exact0 || idx == 0) {        // (bound: one register in sixteen = one cache line in sixteen)
+                        const cx<T> e = Tcur[g.rowbase + g.time_off(idx)];
+                        const double dr = (double)v[idx].re - (double)e.re, di = (double)v[idx].im - (double)e.im;
+                        n0 += dr * dr + di * di;
+                        d0 += (double)e.re * e.re + (double)e.im * e.im;
+                    }
                 }
             }
             if (final_) {                            // the field after this step (channels.py:438-439)
 #pragma unroll
                 for (int idx = 0; idx < 16; ++idx) Tnew[g.rowbase + g.time_off(idx)] = v[idx];
             } else {
-                mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1);
+                mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
+                if (!exact0) d0 = psum;              // exact denominator of the bound: sum Pch over the tile
             }
             if (c.it == 0) {
                 block_sum2(ctx, n0, d0, red);

@@ -33,7 +33,7 @@ def _amp(amp):
     return {"edfa": 2, "ideal": 1}.get(amp, 0) if isinstance(amp, str) else 0
 
 
-def run(func, Ei, cfg, noise=None, max_steps=4096):
+def run(func, Ei, cfg, noise=None, max_steps=4096, trace=True):
     """Run ssfm / manakovSSF / manakovDBP of a cfg dict on the emulator.  Returns (out, info)."""
     emu = load()
     dt = np.complex64 if cfg.get("prec") == "complex64" else np.complex128
@@ -75,7 +75,7 @@ def run(func, Ei, cfg, noise=None, max_steps=4096):
         nz = np.ascontiguousarray(noise, dtype=dt)
     rc = emu.emu_run(N, ncols, prec, C.byref(p), soa.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
                      snaps.ctypes.data_as(C.c_void_p), nz.ctypes.data_as(C.c_void_p) if nz is not None else None,
-                     C.byref(st), C.byref(tr), C.byref(launches))
+                     C.byref(st), C.byref(tr) if trace else None, C.byref(launches))
     assert rc == 0, f"emu_run rc={rc}"
     n = int(tr.count)
     info = st.as_dict()

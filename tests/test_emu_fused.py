@@ -171,6 +171,44 @@ def test_convergence_at_iterate_zero_rebuilds_it_as_final():
     np.testing.assert_allclose(np.concatenate(info["lims"]), np.concatenate(tr["lims"]), rtol=1e-6)
 
 
+def test_lim0_lower_bound_gives_the_same_run_without_rereading_the_step_start_field():
+    """Without a trace lim_0 is only bounded from below (one sample in sixteen, exact denominator): same field,
+    same step / iteration totals as the traced (exact) run, nothing rebuilt."""
+    for name in ("mk_fix_p8_ideal_2span", "mk_adp_p13_ideal_2span", "mk_fix_p13_ideal_k2"):
+        d, cfg = load_golden(name)
+        a, ia = eb.run(cfg["func"], d["Ei"], cfg)
+        b, ib = eb.run(cfg["func"], d["Ei"], cfg, trace=False)
+        assert np.array_equal(a, b)
+        assert (ia["steps"], ia["iterations"], ia["nonconverged_steps"]) == (ib["steps"], ib["iterations"], ib["nonconverged_steps"])
+        assert ib["rebuilt_iterates"] == 0
+
+
+def test_lim0_bound_that_cannot_exclude_convergence_is_rechecked_exactly():
+    """Two ways the bound falls below tol.  (a) iterate 0 really has converged: the iterate is rebuilt to measure
+    lim_0 on all samples, then rebuilt as final -- two rebuilds per step, result as the traced run.  (b) it has
+    not (tol between the bound and lim_0): one rebuild per step, then the iteration goes on as if nothing
+    happened."""
+    E = synth_field(1024, 2, 41, -10.0)
+    cfg = dict(func="manakovSSF", alpha=0.0, D=1e-5, gamma=1e-6, Fc=193.1e12, Fs=64e9, maxIter=10, tol=1e-5,
+               prgsBar=False, Ltotal=0.4, Lspan=0.2, hz=0.05, nlprMethod=False, amp=None, saveSpanN=[])
+    a, ia = eb.run("manakovSSF", E, cfg)
+    b, ib = eb.run("manakovSSF", E, cfg, trace=False)
+    assert np.array_equal(a, b) and ib["iterations"] == ia["iterations"] == ia["steps"]
+    assert ia["rebuilt_iterates"] == ia["steps"] and ib["rebuilt_iterates"] == 2 * ib["steps"]
+    # (b): a run whose lim_0 values are known from the trace; put tol just below the smallest of them
+    d, cfg = load_golden("mk_fix_p0_none")
+    _, it = eb.run("manakovSSF", d["Ei"], cfg)
+    lim0 = min(l[0] for l in it["lims"])
+    cfg2 = dict(cfg, tol=float(lim0) * 0.6)            # bound ~ lim_0 / 4 < tol < lim_0
+    tr = {}
+    ref = orc.manakovSSF(d["Ei"], make_param(orc.parameters, cfg2), trace=tr)
+    a, ia = eb.run("manakovSSF", d["Ei"], cfg2)
+    b, ib = eb.run("manakovSSF", d["Ei"], cfg2, trace=False)
+    assert list(ia["iters"]) == tr["iters"] and rel_l2(a.T, ref) <= TOL_C128
+    assert np.array_equal(a, b) and ib["iterations"] == ia["iterations"]
+    assert ia["rebuilt_iterates"] == 0 and 0 < ib["rebuilt_iterates"] <= ib["steps"]
+
+
 @pytest.mark.parametrize("maxIter", [1, 2])
 def test_iteration_cap(maxIter):
     """maxIter = 1: the only iterate is final by the cap and lim_0 alone decides the warning count."""

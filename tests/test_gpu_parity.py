@@ -300,6 +300,33 @@ def test_c64_long_run_does_not_drift_from_c128(engine):
     assert np.sum(np.abs(a) ** 2) / np.sum(np.abs(b) ** 2) == pytest.approx(1.0, abs=ptol)
 
 
+def test_untraced_runs_bound_lim0_and_give_the_traced_result():
+    """Product runs record no trace: lim_0 is then only bounded from below (one sample in sixteen), which must
+    not change anything; when the bound cannot exclude convergence at iterate 0 the iterate is rebuilt and
+    lim_0 measured on all samples (fused engine)."""
+    _select("fused", 1024)
+    for name in ("mk_fix_p8_ideal_2span", "mk_adp_p13_ideal_2span", "mk_fix_p8_n4096"):
+        d, cfg = load_golden(name)
+        a = oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg), _trace=True)
+        ra = dict(models.last_run)
+        b = oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg))
+        rb = dict(models.last_run)
+        assert np.array_equal(a, b) and (ra["steps"], ra["iterations"]) == (rb["steps"], rb["iterations"])
+        assert rb["rebuilt_iterates"] == 0
+    # tol between the bound and lim_0: every step's iterate 0 is rebuilt once, then the iteration goes on
+    d, cfg = load_golden("mk_fix_p0_none")
+    oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg), _trace=True)
+    lim0 = min(l[0] for l in models.last_run["lims"])
+    cfg2 = dict(cfg, tol=float(lim0) * 0.6)
+    tr = {}
+    ref = orc.manakovSSF(d["Ei"], make_param(orc.parameters, cfg2), trace=tr)
+    a = oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg2), _trace=True)
+    assert list(models.last_run["iters"]) == tr["iters"] and rel_l2(a, ref) <= TOL_C128
+    b = oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg2))
+    assert np.array_equal(a, b) and 0 < models.last_run["rebuilt_iterates"] <= models.last_run["steps"]
+    oa.set_engine("auto")
+
+
 def test_single_process_multi_device_entry_point():
     """ssf_mgpu_run (one host thread per device): 3 independent units on device 0 must equal
     three separate reference calls."""
