@@ -14,6 +14,7 @@ A DeviceArray is a typed, C-contiguous block of device memory (``ssf_device_mall
 recognises device pointers wherever it takes array arguments (include/ssf.h), so the same entry
 points serve both kinds of caller.  Functions return a DeviceArray when their main input is one."""
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -25,16 +26,18 @@ from . import _lib
 _POOL = {}
 _POOL_BYTES = [0]
 _POOL_CAP = 4 << 30
+_POOL_LOCK = threading.Lock()
 
 
 def release_pool():
     """Give the cached device blocks back to the driver."""
     lib = _lib.load()
-    for (dev, _), ptrs in _POOL.items():
-        for p in ptrs:
-            lib.ssf_device_free(dev, p)
-    _POOL.clear()
-    _POOL_BYTES[0] = 0
+    with _POOL_LOCK:
+        for (dev, _), ptrs in _POOL.items():
+            for p in ptrs:
+                lib.ssf_device_free(dev, p)
+        _POOL.clear()
+        _POOL_BYTES[0] = 0
 
 
 class DeviceArray:
@@ -47,11 +50,12 @@ class DeviceArray:
         self.device = _state["device"] if device is None else int(device)
         self._ptr = C.c_void_p()
         self._alloc = max(self.nbytes, 1)
-        cached = _POOL.get((self.device, self._alloc))
-        if cached:
-            self._ptr = cached.pop()
-            _POOL_BYTES[0] -= self._alloc
-            return
+        with _POOL_LOCK:
+            cached = _POOL.get((self.device, self._alloc))
+            if cached:
+                self._ptr = cached.pop()
+                _POOL_BYTES[0] -= self._alloc
+                return
         lib = _lib.load()
         rc = lib.ssf_device_malloc(self.device, self._alloc, C.byref(self._ptr))
         if rc == -3 and _POOL:                      # out of memory: drop the cache and retry once
@@ -118,10 +122,12 @@ class DeviceArray:
     def __del__(self):
         if getattr(self, "_owner", None) is None and getattr(self, "_ptr", None):
             try:
-                if _POOL_BYTES[0] + self._alloc <= _POOL_CAP:
-                    _POOL.setdefault((self.device, self._alloc), []).append(self._ptr)
-                    _POOL_BYTES[0] += self._alloc
-                else:
+                with _POOL_LOCK:
+                    keep = _POOL_BYTES[0] + self._alloc <= _POOL_CAP
+                    if keep:
+                        _POOL.setdefault((self.device, self._alloc), []).append(self._ptr)
+                        _POOL_BYTES[0] += self._alloc
+                if not keep:
                     _lib.load().ssf_device_free(self.device, self._ptr)
             except Exception:
                 pass
@@ -144,8 +150,11 @@ def arg(x, dtype):
     """(pointer, keepalive) of an array argument of the C ABI: numpy arrays are made contiguous in
     ``dtype``; a DeviceArray must already have it (converting would be a hidden device round trip)."""
     if isinstance(x, DeviceArray):
+        from .models import _state
         if x.dtype != np.dtype(dtype):
             raise TypeError(f"device array has dtype {x.dtype.name}, this call needs {np.dtype(dtype).name}")
+        if x.device != _state["device"]:
+            raise ValueError(f"device array lives on GPU {x.device}, the selected device is {_state['device']} (set_device)")
         return x.ptr, x
     a = np.ascontiguousarray(x, dtype=dtype)
     return a.ctypes.data_as(C.c_void_p), a
