@@ -62,7 +62,7 @@ template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    col_body<T, LG, MODE>(ctx, a);
+    col_body<T, LG, MODE, false>(ctx, a);
 }
 template <typename T> __global__ void __launch_bounds__(256) k_amp(const AmpArgs<T> a) {
     SSF_DEV_CTX(1);

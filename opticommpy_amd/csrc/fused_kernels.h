@@ -19,6 +19,7 @@
 // optic/models/channels.py:387-441 (Manakov step), :219-229 (NLSE step).
 #pragma once
 #include "fused_core.h"
+#include "mixed_fft.h"
 #include "ssf_rng.h"
 
 namespace ssf {
@@ -397,6 +398,8 @@ template <typename T> struct RowArgs {
     const double *pnum, *pden;   // partial sums of lim_it written by the I stage
     const double *pnum0, *pden0; // partial sums of lim_0
     int npart;
+    int N2;                   // row length (mixed-radix rows: any 2^a 3^b 5^c; radix-2^n rows: 1 << log2N2)
+    long long N;              // N1 * N2
 };
 
 // linear operator for the 16 registers of a last-radix-16 butterfly: bins k0 + (N/16) q
@@ -435,10 +438,176 @@ template <typename T> SSF_HD cx<T> lin_at(const LinOp &lo, long long k, int log2
     return mk<T>((T)(lo.mag * c), (T)(lo.mag * s));
 }
 
+// Control-block handling of a Manakov Row launch: evaluates the convergence sums the last column stage left
+// (part: this thread's first two entries of each, fetched by the caller before its row), decides final / redo,
+// derives a new step size and operator when needed, and lets the lead thread write the next control block.
+// Returns false if this launch has nothing to transform; lo receives the operator.  Uses the first 4 KiB of LDS.
+template <typename T, class Ctx>
+SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], LinOp &lo) {
+    LinOp *lsh = (LinOp *)ctx.lds;
+    // Only the fields used here are read (scalar loads); the lead thread forwards the block
+    // word by word and patches what changed.  A private copy of the whole struct makes the
+    // compiler fetch the pass-through fields with a vector load, and waiting for that one
+    // means waiting for the row (in-order vmcnt).
+    const Ctrl &c = *a.cin;
+    const int c_state = c.state, c_it = c.it, c_pend0 = c.pend0, c_pendn = c.pendn, c_cap0 = c.cap0, c_bound0 = c.bound0;
+    int n_exact0 = c.exact0;
+    int n_state = c_state, n_final = c.final_, n_cap0 = c_cap0, n_hzv = c.hz_valid;
+    int add_nonconv = 0, add_ahead = 0;
+    double n_hz = c.hz;
+    double *red = (double *)(ctx.lds) + 64;
+    const bool lead = ctx.bid == 0 && ctx.tid == 0;
+    bool act = c_state == ST_AFTER_S || c_state == ST_ROW_ITER;
+    if (c_pend0 || c_pendn) {             // every block reduces the sums in the same order
+        double s0 = part[0][0] + part[1][0], s1 = part[0][1] + part[1][1];
+        double s2 = part[0][2] + part[1][2], s3 = part[0][3] + part[1][3];
+        for (int i = ctx.tid + 2 * ctx.nthreads; i < a.npart; i += ctx.nthreads) {
+            s0 += a.pnum0[i];
+            s1 += a.pden0[i];
+            s2 += a.pnum[i];
+            s3 += a.pden[i];
+        }
+        if (c_pend0) block_sum2(ctx, s0, s1, red);
+        if (c_pendn) block_sum2(ctx, s2, s3, red);
+        ctx.sync();
+        bool redo = false;
+        if (c_pend0) {                                                // lim_0 (channels.py:424, 517-519)
+            const double lim0 = sqrt(s0) / sqrt(s1);
+            if (lead) {
+                const long long idx = c.pend0_idx;
+                if (idx < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[idx * a.k.maxIter] = lim0;
+            }
+            if (c_cap0) {
+                if (!(lim0 < a.k.tol)) add_nonconv = 1;
+                n_cap0 = 0;
+            } else if (c_pendn && lim0 < a.k.tol) {
+                redo = true;                                          // converged at iterate 0 after all ...
+                if (c_bound0) n_exact0 = 1;                           // ... or the bound could not exclude it: measure it
+            }
+        }
+        if (c_pendn) {                                                // lim_it, known before iterate it exists
+            if (redo) {
+                n_state = ST_REDO0;
+                act = false;
+            } else {
+                const double lim = sqrt(s2) / sqrt(s3);
+                if (lead) {
+                    const long long tn = c.trace_n;
+                    if (tn < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[tn * a.k.maxIter + c_it] = lim;
+                }
+                const bool conv = lim < a.k.tol;
+                n_final = conv || c_it == a.k.maxIter - 1;            // channels.py:429-434
+                if (n_final && !conv) add_nonconv += 1;
+                add_ahead = 1;
+            }
+        }
+    }
+    const bool new_lin = act && !n_hzv;
+    if (new_lin) {                        // new step size: every block derives the same hz / operator
+        double mx = 0.0;
+        if (a.k.adaptive) mx = global_max(ctx, a.pmax, a.npart, red);
+        ctx.sync();
+        if (ctx.tid == 0) {
+            const double hz = pick_hz(a.k, c.z, mx);
+            lsh[0] = make_linop(hz / 2, a.k.lin_a, a.k.lin_b, a.k.w2, a.k.invN, a.k.log2N);
+            ((double *)(lsh + 1))[0] = hz;
+        }
+        ctx.sync();
+        n_hz = ((double *)(lsh + 1))[0];
+        lo = lsh[0];
+        n_hzv = 1;
+        ctx.sync();
+    } else if (act) {
+        lo = c.lin;
+    }
+    if (act) n_state = c_state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
+    if (lead) {
+        const unsigned long long *src = (const unsigned long long *)a.cin;
+        unsigned long long *dst = (unsigned long long *)a.cout;
+        for (int i = 0; i < (int)(sizeof(Ctrl) / 8); ++i) dst[i] = src[i];
+        Ctrl *n = a.cout;
+        n->state = n_state;
+        n->final_ = n_final;
+        n->pend0 = 0;
+        n->pendn = 0;
+        n->cap0 = n_cap0;
+        n->bound0 = 0;
+        n->exact0 = n_exact0;
+        n->hz_valid = n_hzv;
+        n->hz = n_hz;
+        n->nonconv = c.nonconv + add_nonconv;
+        n->n_ahead = c.n_ahead + add_ahead;
+        if (new_lin) n->lin = lo;
+    }
+    return act;
+}
+
+// same for any N (fftfreq sign convention: bins 0 .. (N+1)/2 - 1 are non-negative)
+template <typename T> SSF_HD cx<T> lin_at_n(const LinOp &lo, long long k, long long N) {
+    const double kk = (double)(k < (N + 1) / 2 ? k : k - N);
+    double s, c;
+    cis_rad_d(lo.cth * kk * kk, c, s);
+    return mk<T>((T)(lo.mag * c), (T)(lo.mag * s));
+}
+
+// Row stage for row lengths with factors 3 and 5 (mixed_fft.h): one row per workgroup, the row lives in LDS
+// (after the 4 KiB the control logic uses), G -> forward transform -> x linear operator -> inverse -> G.
+template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowArgs<T> &a) {
+    constexpr int kMaxPerThread = 16;                      // L <= 16 * nthreads
+    cx<T> *x = (cx<T> *)(ctx.lds + 4096);
+    const int L = a.N2, T_ = ctx.nthreads;
+    MixPlan p;
+    mix_make_plan(L, &p);
+    const long long rr = ctx.bid;                          // one row per workgroup
+    cx<T> *g = a.G + rr * L;
+    LinOp lo;
+    double part[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (a.use_ctrl) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = ctx.tid + u * ctx.nthreads;
+            if (i < a.npart) {
+                part[u][0] = a.pnum0[i];
+                part[u][1] = a.pden0[i];
+                part[u][2] = a.pnum[i];
+                part[u][3] = a.pden[i];
+            }
+        }
+        ctx.issue_fence();
+    }
+    cx<T> v[kMaxPerThread];
+#pragma unroll
+    for (int m = 0; m < kMaxPerThread; ++m) {
+        const int i = ctx.tid + T_ * m;
+        if (i < L) v[m] = g[i];
+    }
+    if (a.use_ctrl) {
+        ctx.issue_fence();
+        if (!row_ctrl(ctx, a, part, lo)) return;
+    } else {
+        lo = *a.lin;
+    }
+#pragma unroll
+    for (int m = 0; m < kMaxPerThread; ++m) {
+        const int i = ctx.tid + T_ * m;
+        if (i < L) x[i] = v[m];
+    }
+    ctx.sync();
+    mix_dif<-1>(ctx, p, ctx.tid, T_, x);
+    const int N1 = 1 << a.log2N1;
+    const int k1 = (int)(rr & (N1 - 1));
+    for (int pos = ctx.tid; pos < L; pos += T_) {
+        const long long kbin = k1 + (long long)N1 * mix_bin(p, pos);
+        x[pos] = x[pos] * lin_at_n<T>(lo, kbin, a.N);
+    }
+    ctx.sync();
+    mix_dit<+1>(ctx, p, ctx.tid, T_, x);
+    for (int i = ctx.tid; i < L; i += T_) g[i] = x[i];
+}
+
 // LG > 0: row length fixed at compile time (index math folds to immediates); 0: runtime
 template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const RowArgs<T> &a) {
     cx<T> *lds = (cx<T> *)ctx.lds;
-    LinOp *lsh = (LinOp *)ctx.lds;            // only used before the FFT touches the LDS
     LinOp lo;
     const PassPlan p = make_plan(LG > 0 ? LG : a.log2N2);
     const int fpw = ctx.nthreads / p.tpf;                  // row transforms per workgroup
@@ -472,101 +641,7 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     for (int q = 0; q < 16; ++q) v[q] = g[b + p.tpf * q];
     if (a.use_ctrl) {
         ctx.issue_fence();
-        // Only the fields used here are read (scalar loads); the lead thread forwards the block
-        // word by word and patches what changed.  A private copy of the whole struct makes the
-        // compiler fetch the pass-through fields with a vector load, and waiting for that one
-        // means waiting for the row (in-order vmcnt).
-        const Ctrl &c = *a.cin;
-        const int c_state = c.state, c_it = c.it, c_pend0 = c.pend0, c_pendn = c.pendn, c_cap0 = c.cap0, c_bound0 = c.bound0;
-        int n_exact0 = c.exact0;
-        int n_state = c_state, n_final = c.final_, n_cap0 = c_cap0, n_hzv = c.hz_valid;
-        int add_nonconv = 0, add_ahead = 0;
-        double n_hz = c.hz;
-        double *red = (double *)(ctx.lds) + 64;
-        const bool lead = ctx.bid == 0 && ctx.tid == 0;
-        bool act = c_state == ST_AFTER_S || c_state == ST_ROW_ITER;
-        if (c_pend0 || c_pendn) {             // every block reduces the sums in the same order
-            double s0 = part[0][0] + part[1][0], s1 = part[0][1] + part[1][1];
-            double s2 = part[0][2] + part[1][2], s3 = part[0][3] + part[1][3];
-            for (int i = ctx.tid + 2 * ctx.nthreads; i < a.npart; i += ctx.nthreads) {
-                s0 += a.pnum0[i];
-                s1 += a.pden0[i];
-                s2 += a.pnum[i];
-                s3 += a.pden[i];
-            }
-            if (c_pend0) block_sum2(ctx, s0, s1, red);
-            if (c_pendn) block_sum2(ctx, s2, s3, red);
-            ctx.sync();
-            bool redo = false;
-            if (c_pend0) {                                                // lim_0 (channels.py:424, 517-519)
-                const double lim0 = sqrt(s0) / sqrt(s1);
-                if (lead) {
-                    const long long idx = c.pend0_idx;
-                    if (idx < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[idx * a.k.maxIter] = lim0;
-                }
-                if (c_cap0) {
-                    if (!(lim0 < a.k.tol)) add_nonconv = 1;
-                    n_cap0 = 0;
-                } else if (c_pendn && lim0 < a.k.tol) {
-                    redo = true;                                          // converged at iterate 0 after all ...
-                    if (c_bound0) n_exact0 = 1;                           // ... or the bound could not exclude it: measure it
-                }
-            }
-            if (c_pendn) {                                                // lim_it, known before iterate it exists
-                if (redo) {
-                    n_state = ST_REDO0;
-                    act = false;
-                } else {
-                    const double lim = sqrt(s2) / sqrt(s3);
-                    if (lead) {
-                        const long long tn = c.trace_n;
-                        if (tn < a.k.trace_cap && a.k.tr_lim) a.k.tr_lim[tn * a.k.maxIter + c_it] = lim;
-                    }
-                    const bool conv = lim < a.k.tol;
-                    n_final = conv || c_it == a.k.maxIter - 1;            // channels.py:429-434
-                    if (n_final && !conv) add_nonconv += 1;
-                    add_ahead = 1;
-                }
-            }
-        }
-        const bool new_lin = act && !n_hzv;
-        if (new_lin) {                        // new step size: every block derives the same hz / operator
-            double mx = 0.0;
-            if (a.k.adaptive) mx = global_max(ctx, a.pmax, a.npart, red);
-            ctx.sync();
-            if (ctx.tid == 0) {
-                const double hz = pick_hz(a.k, c.z, mx);
-                lsh[0] = make_linop(hz / 2, a.k.lin_a, a.k.lin_b, a.k.w2, a.k.invN, a.k.log2N);
-                ((double *)(lsh + 1))[0] = hz;
-            }
-            ctx.sync();
-            n_hz = ((double *)(lsh + 1))[0];
-            lo = lsh[0];
-            n_hzv = 1;
-            ctx.sync();
-        } else if (act) {
-            lo = c.lin;
-        }
-        if (act) n_state = c_state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
-        if (lead) {
-            const unsigned long long *src = (const unsigned long long *)a.cin;
-            unsigned long long *dst = (unsigned long long *)a.cout;
-            for (int i = 0; i < (int)(sizeof(Ctrl) / 8); ++i) dst[i] = src[i];
-            Ctrl *n = a.cout;
-            n->state = n_state;
-            n->final_ = n_final;
-            n->pend0 = 0;
-            n->pendn = 0;
-            n->cap0 = n_cap0;
-            n->bound0 = 0;
-            n->exact0 = n_exact0;
-            n->hz_valid = n_hzv;
-            n->hz = n_hz;
-            n->nonconv = c.nonconv + add_nonconv;
-            n->n_ahead = c.n_ahead + add_ahead;
-            if (new_lin) n->lin = lo;
-        }
-        if (!act) return;
+        if (!row_ctrl(ctx, a, part, lo)) return;
     } else {
         lo = *a.lin;
     }
@@ -621,14 +696,20 @@ template <typename T> struct ColArgs {
     MkConst k;
     double *pmax, *pnum, *pden, *pnum0, *pden0;
     int npart;                // number of column workgroups (partials per array)
+    int N2;                   // row length when it is not 1 << log2N2 (mixed-radix rows), else 0
+    long long N;              // N1 * N2 in that case
 };
 
 // Thread geometry of the column kernel.  A workgroup owns C adjacent columns of one field
 // group (Manakov: one polarisation pair; the x row is handled by the first half of the
 // threads, the y row by the second half; NLSE: a single row, no split).
-template <typename T, int LG, class Ctx> struct ColGeom {
+// RAGGED: the row length N2 is not a power of two (mixed-radix rows); the last tile of a row is then
+// only partly filled, and its surplus threads (valid == false) load zeros and store nothing.
+template <typename T, int LG, class Ctx, bool RAGGED = false> struct ColGeom {
     PassPlan p;
     int half, pol, t, C, c, b, n2, N2;
+    bool valid;
+    long long N;
     long long rowbase;        // element offset of this thread's row
     long long pbase;          // element offset of the pair's row in P
     SSF_HD ColGeom(Ctx &ctx, const ColArgs<T> &a) {
@@ -639,8 +720,8 @@ template <typename T, int LG, class Ctx> struct ColGeom {
         C = half / p.tpf;
         c = t % C;
         b = t / C;
-        N2 = 1 << a.log2N2;
-        const int tpp = N2 / C;                      // tiles per field group
+        N2 = RAGGED ? a.N2 : 1 << a.log2N2;
+        const int tpp = RAGGED ? (N2 + C - 1) / C : N2 / C;      // tiles per field group
         const int grp = ctx.bid / tpp;
         int tile = ctx.bid - grp * tpp;
         // Workgroups go round-robin over the 8 XCDs (each with its own L2).  Neighbouring tiles share the
@@ -650,7 +731,8 @@ template <typename T, int LG, class Ctx> struct ColGeom {
         // is slower: -1.5 %, the block sits in one memory channel.)
         if (tpp % 8 == 0) tile = (tile & 7) * (tpp >> 3) + (tile >> 3);
         n2 = tile * C + c;
-        const long long N = 1ll << (a.log2N1 + a.log2N2);
+        valid = !RAGGED || n2 < N2;
+        N = RAGGED ? a.N : 1ll << (a.log2N1 + a.log2N2);
         rowbase = (long long)(grp * a.npol + pol) * N;
         pbase = (long long)grp * N;
     }
@@ -660,15 +742,29 @@ template <typename T, int LG, class Ctx> struct ColGeom {
     SSF_HD long long time_off(int idx) const {
         return (long long)rev_pos(p, reg_pos(p, p.npass - 1, b, idx)) * N2 + n2;
     }
+    // guarded accesses (the guard disappears when the row length is a power of two)
+    template <typename V> SSF_HD V ld(const V *ptr, long long i) const {
+        if (RAGGED && !valid) return V{};
+        return ptr[i];
+    }
+    template <typename V> SSF_HD void st(V *ptr, long long i, V x) const {
+        if (!RAGGED || valid) ptr[i] = x;
+    }
 };
 
 // inter-pass twiddle of the N = N1*N2 decomposition, applied on the frequency side of the
 // column kernel (which is HBM-bound and has VALU head-room; the row kernel is VALU-bound):
 // register q holds k1 = b + tpf*q of column n2  ->  v[q] *= cis(SIGN * 2 pi n2 k1 / N)
-template <int SIGN, typename T, class G> SSF_HD void global_twiddle(const G &g, int log2N, cx<T> *v) {
-    const long long N = 1ll << log2N;
-    const cx<double> w0 = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.b) & (N - 1)), log2N));
-    const cx<double> ws = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.p.tpf) & (N - 1)), log2N));
+template <int SIGN, bool RAGGED, typename T, class G> SSF_HD void global_twiddle(const G &g, int log2N, cx<T> *v) {
+    cx<double> w0, ws;
+    if (RAGGED) {                            // N = N1 * N2 with N2 not a power of two: the fraction is rounded once
+        w0 = cis2pi<double>((double)SIGN * ((double)(((long long)g.n2 * g.b) % g.N) / (double)g.N));
+        ws = cis2pi<double>((double)SIGN * ((double)(((long long)g.n2 * g.p.tpf) % g.N) / (double)g.N));
+    } else {
+        const long long N = 1ll << log2N;
+        w0 = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.b) & (N - 1)), log2N));
+        ws = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.p.tpf) & (N - 1)), log2N));
+    }
     cx<double> w[16];                        // (double tree, rounded once: see tw_powers)
     powers16(ws, w);
 #pragma unroll
@@ -735,7 +831,7 @@ SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T>
     for (int idx = 0; idx < 16; ++idx) {
         const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
         const T pw = ax + ay;
-        if (g.pol == 0) Pbuf[g.pbase + g.time_off(idx)] = pw;
+        if (g.pol == 0) g.st(Pbuf, g.pbase + g.time_off(idx), pw);
         const T phi = c8g * (pw + ax + ay) / (T)2;
         m = (double)phi > m ? (double)phi : m;
     }
@@ -775,15 +871,15 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     for (int j = 0; j < 8; ++j) {
         const long long t = own_time_off(g, j);
         const T ax = g.pol ? noth[j] : nown[j], ay = g.pol ? nown[j] : noth[j];
-        const T pw = Pbuf[g.pbase + t];
+        const T pw = g.ld(Pbuf, g.pbase + t);
         pch_sum += (double)pw;                               // sum |E(step start)|^2 of the owned samples (lim_0 bound)
         const T ang = shz * (c8g * (pw + ax + ay) / (T)2);
-        const T prev = first ? shz * (c8g * (pw + pw) / (T)2) : a.Theta[g.pbase + t];
+        const T prev = first ? shz * (c8g * (pw + pw) / (T)2) : g.ld(a.Theta, g.pbase + t);
         // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2)
         const double s = sin_half_angle((double)ang - (double)prev);
         down[j] = (T)(4.0 * s * s);
         rown[j] = cis_t<T>(ang);
-        a.Theta[g.pbase + t] = ang;                          // read and written by the owner only
+        g.st(a.Theta, g.pbase + t, ang);                          // read and written by the owner only
         shC[(size_t)own_idx(g, j) * g.half + g.t] = rown[j];
         shD[(size_t)own_idx(g, j) * g.half + g.t] = down[j];
     }
@@ -792,7 +888,7 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     // the partners swap their halves (any earlier and 64 more registers are live through the phase
     // loop: 68 B/lane of scratch, measured as +5 MB of HBM writes per launch)
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) v[idx] = a.Ehd[g.rowbase + g.time_off(idx)];
+    for (int idx = 0; idx < 16; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
     ctx.sync();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -811,7 +907,7 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
 }
 
 // MODE is one of CM_*; the Manakov mode picks its stage from the Ctrl state.
-template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
+template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
     constexpr bool kMk = MODE == CM_MK;
     // ---- what does this launch do? ------------------------------------------------------
     bool do_inv = false, do_fwd = false;
@@ -915,7 +1011,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
         do_fwd = MODE == CM_NLSE_STEP || MODE == CM_NLSE_FIRST || MODE == CM_PLAIN_FWD;
     }
 
-    ColGeom<T, LG, Ctx> g(ctx, a);
+    ColGeom<T, LG, Ctx, RAGGED> g(ctx, a);
     const PassPlan &p = g.p;
     cx<T> *lds = (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_slots_per_fft(p.L);
     cx<T> v[16];
@@ -926,7 +1022,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     if (kMk) {
         Tcur = c.cur ? a.T1 : a.T0;                  // field at the step start
         Tnew = c.cur ? a.T0 : a.T1;                  // receives the field at the step end
-        const long long psz = (1ll << (a.log2N1 + a.log2N2)) * a.ngroups;
+        const long long psz = g.N * a.ngroups;
         Pcur = a.P + (c.pcur ? psz : 0);
         Palt = a.P + (c.pcur ? 0 : psz);
     }
@@ -934,14 +1030,14 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     // ---- inverse column transform: G -> time samples in registers -------------------------
     if (do_inv) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = a.G[g.rowbase + g.freq_off(q)];
+        for (int q = 0; q < 16; ++q) v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
         ctx.mark(1);
-        global_twiddle<+1>(g, a.log2N1 + a.log2N2, v);
+        global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         fft_dif<+1>(ctx, p, g.b, v, lds);
         ctx.mark(2);
     } else if (!(kMk && op == 3)) {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) v[idx] = Tcur[g.rowbase + g.time_off(idx)];
+        for (int idx = 0; idx < 16; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
     }
 
     // ---- time-domain work ---------------------------------------------------------------
@@ -950,7 +1046,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
         for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * cis_t<T>(a.g_hz * norm2(v[idx]));
     } else if (MODE == CM_NLSE_LAST || MODE == CM_PLAIN_INV) {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) a.T0[g.rowbase + g.time_off(idx)] = v[idx];
+        for (int idx = 0; idx < 16; ++idx) g.st(a.T0, g.rowbase + g.time_off(idx), v[idx]);
     } else if (kMk) {
         const T shz = (T)(a.k.sgn * c.hz), c8g = (T)a.k.c8g;
         cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));
@@ -960,14 +1056,14 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
             T ang[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const T pw = Pcur[g.pbase + own_time_off(g, j)];
+                const T pw = g.ld(Pcur, g.pbase + own_time_off(g, j));
                 ang[j] = shz * (c8g * (pw + pw) / (T)2);
             }
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) {
                 const long long t = g.time_off(idx);
-                if (op == 1) a.Ehd[g.rowbase + t] = v[idx];
-                else v[idx] = a.Ehd[g.rowbase + t];
+                if (op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
+                else v[idx] = g.ld(a.Ehd, g.rowbase + t);
             }
             cx<T> rot[16];
             ctx.sync();                              // inverse transform's LDS reads are done
@@ -981,7 +1077,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
 #pragma unroll
                 for (int idx = 0; idx < 16; ++idx) {
                     if (exact0 || idx == 0) {        // (bound: one register in sixteen = one cache line in sixteen)
-                        const cx<T> e = Tcur[g.rowbase + g.time_off(idx)];
+                        const cx<T> e = g.ld(Tcur, g.rowbase + g.time_off(idx));
                         const double dr = (double)v[idx].re - (double)e.re, di = (double)v[idx].im - (double)e.im;
                         n0 += dr * dr + di * di;
                         d0 += (double)e.re * e.re + (double)e.im * e.im;
@@ -990,7 +1086,7 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
             }
             if (final_) {                            // the field after this step (channels.py:438-439)
 #pragma unroll
-                for (int idx = 0; idx < 16; ++idx) Tnew[g.rowbase + g.time_off(idx)] = v[idx];
+                for (int idx = 0; idx < 16; ++idx) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
             } else {
                 mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
                 if (!exact0) d0 = psum;              // exact denominator of the bound: sum Pch over the tile
@@ -1020,10 +1116,10 @@ template <typename T, int LG, int MODE, class Ctx> SSF_HD void col_body(Ctx &ctx
     if (do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
         fft_dit<-1>(ctx, p, g.b, v, lds);
-        global_twiddle<-1>(g, a.log2N1 + a.log2N2, v);
+        global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a.G[g.rowbase + g.freq_off(q)] = v[q];
+        for (int q = 0; q < 16; ++q) g.st(a.G, g.rowbase + g.freq_off(q), v[q]);
         ctx.mark(5);
         ctx.flush(do_inv ? 0 : 1);
     }

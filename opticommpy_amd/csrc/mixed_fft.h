@@ -1,0 +1,218 @@
+// mixed_fft.h -- in-LDS mixed-radix FFT of one row (lengths with factors 2, 3 and 5), used by the row
+// kernel for the lengths notebooks actually produce: N = SpS x Nsymbols = 2^a * 3^b * 5^c (e.g. 240 000 =
+// 2^7 * 1875).  The power of two goes into the column length (existing radix-2^n column kernel), the rest is
+// the row length L, transformed here.
+//
+// Same pairing as the radix-2^n kernels: the forward transform is decimation in frequency, in place,
+// natural order in -> digit-reversed order out; the inverse is decimation in time and consumes exactly that
+// order.  Nothing is ever reordered; the linear operator is applied to the digit-reversed spectrum through
+// mix_bin().  A pass of radix r over blocks of length M: butterfly (blk, j) gathers x[blk*M + j + (M/r) q],
+// q = 0..r-1, from LDS, transforms the r values in registers and puts them back in the same places --
+// butterflies of a pass touch disjoint positions, so only passes are separated by barriers.
+#pragma once
+#include "fused_core.h"
+
+namespace ssf {
+namespace fused {
+
+constexpr int kMixMaxPass = 6;
+struct MixPlan {
+    int L, npass;
+    int r[kMixMaxPass];       // radix of pass i
+    int M[kMixMaxPass];       // block length of pass i: L / (r[0] * ... * r[i-1])
+};
+
+// radices the butterflies below implement, tried largest first
+SSF_HD bool mix_make_plan(int L, MixPlan *p) {
+    const int cand[] = {25, 16, 15, 9, 8, 5, 4, 3, 2};
+    p->L = L;
+    p->npass = 0;
+    int rest = L;
+    while (rest > 1) {
+        int pick = 0;
+        for (int c : cand)
+            if (rest % c == 0) {
+                pick = c;
+                break;
+            }
+        if (!pick || p->npass == kMixMaxPass) return false;
+        p->r[p->npass] = pick;
+        p->M[p->npass] = rest;
+        rest /= pick;
+        ++p->npass;
+    }
+    return p->npass > 0;
+}
+
+// frequency bin held at LDS position pos after the forward transform (digit reversal)
+SSF_HD int mix_bin(const MixPlan &p, int pos) {
+    int k = 0, w = 1;
+    for (int i = 0; i < p.npass; ++i) {
+        const int s = p.M[i] / p.r[i];
+        const int q = pos / s;
+        pos -= q * s;
+        k += q * w;
+        w *= p.r[i];
+    }
+    return k;
+}
+
+// ---- small DFTs, natural order in and out, X[k] = sum_q x[q] cis(SIGN 2 pi q k / R) ------------------
+template <int SIGN, typename T> SSF_HD void dft3(cx<T> &a, cx<T> &b, cx<T> &c) {
+    const T h = (T)-0.5, s = (T)(SIGN * 0.86602540378443864676);
+    const cx<T> t = b + c, d = b - c;
+    const cx<T> m = mk<T>(a.re + h * t.re, a.im + h * t.im);
+    const cx<T> r = mk<T>(-s * d.im, s * d.re);                 // j s d
+    a = a + t;
+    b = m + r;
+    c = m - r;
+}
+template <int SIGN, typename T> SSF_HD void dft5(cx<T> *v) {
+    const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;
+    const T s1 = (T)(SIGN * 0.95105651629515357212), s2 = (T)(SIGN * 0.58778525229247312917);
+    const cx<T> t1 = v[1] + v[4], t2 = v[2] + v[3], d1 = v[1] - v[4], d2 = v[2] - v[3];
+    const cx<T> a = v[0];
+    const cx<T> m1 = mk<T>(a.re + c1 * t1.re + c2 * t2.re, a.im + c1 * t1.im + c2 * t2.im);
+    const cx<T> m2 = mk<T>(a.re + c2 * t1.re + c1 * t2.re, a.im + c2 * t1.im + c1 * t2.im);
+    const cx<T> r1 = mk<T>(-(s1 * d1.im + s2 * d2.im), s1 * d1.re + s2 * d2.re);       // j (s1 d1 + s2 d2)
+    const cx<T> r2 = mk<T>(-(s2 * d1.im - s1 * d2.im), s2 * d1.re - s1 * d2.re);       // j (s2 d1 - s1 d2)
+    v[0] = a + t1 + t2;
+    v[1] = m1 + r1;
+    v[4] = m1 - r1;
+    v[2] = m2 + r2;
+    v[3] = m2 - r2;
+}
+
+template <int SIGN, int R, typename T> SSF_HD void dft_prime(cx<T> *v) {
+    if constexpr (R == 2) dft2<SIGN>(v[0], v[1]);
+    else if constexpr (R == 3) dft3<SIGN>(v[0], v[1], v[2]);
+    else if constexpr (R == 4) dft4<SIGN>(v[0], v[1], v[2], v[3]);
+    else dft5<SIGN>(v);
+}
+
+// cos / sin (2 pi k / R) for the composite butterflies (literal constants: a device sincospi is not folded)
+template <int R> struct SmallW;
+template <> struct SmallW<9> {
+    static constexpr double c[9] = {1, 0.76604444311897803519, 0.173648177666930348805, -0.500000000000000000163, -0.939692620785908384103, -0.939692620785908384049, -0.499999999999999999702, 0.173648177666930348696, 0.766044443118978035298};
+    static constexpr double s[9] = {0, 0.642787609686539326327, 0.984807753012208059401, 0.866025403784438646678, 0.342020143325668732966, -0.342020143325668733047, -0.866025403784438646949, -0.984807753012208059401, -0.642787609686539326164};
+};
+template <> struct SmallW<15> {
+    static constexpr double c[15] = {1, 0.913545457642600895493, 0.669130606358858213772, 0.309016994374947424076, -0.104528463267653471498, -0.500000000000000000163, -0.809016994374947424104, -0.97814760073380563793, -0.978147600733805637875, -0.809016994374947423941, -0.499999999999999999702, -0.104528463267653471186, 0.309016994374947424185, 0.669130606358858213772, 0.913545457642600895601};
+    static constexpr double s[15] = {0, 0.406736643075800207781, 0.743144825477394235065, 0.951056516295153572111, 0.994521895368273336916, 0.866025403784438646678, 0.587785252292473129135, 0.207911690817759336992, -0.20791169081775933729, -0.587785252292473129406, -0.866025403784438646949, -0.99452189536827333697, -0.951056516295153572111, -0.743144825477394235065, -0.406736643075800207537};
+};
+template <> struct SmallW<25> {
+    static constexpr double c[25] = {1, 0.968583161128631119476, 0.876306680043863587301, 0.728968627421411523174, 0.535826794978996618279, 0.309016994374947424076, 0.062790519529313376117, -0.187381314585724630546, -0.425779291565072648802, -0.637423989748689710354, -0.809016994374947424104, -0.929776485888251403667, -0.992114701314477831018, -0.992114701314477831072, -0.929776485888251403667, -0.809016994374947423941, -0.637423989748689710246, -0.425779291565072648721, -0.187381314585724630125, 0.062790519529313375894, 0.309016994374947424185, 0.535826794978996618171, 0.728968627421411523282, 0.876306680043863587301, 0.968583161128631119476};
+    static constexpr double s[25] = {0, 0.24868988716485478823, 0.481753674101715274988, 0.684547105928688673728, 0.844327925502015078508, 0.951056516295153572111, 0.99802672842827156195, 0.982287250728688681085, 0.904827052466019527712, 0.770513242775789230653, 0.587785252292473129135, 0.368124552684677959063, 0.125333233564304245448, -0.12533323356430424534, -0.368124552684677959171, -0.587785252292473129406, -0.770513242775789230707, -0.904827052466019527766, -0.982287250728688681139, -0.99802672842827156195, -0.951056516295153572111, -0.844327925502015078617, -0.68454710592868867362, -0.481753674101715274988, -0.248689887164854788406};
+};
+
+// R = A * B (Cooley-Tukey in registers): B transforms of length A over x[b + B a], twiddle cis(2 pi b ka / R),
+// A transforms of length B; X[ka + A kb].  The twiddle angles are compile-time fractions after unrolling.
+template <int SIGN, int A, int B, typename T> SSF_HD void dft_ab(cx<T> *v) {
+    constexpr int R = A * B;
+    cx<T> y[R];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        cx<T> t[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) t[a] = v[b + B * a];
+        dft_prime<SIGN, A>(t);
+#pragma unroll
+        for (int ka = 0; ka < A; ++ka) {
+            if (b * ka == 0) {
+                y[ka * B + b] = t[ka];
+            } else {
+                const T c = (T)SmallW<R>::c[(b * ka) % R], s = (T)(SIGN * SmallW<R>::s[(b * ka) % R]);
+                y[ka * B + b] = t[ka] * mk<T>(c, s);
+            }
+        }
+    }
+#pragma unroll
+    for (int ka = 0; ka < A; ++ka) {
+        cx<T> t[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) t[b] = y[ka * B + b];
+        dft_prime<SIGN, B>(t);
+#pragma unroll
+        for (int kb = 0; kb < B; ++kb) v[ka + A * kb] = t[kb];
+    }
+}
+
+template <int SIGN, int R, typename T> SSF_HD void dft_small(cx<T> *v) {
+    if constexpr (R == 2 || R == 3 || R == 4 || R == 5) dft_prime<SIGN, R>(v);
+    else if constexpr (R == 8) dft8<SIGN>(v);
+    else if constexpr (R == 16) dft16<SIGN>(v);
+    else if constexpr (R == 9) dft_ab<SIGN, 3, 3>(v);
+    else if constexpr (R == 15) dft_ab<SIGN, 3, 5>(v);
+    else dft_ab<SIGN, 5, 5>(v);
+}
+
+// w[q] = cis(sign 2 pi j q / M), q = 0..R-1, evaluated in double (a chain of products from the base; see
+// tw_powers for why single precision does not build it in float)
+template <int R, typename T> SSF_HD void mix_twiddles(int sign, int j, int M, cx<T> *w) {
+    double c, s;
+    cis2pi_d((double)(sign * j) / (double)M, c, s);
+    const cx<double> w1 = mk<double>(c, s);
+    cx<double> p = mk<double>(1.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        w[q] = mk<T>((T)p.re, (T)p.im);
+        p = p * w1;
+    }
+}
+
+// one pass of radix R for this thread's butterflies; DIF: transform then twiddle, DIT: twiddle then transform
+template <int SIGN, int R, bool DIF, typename T, class Ctx>
+SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x) {
+    const int M = p.M[i], s = M / R, nbf = p.L / R;
+    for (int bf = t; bf < nbf; bf += nthreads) {
+        const int blk = bf / s, j = bf - blk * s;
+        cx<T> *base = x + blk * M + j;
+        cx<T> v[R], w[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = base[s * q];
+        if (s > 1) mix_twiddles<R>(SIGN, j, M, w);
+        if (DIF) {
+            dft_small<SIGN, R>(v);
+            if (s > 1) {
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = v[q] * w[q];
+            }
+        } else {
+            if (s > 1) {
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = v[q] * w[q];
+            }
+            dft_small<SIGN, R>(v);
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) base[s * q] = v[q];
+    }
+    ctx.sync();
+}
+
+template <int SIGN, bool DIF, typename T, class Ctx>
+SSF_HD void mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x) {
+    switch (p.r[i]) {
+    case 25: mix_pass<SIGN, 25, DIF>(ctx, p, i, t, nthreads, x); break;
+    case 16: mix_pass<SIGN, 16, DIF>(ctx, p, i, t, nthreads, x); break;
+    case 15: mix_pass<SIGN, 15, DIF>(ctx, p, i, t, nthreads, x); break;
+    case 9: mix_pass<SIGN, 9, DIF>(ctx, p, i, t, nthreads, x); break;
+    case 8: mix_pass<SIGN, 8, DIF>(ctx, p, i, t, nthreads, x); break;
+    case 5: mix_pass<SIGN, 5, DIF>(ctx, p, i, t, nthreads, x); break;
+    case 4: mix_pass<SIGN, 4, DIF>(ctx, p, i, t, nthreads, x); break;
+    case 3: mix_pass<SIGN, 3, DIF>(ctx, p, i, t, nthreads, x); break;
+    default: mix_pass<SIGN, 2, DIF>(ctx, p, i, t, nthreads, x); break;
+    }
+}
+
+// x (L values in LDS, all threads of the transform past a barrier): forward, natural -> digit-reversed
+template <int SIGN, typename T, class Ctx> SSF_HD void mix_dif(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x) {
+    for (int i = 0; i < p.npass; ++i) mix_pass_any<SIGN, true>(ctx, p, i, t, nthreads, x);
+}
+// inverse of mix_dif<-SIGN> (unscaled): digit-reversed -> natural
+template <int SIGN, typename T, class Ctx> SSF_HD void mix_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x) {
+    for (int i = p.npass - 1; i >= 0; --i) mix_pass_any<SIGN, false>(ctx, p, i, t, nthreads, x);
+}
+
+}  // namespace fused
+}  // namespace ssf

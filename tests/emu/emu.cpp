@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "fused_engine.h"
+#include "mixed_fft.h"
 #include "rx_pipeline.h"
 
 namespace {
@@ -154,12 +155,12 @@ struct EmuBackend {
         ++launches;
         using namespace ssf::fused;
         switch (a.mode) {
-        case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST>(c, a); }); break;
-        case CM_NLSE_STEP: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_STEP>(c, a); }); break;
-        case CM_NLSE_LAST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST>(c, a); }); break;
-        case CM_MK: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK>(c, a); }); break;
-        case CM_PLAIN_FWD: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD>(c, a); }); break;
-        default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV>(c, a); }); break;
+        case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST, false>(c, a); }); break;
+        case CM_NLSE_STEP: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_STEP, false>(c, a); }); break;
+        case CM_NLSE_LAST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST, false>(c, a); }); break;
+        case CM_MK: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false>(c, a); }); break;
+        case CM_PLAIN_FWD: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD, false>(c, a); }); break;
+        default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV, false>(c, a); }); break;
         }
     }
     template <typename T> void launch_amp(const ssf::fused::AmpArgs<T> &a, int grid, int block) {
@@ -310,6 +311,30 @@ int emu_delay(int64_t N, double delay, double Fs, const void *in, void *out) {
     ssf::rx::RxCore<EmuBackend> core(be);
     return core.delay(N, delay, Fs, in, out);
 }
+// standalone mixed-radix transform of `rows` rows of length L (complex128): dir < 0 forward (output in
+// natural order via mix_bin), dir > 0: forward then inverse (round trip, unscaled: x * L)
+int emu_mixed_fft(int L, int rows, int dir, const void *in, void *out) {
+    using namespace ssf::fused;
+    using Cc = cx<double>;
+    MixPlan p;
+    if (!mix_make_plan(L, &p)) return SSF_ERR_UNSUPPORTED;
+    const Cc *src = (const Cc *)in;
+    Cc *dst = (Cc *)out;
+    run_grid(rows, 128, (size_t)L * sizeof(Cc), [&](EmuCtx &c) {
+        Cc *x = (Cc *)c.lds;
+        for (int i = c.tid; i < L; i += c.nthreads) x[i] = src[(size_t)c.bid * L + i];
+        c.sync();
+        mix_dif<-1>(c, p, c.tid, c.nthreads, x);
+        if (dir > 0) {
+            mix_dit<+1>(c, p, c.tid, c.nthreads, x);
+            for (int i = c.tid; i < L; i += c.nthreads) dst[(size_t)c.bid * L + i] = x[i];
+        } else {
+            for (int i = c.tid; i < L; i += c.nthreads) dst[(size_t)c.bid * L + mix_bin(p, i)] = x[i];
+        }
+    });
+    return 0;
+}
+
 int emu_wdm_tx(const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
                const double *deltaF, void *out, double *power_out) {
     EmuBackend be;
