@@ -64,6 +64,16 @@ __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs
     SSF_DEV_CTX(1);
     col_body<T, LG, MODE, false>(ctx, a);
 }
+// row lengths with factors 3 / 5 (mixed_fft.h): mixed-radix row stage, column stage with ragged last tiles
+template <typename T> __global__ void __launch_bounds__(256, 2) k_row_mixed(const RowArgs<T> a) {
+    SSF_DEV_CTX(0);
+    row_mixed_body<T>(ctx, a);
+}
+template <typename T, int LG, int MODE>
+__global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const ColArgs<T> a) {
+    SSF_DEV_CTX(1);
+    col_body<T, LG, MODE, true>(ctx, a);
+}
 template <typename T> __global__ void __launch_bounds__(256) k_amp(const AmpArgs<T> a) {
     SSF_DEV_CTX(1);
     amp_body<T>(ctx, a);
@@ -106,6 +116,23 @@ template <typename T, int LG> ColFn<T> pick_col_mode(int mode) {
     case CM_MK: return k_col<T, LG, CM_MK>;
     case CM_PLAIN_FWD: return k_col<T, LG, CM_PLAIN_FWD>;
     default: return k_col<T, LG, CM_PLAIN_INV>;
+    }
+}
+template <typename T> ColFn<T> pick_col_ragged(int lg1, int mode) {
+    if (mode == CM_MK) {                      // the Manakov stage is worth its specialised lengths
+        switch (lg1) {
+        case 7: return k_col_ragged<T, 7, CM_MK>;
+        case 8: return k_col_ragged<T, 8, CM_MK>;
+        case 9: return k_col_ragged<T, 9, CM_MK>;
+        default: return k_col_ragged<T, 0, CM_MK>;
+        }
+    }
+    switch (mode) {
+    case CM_NLSE_FIRST: return k_col_ragged<T, 0, CM_NLSE_FIRST>;
+    case CM_NLSE_STEP: return k_col_ragged<T, 0, CM_NLSE_STEP>;
+    case CM_NLSE_LAST: return k_col_ragged<T, 0, CM_NLSE_LAST>;
+    case CM_PLAIN_FWD: return k_col_ragged<T, 0, CM_PLAIN_FWD>;
+    default: return k_col_ragged<T, 0, CM_PLAIN_INV>;
     }
 }
 template <typename T> ColFn<T> pick_col(int lg1, int mode) {
@@ -225,7 +252,7 @@ struct HipBackend {
         col_lds_max = col_lds;
     }
     template <typename T> void launch_row(const RowArgs<T> &a, int grid, int block, size_t lds) {
-        RowFn<T> f = pick_row<T>(a.log2N2, block, row_occ);
+        RowFn<T> f = a.mixed ? (RowFn<T>)k_row_mixed<T> : pick_row<T>(a.log2N2, block, row_occ);
         arm((const void *)f);
         stamp_begin(0);
         f<<<grid, block, lds, pl->stream>>>(a);
@@ -233,7 +260,7 @@ struct HipBackend {
         chk(hipGetLastError(), "launch k_row");
     }
     template <typename T> void launch_col(const ColArgs<T> &a, int grid, int block, size_t lds) {
-        ColFn<T> f = pick_col<T>(a.log2N1, a.mode);
+        ColFn<T> f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
         arm((const void *)f);
         stamp_begin(a.mode == CM_MK ? 1 : 3);
         f<<<grid, block, lds, pl->stream>>>(a);
@@ -370,6 +397,10 @@ int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int
 }
 
 bool fused_supports(int64_t N, int nrows, int precision) {
+    if (N >= 256 && (N & (N - 1)) && nrows >= 1) {          // 2^a 3^b 5^c: mixed-radix rows
+        int l1, n2;
+        return fused::choose_mixed_split(N, precision, &l1, &n2);
+    }
     if (N < 256 || (N & (N - 1)) || nrows < 1) return false;
     int l = 0;
     while ((1ll << l) < N) ++l;

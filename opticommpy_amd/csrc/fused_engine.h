@@ -49,6 +49,34 @@ inline bool choose_split(int log2N, int precision, Split *s) {
     return true;
 }
 
+// Lengths with factors 3 and 5 (N = 2^a * m, m odd and 5-smooth -- notebook lengths are SpS x Nsymbols):
+// the column length stays a power of two (2^7 .. 2^10 out of the 2^a), the rest is the row length, transformed
+// by the mixed-radix row kernel (mixed_fft.h).  Rows of up to 4096 values (16 per thread, one row per workgroup).
+inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
+    (void)precision;
+    if (N < 1 || (N & (N - 1)) == 0) return false;
+    int a = 0;
+    int64_t m = N;
+    while (m % 2 == 0) {
+        m /= 2;
+        ++a;
+    }
+    int64_t rest = m;
+    for (int q : {3, 5})
+        while (rest % q == 0) rest /= q;
+    if (rest != 1 || a < 7) return false;
+    for (int l = std::min(a, 9); l <= std::min(a, 10); ++l) {      // prefer the specialised column lengths (<= 2^9)
+        const int64_t n2 = N >> l;
+        MixPlan mp;
+        if (n2 >= 64 && n2 <= 4096 && mix_make_plan((int)n2, &mp)) {
+            *l1 = l;
+            *N2 = (int)n2;
+            return true;
+        }
+    }
+    return false;
+}
+
 template <typename T, class Backend> class FusedCore {
   public:
     using C = cx<T>;
@@ -56,6 +84,7 @@ template <typename T, class Backend> class FusedCore {
     int64_t N;
     int nrows, log2N;
     Split sp;
+    int N2mix = 0;               // > 0: row length of the mixed-radix path (then sp.l2 is unused)
     size_t field_bytes;
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
     T *P = nullptr, *Theta = nullptr;
@@ -78,19 +107,24 @@ template <typename T, class Backend> class FusedCore {
     FusedCore(Backend &b, int64_t N_, int nrows_, int precision) : be(b), N(N_), nrows(nrows_) {
         log2N = 0;
         while ((1ll << log2N) < N) ++log2N;
-        choose_split(log2N, precision, &sp);
+        if ((N & (N - 1)) == 0) {
+            choose_split(log2N, precision, &sp);
+        } else {
+            choose_mixed_split(N, precision, &sp.l1, &N2mix);
+            sp.l2 = 0;
+        }
         field_bytes = sizeof(C) * (size_t)N * (size_t)nrows;
     }
 
     // npol = 2: a workgroup carries both rows of a polarisation pair (x threads | y threads)
     void col_geometry(int groups, int npol, int *block, int *grid, size_t *lds) const {
-        const int tpf = (1 << sp.l1) / 16, N2 = 1 << sp.l2;
+        const int tpf = (1 << sp.l1) / 16, N2 = N2mix ? N2mix : 1 << sp.l2;
         int half = 256;
         if (const char *e = std::getenv("SSF_COL_HALF")) {        // tuning knob: threads per polarisation row
             const int h = std::atoi(e);
             if (h >= tpf && h <= 512 && (h & (h - 1)) == 0) half = h;
         }
-        if (half / tpf > N2) half = N2 * tpf;
+        while (half / tpf > N2 && half > tpf) half >>= 1;    // (a power of two also when N2 is not)
         // a grid that only just covers the 256 CUs leaves every CU with one lock-stepped workgroup:
         // prefer two smaller independent ones (measured +3 % at N = 2^20) while rows stay >= 128 B wide
         while (!std::getenv("SSF_COL_HALF") && (long long)groups * (N2 / (half / tpf)) < 512 &&
@@ -98,19 +132,25 @@ template <typename T, class Backend> class FusedCore {
             half >>= 1;
         const int Cc = half / tpf;
         *block = half * npol;
-        *grid = groups * (N2 / Cc);
+        *grid = groups * ((N2 + Cc - 1) / Cc);
         *lds = std::max((size_t)npol * Cc * lds_slots_per_fft(1 << sp.l1) * sizeof(C), (size_t)half * npol * 16 + 1024);
     }
 
     int init() {
         if (const char *e = std::getenv("SSF_LIM0_BOUND")) lim0_bound = std::atoi(e) != 0;
-        const int tpf2 = (1 << sp.l2) / 16;
         const int64_t nfft = (int64_t)nrows << sp.l1;
-        int fpw = tpf2 >= 256 ? 1 : 256 / tpf2;               // row transforms per workgroup
-        while (nfft % fpw) fpw >>= 1;                          // (nrows need not be a power of two)
-        row_block = fpw * tpf2;
-        row_grid = (int)(nfft / fpw);
-        row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 16 + 2048);
+        if (N2mix) {                                           // one row per workgroup, the row in LDS after 4 KiB of scratch
+            row_block = 256;
+            row_grid = (int)nfft;
+            row_lds = 4096 + (size_t)N2mix * sizeof(C);
+        } else {
+            const int tpf2 = (1 << sp.l2) / 16;
+            int fpw = tpf2 >= 256 ? 1 : 256 / tpf2;           // row transforms per workgroup
+            while (nfft % fpw) fpw >>= 1;                      // (nrows need not be a power of two)
+            row_block = fpw * tpf2;
+            row_grid = (int)(nfft / fpw);
+            row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 16 + 2048);
+        }
         col_geometry(std::max(nrows / 2, 1), 2, &col_block_mk, &col_grid_mk, &col_lds_mk);
         col_geometry(nrows, 1, &col_block_1, &col_grid_1, &col_lds_1);
         npart_max = std::max(col_grid_mk, col_grid_1);
@@ -167,6 +207,9 @@ template <typename T, class Backend> class FusedCore {
         a.log2N1 = sp.l1;
         a.log2N2 = sp.l2;
         a.nfft = (int)((int64_t)nrows << sp.l1);
+        a.N2 = N2mix ? N2mix : 1 << sp.l2;
+        a.N = N;
+        a.mixed = N2mix ? 1 : 0;
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {
@@ -179,6 +222,8 @@ template <typename T, class Backend> class FusedCore {
         a.Theta = Theta;
         a.log2N1 = sp.l1;
         a.log2N2 = sp.l2;
+        a.N2 = N2mix;
+        a.N = N;
         a.npol = npol;
         a.mode = mode;
         a.ngroups = std::max(nrows / 2, 1);

@@ -400,6 +400,7 @@ template <typename T> struct RowArgs {
     int npart;
     int N2;                   // row length (mixed-radix rows: any 2^a 3^b 5^c; radix-2^n rows: 1 << log2N2)
     long long N;              // N1 * N2
+    int mixed;                // 1: row_mixed_body (N2 has factors 3 / 5)
 };
 
 // linear operator for the 16 registers of a last-radix-16 butterfly: bins k0 + (N/16) q

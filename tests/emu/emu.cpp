@@ -149,18 +149,37 @@ struct EmuBackend {
     double time_end() { return 0.0; }
     template <typename T> void launch_row(const ssf::fused::RowArgs<T> &a, int grid, int block, size_t lds) {
         ++launches;
-        run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
+        if (a.mixed) run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_mixed_body<T>(c, a); });
+        else run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
     }
     template <typename T> void launch_col(const ssf::fused::ColArgs<T> &a, int grid, int block, size_t lds) {
         ++launches;
         using namespace ssf::fused;
         switch (a.mode) {
-        case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST, false>(c, a); }); break;
-        case CM_NLSE_STEP: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_STEP, false>(c, a); }); break;
-        case CM_NLSE_LAST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST, false>(c, a); }); break;
-        case CM_MK: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false>(c, a); }); break;
-        case CM_PLAIN_FWD: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD, false>(c, a); }); break;
-        default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV, false>(c, a); }); break;
+        case CM_NLSE_FIRST:
+            if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST, true>(c, a); });
+            else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST, false>(c, a); });
+            break;
+        case CM_NLSE_STEP:
+            if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_STEP, true>(c, a); });
+            else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_STEP, false>(c, a); });
+            break;
+        case CM_NLSE_LAST:
+            if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST, true>(c, a); });
+            else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST, false>(c, a); });
+            break;
+        case CM_MK:
+            if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, true>(c, a); });
+            else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false>(c, a); });
+            break;
+        case CM_PLAIN_FWD:
+            if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD, true>(c, a); });
+            else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD, false>(c, a); });
+            break;
+        default:
+            if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV, true>(c, a); });
+            else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV, false>(c, a); });
+            break;
         }
     }
     template <typename T> void launch_amp(const ssf::fused::AmpArgs<T> &a, int grid, int block) {
@@ -234,6 +253,10 @@ int lin_t(int64_t N, int nrows, int prec, double Fs, double Fc, double alpha, do
 extern "C" {
 
 int emu_supported(int64_t N, int precision) {
+    if (N >= 2 && (N & (N - 1))) {
+        int l1, n2;
+        return ssf::fused::choose_mixed_split(N, precision, &l1, &n2) ? 1 : 0;
+    }
     if (N < 2 || (N & (N - 1))) return 0;
     int l = 0;
     while ((1ll << l) < N) ++l;

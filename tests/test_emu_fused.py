@@ -309,3 +309,59 @@ def test_edge_cases_on_emulated_kernels(case):
         assert list(info["iters"]) == tr["iters"]
     finally:
         logging.disable(logging.NOTSET)
+
+
+# ------------------------------------------------------------------ lengths with factors 3 and 5
+@pytest.mark.parametrize("N,adaptive,K", [(9600, False, 1), (9600, True, 2), (48000, False, 1), (32000, True, 1)])
+def test_mixed_radix_rows_vs_oracle(N, adaptive, K):
+    """N = 2^a * m (m odd, 5-smooth): power-of-two column transforms with ragged tiles, mixed-radix row
+    transforms in LDS (mixed_fft.h).  9600 = 2^7 * 75, 48000 = 2^7 * 375, 32000 = 2^8 * 125."""
+    assert eb.load().emu_supported(N, 1)
+    E = synth_field(N, 2 * K, 3, 8.0)
+    cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5, prgsBar=False,
+               Ltotal=1.3, Lspan=0.65, hz=0.25, nlprMethod=adaptive, maxNlinPhaseRot=2e-2, amp="ideal", saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+    out, info = eb.run("manakovSSF", E, cfg)
+    assert rel_l2(out.T, ref) <= TOL_C128 and list(info["iters"]) == tr["iters"]
+    np.testing.assert_allclose(info["hz"], tr["hz"], rtol=1e-9)
+    out2, info2 = eb.run("manakovSSF", E, cfg, trace=False)
+    assert np.array_equal(out, out2) and info2["iterations"] == info["iterations"]
+
+
+def test_mixed_radix_other_entry_points():
+    N = 9600
+    E = synth_field(N, 2, 5, 6.0)
+    cfg = dict(func="ssfm", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, prgsBar=False, Ltotal=2.0, Lspan=1.0, hz=0.25,
+               amp="ideal", saveSpanN=[])
+    s = E[:, 0].copy()
+    out, _ = eb.run("ssfm", s, cfg)
+    assert rel_l2(out.reshape(-1), orc.ssfm(s, make_param(orc.parameters, cfg))) <= TOL_C128
+    mk = dict(func="manakovDBP", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5, prgsBar=False,
+              Ltotal=2.0, Lspan=1.0, hz=0.5, nlprMethod=False, amp="ideal", saveSpanN=[])
+    out, info = eb.run("manakovDBP", E, mk)
+    tr = {}
+    ref = orc.manakovDBP(E, make_param(orc.parameters, mk), trace=tr)
+    assert rel_l2(out.T, ref) <= TOL_C128 and list(info["iters"]) == tr["iters"]
+    lp = orc.parameters()
+    lp.Fs, lp.L, lp.alpha, lp.D, lp.Fc = 512e9, 3.0, 0.2, 16, 193.1e12
+    assert rel_l2(eb.linear_channel(E, 512e9, 193.1e12, 0.2, 16, 3.0), orc.linearFiberChannel(E, lp)) < 1e-13
+    c64 = dict(mk, func="manakovSSF", prec="complex64")
+    out, _ = eb.run("manakovSSF", E.astype(np.complex64), c64)
+    ref = orc.manakovSSF(E, make_param(orc.parameters, dict(mk, func="manakovSSF")))
+    assert rel_l2(out.T.astype(np.complex128), ref) <= 5e-4
+
+
+def test_mixed_radix_transform_lengths():
+    """The in-LDS transform alone: forward (through the digit-reversal map) and round trip against numpy."""
+    import ctypes as C
+    e = eb.load()
+    e.emu_mixed_fft.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(0)
+    for L in (2, 3, 5, 9, 15, 16, 25, 27, 45, 75, 125, 128, 225, 375, 405, 625, 1000, 1125, 1875, 2025, 3125, 3375, 3750):
+        x = rng.normal(size=(2, L)) + 1j * rng.normal(size=(2, L))
+        y, z = np.empty_like(x), np.empty_like(x)
+        assert e.emu_mixed_fft(L, 2, -1, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)) == 0
+        assert e.emu_mixed_fft(L, 2, +1, x.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p)) == 0
+        assert rel_l2(y, np.fft.fft(x, axis=1)) < 1e-14 and rel_l2(z / L, x) < 1e-14, L
+    assert e.emu_mixed_fft(7, 1, -1, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)) == -6
