@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs
     col_body<T, LG, MODE, false>(ctx, a);
 }
 // row lengths with factors 3 / 5 (mixed_fft.h): mixed-radix row stage, column stage with ragged last tiles
-template <typename T> __global__ void __launch_bounds__(256, 2) k_row_mixed(const RowArgs<T> a) {
+template <typename T> __global__ void __launch_bounds__(1024) k_row_mixed(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
     row_mixed_body<T>(ctx, a);
 }

@@ -141,6 +141,8 @@ template <typename T, class Backend> class FusedCore {
         const int64_t nfft = (int64_t)nrows << sp.l1;
         if (N2mix) {                                           // one row per workgroup, the row in LDS after 4 KiB of scratch
             row_block = 256;
+            if (const char *e = std::getenv("SSF_MIX_BLOCK")) row_block = std::max(64, std::min(1024, std::atoi(e)));
+            while (16 * row_block < N2mix) row_block *= 2;     // 16 values per thread at most
             row_grid = (int)nfft;
             row_lds = 4096 + (size_t)N2mix * sizeof(C);
         } else {
@@ -210,6 +212,7 @@ template <typename T, class Backend> class FusedCore {
         a.N2 = N2mix ? N2mix : 1 << sp.l2;
         a.N = N;
         a.mixed = N2mix ? 1 : 0;
+        if (N2mix) mix_make_plan(N2mix, &a.plan);
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {

@@ -401,6 +401,7 @@ template <typename T> struct RowArgs {
     int N2;                   // row length (mixed-radix rows: any 2^a 3^b 5^c; radix-2^n rows: 1 << log2N2)
     long long N;              // N1 * N2
     int mixed;                // 1: row_mixed_body (N2 has factors 3 / 5)
+    MixPlan plan;             // its pass plan
 };
 
 // linear operator for the 16 registers of a last-radix-16 butterfly: bins k0 + (N/16) q
@@ -557,8 +558,7 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
     constexpr int kMaxPerThread = 16;                      // L <= 16 * nthreads
     cx<T> *x = (cx<T> *)(ctx.lds + 4096);
     const int L = a.N2, T_ = ctx.nthreads;
-    MixPlan p;
-    mix_make_plan(L, &p);
+    const MixPlan &p = a.plan;                             // (host-made: indexed from the kernel arguments, not from scratch)
     const long long rr = ctx.bid;                          // one row per workgroup
     cx<T> *g = a.G + rr * L;
     LinOp lo;
@@ -580,7 +580,7 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
 #pragma unroll
     for (int m = 0; m < kMaxPerThread; ++m) {
         const int i = ctx.tid + T_ * m;
-        if (i < L) v[m] = g[i];
+        v[m] = i < L ? g[i] : mk<T>((T)0, (T)0);
     }
     if (a.use_ctrl) {
         ctx.issue_fence();

@@ -105,11 +105,12 @@ template <> struct SmallW<25> {
     static constexpr double s[25] = {0, 0.24868988716485478823, 0.481753674101715274988, 0.684547105928688673728, 0.844327925502015078508, 0.951056516295153572111, 0.99802672842827156195, 0.982287250728688681085, 0.904827052466019527712, 0.770513242775789230653, 0.587785252292473129135, 0.368124552684677959063, 0.125333233564304245448, -0.12533323356430424534, -0.368124552684677959171, -0.587785252292473129406, -0.770513242775789230707, -0.904827052466019527766, -0.982287250728688681139, -0.99802672842827156195, -0.951056516295153572111, -0.844327925502015078617, -0.68454710592868867362, -0.481753674101715274988, -0.248689887164854788406};
 };
 
-// R = A * B (Cooley-Tukey in registers): B transforms of length A over x[b + B a], twiddle cis(2 pi b ka / R),
-// A transforms of length B; X[ka + A kb].  The twiddle angles are compile-time fractions after unrolling.
+// R = A * B (Cooley-Tukey in registers, in place): B transforms of length A over x[b + B a], twiddle
+// cis(2 pi b ka / R), A transforms of length B over the slots b + B ka.  Slot kb + B ka then holds X[ka + A kb]:
+// the result is left in that permuted order (dft_slot_bin) and the caller stores each slot where it belongs,
+// which keeps the butterfly at R live values instead of 2 R.
 template <int SIGN, int A, int B, typename T> SSF_HD void dft_ab(cx<T> *v) {
     constexpr int R = A * B;
-    cx<T> y[R];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         cx<T> t[A];
@@ -119,22 +120,30 @@ template <int SIGN, int A, int B, typename T> SSF_HD void dft_ab(cx<T> *v) {
 #pragma unroll
         for (int ka = 0; ka < A; ++ka) {
             if (b * ka == 0) {
-                y[ka * B + b] = t[ka];
+                v[b + B * ka] = t[ka];
             } else {
                 const T c = (T)SmallW<R>::c[(b * ka) % R], s = (T)(SIGN * SmallW<R>::s[(b * ka) % R]);
-                y[ka * B + b] = t[ka] * mk<T>(c, s);
+                v[b + B * ka] = t[ka] * mk<T>(c, s);
             }
         }
     }
 #pragma unroll
-    for (int ka = 0; ka < A; ++ka) {
-        cx<T> t[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b) t[b] = y[ka * B + b];
-        dft_prime<SIGN, B>(t);
-#pragma unroll
-        for (int kb = 0; kb < B; ++kb) v[ka + A * kb] = t[kb];
-    }
+    for (int ka = 0; ka < A; ++ka) dft_prime<SIGN, B>(v + B * ka);
+}
+// frequency index of register slot s after dft_small<R>
+template <int R> SSF_HD constexpr int dft_slot_bin(int s) {
+    if (R == 9) return s / 3 + 3 * (s % 3);
+    if (R == 15) return s / 5 + 3 * (s % 5);
+    if (R == 25) return s / 5 + 5 * (s % 5);
+    return s;
+}
+
+// ... and the slot that holds bin k
+template <int R> SSF_HD constexpr int dft_bin_slot(int k) {
+    if (R == 9) return k / 3 + 3 * (k % 3);
+    if (R == 15) return k / 3 + 5 * (k % 3);
+    if (R == 25) return k / 5 + 5 * (k % 5);
+    return k;
 }
 
 template <int SIGN, int R, typename T> SSF_HD void dft_small(cx<T> *v) {
@@ -146,46 +155,44 @@ template <int SIGN, int R, typename T> SSF_HD void dft_small(cx<T> *v) {
     else dft_ab<SIGN, 5, 5>(v);
 }
 
-// w[q] = cis(sign 2 pi j q / M), q = 0..R-1, evaluated in double (a chain of products from the base; see
-// tw_powers for why single precision does not build it in float)
-template <int R, typename T> SSF_HD void mix_twiddles(int sign, int j, int M, cx<T> *w) {
-    double c, s;
-    cis2pi_d((double)(sign * j) / (double)M, c, s);
-    const cx<double> w1 = mk<double>(c, s);
-    cx<double> p = mk<double>(1.0, 0.0);
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-        w[q] = mk<T>((T)p.re, (T)p.im);
-        p = p * w1;
-    }
-}
-
-// one pass of radix R for this thread's butterflies; DIF: transform then twiddle, DIT: twiddle then transform
+// one pass of radix R for this thread's butterflies; DIF: transform then twiddle, DIT: twiddle then transform.
+// The twiddles cis(sign 2 pi j q / M) are a chain of products from the base, evaluated in double (see
+// tw_powers for why single precision does not build it in float) and consumed as they are produced.
 template <int SIGN, int R, bool DIF, typename T, class Ctx>
 SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x) {
     const int M = p.M[i], s = M / R, nbf = p.L / R;
     for (int bf = t; bf < nbf; bf += nthreads) {
         const int blk = bf / s, j = bf - blk * s;
         cx<T> *base = x + blk * M + j;
-        cx<T> v[R], w[R];
+        cx<T> v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = base[s * q];
-        if (s > 1) mix_twiddles<R>(SIGN, j, M, w);
-        if (DIF) {
-            dft_small<SIGN, R>(v);
-            if (s > 1) {
+        cx<double> w1 = mk<double>(1.0, 0.0);
+        if (s > 1) {
+            double c, sn;
+            cis2pi_d((double)(SIGN * j) / (double)M, c, sn);
+            w1 = mk<double>(c, sn);
+        }
+        if (!DIF && s > 1) {                         // inputs are in natural order q
+            cx<double> pw = w1;
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = v[q] * w[q];
+            for (int q = 1; q < R; ++q) {
+                v[q] = v[q] * mk<T>((T)pw.re, (T)pw.im);
+                pw = pw * w1;
             }
-        } else {
-            if (s > 1) {
+        }
+        dft_small<SIGN, R>(v);
+        if (DIF && s > 1) {                          // outputs sit in slot order: walk the bins, pick the slot
+            cx<double> pw = w1;
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = v[q] * w[q];
+            for (int kq = 1; kq < R; ++kq) {
+                const int slot = dft_bin_slot<R>(kq);          // compile-time after unrolling
+                v[slot] = v[slot] * mk<T>((T)pw.re, (T)pw.im);
+                pw = pw * w1;
             }
-            dft_small<SIGN, R>(v);
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) base[s * q] = v[q];
+        for (int sl = 0; sl < R; ++sl) base[s * dft_slot_bin<R>(sl)] = v[sl];
     }
     ctx.sync();
 }

@@ -54,8 +54,6 @@ def _reset_engine():
 
 
 def _select(engine, N):
-    if engine == "fused" and not _is_pow2(N):
-        pytest.skip("fused engine handles N = 2^m; other lengths run on the rocFFT engine")
     if engine == "fused" and not models.engine_supported("fused", N):
         pytest.skip("fused engine does not support this length (yet)")
     oa.set_engine(engine)
@@ -324,6 +322,45 @@ def test_untraced_runs_bound_lim0_and_give_the_traced_result():
     assert list(models.last_run["iters"]) == tr["iters"] and rel_l2(a, ref) <= TOL_C128
     b = oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg2))
     assert np.array_equal(a, b) and 0 < models.last_run["rebuilt_iterates"] <= models.last_run["steps"]
+    oa.set_engine("auto")
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("N,adaptive,prec", [(48000, False, "complex128"), (240000, True, "complex128"),
+                                             (240000, False, "complex64"), (960000, False, "complex128")])
+def test_notebook_lengths_vs_oracle(engine, N, adaptive, prec):
+    """N = SpS x Nsymbols = 2^a * 3^b * 5^c (240 000 = 16 x 15 000 is the reference notebooks' default): the fused
+    engine takes these with power-of-two column transforms and mixed-radix row transforms (mixed_fft.h)."""
+    _select(engine, N)
+    assert models.engine_supported("fused", N)
+    E = synth_field(N, 2, 9, 8.4, np.dtype(prec).type)
+    cfg = _mk_cfg(Ltotal=0.8, Lspan=0.4, hz=0.08, nlprMethod=adaptive, amp="ideal", saveSpanN=[], prec=prec)
+    tr = {}
+    ref = orc.manakovSSF(E.astype(np.complex128), make_param(orc.parameters, dict(cfg, prec="complex128")), trace=tr)
+    out, _, run = _run_hip(cfg, E)
+    assert run["engine"] == engine
+    if prec == "complex128":
+        assert rel_l2(out, ref) <= TOL_C128 and list(run["iters"]) == tr["iters"]
+        out2 = oa.manakovSSF(E, make_param(oa.parameters, cfg))                    # untraced (lim_0 bound)
+        assert np.array_equal(out, out2) if engine == "fused" else rel_l2(out2, ref) <= TOL_C128
+    else:
+        assert rel_l2(out.astype(np.complex128), ref) <= TOL_C64
+
+
+def test_notebook_length_other_entry_points_on_the_fused_engine():
+    N = 48000
+    _select("fused", N)
+    E = synth_field(N, 2, 5, 6.0)
+    s = E[:, 0].copy()
+    cfg = dict(func="ssfm", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, prgsBar=False, Ltotal=2.0, Lspan=1.0, hz=0.25,
+               amp="ideal", saveSpanN=[])
+    assert rel_l2(oa.ssfm(s, make_param(oa.parameters, cfg)), orc.ssfm(s, make_param(orc.parameters, cfg))) <= TOL_C128
+    assert models.last_run["engine"] == "fused"
+    mk = _mk_cfg(func="manakovDBP", Ltotal=2.0, Lspan=1.0, hz=0.5, nlprMethod=False, amp="ideal", saveSpanN=[])
+    assert rel_l2(oa.manakovDBP(E, make_param(oa.parameters, mk)), orc.manakovDBP(E, make_param(orc.parameters, mk))) <= TOL_C128
+    lp = make_param(oa.parameters, dict(Fs=512e9, L=3.0, alpha=0.2, D=16, Fc=193.1e12))
+    lo = make_param(orc.parameters, dict(Fs=512e9, L=3.0, alpha=0.2, D=16, Fc=193.1e12))
+    assert rel_l2(oa.linearFiberChannel(E, lp), orc.linearFiberChannel(E, lo)) <= 1e-12
     oa.set_engine("auto")
 
 
