@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs
     col_body<T, LG, MODE, false>(ctx, a);
 }
 // row lengths with factors 3 / 5 (mixed_fft.h): mixed-radix row stage, column stage with ragged last tiles
-template <typename T> __global__ void __launch_bounds__(1024) k_row_mixed(const RowArgs<T> a) {
+template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT, MAXT <= 256 ? 2 : 1) k_row_mixed(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
     row_mixed_body<T>(ctx, a);
 }
@@ -252,7 +252,8 @@ struct HipBackend {
         col_lds_max = col_lds;
     }
     template <typename T> void launch_row(const RowArgs<T> &a, int grid, int block, size_t lds) {
-        RowFn<T> f = a.mixed ? (RowFn<T>)k_row_mixed<T> : pick_row<T>(a.log2N2, block, row_occ);
+        RowFn<T> f = !a.mixed ? pick_row<T>(a.log2N2, block, row_occ)
+                     : block <= 256 ? (RowFn<T>)k_row_mixed<T, 256> : block <= 512 ? (RowFn<T>)k_row_mixed<T, 512> : (RowFn<T>)k_row_mixed<T, 1024>;
         arm((const void *)f);
         stamp_begin(0);
         f<<<grid, block, lds, pl->stream>>>(a);

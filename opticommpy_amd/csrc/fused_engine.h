@@ -85,6 +85,8 @@ template <typename T, class Backend> class FusedCore {
     int nrows, log2N;
     Split sp;
     int N2mix = 0;               // > 0: row length of the mixed-radix path (then sp.l2 is unused)
+    int mix_rows = 1;            // rows per workgroup there
+    cx<double> *wtab = nullptr;  // cis(-2 pi k / N2mix)
     size_t field_bytes;
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
     T *P = nullptr, *Theta = nullptr;
@@ -139,12 +141,16 @@ template <typename T, class Backend> class FusedCore {
     int init() {
         if (const char *e = std::getenv("SSF_LIM0_BOUND")) lim0_bound = std::atoi(e) != 0;
         const int64_t nfft = (int64_t)nrows << sp.l1;
-        if (N2mix) {                                           // one row per workgroup, the row in LDS after 4 KiB of scratch
-            row_block = 256;
-            if (const char *e = std::getenv("SSF_MIX_BLOCK")) row_block = std::max(64, std::min(1024, std::atoi(e)));
-            while (16 * row_block < N2mix) row_block *= 2;     // 16 values per thread at most
-            row_grid = (int)nfft;
-            row_lds = 4096 + (size_t)N2mix * sizeof(C);
+        if (N2mix) {               // rows in LDS after 4 KiB of scratch; 128 threads per row while 16 values per thread suffice
+            int tpr = 128;
+            if (const char *e = std::getenv("SSF_MIX_TPR")) tpr = std::max(64, std::min(1024, std::atoi(e)));
+            while (16 * tpr < N2mix) tpr *= 2;
+            mix_rows = std::max(1, 256 / tpr);
+            while (nfft % mix_rows) mix_rows >>= 1;
+            while (mix_rows > 1 && 4096 + (size_t)mix_rows * N2mix * sizeof(C) > 72 * 1024) mix_rows >>= 1;   // two workgroups per CU
+            row_block = tpr * mix_rows;
+            row_grid = (int)(nfft / mix_rows);
+            row_lds = 4096 + (size_t)mix_rows * N2mix * sizeof(C);
         } else {
             const int tpf2 = (1 << sp.l2) / 16;
             int fpw = tpf2 >= 256 ? 1 : 256 / tpf2;           // row transforms per workgroup
@@ -164,6 +170,16 @@ template <typename T, class Backend> class FusedCore {
         if (!(ctrl = (Ctrl *)be.alloc(2 * sizeof(Ctrl)))) return oom();
         if (!(linops = (LinOp *)be.alloc(2 * sizeof(LinOp)))) return oom();
         if (!(part = (double *)be.alloc(sizeof(double) * 5 * (size_t)npart_max))) return oom();
+        if (N2mix) {
+            if (!(wtab = (cx<double> *)be.alloc(sizeof(cx<double>) * (size_t)N2mix))) return oom();
+            std::vector<cx<double>> w((size_t)N2mix);
+            for (int q = 0; q < N2mix; ++q) {                  // octant-reduced angles: exact symmetries, < 1 ulp
+                const double a = -2.0 * 3.14159265358979323846 * (double)q / (double)N2mix;
+                w[(size_t)q].re = std::cos(a);
+                w[(size_t)q].im = std::sin(a);
+            }
+            be.h2d(wtab, w.data(), sizeof(cx<double>) * (size_t)N2mix);
+        }
         be.prepare(row_lds, std::max(col_lds_mk, col_lds_1));
         return SSF_OK;
     }
@@ -173,7 +189,7 @@ template <typename T, class Backend> class FusedCore {
     }
     ~FusedCore() {
         for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)Theta, (void *)ctrl, (void *)linops,
-                        (void *)part, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
+                        (void *)part, (void *)wtab, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
             if (p) be.free(p);
         for (C *s : snaps) be.free(s);
     }
@@ -213,6 +229,8 @@ template <typename T, class Backend> class FusedCore {
         a.N = N;
         a.mixed = N2mix ? 1 : 0;
         if (N2mix) mix_make_plan(N2mix, &a.plan);
+        a.wtab = wtab;
+        a.rows_per_wg = mix_rows;
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {

@@ -402,6 +402,8 @@ template <typename T> struct RowArgs {
     long long N;              // N1 * N2
     int mixed;                // 1: row_mixed_body (N2 has factors 3 / 5)
     MixPlan plan;             // its pass plan
+    const cx<double> *wtab;   // cis(-2 pi k / N2), k < N2
+    int rows_per_wg;          // rows a workgroup handles side by side (nthreads / rows_per_wg threads each)
 };
 
 // linear operator for the 16 registers of a last-radix-16 butterfly: bins k0 + (N/16) q
@@ -517,6 +519,7 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
         ctx.sync();
         n_hz = ((double *)(lsh + 1))[0];
         lo = lsh[0];
+        if (lead) a.cout->lin = lsh[0];   // (straight from LDS: callers that only need cth / mag keep no copy)
         n_hzv = 1;
         ctx.sync();
     } else if (act) {
@@ -526,7 +529,8 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
     if (lead) {
         const unsigned long long *src = (const unsigned long long *)a.cin;
         unsigned long long *dst = (unsigned long long *)a.cout;
-        for (int i = 0; i < (int)(sizeof(Ctrl) / 8); ++i) dst[i] = src[i];
+        const int nfwd = (int)((new_lin ? offsetof(Ctrl, lin) : sizeof(Ctrl)) / 8);
+        for (int i = 0; i < nfwd; ++i) dst[i] = src[i];
         Ctrl *n = a.cout;
         n->state = n_state;
         n->final_ = n_final;
@@ -539,7 +543,6 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
         n->hz = n_hz;
         n->nonconv = c.nonconv + add_nonconv;
         n->n_ahead = c.n_ahead + add_ahead;
-        if (new_lin) n->lin = lo;
     }
     return act;
 }
@@ -555,11 +558,12 @@ template <typename T> SSF_HD cx<T> lin_at_n(const LinOp &lo, long long k, long l
 // Row stage for row lengths with factors 3 and 5 (mixed_fft.h): one row per workgroup, the row lives in LDS
 // (after the 4 KiB the control logic uses), G -> forward transform -> x linear operator -> inverse -> G.
 template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowArgs<T> &a) {
-    constexpr int kMaxPerThread = 16;                      // L <= 16 * nthreads
-    cx<T> *x = (cx<T> *)(ctx.lds + 4096);
-    const int L = a.N2, T_ = ctx.nthreads;
+    constexpr int kMaxPerThread = 16;                      // L <= 16 * threads per row
+    const int L = a.N2, R_ = a.rows_per_wg, T_ = ctx.nthreads / R_;
+    const int f = ctx.tid / T_, t = ctx.tid - f * T_;      // row within the workgroup, thread within the row
+    cx<T> *x = (cx<T> *)(ctx.lds + 4096) + (size_t)f * L;
     const MixPlan &p = a.plan;                             // (host-made: indexed from the kernel arguments, not from scratch)
-    const long long rr = ctx.bid;                          // one row per workgroup
+    const long long rr = (long long)ctx.bid * R_ + f;      // global row index (grid is exact)
     cx<T> *g = a.G + rr * L;
     LinOp lo;
     double part[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -577,9 +581,10 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
         ctx.issue_fence();
     }
     cx<T> v[kMaxPerThread];
+    ctx.mark(0);
 #pragma unroll
     for (int m = 0; m < kMaxPerThread; ++m) {
-        const int i = ctx.tid + T_ * m;
+        const int i = t + T_ * m;
         v[m] = i < L ? g[i] : mk<T>((T)0, (T)0);
     }
     if (a.use_ctrl) {
@@ -590,20 +595,77 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
     }
 #pragma unroll
     for (int m = 0; m < kMaxPerThread; ++m) {
-        const int i = ctx.tid + T_ * m;
+        const int i = t + T_ * m;
         if (i < L) x[i] = v[m];
     }
     ctx.sync();
-    mix_dif<-1>(ctx, p, ctx.tid, T_, x);
+    ctx.mark(1);
+    mix_dif<-1>(ctx, p, t, T_, x, a.wtab);
+    ctx.mark(2);
     const int N1 = 1 << a.log2N1;
     const int k1 = (int)(rr & (N1 - 1));
-    for (int pos = ctx.tid; pos < L; pos += T_) {
-        const long long kbin = k1 + (long long)N1 * mix_bin(p, pos);
-        x[pos] = x[pos] * lin_at_n<T>(lo, kbin, a.N);
+    {
+        // Every thread takes a run of consecutive row bins k2, i.e. bins k = k1 + N1 k2 in steps of d = N1.  The
+        // operator phase cth * kk^2 (kk = signed bin) then follows a second-order recurrence:
+        //   u(k + d) = u(k) v(k),  v(k + d) = v(k) cis(2 cth d^2),  v(k) = cis(cth (2 kk d + d^2)),
+        // two complex products per value instead of a sincos; it restarts where the signed bin wraps (N/2).
+        const int cnt = (L + T_ - 1) / T_;
+        const int k2a = t * cnt, k2b = k2a + cnt < L ? k2a + cnt : L;
+        const double cth = lo.cth, d = (double)N1;
+        const long long npos = (a.N + 1) / 2;
+        double c, s;
+        cis_rad_d(2.0 * cth * d * d, c, s);
+        const cx<double> c2 = mk<double>(c, s);
+        cx<double> u = mk<double>(0.0, 0.0), vv = u;
+        long long kprev = 0;
+        int dig[kMixMaxPass] = {0, 0, 0, 0, 0, 0}, pos = 0;
+        for (int k2 = k2a; k2 < k2b; ++k2) {
+            const long long kbin = k1 + (long long)N1 * k2;
+            const long long kk = kbin < npos ? kbin : kbin - a.N;
+            if (k2 == k2a || kk != kprev + N1) {                      // (re)start of the recurrence
+                const double fk = (double)kk;
+                cis_rad_d(cth * fk * fk, c, s);
+                u = mk<double>(lo.mag * c, lo.mag * s);
+                cis_rad_d(cth * (2.0 * fk * d + d * d), c, s);
+                vv = mk<double>(c, s);
+            }
+            if (k2 == k2a) {                                          // digits of k2 once, then a mixed-radix counter
+                int kd = k2;
+                pos = 0;
+#pragma unroll
+                for (int i = 0; i < kMixMaxPass; ++i)                  // (static indices: dig stays in registers)
+                    if (i < p.npass) {
+                        dig[i] = kd % p.r[i];
+                        kd /= p.r[i];
+                        pos += dig[i] * (p.M[i] / p.r[i]);
+                    }
+            }
+            x[pos] = x[pos] * mk<T>((T)u.re, (T)u.im);
+            u = u * vv;
+            vv = vv * c2;
+            kprev = kk;
+            bool carry = true;                                         // k2 + 1
+#pragma unroll
+            for (int i = 0; i < kMixMaxPass; ++i)
+                if (carry && i < p.npass) {
+                    const int st = p.M[i] / p.r[i];
+                    if (++dig[i] < p.r[i]) {
+                        pos += st;
+                        carry = false;
+                    } else {
+                        dig[i] = 0;
+                        pos -= (p.r[i] - 1) * st;
+                    }
+                }
+        }
     }
     ctx.sync();
-    mix_dit<+1>(ctx, p, ctx.tid, T_, x);
-    for (int i = ctx.tid; i < L; i += T_) g[i] = x[i];
+    ctx.mark(3);
+    mix_dit<+1>(ctx, p, t, T_, x, a.wtab);
+    ctx.mark(4);
+    for (int i = t; i < L; i += T_) g[i] = x[i];
+    ctx.mark(5);
+    ctx.flush(0);
 }
 
 // LG > 0: row length fixed at compile time (index math folds to immediates); 0: runtime

@@ -57,6 +57,17 @@ SSF_HD int mix_bin(const MixPlan &p, int pos) {
     return k;
 }
 
+// ... and the LDS position that holds bin k
+SSF_HD int mix_pos(const MixPlan &p, int k) {
+    int pos = 0;
+    for (int i = 0; i < p.npass; ++i) {
+        const int q = k % p.r[i];
+        k /= p.r[i];
+        pos += q * (p.M[i] / p.r[i]);
+    }
+    return pos;
+}
+
 // ---- small DFTs, natural order in and out, X[k] = sum_q x[q] cis(SIGN 2 pi q k / R) ------------------
 template <int SIGN, typename T> SSF_HD void dft3(cx<T> &a, cx<T> &b, cx<T> &c) {
     const T h = (T)-0.5, s = (T)(SIGN * 0.86602540378443864676);
@@ -159,8 +170,8 @@ template <int SIGN, int R, typename T> SSF_HD void dft_small(cx<T> *v) {
 // The twiddles cis(sign 2 pi j q / M) are a chain of products from the base, evaluated in double (see
 // tw_powers for why single precision does not build it in float) and consumed as they are produced.
 template <int SIGN, int R, bool DIF, typename T, class Ctx>
-SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x) {
-    const int M = p.M[i], s = M / R, nbf = p.L / R;
+SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab) {
+    const int M = p.M[i], s = M / R, nbf = p.L / R, wstep = p.L / M;
     for (int bf = t; bf < nbf; bf += nthreads) {
         const int blk = bf / s, j = bf - blk * s;
         cx<T> *base = x + blk * M + j;
@@ -169,9 +180,14 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
         for (int q = 0; q < R; ++q) v[q] = base[s * q];
         cx<double> w1 = mk<double>(1.0, 0.0);
         if (s > 1) {
-            double c, sn;
-            cis2pi_d((double)(SIGN * j) / (double)M, c, sn);
-            w1 = mk<double>(c, sn);
+            if (wtab) {                              // wtab[k] = cis(-2 pi k / L): one load instead of a sincospi
+                const cx<double> w = wtab[wstep * j];
+                w1 = mk<double>(w.re, SIGN < 0 ? w.im : -w.im);
+            } else {
+                double c, sn;
+                cis2pi_d((double)(SIGN * j) / (double)M, c, sn);
+                w1 = mk<double>(c, sn);
+            }
         }
         if (!DIF && s > 1) {                         // inputs are in natural order q
             cx<double> pw = w1;
@@ -198,27 +214,29 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
 }
 
 template <int SIGN, bool DIF, typename T, class Ctx>
-SSF_HD void mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x) {
+SSF_HD void mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab) {
     switch (p.r[i]) {
-    case 25: mix_pass<SIGN, 25, DIF>(ctx, p, i, t, nthreads, x); break;
-    case 16: mix_pass<SIGN, 16, DIF>(ctx, p, i, t, nthreads, x); break;
-    case 15: mix_pass<SIGN, 15, DIF>(ctx, p, i, t, nthreads, x); break;
-    case 9: mix_pass<SIGN, 9, DIF>(ctx, p, i, t, nthreads, x); break;
-    case 8: mix_pass<SIGN, 8, DIF>(ctx, p, i, t, nthreads, x); break;
-    case 5: mix_pass<SIGN, 5, DIF>(ctx, p, i, t, nthreads, x); break;
-    case 4: mix_pass<SIGN, 4, DIF>(ctx, p, i, t, nthreads, x); break;
-    case 3: mix_pass<SIGN, 3, DIF>(ctx, p, i, t, nthreads, x); break;
-    default: mix_pass<SIGN, 2, DIF>(ctx, p, i, t, nthreads, x); break;
+    case 25: mix_pass<SIGN, 25, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 16: mix_pass<SIGN, 16, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 15: mix_pass<SIGN, 15, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 9: mix_pass<SIGN, 9, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 8: mix_pass<SIGN, 8, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 5: mix_pass<SIGN, 5, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 4: mix_pass<SIGN, 4, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 3: mix_pass<SIGN, 3, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    default: mix_pass<SIGN, 2, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
     }
 }
 
 // x (L values in LDS, all threads of the transform past a barrier): forward, natural -> digit-reversed
-template <int SIGN, typename T, class Ctx> SSF_HD void mix_dif(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x) {
-    for (int i = 0; i < p.npass; ++i) mix_pass_any<SIGN, true>(ctx, p, i, t, nthreads, x);
+template <int SIGN, typename T, class Ctx>
+SSF_HD void mix_dif(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab = nullptr) {
+    for (int i = 0; i < p.npass; ++i) mix_pass_any<SIGN, true>(ctx, p, i, t, nthreads, x, wtab);
 }
 // inverse of mix_dif<-SIGN> (unscaled): digit-reversed -> natural
-template <int SIGN, typename T, class Ctx> SSF_HD void mix_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x) {
-    for (int i = p.npass - 1; i >= 0; --i) mix_pass_any<SIGN, false>(ctx, p, i, t, nthreads, x);
+template <int SIGN, typename T, class Ctx>
+SSF_HD void mix_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab = nullptr) {
+    for (int i = p.npass - 1; i >= 0; --i) mix_pass_any<SIGN, false>(ctx, p, i, t, nthreads, x, wtab);
 }
 
 }  // namespace fused

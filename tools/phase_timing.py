@@ -26,7 +26,8 @@ COL = ["entry", "G loads done", "inv FFT", "time-domain work", "fwd FFT", "store
 def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     prec = np.complex64 if len(sys.argv) > 2 and sys.argv[2] == "c64" else np.complex128
-    E = synth_field(1 << lg, 2, 2, 8.4).astype(prec)
+    N = int(os.environ.get("PHASE_N", 1 << lg))
+    E = synth_field(N, 2, 2, 8.4).astype(prec)
     p = oa.parameters()
     for k, v in dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, Ltotal=4.0, Lspan=4.0, hz=0.08, maxIter=10,
                      tol=1e-5, nlprMethod=False, amp="ideal", prgsBar=False, prec=prec, saveSpanN=[]).items():
