@@ -26,8 +26,12 @@ def main():
     for case in range(cases):
         lg = int(rng.integers(8, 15))
         N = 1 << lg
-        if rng.integers(0, 5) == 0:
+        pick = rng.integers(0, 5)
+        if pick == 0:
             N = int(rng.choice([1500, 3000, 6000, 10000]))          # rocFFT engine only
+        elif pick == 1:                                             # fused engine, mixed-radix rows
+            N = int(rng.choice([128 * 75, 128 * 81, 128 * 125, 256 * 45, 512 * 27, 1024 * 15, 128 * 225, 256 * 135,
+                                48000, 128 * 405, 512 * 125, 1024 * 75]))
         K = int(rng.choice([1, 1, 1, 2, 3]))
         func = str(rng.choice(["manakovSSF", "manakovSSF", "manakovDBP", "ssfm"]))
         p_dbm = float(rng.choice([-20, -5, 0, 6, 10, 14]))
