@@ -914,6 +914,17 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     cx<T> *shC = (cx<T> *)(shN + 16 * (size_t)g.half);       // 16*half rotations
     T *shD = (T *)(shC + 16 * (size_t)g.half);               // 16*half |d rot|^2
     T nown[8], noth[8];
+    // The step-start powers and the last phases of the owned samples are fetched here, all at once, and arrive
+    // while the partners swap their powers.  (Fetched inside the phase loop, each pair of loads waits for the
+    // Theta store of the sample before it - the compiler has to assume they alias - and the loop pays eight
+    // memory round trips in a row.)
+    T pw8[8], prev8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long t = own_time_off(g, j);
+        pw8[j] = g.ld(Pbuf, g.pbase + t);
+        prev8[j] = first ? (T)0 : g.ld(a.Theta, g.pbase + t);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const T lo = norm2(v[j]), hi = norm2(v[j + 8]);
@@ -924,47 +935,48 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) shN[(size_t)oth_idx(g, j) * g.half + g.t] = noth[j];
     ctx.sync();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) noth[j] = shN[(size_t)own_idx(g, j) * g.half + g.t];
-    ctx.mark(6);
     const T c8g = (T)a.k.c8g;
-    cx<T> rown[8], roth[8];
-    T down[8], doth[8];
+    T ang8[8];                                               // the new phases; prev8 <- the old ones
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const T po = shN[(size_t)own_idx(g, j) * g.half + g.t];
+        const T ax = g.pol ? po : nown[j], ay = g.pol ? nown[j] : po;
+        const T pw = pw8[j];
+        pch_sum += (double)pw;                               // sum |E(step start)|^2 of the owned samples (lim_0 bound)
+        ang8[j] = shz * (c8g * (pw + ax + ay) / (T)2);
+        if (first) prev8[j] = shz * (c8g * (pw + pw) / (T)2);
+    }
+    ctx.mark(6);
+    // E_hd goes into the dead iterate's registers and is fetched before the phase loop, so that it arrives while
+    // the sines and cosines are evaluated.  To make room the loop keeps nothing but the two phases per sample:
+    // rotation and |d rot|^2 go to LDS and all sixteen come back from there (own and partner's alike) once the
+    // partners have met.
+#ifndef SSF_EHD_EARLY
+#define SSF_EHD_EARLY 8
+#endif
+#pragma unroll
+    for (int idx = 0; idx < SSF_EHD_EARLY; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const long long t = own_time_off(g, j);
-        const T ax = g.pol ? noth[j] : nown[j], ay = g.pol ? nown[j] : noth[j];
-        const T pw = g.ld(Pbuf, g.pbase + t);
-        pch_sum += (double)pw;                               // sum |E(step start)|^2 of the owned samples (lim_0 bound)
-        const T ang = shz * (c8g * (pw + ax + ay) / (T)2);
-        const T prev = first ? shz * (c8g * (pw + pw) / (T)2) : g.ld(a.Theta, g.pbase + t);
+        const T ang = ang8[j], prev = prev8[j];
         // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2)
         const double s = sin_half_angle((double)ang - (double)prev);
-        down[j] = (T)(4.0 * s * s);
-        rown[j] = cis_t<T>(ang);
         g.st(a.Theta, g.pbase + t, ang);                          // read and written by the owner only
-        shC[(size_t)own_idx(g, j) * g.half + g.t] = rown[j];
-        shD[(size_t)own_idx(g, j) * g.half + g.t] = down[j];
+        shC[(size_t)own_idx(g, j) * g.half + g.t] = cis_t<T>(ang);
+        shD[(size_t)own_idx(g, j) * g.half + g.t] = (T)(4.0 * s * s);
     }
     ctx.mark(7);
-    // E_hd goes into the dead iterate's registers once the phases are done: fetched here, it arrives while
-    // the partners swap their halves (any earlier and 64 more registers are live through the phase
-    // loop: 68 B/lane of scratch, measured as +5 MB of HBM writes per launch)
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
+    for (int idx = SSF_EHD_EARLY; idx < 16; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
     ctx.sync();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        roth[j] = shC[(size_t)oth_idx(g, j) * g.half + g.t];
-        doth[j] = shD[(size_t)oth_idx(g, j) * g.half + g.t];
-    }
 #pragma unroll
     for (int idx = 0; idx < 16; ++idx) {
         const cx<T> e = v[idx];
         const double w = (double)norm2(e);
-        num += w * (double)pick16(g, idx, down, doth);
+        num += w * (double)shD[(size_t)idx * g.half + g.t];
         den += w;
-        v[idx] = e * pick16(g, idx, rown, roth);
+        v[idx] = e * shC[(size_t)idx * g.half + g.t];
     }
     ctx.sync();
 }

@@ -28,3 +28,6 @@ for kind, name in ((0, "row"), (1, "col")):
     print(name, "loads-done by bid octile:   ", " ".join(f"{np.median(ld[(bids * 8 // len(bids)) == x]):.1f}/{ld[(bids * 8 // len(bids)) == x].max():.1f}" for x in range(8)))
     late = bids[ld > np.percentile(ld, 90)]
     print(name, "latest 10 %: bids", late[:40], "...", "bid%8 hist", np.bincount(late % 8, minlength=8), "end med/max", np.median(end), end.max())
+    order = np.argsort(-end)[:6]
+    print(name, "last finishers (bid: loads-done/end us):", " ".join(f"{bids[i]}:{ld[i]:.1f}/{end[i]:.1f}" for i in order),
+          "| bid 0:", f"{ld[bids == 0][0]:.1f}/{end[bids == 0][0]:.1f}", "| 99th pct end", f"{np.percentile(end, 99):.1f}")
