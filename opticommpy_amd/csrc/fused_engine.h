@@ -50,7 +50,7 @@ inline bool choose_split(int log2N, int precision, Split *s) {
 }
 
 // Lengths with factors 3 and 5 (N = 2^a * m, m odd and 5-smooth -- notebook lengths are SpS x Nsymbols):
-// the column length stays a power of two (2^7 .. 2^10 out of the 2^a), the rest is the row length, transformed
+// the column length stays a power of two (2^8 if possible, else 2^9, 2^7, 2^10 out of the 2^a), the rest is the row length, transformed
 // by the mixed-radix row kernel (mixed_fft.h).  Rows of up to 4096 values (16 per thread, one row per workgroup).
 inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
     (void)precision;
@@ -65,7 +65,18 @@ inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
     for (int q : {3, 5})
         while (rest % q == 0) rest /= q;
     if (rest != 1 || a < 7) return false;
-    for (int l = std::min(a, 9); l <= std::min(a, 10); ++l) {      // prefer the specialised column lengths (<= 2^9)
+    if (const char *e = std::getenv("SSF_MIX_L1")) {               // tuning knob: force log2 N1
+        const int l = std::atoi(e);
+        const int64_t n2 = N >> l;
+        MixPlan mp;
+        if (l >= 7 && l <= std::min(a, 10) && n2 >= 64 && n2 <= 4096 && mix_make_plan((int)n2, &mp)) {
+            *l1 = l;
+            *N2 = (int)n2;
+            return true;
+        }
+    }
+    for (int l : {8, 9, 7, 10}) {      // measured (tools/exp/mix_split_sweep.py): 2^8 columns beat 2^9 by 8-13 %, 2^10 loses 15-25 %
+        if (l > a) continue;
         const int64_t n2 = N >> l;
         MixPlan mp;
         if (n2 >= 64 && n2 <= 4096 && mix_make_plan((int)n2, &mp)) {
@@ -86,6 +97,7 @@ template <typename T, class Backend> class FusedCore {
     Split sp;
     int N2mix = 0;               // > 0: row length of the mixed-radix path (then sp.l2 is unused)
     int mix_rows = 1;            // rows per workgroup there
+    MixPlan mix_plan{};          // radices of the row passes, chosen for the threads a row gets
     cx<double> *wtab = nullptr;  // cis(-2 pi k / N2mix)
     size_t field_bytes;
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
@@ -148,9 +160,24 @@ template <typename T, class Backend> class FusedCore {
             mix_rows = std::max(1, 256 / tpr);
             while (nfft % mix_rows) mix_rows >>= 1;
             while (mix_rows > 1 && 4096 + (size_t)mix_rows * N2mix * sizeof(C) > 72 * 1024) mix_rows >>= 1;   // two workgroups per CU
+            while (mix_rows > 1 && nfft / mix_rows < 512) {           // few rows: a workgroup per row rather than idle CUs
+                mix_rows >>= 1;                                       // (240 000 = 256 rows of 1875: +9 % measured)
+                tpr *= 2;
+            }
             row_block = tpr * mix_rows;
             row_grid = (int)(nfft / mix_rows);
             row_lds = 4096 + (size_t)mix_rows * N2mix * sizeof(C);
+            mix_make_plan(N2mix, &mix_plan, tpr);
+            if (const char *e = std::getenv("SSF_MIX_PLAN")) {       // experiments: "15,5,5,5"
+                int r[kMixMaxPass], n = 0;
+                for (const char *q = e; *q && n < kMixMaxPass;) {
+                    r[n++] = std::atoi(q);
+                    while (*q && *q != ',') ++q;
+                    if (*q == ',') ++q;
+                }
+                MixPlan mp;
+                if (mix_plan_from_radices(N2mix, r, n, &mp)) mix_plan = mp;
+            }
         } else {
             const int tpf2 = (1 << sp.l2) / 16;
             int fpw = tpf2 >= 256 ? 1 : 256 / tpf2;           // row transforms per workgroup
@@ -228,7 +255,7 @@ template <typename T, class Backend> class FusedCore {
         a.N2 = N2mix ? N2mix : 1 << sp.l2;
         a.N = N;
         a.mixed = N2mix ? 1 : 0;
-        if (N2mix) mix_make_plan(N2mix, &a.plan);
+        if (N2mix) a.plan = mix_plan;
         a.wtab = wtab;
         a.rows_per_wg = mix_rows;
         return a;

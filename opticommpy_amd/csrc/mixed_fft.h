@@ -22,26 +22,57 @@ struct MixPlan {
     int M[kMixMaxPass];       // block length of pass i: L / (r[0] * ... * r[i-1])
 };
 
-// radices the butterflies below implement, tried largest first
-SSF_HD bool mix_make_plan(int L, MixPlan *p) {
-    const int cand[] = {25, 16, 15, 9, 8, 5, 4, 3, 2};
+// Radices the butterflies below implement, and what one butterfly costs one thread (relative units: butterfly
+// arithmetic + twiddle chain + the LDS round trip of its r values).  A pass over a row of L values with T threads
+// takes ceil((L / r) / T) butterflies in a row per thread, so large radices waste threads on short rows: the plan is
+// the ordered factorisation with the smallest sum over passes (+ one barrier each).  T = 0: largest radix first.
+constexpr int kMixRadices[] = {25, 16, 15, 9, 8, 5, 4, 3, 2};
+constexpr double kMixRadixCost[] = {440, 256, 237, 125, 108, 65, 48, 30, 20};   // (fitted to plan sweeps at L = 1875, 375: tools/exp/mix_plan_sweep.py)
+constexpr double kMixBarrierCost = 100;
+
+inline bool mix_plan_from_radices(int L, const int *r, int n, MixPlan *p) {
     p->L = L;
     p->npass = 0;
     int rest = L;
-    while (rest > 1) {
-        int pick = 0;
-        for (int c : cand)
-            if (rest % c == 0) {
-                pick = c;
-                break;
-            }
-        if (!pick || p->npass == kMixMaxPass) return false;
-        p->r[p->npass] = pick;
+    for (int i = 0; i < n; ++i) {
+        if (r[i] < 2 || rest % r[i] || p->npass == kMixMaxPass) return false;
+        p->r[p->npass] = r[i];
         p->M[p->npass] = rest;
-        rest /= pick;
+        rest /= r[i];
         ++p->npass;
     }
-    return p->npass > 0;
+    return rest == 1 && p->npass > 0;
+}
+
+inline bool mix_make_plan(int L, MixPlan *p, int T = 0) {
+    // enumerate ordered factorisations; the cost of a pass depends on its radix and on L only
+    int cur[kMixMaxPass], best_r[kMixMaxPass], best_n = 0;
+    double best = 1e300;
+    struct Rec {
+        static void go(int L, int rest, int T, int depth, double cost, int *cur, double *best, int *best_r, int *best_n) {
+            if (rest == 1) {
+                if (depth > 0 && cost < *best) {
+                    *best = cost;
+                    *best_n = depth;
+                    for (int i = 0; i < depth; ++i) best_r[i] = cur[i];
+                }
+                return;
+            }
+            if (depth == kMixMaxPass || cost >= *best) return;
+            for (int c = 0; c < (int)(sizeof(kMixRadices) / sizeof(int)); ++c) {
+                const int r = kMixRadices[c];
+                if (rest % r) continue;
+                double pass;
+                if (T > 0) pass = (double)(((L / r) + T - 1) / T) * kMixRadixCost[c] + kMixBarrierCost;
+                else pass = 1.0;                                       // fewest passes; ties: largest radix first (loop order)
+                cur[depth] = r;
+                go(L, rest / r, T, depth + 1, cost + pass, cur, best, best_r, best_n);
+            }
+        }
+    };
+    Rec::go(L, L, T, 0, 0.0, cur, &best, best_r, &best_n);
+    if (!best_n) return false;
+    return mix_plan_from_radices(L, best_r, best_n, p);
 }
 
 // frequency bin held at LDS position pos after the forward transform (digit reversal)

@@ -336,11 +336,12 @@ int emu_delay(int64_t N, double delay, double Fs, const void *in, void *out) {
 }
 // standalone mixed-radix transform of `rows` rows of length L (complex128): dir < 0 forward (output in
 // natural order via mix_bin), dir > 0: forward then inverse (round trip, unscaled: x * L)
-int emu_mixed_fft(int L, int rows, int dir, const void *in, void *out) {
+// plan_threads: the thread count the radix plan is made for (0: largest radix first)
+int emu_mixed_fft_t(int L, int rows, int dir, int plan_threads, const void *in, void *out) {
     using namespace ssf::fused;
     using Cc = cx<double>;
     MixPlan p;
-    if (!mix_make_plan(L, &p)) return SSF_ERR_UNSUPPORTED;
+    if (!mix_make_plan(L, &p, plan_threads)) return SSF_ERR_UNSUPPORTED;
     const Cc *src = (const Cc *)in;
     Cc *dst = (Cc *)out;
     run_grid(rows, 128, (size_t)L * sizeof(Cc), [&](EmuCtx &c) {
@@ -357,6 +358,8 @@ int emu_mixed_fft(int L, int rows, int dir, const void *in, void *out) {
     });
     return 0;
 }
+
+int emu_mixed_fft(int L, int rows, int dir, const void *in, void *out) { return emu_mixed_fft_t(L, rows, dir, 0, in, out); }
 
 int emu_wdm_tx(const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
                const double *deltaF, void *out, double *power_out) {

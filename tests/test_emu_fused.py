@@ -365,3 +365,13 @@ def test_mixed_radix_transform_lengths():
         assert e.emu_mixed_fft(L, 2, +1, x.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p)) == 0
         assert rel_l2(y, np.fft.fft(x, axis=1)) < 1e-14 and rel_l2(z / L, x) < 1e-14, L
     assert e.emu_mixed_fft(7, 1, -1, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)) == -6
+    # radix plans made for a thread count (the engine's choice: mix_make_plan with the threads a row gets) pick other
+    # radices and orders than largest-first: every one must give the same transform
+    e.emu_mixed_fft_t.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    for L in (75, 375, 768, 1280, 1536, 1875, 2025, 3125):
+        x = rng.normal(size=(1, L)) + 1j * rng.normal(size=(1, L))
+        y, z = np.empty_like(x), np.empty_like(x)
+        for T in (64, 128, 256):
+            assert e.emu_mixed_fft_t(L, 1, -1, T, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)) == 0
+            assert e.emu_mixed_fft_t(L, 1, +1, T, x.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p)) == 0
+            assert rel_l2(y, np.fft.fft(x, axis=1)) < 1e-14 and rel_l2(z / L, x) < 1e-14, (L, T)
