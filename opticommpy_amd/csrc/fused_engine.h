@@ -51,7 +51,9 @@ inline bool choose_split(int log2N, int precision, Split *s) {
 
 // Lengths with factors 3 and 5 (N = 2^a * m, m odd and 5-smooth -- notebook lengths are SpS x Nsymbols):
 // the column length stays a power of two (2^8 if possible, else 2^9, 2^7, 2^10 out of the 2^a), the rest is the row length, transformed
-// by the mixed-radix row kernel (mixed_fft.h).  Rows of up to 4096 values (16 per thread, one row per workgroup).
+// by the mixed-radix row kernel (mixed_fft.h).  Rows of up to 8192 values (16 per thread, 512 threads, one row per workgroup:
+// 132 KiB of LDS in double precision).
+constexpr int64_t kMixMaxRow = 8192;
 inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
     (void)precision;
     if (N < 1 || (N & (N - 1)) == 0) return false;
@@ -69,7 +71,7 @@ inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
         const int l = std::atoi(e);
         const int64_t n2 = N >> l;
         MixPlan mp;
-        if (l >= 7 && l <= std::min(a, 10) && n2 >= 64 && n2 <= 4096 && mix_make_plan((int)n2, &mp)) {
+        if (l >= 7 && l <= std::min(a, 10) && n2 >= 64 && n2 <= kMixMaxRow && mix_make_plan((int)n2, &mp)) {
             *l1 = l;
             *N2 = (int)n2;
             return true;
@@ -79,7 +81,7 @@ inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
         if (l > a) continue;
         const int64_t n2 = N >> l;
         MixPlan mp;
-        if (n2 >= 64 && n2 <= 4096 && mix_make_plan((int)n2, &mp)) {
+        if (n2 >= 64 && n2 <= kMixMaxRow && mix_make_plan((int)n2, &mp)) {
             *l1 = l;
             *N2 = (int)n2;
             return true;

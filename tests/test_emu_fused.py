@@ -368,7 +368,7 @@ def test_mixed_radix_transform_lengths():
     # radix plans made for a thread count (the engine's choice: mix_make_plan with the threads a row gets) pick other
     # radices and orders than largest-first: every one must give the same transform
     e.emu_mixed_fft_t.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    for L in (75, 375, 768, 1280, 1536, 1875, 2025, 3125):
+    for L in (75, 375, 768, 1280, 1536, 1875, 2025, 3125, 5625, 6144):
         x = rng.normal(size=(1, L)) + 1j * rng.normal(size=(1, L))
         y, z = np.empty_like(x), np.empty_like(x)
         for T in (64, 128, 256):

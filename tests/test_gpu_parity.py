@@ -327,7 +327,8 @@ def test_untraced_runs_bound_lim0_and_give_the_traced_result():
 
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("N,adaptive,prec", [(48000, False, "complex128"), (240000, True, "complex128"),
-                                             (240000, False, "complex64"), (960000, False, "complex128")])
+                                             (240000, False, "complex64"), (960000, False, "complex128"),
+                                             (1440000, False, "complex128"), (1440000, True, "complex64")])
 def test_notebook_lengths_vs_oracle(engine, N, adaptive, prec):
     """N = SpS x Nsymbols = 2^a * 3^b * 5^c (240 000 = 16 x 15 000 is the reference notebooks' default): the fused
     engine takes these with power-of-two column transforms and mixed-radix row transforms (mixed_fft.h)."""

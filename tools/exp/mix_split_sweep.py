@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import opticommpy_amd as oa
 from helpers import make_param, synth_field
 from opticommpy_amd import models
-for N in (960000, 786432, 1310720, 480000, 1920000, 1536000, 393216):
+for N in (1310720, 1920000, 1536000, 1440000, 2880000, 1572864):
     E = synth_field(N, 2, 2, 8.4)
     cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False,
                amp="ideal", saveSpanN=[], Ltotal=15.96, Lspan=15.96, hz=0.08, nlprMethod=False)
