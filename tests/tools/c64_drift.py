@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Single- vs double-precision agreement over long runs on the GPU (the c128 path is the one
 pinned against the oracle; this measures how far c64 drifts from it).  Usage (GPU box):
-    python tools/c64_drift.py [log2N] [Ltotal_km]"""
+    python tests/tools/c64_drift.py [log2N] [Ltotal_km]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import opticommpy_amd as oa  # noqa: E402

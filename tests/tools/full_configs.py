@@ -2,7 +2,7 @@
 """Run BASELINE.json's configurations at full size through the public Python API (on a GPU box)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import opticommpy_amd as oa
 from opticommpy_amd import models, mgpu, _lib

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the fused engine's kernels and state machine on the CPU emulator against the
 oracle: random sizes, fibre / solver parameters, step modes, amplifier modes, polarisation-pair counts,
-traced and untraced (lim_0 bound) runs.  Usage: python tools/fuzz_emu.py [cases] [seed]"""
+traced and untraced (lim_0 bound) runs.  Usage: python tests/tools/fuzz_emu.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import emu_binding as eb  # noqa: E402

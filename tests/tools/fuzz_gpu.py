@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Differential fuzzing on the GPU through the public API: random sizes / fibre / solver parameters, both
 engines, traced and untraced runs, against the oracle (field and per-step iteration counts).
-Usage (GPU box): python tools/fuzz_gpu.py [cases] [seed]"""
+Usage (GPU box): python tests/tools/fuzz_gpu.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import opticommpy_amd as oa  # noqa: E402

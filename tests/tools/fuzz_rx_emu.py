@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the receiver / transmitter pipelines on the CPU emulator against their oracles.
-Usage: python tools/fuzz_rx_emu.py [cases] [seed]"""
+Usage: python tests/tools/fuzz_rx_emu.py [cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import emu_binding as eb  # noqa: E402
