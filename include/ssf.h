@@ -23,6 +23,8 @@
  *   ssf_linear_channel                   linearFiberChannel               channels.py:30-109
  *   ssf_overlap_save                     blockwiseFFTConv as used by edc  optic/dsp/core.py:973-1046,
  *                                                                          optic/dsp/equalization.py:113-117
+ *   ssf_nlin_phase_rot                   nlinPhaseRot                     channels.py:471-493
+ *   ssf_convergence_condition            convergenceCondition             channels.py:496-519
  *   ssf_fir_filter / ssf_delay_signal / ssf_decimate / ssf_rx_run   receiver side, see below
  *   ssf_device_malloc / ssf_device_free / ssf_device_memcpy         device-resident arrays, see below
  *   ssf_wdm_tx                           simpleWDMTx signal path          optic/models/tx.py:178-217
@@ -239,6 +241,16 @@ int  ssf_fir_filter(int device, int64_t sigLen, int32_t ncols, int32_t ntaps, co
                     const void *sig_in, void *sig_out);
 /* one column delayed by `delay` seconds (NFFT = 1024 as the reference's default) */
 int  ssf_delay_signal(int device, int64_t N, double delay, double Fs, const void *sig_in, void *sig_out);
+/* The two helpers of the Manakov step the reference exports on their own (inside ssf_execute they are fused into
+ * the column kernel).  n = number of samples of each array, complex128 interleaved, host or device pointers.
+ *   ssf_nlin_phase_rot         nlinPhaseRot          optic/models/channels.py:471-493 (modelsGPU.py:514-535)
+ *       phi[i] = (8/9) gamma (Pch[i] + |Ex[i]|^2 + |Ey[i]|^2) / 2     (Pch: the real part, n doubles)
+ *   ssf_convergence_condition  convergenceCondition  optic/models/channels.py:496-519 (modelsGPU.py:538-561)
+ *       *lim = sqrt(|Ex_fd - Ex_conv|^2 + |Ey_fd - Ey_conv|^2) / sqrt(|Ex_conv|^2 + |Ey_conv|^2)  (Frobenius norms) */
+int  ssf_nlin_phase_rot(int device, int64_t n, double gamma, const void *Ex, const void *Ey, const double *Pch,
+                        double *phi);
+int  ssf_convergence_condition(int device, int64_t n, const void *Ex_fd, const void *Ey_fd, const void *Ex_conv,
+                               const void *Ey_conv, double *lim);
 /* maximum-variance sampling phase per column, then every decFactor-th sample; N % SpSin == 0,
  * ncols <= 8; sig_out: (ceil(N / decFactor), ncols); sampDelay (may be NULL): ncols phases */
 int  ssf_decimate(int device, int64_t N, int32_t ncols, int32_t SpSin, int32_t decFactor,

@@ -97,6 +97,9 @@ SYMBOLS = {
     "ssf_device_memcpy": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     "ssf_fir_filter": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ssf_delay_signal": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "ssf_nlin_phase_rot": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ssf_convergence_condition": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_double)]),
     "ssf_decimate": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                C.POINTER(C.c_int32)]),
     "ssf_rx_run": (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_int32, C.POINTER(RxParams), C.c_void_p, C.c_void_p,

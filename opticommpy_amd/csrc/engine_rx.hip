@@ -44,6 +44,14 @@ __global__ void __launch_bounds__(256) k_rx_combine(const CombineArgs a) {
     SSF_RX_CTX();
     combine_body(ctx, a);
 }
+__global__ void __launch_bounds__(256) k_nlin_phase(const NlinPhaseArgs a) {
+    SSF_RX_CTX();
+    nlin_phase_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_conv_sums(const ConvSumsArgs a) {
+    SSF_RX_CTX();
+    conv_sums_body(ctx, a);
+}
 __global__ void __launch_bounds__(256) k_tx_absmax(const AbsMaxArgs a) {
     SSF_RX_CTX();
     absmax_body(ctx, a);
@@ -145,6 +153,15 @@ struct HipRxBackend {
         chk(hipGetLastError(), "launch k_rx_combine");
     }
     void memset(void *d, int v, size_t n) { chk(hipMemsetAsync(d, v, n, st), "hipMemsetAsync"); }
+    void launch_nlin_phase(const NlinPhaseArgs &a) {
+        const long long nb = (a.n + 255) / 256;
+        k_nlin_phase<<<(unsigned)std::min<long long>(nb, 16384), 256, 64, st>>>(a);
+        chk(hipGetLastError(), "launch k_nlin_phase");
+    }
+    void launch_conv_sums(const ConvSumsArgs &a, int nblocks) {
+        k_conv_sums<<<(unsigned)nblocks, 256, 4096, st>>>(a);
+        chk(hipGetLastError(), "launch k_conv_sums");
+    }
     void launch_absmax(const AbsMaxArgs &a, int nblocks) {
         k_tx_absmax<<<(unsigned)nblocks, 256, 4096, st>>>(a);
         chk(hipGetLastError(), "launch k_tx_absmax");
@@ -268,6 +285,14 @@ int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, voi
 int tx_wdm(int device, const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
            const double *deltaF, void *out, double *power_out, std::string *err) {
     return with_core(device, err, [&](RxCore<Pooled> &c) { return c.wdm_tx(*p, symbols, taps, phi, amp, deltaF, out, power_out); });
+}
+int mk_nlin_phase(int device, int64_t n, double gamma, const void *Ex, const void *Ey, const double *Pch, double *phi,
+                  std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.nlin_phase(n, gamma, Ex, Ey, Pch, phi); });
+}
+int mk_convergence(int device, int64_t n, const void *xfd, const void *yfd, const void *xc, const void *yc, double *lim,
+                   std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.convergence(n, xfd, yfd, xc, yc, lim); });
 }
 int rx_decimate(int device, int64_t N, int ncols, int SpSin, int decFactor, const void *in, void *out, int32_t *sampDelay,
                 std::string *err) {

@@ -170,6 +170,45 @@ template <class Ctx> SSF_HD void real_part_body(Ctx &ctx, const RealPartArgs &a)
 }
 
 // =====================================================================================================
+// The two helpers of the Manakov step that the reference also exports on their own (SURVEY.md 8a rows 3, 4;
+// optic/models/channels.py:471-493 and 496-519, cupy twins optic/models/modelsGPU.py:514-561).  Inside
+// manakovSSF / manakovDBP they are fused into the column kernel (fused_kernels.h: mk_advance); these stand-alone
+// kernels serve callers that use the functions by themselves.
+struct NlinPhaseArgs {      // phi = ((8/9) gamma (Pch + Ex conj(Ex) + Ey conj(Ey)) / 2).real
+    const Cd *Ex, *Ey;
+    const double *Pch;
+    double *phi;
+    long long n;
+    double c8g;             // (8/9) gamma
+};
+template <class Ctx> SSF_HD void nlin_phase_body(Ctx &ctx, const NlinPhaseArgs &a) {
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < a.n; i += (long long)ctx.nblocks * ctx.nthreads) {
+        const double px = a.Ex[i].re * a.Ex[i].re + a.Ex[i].im * a.Ex[i].im;
+        const double py = a.Ey[i].re * a.Ey[i].re + a.Ey[i].im * a.Ey[i].im;
+        a.phi[i] = a.c8g * (a.Pch[i] + px + py) / 2;
+    }
+}
+struct ConvSumsArgs {       // block partials of |Ex_fd - Ex_conv|^2 + |Ey_fd - Ey_conv|^2 and |Ex_conv|^2 + |Ey_conv|^2
+    const Cd *xfd, *yfd, *xc, *yc;
+    double *pnum, *pden;    // nblocks each
+    long long n;
+};
+template <class Ctx> SSF_HD void conv_sums_body(Ctx &ctx, const ConvSumsArgs &a) {
+    double num = 0, den = 0;
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < a.n; i += (long long)ctx.nblocks * ctx.nthreads) {
+        const double dxr = a.xfd[i].re - a.xc[i].re, dxi = a.xfd[i].im - a.xc[i].im;
+        const double dyr = a.yfd[i].re - a.yc[i].re, dyi = a.yfd[i].im - a.yc[i].im;
+        num += dxr * dxr + dxi * dxi + dyr * dyr + dyi * dyi;
+        den += a.xc[i].re * a.xc[i].re + a.xc[i].im * a.xc[i].im + a.yc[i].re * a.yc[i].re + a.yc[i].im * a.yc[i].im;
+    }
+    fused::block_sum2(ctx, num, den, (double *)ctx.lds);
+    if (ctx.tid == 0) {
+        a.pnum[ctx.bid] = num;
+        a.pden[ctx.bid] = den;
+    }
+}
+
+// =====================================================================================================
 // WDM transmitter (optic/models/tx.py:42-228): after the pulse-shaping filter
 // (an overlap-save launch on the zero-stuffed symbols) each (channel, polarisation) needs
 //   max |x|                       -> absmax_body      sigTx / np.max(np.abs(sigTx))        (tx.py:204)

@@ -484,6 +484,45 @@ template <class Backend> struct RxCore {
     }
 
     // delaySignal (core.py:880-922) of one column
+    // channels.py:471-493: phi (n doubles) from Ex, Ey (n complex128 each) and the real part of Pch (n doubles)
+    int nlin_phase(long long n, double gamma, const void *Ex, const void *Ey, const double *Pch, double *phi) {
+        if (n < 1) return fail(SSF_ERR_BAD_ARG, "bad size");
+        Cd *x = dalloc((size_t)n), *y = dalloc((size_t)n);
+        double *pc = (double *)dalloc((size_t)(n + 1) / 2), *ph = (double *)dalloc((size_t)(n + 1) / 2);
+        if (!x || !y || !pc || !ph) return fail(SSF_ERR_OOM, "out of device memory");
+        be.h2d_big(x, Ex, sizeof(Cd) * (size_t)n);
+        be.h2d_big(y, Ey, sizeof(Cd) * (size_t)n);
+        be.h2d_big(pc, Pch, sizeof(double) * (size_t)n);
+        NlinPhaseArgs a{x, y, pc, ph, n, (8.0 / 9.0) * gamma};
+        be.launch_nlin_phase(a);
+        be.sync();
+        be.d2h_big(phi, ph, sizeof(double) * (size_t)n);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+    // channels.py:496-519: sqrt(|Ex_fd - Ex_conv|^2 + |Ey_fd - Ey_conv|^2) / sqrt(|Ex_conv|^2 + |Ey_conv|^2)
+    int convergence(long long n, const void *xfd, const void *yfd, const void *xc, const void *yc, double *lim) {
+        if (n < 1 || !lim) return fail(SSF_ERR_BAD_ARG, "bad size");
+        const int nblocks = (int)std::min<long long>(512, (n + 255) / 256);
+        Cd *d[4];
+        for (auto &q : d) q = dalloc((size_t)n);
+        double *dpart = (double *)dalloc((size_t)nblocks);          // 2 * nblocks doubles
+        if (!d[0] || !d[1] || !d[2] || !d[3] || !dpart) return fail(SSF_ERR_OOM, "out of device memory");
+        const void *src[4] = {xfd, yfd, xc, yc};
+        for (int i = 0; i < 4; ++i) be.h2d_big(d[i], src[i], sizeof(Cd) * (size_t)n);
+        ConvSumsArgs a{d[0], d[1], d[2], d[3], dpart, dpart + nblocks, n};
+        be.launch_conv_sums(a, nblocks);
+        be.sync();
+        std::vector<double> part((size_t)2 * nblocks);
+        be.d2h(part.data(), dpart, sizeof(double) * 2 * nblocks);
+        if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
+        double num = 0, den = 0;                                    // fixed order
+        for (int i = 0; i < nblocks; ++i) {
+            num += part[i];
+            den += part[(size_t)nblocks + i];
+        }
+        *lim = std::sqrt(num) / std::sqrt(den);
+        return SSF_OK;
+    }
     int delay(long long N, double delay_s, double Fs, const void *in, void *out) {
         if (N < 1 || !(Fs > 0)) return fail(SSF_ERR_BAD_ARG, "bad size");
         Cd *a = dalloc((size_t)N), *b = dalloc((size_t)N);

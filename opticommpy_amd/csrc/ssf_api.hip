@@ -369,6 +369,21 @@ int ssf_delay_signal(int device, int64_t N, double delay, double Fs, const void 
     return rc ? set_err(rc, "ssf_delay_signal: " + err) : SSF_OK;
 }
 
+int ssf_nlin_phase_rot(int device, int64_t n, double gamma, const void *Ex, const void *Ey, const double *Pch, double *phi) {
+    if (!Ex || !Ey || !Pch || !phi) return set_err(SSF_ERR_BAD_ARG, "ssf_nlin_phase_rot: NULL argument");
+    std::string err;
+    const int rc = mk_nlin_phase(device, n, gamma, Ex, Ey, Pch, phi, &err);
+    return rc ? set_err(rc, "ssf_nlin_phase_rot: " + err) : SSF_OK;
+}
+
+int ssf_convergence_condition(int device, int64_t n, const void *Ex_fd, const void *Ey_fd, const void *Ex_conv,
+                              const void *Ey_conv, double *lim) {
+    if (!Ex_fd || !Ey_fd || !Ex_conv || !Ey_conv || !lim) return set_err(SSF_ERR_BAD_ARG, "ssf_convergence_condition: NULL argument");
+    std::string err;
+    const int rc = mk_convergence(device, n, Ex_fd, Ey_fd, Ex_conv, Ey_conv, lim, &err);
+    return rc ? set_err(rc, "ssf_convergence_condition: " + err) : SSF_OK;
+}
+
 int ssf_decimate(int device, int64_t N, int32_t ncols, int32_t SpSin, int32_t decFactor, const void *in, void *out,
                  int32_t *sampDelay) {
     if (!in || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_decimate: NULL argument");

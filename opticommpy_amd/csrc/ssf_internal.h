@@ -83,6 +83,10 @@ int rx_fir(int device, int64_t sigLen, int ncols, int ntaps, const void *taps, c
 int rx_overlap_save(int device, int64_t sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out,
                     std::string *err);
 int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, void *out, std::string *err);
+int mk_nlin_phase(int device, int64_t n, double gamma, const void *Ex, const void *Ey, const double *Pch, double *phi,
+                  std::string *err);
+int mk_convergence(int device, int64_t n, const void *xfd, const void *yfd, const void *xc, const void *yc, double *lim,
+                   std::string *err);
 int tx_wdm(int device, const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
            const double *deltaF, void *out, double *power_out, std::string *err);
 int rx_decimate(int device, int64_t N, int ncols, int SpSin, int decFactor, const void *in, void *out, int32_t *sampDelay,

@@ -527,6 +527,56 @@ def edc(sigIn, param):
     return res.flatten() if one_d else res
 
 
+def nlinPhaseRot(Ex, Ey, Pch, γ):
+    """Nonlinear phase shift per unit length of the Manakov step (optic/models/channels.py:471-493, cupy twin
+    optic/models/modelsGPU.py:514-535): ``((8/9) γ (Pch + Ex conj(Ex) + Ey conj(Ey)) / 2).real`` on the GPU.
+    ``manakovSSF`` evaluates this inside its column kernel; this is the function by itself.  Arrays of any common
+    shape (numpy or DeviceArray, complex128; complex64 input is evaluated in double and returned as float32)."""
+    dev = _dev
+    lib = _lib.load()
+    on_dev = dev.is_device(Ex)
+    single = (Ex.dtype == np.complex64)
+    shape = Ex.shape
+    if tuple(Ey.shape) != tuple(shape) or tuple(Pch.shape) != tuple(shape):
+        raise ValueError("nlinPhaseRot: Ex, Ey and Pch must have the same shape")
+    if dev.is_device(Pch):
+        if Pch.dtype != np.float64:
+            raise TypeError("nlinPhaseRot: a device-resident Pch must be float64 (the real part)")
+        pp, kp = Pch.ptr, Pch
+    else:
+        kp = np.ascontiguousarray(np.real(Pch), dtype=np.float64)
+        pp = kp.ctypes.data_as(C.c_void_p)
+    px, kx = dev.arg(Ex, np.complex128)
+    py, ky = dev.arg(Ey, np.complex128)
+    out = dev.empty(on_dev, shape, np.float64)
+    n = int(np.prod(shape))
+    rc = lib.ssf_nlin_phase_rot(_state["device"], n, float(γ), px, py, pp, dev.out_ptr(out))
+    _lib.raise_for(lib, None, rc)
+    del kx, ky, kp
+    return out.astype(np.float32) if (single and not on_dev) else out
+
+
+def convergenceCondition(Ex_fd, Ey_fd, Ex_conv, Ey_conv):
+    """Convergence measure of the trapezoidal iteration (optic/models/channels.py:496-519, cupy twin
+    optic/models/modelsGPU.py:538-561): ``sqrt(|Ex_fd - Ex_conv|² + |Ey_fd - Ey_conv|²) / sqrt(|Ex_conv|² + |Ey_conv|²)``
+    (Frobenius norms over the whole arrays), reduced on the GPU; returns a Python float."""
+    dev = _dev
+    lib = _lib.load()
+    shape = tuple(Ex_fd.shape)
+    for a in (Ey_fd, Ex_conv, Ey_conv):
+        if tuple(a.shape) != shape:
+            raise ValueError("convergenceCondition: all four arrays must have the same shape")
+    ptrs, keep = [], []
+    for a in (Ex_fd, Ey_fd, Ex_conv, Ey_conv):
+        p_, k_ = dev.arg(a, np.complex128)
+        ptrs.append(p_)
+        keep.append(k_)
+    lim = C.c_double()
+    rc = lib.ssf_convergence_condition(_state["device"], int(np.prod(shape)), *ptrs, C.byref(lim))
+    _lib.raise_for(lib, None, rc)
+    return float(lim.value)
+
+
 def signalPower(x):
     """Total power of x (optic/dsp/core.py:69-84)."""
     return np.sum(np.mean(x * np.conj(x), axis=0).real)

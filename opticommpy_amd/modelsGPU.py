@@ -2,5 +2,6 @@
 ``from optic.models.modelsGPU import manakovSSF`` switches to
 ``from opticommpy_amd.modelsGPU import manakovSSF`` and nothing else changes."""
 from .models import (  # noqa: F401
-    checkGPU, edfa, gaussianComplexNoise, manakovDBP, manakovSSF, setPowerforParSSFM, ssfm,
+    checkGPU, convergenceCondition, edfa, gaussianComplexNoise, manakovDBP, manakovSSF, nlinPhaseRot,
+    setPowerforParSSFM, ssfm,
 )

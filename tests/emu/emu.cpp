@@ -199,6 +199,8 @@ struct EmuBackend {
     void launch_front(const ssf::rx::FrontArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::front_body(c, a); }); }
     void launch_iqmix(const ssf::rx::IqMixArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::iqmix_body(c, a); }); }
     void launch_combine(const ssf::rx::CombineArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::combine_body(c, a); }); }
+    void launch_nlin_phase(const ssf::rx::NlinPhaseArgs &a) { run_grid(ew_grid(a.n), 64, 64, [&](EmuCtx &c) { ssf::rx::nlin_phase_body(c, a); }); }
+    void launch_conv_sums(const ssf::rx::ConvSumsArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::conv_sums_body(c, a); }); }
     void launch_absmax(const ssf::rx::AbsMaxArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::absmax_body(c, a); }); }
     void launch_iqm(const ssf::rx::IqmArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::iqm_body(c, a); }); }
     void launch_shift_add(const ssf::rx::ShiftAddArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::shift_add_body(c, a); }); }
@@ -328,6 +330,16 @@ int emu_fir(int64_t sigLen, int ncols, int ntaps, const void *taps, const void *
     EmuBackend be;
     ssf::rx::RxCore<EmuBackend> core(be);
     return core.fir(sigLen, ncols, ntaps, taps, in, out);
+}
+int emu_nlin_phase_rot(int64_t n, double gamma, const void *Ex, const void *Ey, const double *Pch, double *phi) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    return core.nlin_phase(n, gamma, Ex, Ey, Pch, phi);
+}
+int emu_convergence_condition(int64_t n, const void *xfd, const void *yfd, const void *xc, const void *yc, double *lim) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    return core.convergence(n, xfd, yfd, xc, yc, lim);
 }
 int emu_delay(int64_t N, double delay, double Fs, const void *in, void *out) {
     EmuBackend be;
