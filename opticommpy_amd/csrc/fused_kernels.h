@@ -637,7 +637,7 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
                     if (i < p.npass) {
                         dig[i] = kd % p.r[i];
                         kd /= p.r[i];
-                        pos += dig[i] * (p.M[i] / p.r[i]);
+                        pos += dig[i] * p.S[i];
                     }
             }
             x[pos] = x[pos] * mk<T>((T)u.re, (T)u.im);
@@ -648,7 +648,7 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
 #pragma unroll
             for (int i = 0; i < kMixMaxPass; ++i)
                 if (carry && i < p.npass) {
-                    const int st = p.M[i] / p.r[i];
+                    const int st = p.S[i];
                     if (++dig[i] < p.r[i]) {
                         pos += st;
                         carry = false;

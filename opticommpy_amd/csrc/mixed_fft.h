@@ -20,14 +20,16 @@ struct MixPlan {
     int L, npass;
     int r[kMixMaxPass];       // radix of pass i
     int M[kMixMaxPass];       // block length of pass i: L / (r[0] * ... * r[i-1])
+    int S[kMixMaxPass];       // butterfly stride of pass i: M[i] / r[i]   (kept here: the kernels never divide by a runtime value)
+    int W[kMixMaxPass];       // twiddle-table step of pass i: L / M[i]
 };
 
 // Radices the butterflies below implement, and what one butterfly costs one thread (relative units: butterfly
 // arithmetic + twiddle chain + the LDS round trip of its r values).  A pass over a row of L values with T threads
 // takes ceil((L / r) / T) butterflies in a row per thread, so large radices waste threads on short rows: the plan is
 // the ordered factorisation with the smallest sum over passes (+ one barrier each).  T = 0: largest radix first.
-constexpr int kMixRadices[] = {25, 16, 15, 9, 8, 5, 4, 3, 2};
-constexpr double kMixRadixCost[] = {440, 256, 237, 125, 108, 65, 48, 30, 20};   // (fitted to plan sweeps at L = 1875, 375: tools/exp/mix_plan_sweep.py)
+constexpr int kMixRadices[] = {25, 20, 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+constexpr double kMixRadixCost[] = {440, 335, 256, 237, 180, 145, 125, 108, 80, 65, 48, 30, 20};   // (fitted to plan sweeps at L = 1875, 375: tools/exp/mix_plan_sweep.py)
 constexpr double kMixBarrierCost = 100;
 
 inline bool mix_plan_from_radices(int L, const int *r, int n, MixPlan *p) {
@@ -38,6 +40,8 @@ inline bool mix_plan_from_radices(int L, const int *r, int n, MixPlan *p) {
         if (r[i] < 2 || rest % r[i] || p->npass == kMixMaxPass) return false;
         p->r[p->npass] = r[i];
         p->M[p->npass] = rest;
+        p->S[p->npass] = rest / r[i];
+        p->W[p->npass] = L / rest;
         rest /= r[i];
         ++p->npass;
     }
@@ -79,7 +83,7 @@ inline bool mix_make_plan(int L, MixPlan *p, int T = 0) {
 SSF_HD int mix_bin(const MixPlan &p, int pos) {
     int k = 0, w = 1;
     for (int i = 0; i < p.npass; ++i) {
-        const int s = p.M[i] / p.r[i];
+        const int s = p.S[i];
         const int q = pos / s;
         pos -= q * s;
         k += q * w;
@@ -94,7 +98,7 @@ SSF_HD int mix_pos(const MixPlan &p, int k) {
     for (int i = 0; i < p.npass; ++i) {
         const int q = k % p.r[i];
         k /= p.r[i];
-        pos += q * (p.M[i] / p.r[i]);
+        pos += q * p.S[i];
     }
     return pos;
 }
@@ -146,6 +150,22 @@ template <> struct SmallW<25> {
     static constexpr double c[25] = {1, 0.968583161128631119476, 0.876306680043863587301, 0.728968627421411523174, 0.535826794978996618279, 0.309016994374947424076, 0.062790519529313376117, -0.187381314585724630546, -0.425779291565072648802, -0.637423989748689710354, -0.809016994374947424104, -0.929776485888251403667, -0.992114701314477831018, -0.992114701314477831072, -0.929776485888251403667, -0.809016994374947423941, -0.637423989748689710246, -0.425779291565072648721, -0.187381314585724630125, 0.062790519529313375894, 0.309016994374947424185, 0.535826794978996618171, 0.728968627421411523282, 0.876306680043863587301, 0.968583161128631119476};
     static constexpr double s[25] = {0, 0.24868988716485478823, 0.481753674101715274988, 0.684547105928688673728, 0.844327925502015078508, 0.951056516295153572111, 0.99802672842827156195, 0.982287250728688681085, 0.904827052466019527712, 0.770513242775789230653, 0.587785252292473129135, 0.368124552684677959063, 0.125333233564304245448, -0.12533323356430424534, -0.368124552684677959171, -0.587785252292473129406, -0.770513242775789230707, -0.904827052466019527766, -0.982287250728688681139, -0.99802672842827156195, -0.951056516295153572111, -0.844327925502015078617, -0.68454710592868867362, -0.481753674101715274988, -0.248689887164854788406};
 };
+template <> struct SmallW<6> {
+    static constexpr double c[6] = {1, 0.500000000000000000000, -0.500000000000000000000, -1.00000000000000000000, -0.500000000000000000000, 0.500000000000000000000};
+    static constexpr double s[6] = {0, 0.866025403784438646764, 0.866025403784438646764, 0, -0.866025403784438646764, -0.866025403784438646764};
+};
+template <> struct SmallW<10> {
+    static constexpr double c[10] = {1, 0.809016994374947424102, 0.309016994374947424102, -0.309016994374947424102, -0.809016994374947424102, -1.00000000000000000000, -0.809016994374947424102, -0.309016994374947424102, 0.309016994374947424102, 0.809016994374947424102};
+    static constexpr double s[10] = {0, 0.587785252292473129169, 0.951056516295153572116, 0.951056516295153572116, 0.587785252292473129169, 0, -0.587785252292473129169, -0.951056516295153572116, -0.951056516295153572116, -0.587785252292473129169};
+};
+template <> struct SmallW<12> {
+    static constexpr double c[12] = {1, 0.866025403784438646764, 0.500000000000000000000, 0, -0.500000000000000000000, -0.866025403784438646764, -1.00000000000000000000, -0.866025403784438646764, -0.500000000000000000000, 0, 0.500000000000000000000, 0.866025403784438646764};
+    static constexpr double s[12] = {0, 0.500000000000000000000, 0.866025403784438646764, 1.00000000000000000000, 0.866025403784438646764, 0.500000000000000000000, 0, -0.500000000000000000000, -0.866025403784438646764, -1.00000000000000000000, -0.866025403784438646764, -0.500000000000000000000};
+};
+template <> struct SmallW<20> {
+    static constexpr double c[20] = {1, 0.951056516295153572116, 0.809016994374947424102, 0.587785252292473129169, 0.309016994374947424102, 0, -0.309016994374947424102, -0.587785252292473129169, -0.809016994374947424102, -0.951056516295153572116, -1.00000000000000000000, -0.951056516295153572116, -0.809016994374947424102, -0.587785252292473129169, -0.309016994374947424102, 0, 0.309016994374947424102, 0.587785252292473129169, 0.809016994374947424102, 0.951056516295153572116};
+    static constexpr double s[20] = {0, 0.309016994374947424102, 0.587785252292473129169, 0.809016994374947424102, 0.951056516295153572116, 1.00000000000000000000, 0.951056516295153572116, 0.809016994374947424102, 0.587785252292473129169, 0.309016994374947424102, 0, -0.309016994374947424102, -0.587785252292473129169, -0.809016994374947424102, -0.951056516295153572116, -1.00000000000000000000, -0.951056516295153572116, -0.809016994374947424102, -0.587785252292473129169, -0.309016994374947424102};
+};
 
 // R = A * B (Cooley-Tukey in registers, in place): B transforms of length A over x[b + B a], twiddle
 // cis(2 pi b ka / R), A transforms of length B over the slots b + B ka.  Slot kb + B ka then holds X[ka + A kb]:
@@ -172,29 +192,31 @@ template <int SIGN, int A, int B, typename T> SSF_HD void dft_ab(cx<T> *v) {
 #pragma unroll
     for (int ka = 0; ka < A; ++ka) dft_prime<SIGN, B>(v + B * ka);
 }
-// frequency index of register slot s after dft_small<R>
+// the composite radices: R = A * B
+template <int R> struct MixAB { static constexpr int A = 1, B = R; };
+template <> struct MixAB<6> { static constexpr int A = 2, B = 3; };
+template <> struct MixAB<9> { static constexpr int A = 3, B = 3; };
+template <> struct MixAB<10> { static constexpr int A = 2, B = 5; };
+template <> struct MixAB<12> { static constexpr int A = 3, B = 4; };
+template <> struct MixAB<15> { static constexpr int A = 3, B = 5; };
+template <> struct MixAB<20> { static constexpr int A = 4, B = 5; };
+template <> struct MixAB<25> { static constexpr int A = 5, B = 5; };
+
+// frequency index of register slot s after dft_small<R>  (dft_ab leaves X[ka + A kb] in slot kb + B ka)
 template <int R> SSF_HD constexpr int dft_slot_bin(int s) {
-    if (R == 9) return s / 3 + 3 * (s % 3);
-    if (R == 15) return s / 5 + 3 * (s % 5);
-    if (R == 25) return s / 5 + 5 * (s % 5);
-    return s;
+    return MixAB<R>::A == 1 ? s : s / MixAB<R>::B + MixAB<R>::A * (s % MixAB<R>::B);
 }
 
 // ... and the slot that holds bin k
 template <int R> SSF_HD constexpr int dft_bin_slot(int k) {
-    if (R == 9) return k / 3 + 3 * (k % 3);
-    if (R == 15) return k / 3 + 5 * (k % 3);
-    if (R == 25) return k / 5 + 5 * (k % 5);
-    return k;
+    return MixAB<R>::A == 1 ? k : k / MixAB<R>::A + MixAB<R>::B * (k % MixAB<R>::A);
 }
 
 template <int SIGN, int R, typename T> SSF_HD void dft_small(cx<T> *v) {
     if constexpr (R == 2 || R == 3 || R == 4 || R == 5) dft_prime<SIGN, R>(v);
     else if constexpr (R == 8) dft8<SIGN>(v);
     else if constexpr (R == 16) dft16<SIGN>(v);
-    else if constexpr (R == 9) dft_ab<SIGN, 3, 3>(v);
-    else if constexpr (R == 15) dft_ab<SIGN, 3, 5>(v);
-    else dft_ab<SIGN, 5, 5>(v);
+    else dft_ab<SIGN, MixAB<R>::A, MixAB<R>::B>(v);
 }
 
 // one pass of radix R for this thread's butterflies; DIF: transform then twiddle, DIT: twiddle then transform.
@@ -202,7 +224,7 @@ template <int SIGN, int R, typename T> SSF_HD void dft_small(cx<T> *v) {
 // tw_powers for why single precision does not build it in float) and consumed as they are produced.
 template <int SIGN, int R, bool DIF, typename T, class Ctx>
 SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab) {
-    const int M = p.M[i], s = M / R, nbf = p.L / R, wstep = p.L / M;
+    const int M = p.M[i], s = p.S[i], nbf = p.L / R, wstep = p.W[i];
     for (int bf = t; bf < nbf; bf += nthreads) {
         const int blk = bf / s, j = bf - blk * s;
         cx<T> *base = x + blk * M + j;
@@ -220,22 +242,37 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
                 w1 = mk<double>(c, sn);
             }
         }
+        // w^q, q = 1 .. R-1, as NCH interleaved chains w^(q + NCH) = w^q w^NCH (one chain of R - 1 dependent products is
+        // pure latency: a thread has a single butterfly in flight); ch[q % NCH] holds the next power of its residue.
+        // Four chains for the middle radices; the large ones (20, 25) leave no registers for more than one (scratch otherwise).
+        constexpr int NCH = (R <= 5 || R >= 20) ? 1 : 4;
+        cx<double> ch[4] = {w1, w1, w1, w1}, wn = w1;
+        if (s > 1 && NCH > 1) {
+            const cx<double> w2 = w1 * w1;
+            if (NCH == 2) {
+                wn = w2;
+                ch[0] = w2;
+            } else {
+                ch[2] = w2;
+                ch[3] = w2 * w1;
+                wn = w2 * w2;
+                ch[0] = wn;
+            }
+        }
         if (!DIF && s > 1) {                         // inputs are in natural order q
-            cx<double> pw = w1;
 #pragma unroll
             for (int q = 1; q < R; ++q) {
-                v[q] = v[q] * mk<T>((T)pw.re, (T)pw.im);
-                pw = pw * w1;
+                v[q] = v[q] * mk<T>((T)ch[q % NCH].re, (T)ch[q % NCH].im);
+                if (q + NCH < R) ch[q % NCH] = ch[q % NCH] * wn;
             }
         }
         dft_small<SIGN, R>(v);
         if (DIF && s > 1) {                          // outputs sit in slot order: walk the bins, pick the slot
-            cx<double> pw = w1;
 #pragma unroll
             for (int kq = 1; kq < R; ++kq) {
                 const int slot = dft_bin_slot<R>(kq);          // compile-time after unrolling
-                v[slot] = v[slot] * mk<T>((T)pw.re, (T)pw.im);
-                pw = pw * w1;
+                v[slot] = v[slot] * mk<T>((T)ch[kq % NCH].re, (T)ch[kq % NCH].im);
+                if (kq + NCH < R) ch[kq % NCH] = ch[kq % NCH] * wn;
             }
         }
 #pragma unroll
@@ -248,10 +285,14 @@ template <int SIGN, bool DIF, typename T, class Ctx>
 SSF_HD void mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab) {
     switch (p.r[i]) {
     case 25: mix_pass<SIGN, 25, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 20: mix_pass<SIGN, 20, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
     case 16: mix_pass<SIGN, 16, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
     case 15: mix_pass<SIGN, 15, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 12: mix_pass<SIGN, 12, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 10: mix_pass<SIGN, 10, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
     case 9: mix_pass<SIGN, 9, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
     case 8: mix_pass<SIGN, 8, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 6: mix_pass<SIGN, 6, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
     case 5: mix_pass<SIGN, 5, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
     case 4: mix_pass<SIGN, 4, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
     case 3: mix_pass<SIGN, 3, DIF>(ctx, p, i, t, nthreads, x, wtab); break;

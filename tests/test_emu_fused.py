@@ -358,7 +358,8 @@ def test_mixed_radix_transform_lengths():
     e = eb.load()
     e.emu_mixed_fft.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(0)
-    for L in (2, 3, 5, 9, 15, 16, 25, 27, 45, 75, 125, 128, 225, 375, 405, 625, 1000, 1125, 1875, 2025, 3125, 3375, 3750):
+    for L in (2, 3, 5, 6, 9, 10, 12, 15, 16, 20, 25, 27, 45, 60, 75, 120, 125, 128, 225, 240, 375, 405, 600, 625, 1000, 1125, 1875,
+              2025, 3125, 3375, 3750):
         x = rng.normal(size=(2, L)) + 1j * rng.normal(size=(2, L))
         y, z = np.empty_like(x), np.empty_like(x)
         assert e.emu_mixed_fft(L, 2, -1, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)) == 0
@@ -368,7 +369,7 @@ def test_mixed_radix_transform_lengths():
     # radix plans made for a thread count (the engine's choice: mix_make_plan with the threads a row gets) pick other
     # radices and orders than largest-first: every one must give the same transform
     e.emu_mixed_fft_t.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    for L in (75, 375, 768, 1280, 1536, 1875, 2025, 3125, 5625, 6144):
+    for L in (75, 375, 768, 1280, 1536, 1875, 2025, 3072, 3125, 3750, 5120, 5625, 6000, 6144, 7500):
         x = rng.normal(size=(1, L)) + 1j * rng.normal(size=(1, L))
         y, z = np.empty_like(x), np.empty_like(x)
         for T in (64, 128, 256):
