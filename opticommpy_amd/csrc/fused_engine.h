@@ -178,7 +178,7 @@ template <typename T, class Backend> class FusedCore {
                     if (*q == ',') ++q;
                 }
                 MixPlan mp;
-                if (mix_plan_from_radices(N2mix, r, n, &mp)) mix_plan = mp;
+                if (mix_plan_from_radices(N2mix, r, n, &mp) && mp.r[mp.npass - 1] <= kMixMaxOpRadix) mix_plan = mp;
             }
         } else {
             const int tpf2 = (1 << sp.l2) / 16;

@@ -604,64 +604,24 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
     ctx.mark(2);
     const int N1 = 1 << a.log2N1;
     const int k1 = (int)(rr & (N1 - 1));
+    // x linear operator: folded into the first pass of the inverse transform (mixed_fft.h: mix_apply_op), which reads
+    // the spectrum in runs of bins N / R apart.  (As a pass of its own over the row in LDS it was 6 of the 30 us of
+    // a launch at rows of 3750: one read-modify-write per bin, each waiting for the one before it.)
+    MixRowOp op;
     {
-        // Every thread takes a run of consecutive row bins k2, i.e. bins k = k1 + N1 k2 in steps of d = N1.  The
-        // operator phase cth * kk^2 (kk = signed bin) then follows a second-order recurrence:
-        //   u(k + d) = u(k) v(k),  v(k + d) = v(k) cis(2 cth d^2),  v(k) = cis(cth (2 kk d + d^2)),
-        // two complex products per value instead of a sincos; it restarts where the signed bin wraps (N/2).
-        const int cnt = (L + T_ - 1) / T_;
-        const int k2a = t * cnt, k2b = k2a + cnt < L ? k2a + cnt : L;
-        const double cth = lo.cth, d = (double)N1;
-        const long long npos = (a.N + 1) / 2;
+        const int Rl = p.r[p.npass - 1];
+        op.cth = lo.cth;
+        op.mag = lo.mag;
+        op.D = (double)(a.N / Rl);
         double c, s;
-        cis_rad_d(2.0 * cth * d * d, c, s);
-        const cx<double> c2 = mk<double>(c, s);
-        cx<double> u = mk<double>(0.0, 0.0), vv = u;
-        long long kprev = 0;
-        int dig[kMixMaxPass] = {0, 0, 0, 0, 0, 0}, pos = 0;
-        for (int k2 = k2a; k2 < k2b; ++k2) {
-            const long long kbin = k1 + (long long)N1 * k2;
-            const long long kk = kbin < npos ? kbin : kbin - a.N;
-            if (k2 == k2a || kk != kprev + N1) {                      // (re)start of the recurrence
-                const double fk = (double)kk;
-                cis_rad_d(cth * fk * fk, c, s);
-                u = mk<double>(lo.mag * c, lo.mag * s);
-                cis_rad_d(cth * (2.0 * fk * d + d * d), c, s);
-                vv = mk<double>(c, s);
-            }
-            if (k2 == k2a) {                                          // digits of k2 once, then a mixed-radix counter
-                int kd = k2;
-                pos = 0;
-#pragma unroll
-                for (int i = 0; i < kMixMaxPass; ++i)                  // (static indices: dig stays in registers)
-                    if (i < p.npass) {
-                        dig[i] = kd % p.r[i];
-                        kd /= p.r[i];
-                        pos += dig[i] * p.S[i];
-                    }
-            }
-            x[pos] = x[pos] * mk<T>((T)u.re, (T)u.im);
-            u = u * vv;
-            vv = vv * c2;
-            kprev = kk;
-            bool carry = true;                                         // k2 + 1
-#pragma unroll
-            for (int i = 0; i < kMixMaxPass; ++i)
-                if (carry && i < p.npass) {
-                    const int st = p.S[i];
-                    if (++dig[i] < p.r[i]) {
-                        pos += st;
-                        carry = false;
-                    } else {
-                        dig[i] = 0;
-                        pos -= (p.r[i] - 1) * st;
-                    }
-                }
-        }
+        cis_rad_d(2.0 * lo.cth * op.D * op.D, c, s);
+        op.c2 = mk<double>(c, s);
+        op.k1 = k1;
+        op.N1 = N1;
+        op.N = a.N;
     }
-    ctx.sync();
     ctx.mark(3);
-    mix_dit<+1>(ctx, p, t, T_, x, a.wtab);
+    mix_dit<+1>(ctx, p, t, T_, x, a.wtab, true, op);
     ctx.mark(4);
     for (int i = t; i < L; i += T_) g[i] = x[i];
     ctx.mark(5);

@@ -31,6 +31,8 @@ struct MixPlan {
 constexpr int kMixRadices[] = {25, 20, 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
 constexpr double kMixRadixCost[] = {440, 335, 256, 237, 180, 145, 125, 108, 80, 65, 48, 30, 20};   // (fitted to plan sweeps at L = 1875, 375: tools/exp/mix_plan_sweep.py)
 constexpr double kMixBarrierCost = 100;
+constexpr double kMixOpCostFixed = 350, kMixOpCostPerValue = 12;   // mix_apply_op: four sin/cos per butterfly + two products per value
+constexpr int kMixMaxOpRadix = 16;   // the plan's last pass also applies the row operator (mix_apply_op): no room for that at 20 / 25
 
 inline bool mix_plan_from_radices(int L, const int *r, int n, MixPlan *p) {
     p->L = L;
@@ -55,7 +57,11 @@ inline bool mix_make_plan(int L, MixPlan *p, int T = 0) {
     struct Rec {
         static void go(int L, int rest, int T, int depth, double cost, int *cur, double *best, int *best_r, int *best_n) {
             if (rest == 1) {
-                if (depth > 0 && cost < *best) {
+                if (depth > 0 && T > 0) {                              // the last pass also applies the row operator
+                    const int rl = cur[depth - 1];
+                    cost += (double)(((L / rl) + T - 1) / T) * (kMixOpCostFixed + kMixOpCostPerValue * rl);
+                }
+                if (depth > 0 && cur[depth - 1] <= kMixMaxOpRadix && cost < *best) {
                     *best = cost;
                     *best_n = depth;
                     for (int i = 0; i < depth; ++i) best_r[i] = cur[i];
@@ -219,11 +225,47 @@ template <int SIGN, int R, typename T> SSF_HD void dft_small(cx<T> *v) {
     else dft_ab<SIGN, MixAB<R>::A, MixAB<R>::B>(v);
 }
 
+// The linear operator of the row stage, applied where the inverse transform picks the spectrum up (its first pass,
+// the plan's last: stride 1).  The R values of one butterfly there are the bins k2 = kb + q L/R, q = 0 .. R-1, of the
+// row, i.e. the bins k = k0 + q N/R of the whole transform with k0 = k1 + N1 kb < N/R: they span the spectrum once, so
+// the signed bin kk wraps once inside the butterfly.  H(k) = mag cis(cth kk^2) follows a second-order recurrence along
+// q within each of the two runs (two complex products per value, four sin/cos evaluations per butterfly).
+struct MixRowOp {
+    double cth, mag;        // LinOp
+    double D;               // N / R as a double, R = radix of the plan's last pass
+    cx<double> c2;          // cis(2 cth D^2)
+    long long k1, N1, N;    // row (bin offset), bins between row elements, transform length
+};
+template <int R, typename T> SSF_HD void mix_apply_op(const MixPlan &p, const MixRowOp &op, int blk, cx<T> *v) {
+    const long long k0 = op.k1 + op.N1 * (long long)mix_bin(p, blk * R);
+    const long long D = op.N / R, npos = (op.N + 1) / 2;
+    cx<double> u = mk<double>(0.0, 0.0), vv = u;
+    bool wrapped = false;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const long long kbin = k0 + q * D;
+        const bool neg = kbin >= npos;
+        if (q == 0 || (neg && !wrapped)) {           // (re)start: first value, and the first negative bin
+            const double fk = (double)(neg ? kbin - op.N : kbin);
+            double c, s;
+            cis_rad_d(op.cth * fk * fk, c, s);
+            u = mk<double>(op.mag * c, op.mag * s);
+            cis_rad_d(op.cth * (2.0 * fk * op.D + op.D * op.D), c, s);
+            vv = mk<double>(c, s);
+            wrapped = neg;
+        }
+        v[q] = v[q] * mk<T>((T)u.re, (T)u.im);
+        u = u * vv;
+        vv = vv * op.c2;
+    }
+}
+
 // one pass of radix R for this thread's butterflies; DIF: transform then twiddle, DIT: twiddle then transform.
 // The twiddles cis(sign 2 pi j q / M) are a chain of products from the base, evaluated in double (see
 // tw_powers for why single precision does not build it in float) and consumed as they are produced.
 template <int SIGN, int R, bool DIF, typename T, class Ctx>
-SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab) {
+SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab,
+                     bool use_op, const MixRowOp &op) {
     const int M = p.M[i], s = p.S[i], nbf = p.L / R, wstep = p.W[i];
     for (int bf = t; bf < nbf; bf += nthreads) {
         const int blk = bf / s, j = bf - blk * s;
@@ -231,6 +273,9 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
         cx<T> v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = base[s * q];
+        if constexpr (!DIF && R <= kMixMaxOpRadix) {               // (only given for the stride-1 pass: j = 0, bf = blk)
+            if (use_op) mix_apply_op<R>(p, op, blk, v);
+        }
         cx<double> w1 = mk<double>(1.0, 0.0);
         if (s > 1) {
             if (wtab) {                              // wtab[k] = cis(-2 pi k / L): one load instead of a sincospi
@@ -282,33 +327,43 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
 }
 
 template <int SIGN, bool DIF, typename T, class Ctx>
-SSF_HD void mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab) {
+SSF_HD void mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab,
+                         bool use_op, const MixRowOp &op) {
     switch (p.r[i]) {
-    case 25: mix_pass<SIGN, 25, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 20: mix_pass<SIGN, 20, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 16: mix_pass<SIGN, 16, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 15: mix_pass<SIGN, 15, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 12: mix_pass<SIGN, 12, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 10: mix_pass<SIGN, 10, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 9: mix_pass<SIGN, 9, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 8: mix_pass<SIGN, 8, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 6: mix_pass<SIGN, 6, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 5: mix_pass<SIGN, 5, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 4: mix_pass<SIGN, 4, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    case 3: mix_pass<SIGN, 3, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
-    default: mix_pass<SIGN, 2, DIF>(ctx, p, i, t, nthreads, x, wtab); break;
+    case 25: mix_pass<SIGN, 25, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 20: mix_pass<SIGN, 20, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 16: mix_pass<SIGN, 16, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 15: mix_pass<SIGN, 15, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 12: mix_pass<SIGN, 12, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 10: mix_pass<SIGN, 10, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 9: mix_pass<SIGN, 9, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 8: mix_pass<SIGN, 8, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 6: mix_pass<SIGN, 6, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 5: mix_pass<SIGN, 5, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 4: mix_pass<SIGN, 4, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 3: mix_pass<SIGN, 3, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    default: mix_pass<SIGN, 2, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
     }
 }
 
 // x (L values in LDS, all threads of the transform past a barrier): forward, natural -> digit-reversed
 template <int SIGN, typename T, class Ctx>
 SSF_HD void mix_dif(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab = nullptr) {
-    for (int i = 0; i < p.npass; ++i) mix_pass_any<SIGN, true>(ctx, p, i, t, nthreads, x, wtab);
+    const MixRowOp none{};
+    for (int i = 0; i < p.npass; ++i) mix_pass_any<SIGN, true>(ctx, p, i, t, nthreads, x, wtab, false, none);
 }
-// inverse of mix_dif<-SIGN> (unscaled): digit-reversed -> natural
+// inverse of mix_dif<-SIGN> (unscaled): digit-reversed -> natural; with_op: the spectrum is multiplied by the row
+// operator `op` on the way in (first pass)
+template <int SIGN, typename T, class Ctx>
+SSF_HD void mix_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab, bool with_op,
+                    const MixRowOp &op) {
+    for (int i = p.npass - 1; i >= 0; --i)
+        mix_pass_any<SIGN, false>(ctx, p, i, t, nthreads, x, wtab, with_op && i == p.npass - 1, op);
+}
 template <int SIGN, typename T, class Ctx>
 SSF_HD void mix_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab = nullptr) {
-    for (int i = p.npass - 1; i >= 0; --i) mix_pass_any<SIGN, false>(ctx, p, i, t, nthreads, x, wtab);
+    const MixRowOp none{};
+    mix_dit<SIGN>(ctx, p, t, nthreads, x, wtab, false, none);
 }
 
 }  // namespace fused
