@@ -22,6 +22,8 @@ def main():
     for case in range(cases):
         lg = int(rng.integers(8, 13))
         N = 1 << lg
+        if rng.integers(0, 4) == 0:                                 # mixed-radix rows (2^a 3^b 5^c)
+            N = int(rng.choice([128 * 75, 128 * 81, 256 * 75, 128 * 90, 256 * 100, 128 * 125]))
         K = int(rng.choice([1, 1, 1, 2, 3]))
         func = str(rng.choice(["manakovSSF", "manakovSSF", "manakovDBP", "ssfm"]))
         p_dbm = float(rng.choice([-20, -5, 0, 6, 10, 14]))
@@ -57,7 +59,7 @@ def main():
             print("MISMATCH case", case, cfg, "N", N, "K", K, "p", p_dbm, "rel", rel_l2(got, ref) if np.all(np.isfinite(ref)) else "nan-ref",
                   "iters", list(info.get("iters", []))[:8], tr.get("iters", [])[:8], flush=True)
         elif case % 20 == 0:
-            print(f"case {case} ok ({func}, N=2^{lg}, K={K}, steps={info['steps']}, it={info['iterations']}, rebuilt={info['rebuilt_iterates']}/{info2['rebuilt_iterates']})", flush=True)
+            print(f"case {case} ok ({func}, N={N}, K={K}, steps={info['steps']}, it={info['iterations']}, rebuilt={info['rebuilt_iterates']}/{info2['rebuilt_iterates']})", flush=True)
     print("done:", cases, "cases,", bad, "mismatches")
 
 
