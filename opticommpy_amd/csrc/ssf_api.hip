@@ -265,37 +265,46 @@ int ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_t
     if (n_dev < 1 || !dev_ids || n_units < 1 || !params || !fields_in || !fields_out)
         return set_err(SSF_ERR_BAD_ARG, "ssf_mgpu_run: bad argument");
     const size_t unit_bytes = (size_t)rows_per_unit * (size_t)N * (precision == SSF_C128 ? 16 : 8);
-    std::vector<int> rcs((size_t)n_dev, SSF_OK);
-    std::vector<std::string> errs((size_t)n_dev);
+    // Two lanes (plan + stream + host thread) per device when it has more than one unit: one unit's transfers overlap
+    // the other's kernels, and the kernels of two independent fields fill each other's load / store phases
+    // (measured +12-15 % field-steps/s).  Units are independent: the results do not depend on it.
+    int lanes = 2;
+    if (const char *e = std::getenv("SSF_MGPU_LANES")) lanes = std::max(1, std::min(4, std::atoi(e)));
+    const int nslots = n_dev * lanes;
+    std::vector<int> rcs((size_t)nslots, SSF_OK);
+    std::vector<std::string> errs((size_t)nslots);
     std::vector<std::thread> th;
     for (int d = 0; d < n_dev; ++d) {
         // contiguous block of units per device: [u0, u1)
         const int u0 = (int)((int64_t)n_units * d / n_dev), u1 = (int)((int64_t)n_units * (d + 1) / n_dev);
-        th.emplace_back([=, &rcs, &errs] {
-            if (u0 >= u1) return;
-            ssf_plan *pl = nullptr;
-            int rc = ssf_plan_create(dev_ids[d], N, rows_per_unit, precision, engine, &pl);
-            if (rc) {
-                rcs[(size_t)d] = rc;
-                errs[(size_t)d] = ssf_last_error(nullptr);
-                return;
-            }
-            for (int u = u0; u < u1 && rc == SSF_OK; ++u) {
-                ssf_stats st{};
-                rc = ssf_run(pl, params, (const char *)fields_in + (size_t)u * unit_bytes,
-                             (char *)fields_out + (size_t)u * unit_bytes, nullptr, nullptr, &st, nullptr);
-                if (stats) stats[u] = st;
-            }
-            if (rc) {
-                rcs[(size_t)d] = rc;
-                errs[(size_t)d] = ssf_last_error(pl);
-            }
-            ssf_plan_destroy(pl);
-        });
+        for (int l = 0; l < lanes; ++l) {
+            const int slot = d * lanes + l;
+            th.emplace_back([=, &rcs, &errs] {
+                if (u0 + l >= u1) return;
+                ssf_plan *pl = nullptr;
+                int rc = ssf_plan_create(dev_ids[d], N, rows_per_unit, precision, engine, &pl);
+                if (rc) {
+                    rcs[(size_t)slot] = rc;
+                    errs[(size_t)slot] = ssf_last_error(nullptr);
+                    return;
+                }
+                for (int u = u0 + l; u < u1 && rc == SSF_OK; u += lanes) {
+                    ssf_stats st{};
+                    rc = ssf_run(pl, params, (const char *)fields_in + (size_t)u * unit_bytes,
+                                 (char *)fields_out + (size_t)u * unit_bytes, nullptr, nullptr, &st, nullptr);
+                    if (stats) stats[u] = st;
+                }
+                if (rc) {
+                    rcs[(size_t)slot] = rc;
+                    errs[(size_t)slot] = ssf_last_error(pl);
+                }
+                ssf_plan_destroy(pl);
+            });
+        }
     }
     for (auto &t : th) t.join();
-    for (int d = 0; d < n_dev; ++d)
-        if (rcs[(size_t)d]) return set_err(rcs[(size_t)d], "device " + std::to_string(dev_ids[d]) + ": " + errs[(size_t)d]);
+    for (int i = 0; i < nslots; ++i)
+        if (rcs[(size_t)i]) return set_err(rcs[(size_t)i], "device " + std::to_string(dev_ids[i / lanes]) + ": " + errs[(size_t)i]);
     return SSF_OK;
 }
 
