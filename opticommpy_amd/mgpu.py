@@ -16,6 +16,7 @@ Two ways to use the GPUs of one node:
 """
 import copy
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -44,6 +45,18 @@ def _dist():
     return None
 
 
+_LANES = {}
+
+
+def _lane_pool(lanes):
+    """Long-lived worker threads (their cached plans are reused from call to call)."""
+    pool = _LANES.get(lanes)
+    if pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = _LANES[lanes] = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ssf-lane")
+    return pool
+
+
 def run_sharded(fields, param, compute=None, gather=True):
     """Propagate a list of independent fields, sharded over the ranks of the initialised
     torch.distributed group (or all of them locally when there is no group).
@@ -62,8 +75,20 @@ def run_sharded(fields, param, compute=None, gather=True):
     n = len(fields)
     mine = shard_range(n, world, rank)
     outs = [None] * n
-    for u in mine:
-        outs[u] = np.asarray(compute(fields[u], copy.deepcopy(param)))
+    # Two lanes per GPU: the rank's units are taken by two host threads (each with its own plan and stream; ctypes
+    # releases the GIL inside the library), so that one unit's transfers overlap the other's kernels and the kernels of
+    # two independent fields fill each other's load / store phases (ssf_mgpu_run does the same).
+    lanes = max(1, min(int(os.environ.get("SSF_MGPU_LANES", "2")), len(mine)))
+
+    def one(u):
+        return u, np.asarray(compute(fields[u], copy.deepcopy(param)))
+
+    if lanes > 1:
+        for u, o in _lane_pool(lanes).map(one, mine):
+            outs[u] = o
+    else:
+        for u in mine:
+            outs[u] = one(u)[1]
     if not (dist and gather and world > 1):
         return outs
     import torch

@@ -13,6 +13,7 @@ import atexit
 import ctypes as C
 import logging as logg
 import os
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -71,18 +72,32 @@ class _Plan:
             self.h = None
 
 
-_plans = OrderedDict()
+# Plans are cached per host thread: a plan (device buffers + stream + control block) is not thread-safe, and
+# mgpu.run_sharded drives two lanes per GPU from two threads.
+_tls = threading.local()
+_all_plan_caches = []
+_caches_lock = threading.Lock()
 _MAX_PLANS = 4
+
+
+def _plans():
+    d = getattr(_tls, "plans", None)
+    if d is None:
+        d = _tls.plans = OrderedDict()
+        with _caches_lock:
+            _all_plan_caches.append(d)
+    return d
 
 
 def _get_plan(N, nrows, prec_code):
     key = (_state["device"], int(N), int(nrows), prec_code, _state["engine"])
-    pl = _plans.pop(key, None)
+    plans = _plans()
+    pl = plans.pop(key, None)
     if pl is None:
-        while len(_plans) >= _MAX_PLANS:
-            _plans.popitem(last=False)[1].close()
+        while len(plans) >= _MAX_PLANS:
+            plans.popitem(last=False)[1].close()
         pl = _Plan(*key)
-    _plans[key] = pl
+    plans[key] = pl
     return pl
 
 
@@ -98,9 +113,13 @@ def engine_supported(name, N, nrows=2, prec=np.complex128):
 
 
 def release_plans():
-    """Free every cached plan (device memory, FFT plans, streams)."""
-    while _plans:
-        _plans.popitem()[1].close()
+    """Free every cached plan (device memory, FFT plans, streams) of every thread; call it when no propagation is
+    in flight."""
+    with _caches_lock:
+        caches = list(_all_plan_caches)
+    for d in caches:
+        while d:
+            d.popitem()[1].close()
 
 
 atexit.register(release_plans)

@@ -383,6 +383,27 @@ def test_single_process_multi_device_entry_point():
         assert stats[u]["steps"] == tr["steps"] and stats[u]["iterations"] == tr["iterations"]
 
 
+def test_run_sharded_drives_two_lanes_per_gpu(monkeypatch):
+    """mgpu.run_sharded without a process group: the local units go through two host threads (own plan and stream
+    each); outputs are those of one-at-a-time calls, bit for bit, for the default and for a chained compute."""
+    from opticommpy_amd import mgpu
+    N = 1 << 13
+    fields = [synth_field(N, 2, 80 + u, 4.0 + u) for u in range(5)]
+    cfg = _mk_cfg(Ltotal=2, Lspan=1, hz=0.1, nlprMethod=True, amp="ideal", saveSpanN=[])
+    seq = [oa.manakovSSF(f, make_param(oa.parameters, cfg)) for f in fields]
+    outs = mgpu.run_sharded(fields, make_param(oa.parameters, cfg))
+    assert all(np.array_equal(a, b) for a, b in zip(outs, seq))
+
+    def chain(E, p):                                   # forward channel, then back-propagation (config 5's shape)
+        return oa.manakovDBP(oa.manakovSSF(E, p), p)
+    seq2 = [chain(f, make_param(oa.parameters, cfg)) for f in fields]
+    outs2 = mgpu.run_sharded(fields, make_param(oa.parameters, cfg), compute=chain)
+    assert all(np.array_equal(a, b) for a, b in zip(outs2, seq2))
+    monkeypatch.setenv("SSF_MGPU_LANES", "1")
+    outs1 = mgpu.run_sharded(fields, make_param(oa.parameters, cfg))
+    assert all(np.array_equal(a, b) for a, b in zip(outs1, seq))
+
+
 def test_measured_copy_ceiling_probe():
     """ssf_device_copy_bandwidth: plausible (between 1 and 12 TB/s for 32 MiB in + out), bad sizes refused."""
     import ctypes as C
