@@ -442,6 +442,23 @@ template <typename T> SSF_HD cx<T> lin_at(const LinOp &lo, long long k, int log2
     return mk<T>((T)(lo.mag * c), (T)(lo.mag * s));
 }
 
+// Forward nwords 8-byte words of the control block (lead thread).  Eight words are fetched before any is stored:
+// copied one by one, every load waits for the store before it (the compiler must assume the blocks alias), i.e. 35
+// memory round trips in a row -- 3.5 us that the lead workgroup finishes late, a quarter of a launch at small N.
+SSF_HD void ctrl_forward(const Ctrl *cin, Ctrl *cout, int nwords) {
+    const unsigned long long *src = (const unsigned long long *)cin;
+    unsigned long long *dst = (unsigned long long *)cout;
+    int i = 0;
+    for (; i + 8 <= nwords; i += 8) {
+        unsigned long long w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = src[i + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[i + q] = w[q];
+    }
+    for (; i < nwords; ++i) dst[i] = src[i];
+}
+
 // Control-block handling of a Manakov Row launch: evaluates the convergence sums the last column stage left
 // (part: this thread's first two entries of each, fetched by the caller before its row), decides final / redo,
 // derives a new step size and operator when needed, and lets the lead thread write the next control block.
@@ -527,10 +544,7 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
     }
     if (act) n_state = c_state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
     if (lead) {
-        const unsigned long long *src = (const unsigned long long *)a.cin;
-        unsigned long long *dst = (unsigned long long *)a.cout;
-        const int nfwd = (int)((new_lin ? offsetof(Ctrl, lin) : sizeof(Ctrl)) / 8);
-        for (int i = 0; i < nfwd; ++i) dst[i] = src[i];
+        ctrl_forward(a.cin, a.cout, (int)((new_lin ? offsetof(Ctrl, lin) : sizeof(Ctrl)) / 8));
         Ctrl *n = a.cout;
         n->state = n_state;
         n->final_ = n_final;
@@ -978,9 +992,7 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
             do_fwd = true;
         }
         if (ctx.bid == 0 && ctx.tid == 0) {                               // forward the control block
-            const unsigned long long *src = (const unsigned long long *)a.cin;
-            unsigned long long *dst = (unsigned long long *)a.cout;
-            for (int i = 0; i < (int)(sizeof(Ctrl) / 8); ++i) dst[i] = src[i];
+            ctrl_forward(a.cin, a.cout, (int)(sizeof(Ctrl) / 8));
             Ctrl *n = a.cout;
             if (op == 0) {
                 n->state = ST_AFTER_S;
