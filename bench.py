@@ -75,8 +75,17 @@ def main():
     if world > 1 or os.environ.get("SSF_BENCH_FORCE_DIST"):      # (the env var exercises the RCCL path on one GPU)
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # (test knobs: SSF_BENCH_BACKEND=gloo + SSF_BENCH_DEVICE=0 run several ranks against one GPU, which RCCL
+        # refuses; the driver's runs use neither)
+        backend = os.environ.get("SSF_BENCH_BACKEND", "nccl")
+        if "SSF_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["SSF_BENCH_DEVICE"])
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        tdev = "cuda" if backend == "nccl" else "cpu"
 
     from opticommpy_amd import _lib
     lib = _lib.load()
@@ -93,11 +102,13 @@ def main():
     h = C.c_void_p()
     _lib.raise_for(lib, None, lib.ssf_plan_create(local_rank, N, 2, prec, engine, C.byref(h)))
 
-    def run(steps, field):
+    def run(steps, field, sync=True):
+        # sync: every rank makes this call (the timed run and its warm-up); the rank-0-only passes further down
+        # must not enter a barrier the other ranks never reach
         st = _lib.Stats()
         cp = make_params(_lib, steps, 0.08)
         _lib.raise_for(lib, h, lib.ssf_upload(h, field.ctypes.data_as(C.c_void_p)))      # field resident in HBM
-        if dist is not None:
+        if dist is not None and sync:
             dist.barrier()
         t0 = time.perf_counter()
         rc = lib.ssf_execute(h, C.byref(cp), 1, 1, None, C.byref(st), None)              # synchronous at return
@@ -111,7 +122,7 @@ def main():
     assert st.steps == args.steps, (st.steps, args.steps)
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         dist.barrier()
@@ -121,7 +132,7 @@ def main():
     if dist is not None:
         # "gather of results only" (SURVEY.md 8e): one RCCL all-gather of a per-rank checksum
         import torch
-        cs = torch.tensor([float(np.sum(np.abs(out_soa) ** 2))], dtype=torch.float64, device="cuda")
+        cs = torch.tensor([float(np.sum(np.abs(out_soa) ** 2))], dtype=torch.float64, device=tdev)
         allcs = [torch.zeros_like(cs) for _ in range(world)]
         dist.all_gather(allcs, cs)
         checksums = [float(x.item()) for x in allcs]
@@ -131,7 +142,7 @@ def main():
     kernels = None
     if rank == 0 and not args.no_kernel_times and lib.ssf_set_profiling(h, 1) == 0:
         nprof = min(args.steps, 200)
-        _, stp = run(nprof, soa)
+        _, stp = run(nprof, soa, sync=False)
         kt = _lib.KernelTimes()
         lib.ssf_get_kernel_times(h, C.byref(kt))
         lib.ssf_set_profiling(h, 0)
@@ -207,7 +218,7 @@ def main():
             ref = orc.manakovSSF(E, p, trace=tr)
             tc = time.perf_counter() - t0
             # same n steps on the GPU for the in-run parity gate
-            _, stp = run(n, soa)
+            _, stp = run(n, soa, sync=False)
             got = np.empty_like(soa)
             _lib.raise_for(lib, h, lib.ssf_download(h, got.ctypes.data_as(C.c_void_p)))
             err = float(np.linalg.norm(got.T.astype(np.complex128) - ref) / np.linalg.norm(ref))
@@ -230,6 +241,7 @@ def main():
         print(json.dumps(rec))
     lib.ssf_plan_destroy(h)
     if dist is not None:
+        dist.barrier()                      # rank 0 arrives after its extra passes; nobody tears the group down early
         dist.destroy_process_group()
 
 
