@@ -372,6 +372,13 @@ int emu_mixed_fft_t(int L, int rows, int dir, int plan_threads, const void *in, 
 }
 
 int emu_mixed_fft(int L, int rows, int dir, const void *in, void *out) { return emu_mixed_fft_t(L, rows, dir, 0, in, out); }
+// the radix plan mix_make_plan picks for a row of L values transformed by `threads` threads: radices[0..n-1], n returned (0: none)
+int emu_mix_plan(int L, int threads, int *radices) {
+    ssf::fused::MixPlan p;
+    if (!ssf::fused::mix_make_plan(L, &p, threads)) return 0;
+    for (int i = 0; i < p.npass; ++i) radices[i] = p.r[i];
+    return p.npass;
+}
 
 int emu_wdm_tx(const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
                const double *deltaF, void *out, double *power_out) {

@@ -376,3 +376,23 @@ def test_mixed_radix_transform_lengths():
             assert e.emu_mixed_fft_t(L, 1, -1, T, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)) == 0
             assert e.emu_mixed_fft_t(L, 1, +1, T, x.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p)) == 0
             assert rel_l2(y, np.fft.fft(x, axis=1)) < 1e-14 and rel_l2(z / L, x) < 1e-14, (L, T)
+
+
+def test_mixed_radix_planner_covers_every_row_length_the_split_can_ask_for():
+    """mix_make_plan for every 5-smooth row length 64 .. 8192 and the thread counts the engine uses: the radices multiply
+    to L, there are at most six passes, every radix is implemented, and the last pass (which also applies the row
+    operator, mix_apply_op) has a radix <= 16."""
+    import ctypes as C
+    e = eb.load()
+    e.emu_mix_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    ok_radices = {25, 20, 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2}
+    lengths = sorted({2 ** a * 3 ** b * 5 ** c for a in range(14) for b in range(9) for c in range(6)
+                      if 64 <= 2 ** a * 3 ** b * 5 ** c <= 8192})
+    assert len(lengths) > 100
+    r = (C.c_int * 8)()
+    for L in lengths:
+        for T in (0, 64, 128, 256, 512):
+            n = e.emu_mix_plan(L, T, r)
+            rad = list(r[:n])
+            assert 1 <= n <= 6 and int(np.prod(rad)) == L and set(rad) <= ok_radices and rad[-1] <= 16, (L, T, rad)
+    assert e.emu_mix_plan(7 * 64, 128, r) == 0
