@@ -348,6 +348,29 @@ def test_notebook_lengths_vs_oracle(engine, N, adaptive, prec):
         assert rel_l2(out.astype(np.complex128), ref) <= TOL_C64
 
 
+def test_every_small_mixed_row_length_agrees_with_the_rocfft_engine():
+    """All odd 5-smooth row lengths 64..640 (N = 128 x row length: 2^7 columns, so each one is the engine's row length) and
+    a few even multiples (2^8 columns, row length m / 2): four Manakov steps on the fused engine against the rocFFT engine
+    (every radix, plan shape and ragged last tile)."""
+    rows = sorted({2 ** a * 3 ** b * 5 ** c for a in range(8) for b in range(6) for c in range(5)
+                   if 64 <= 2 ** a * 3 ** b * 5 ** c <= 640 and (2 ** a * 3 ** b * 5 ** c) % 2 == 1})
+    rows += [150, 250, 270, 486, 500, 540, 600, 1250, 1620]
+    cfg = _mk_cfg(Ltotal=0.4, Lspan=0.4, hz=0.1, nlprMethod=False, amp="ideal", saveSpanN=[])
+    for m in rows:
+        N = 128 * m
+        if not models.engine_supported("fused", N):
+            continue
+        E = synth_field(N, 2, m, 8.4)
+        outs = {}
+        for eng in ("fused", "rocfft"):
+            oa.set_engine(eng)
+            outs[eng] = oa.manakovSSF(E, make_param(oa.parameters, cfg), _trace=True)
+            outs[eng + "_it"] = list(models.last_run["iters"])
+            assert models.last_run["engine"] == eng
+        assert rel_l2(outs["fused"], outs["rocfft"]) <= 1e-11 and outs["fused_it"] == outs["rocfft_it"], m
+    oa.set_engine("auto")
+
+
 def test_notebook_length_other_entry_points_on_the_fused_engine():
     N = 48000
     _select("fused", N)
