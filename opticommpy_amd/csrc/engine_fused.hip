@@ -74,6 +74,15 @@ __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const 
     SSF_DEV_CTX(1);
     col_body<T, LG, MODE, true>(ctx, a);
 }
+// complex64 Manakov: packed polarisation pairs (fused_kernels.h: col_pk_body), 256 threads = 16 columns of 256
+template <int LG> __global__ void __launch_bounds__(256, 2) k_col_pk(const ColArgs<pf2> a) {
+    SSF_DEV_CTX(1);
+    col_pk_body<LG>(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_repack(const RepackArgs a) {
+    SSF_DEV_CTX(1);
+    repack_body(ctx, a);
+}
 template <typename T> __global__ void __launch_bounds__(256) k_amp(const AmpArgs<T> a) {
     SSF_DEV_CTX(1);
     amp_body<T>(ctx, a);
@@ -252,8 +261,11 @@ struct HipBackend {
         col_lds_max = col_lds;
     }
     template <typename T> void launch_row(const RowArgs<T> &a, int grid, int block, size_t lds) {
-        RowFn<T> f = !a.mixed ? pick_row<T>(a.log2N2, block, row_occ)
-                     : block <= 256 ? (RowFn<T>)k_row_mixed<T, 256> : block <= 512 ? (RowFn<T>)k_row_mixed<T, 512> : (RowFn<T>)k_row_mixed<T, 1024>;
+        RowFn<T> f;
+        if constexpr (std::is_same<T, pf2>::value) f = pick_row<T>(a.log2N2, block, row_occ);     // (no mixed-radix rows there)
+        else
+            f = !a.mixed ? pick_row<T>(a.log2N2, block, row_occ)
+                : block <= 256 ? (RowFn<T>)k_row_mixed<T, 256> : block <= 512 ? (RowFn<T>)k_row_mixed<T, 512> : (RowFn<T>)k_row_mixed<T, 1024>;
         arm((const void *)f);
         stamp_begin(0);
         f<<<grid, block, lds, pl->stream>>>(a);
@@ -261,7 +273,17 @@ struct HipBackend {
         chk(hipGetLastError(), "launch k_row");
     }
     template <typename T> void launch_col(const ColArgs<T> &a, int grid, int block, size_t lds) {
-        ColFn<T> f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
+        ColFn<T> f;
+        if constexpr (std::is_same<T, pf2>::value) {
+            switch (a.log2N1) {
+            case 7: f = k_col_pk<7>; break;
+            case 8: f = k_col_pk<8>; break;
+            case 9: f = k_col_pk<9>; break;
+            case 10: f = k_col_pk<10>; break;
+            default: f = k_col_pk<0>; break;
+            }
+        } else
+            f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
         arm((const void *)f);
         stamp_begin(a.mode == CM_MK ? 1 : 3);
         f<<<grid, block, lds, pl->stream>>>(a);
@@ -277,6 +299,10 @@ struct HipBackend {
         chk(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         armed.push_back(f);
+    }
+    void launch_repack(const RepackArgs &a, int grid, int block) {
+        k_repack<<<grid, block, 0, pl->stream>>>(a);
+        chk(hipGetLastError(), "launch k_repack");
     }
     template <typename T> void launch_amp(const AmpArgs<T> &a, int grid, int block) {
         k_amp<T><<<grid, block, 0, pl->stream>>>(a);

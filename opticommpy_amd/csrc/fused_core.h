@@ -41,6 +41,104 @@ template <int SIGN, typename T> SSF_HD cx<T> mulj(cx<T> a) {
     return SIGN > 0 ? mk<T>(-a.im, a.re) : mk<T>(a.im, -a.re);
 }
 
+// ---------------------------------------------------------------------------------------
+// Packed polarisation pair: single precision moves half the bytes of double precision for the same number of
+// butterflies and twiddles, so the complex64 Manakov path carries BOTH polarisations of a sample in one
+// element: re = (x.re, y.re), im = (x.im, y.im), two floats per register pair.  Every butterfly then is one
+// packed instruction (v_pk_add_f32 / v_pk_fma_f32) for the two polarisations, twiddles and the linear operator
+// are per-thread scalars shared by both, and |Ex|^2 + |Ey|^2 is local to the thread (no exchange through LDS).
+// scalar_t<T> is the type of such a per-element scalar: T itself for float / double, float for the pair.
+#if defined(__HIPCC__)
+typedef float pf2 __attribute__((ext_vector_type(2)));
+#else
+typedef float pf2 __attribute__((vector_size(8)));
+#endif
+template <typename T> struct LaneOf { using S = T; };
+template <> struct LaneOf<pf2> { using S = float; };
+template <typename T> using scalar_t = typename LaneOf<T>::S;
+template <typename T> SSF_HD T splat(scalar_t<T> a) { return a; }
+template <> SSF_HD pf2 splat<pf2>(float a) {
+    pf2 r;
+    r[0] = a;
+    r[1] = a;
+    return r;
+}
+SSF_HD pf2 mk2(float a, float b) {
+    pf2 r;
+    r[0] = a;
+    r[1] = b;
+    return r;
+}
+// value (element type T) times a scalar complex factor (twiddle, operator, rotation)
+template <typename T> SSF_HD cx<T> tmul(cx<T> v, cx<scalar_t<T>> w) {
+    if constexpr (sizeof(T) == sizeof(scalar_t<T>)) return v * w;
+    else {
+        const T wr = splat<T>(w.re), wi = splat<T>(w.im);
+        return mk<T>(v.re * wr - v.im * wi, v.re * wi + v.im * wr);
+    }
+}
+// sum over the lanes of an element-wise quantity (the pair: both polarisations)
+template <typename T> SSF_HD scalar_t<T> lane_sum(T a) { return a; }
+template <> SSF_HD float lane_sum<pf2>(pf2 a) { return a[0] + a[1]; }
+// fused multiply-add with a scalar factor, per lane
+template <typename T> SSF_HD T fma_s(T x, scalar_t<T> a, T c);
+template <> SSF_HD float fma_s<float>(float x, float a, float c) { return __builtin_fmaf(x, a, c); }
+template <> SSF_HD double fma_s<double>(double x, double a, double c) { return __builtin_fma(x, a, c); }
+template <> SSF_HD pf2 fma_s<pf2>(pf2 x, float a, pf2 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_elementwise_fma(x, splat<pf2>(a), c);
+#else
+    return mk2(__builtin_fmaf(x[0], a, c[0]), __builtin_fmaf(x[1], a, c[1]));
+#endif
+}
+
+// Streaming-memory policy (compile-time, SSF_MEMPOL bits): the exchange buffer G and the time-domain fields are
+// written by one launch and read by the next one, normally from another XCD: keeping them in the writer's L2 buys
+// nothing and leaves the whole output dirty until the end-of-kernel write-back.  A non-temporal access streams
+// through instead.  bit 0: G stores, bit 1: G loads, bit 2: field / E_hd stores, bit 3: field / E_hd loads.
+#ifndef SSF_MEMPOL
+#define SSF_MEMPOL 0
+#endif
+template <int BIT, typename T> SSF_HD cx<T> ld_pol(const cx<T> *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr ((SSF_MEMPOL >> BIT) & 1) {
+        if constexpr (sizeof(T) == sizeof(scalar_t<T>)) {
+            typedef T vec2 __attribute__((ext_vector_type(2)));
+            const vec2 v = __builtin_nontemporal_load((const vec2 *)p);
+            return mk<T>(v.x, v.y);
+        } else {                                             // packed pair: one 16-byte access
+            typedef float vec4 __attribute__((ext_vector_type(4)));
+            const vec4 v = __builtin_nontemporal_load((const vec4 *)p);
+            return mk<T>(mk2(v.x, v.y), mk2(v.z, v.w));
+        }
+    }
+#endif
+    return *p;
+}
+template <int BIT, typename T> SSF_HD void st_pol(cx<T> *p, cx<T> x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr ((SSF_MEMPOL >> BIT) & 1) {
+        if constexpr (sizeof(T) == sizeof(scalar_t<T>)) {
+            typedef T vec2 __attribute__((ext_vector_type(2)));
+            vec2 v;
+            v.x = x.re;
+            v.y = x.im;
+            __builtin_nontemporal_store(v, (vec2 *)p);
+        } else {
+            typedef float vec4 __attribute__((ext_vector_type(4)));
+            vec4 v;
+            v.x = x.re[0];
+            v.y = x.re[1];
+            v.z = x.im[0];
+            v.w = x.im[1];
+            __builtin_nontemporal_store(v, (vec4 *)p);
+        }
+        return;
+    }
+#endif
+    *p = x;
+}
+
 // cis(2*pi*frac) evaluated in double (frac is exact: integer / power of two)
 SSF_HD void cis2pi_d(double frac, double &c, double &s) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -198,16 +296,19 @@ template <> struct KConst<float> {
 };
 // (a true fused multiply-add is essential: the correction x*lo is below half an ulp of x*hi)
 template <typename T> SSF_HD T mul_h(T x) {
-    if constexpr (sizeof(T) == 8) return x * KConst<T>::h_hi;
-    else return __builtin_fmaf(x, KConst<T>::h_hi, x * KConst<T>::h_lo);
+    using K = KConst<scalar_t<T>>;
+    if constexpr (sizeof(scalar_t<T>) == 8) return x * K::h_hi;
+    else return fma_s<T>(x, K::h_hi, x * K::h_lo);
 }
 template <typename T> SSF_HD T mul_c(T x) {
-    if constexpr (sizeof(T) == 8) return x * KConst<T>::c_hi;
-    else return __builtin_fmaf(x, KConst<T>::c_hi, x * KConst<T>::c_lo);
+    using K = KConst<scalar_t<T>>;
+    if constexpr (sizeof(scalar_t<T>) == 8) return x * K::c_hi;
+    else return fma_s<T>(x, K::c_hi, x * K::c_lo);
 }
 template <typename T> SSF_HD T mul_s(T x) {
-    if constexpr (sizeof(T) == 8) return x * KConst<T>::s_hi;
-    else return __builtin_fmaf(x, KConst<T>::s_hi, x * KConst<T>::s_lo);
+    using K = KConst<scalar_t<T>>;
+    if constexpr (sizeof(scalar_t<T>) == 8) return x * K::s_hi;
+    else return fma_s<T>(x, K::s_hi, x * K::s_lo);
 }
 // a * (cr + j*SIGN*ci) with cr, ci in {cos(pi/8), sin(pi/8)} up to sign: CR/CI select (+-)c or (+-)s
 template <int SIGN, int CR, int CI, typename T> SSF_HD cx<T> rot16(cx<T> a) {
@@ -216,25 +317,28 @@ template <int SIGN, int CR, int CI, typename T> SSF_HD cx<T> rot16(cx<T> a) {
     const T ir = (CR == 1 || CR == -1) ? mul_c(a.im) : mul_s(a.im);
     const T ri = (CI == 1 || CI == -1) ? mul_c(a.re) : mul_s(a.re);
     const T ii = (CI == 1 || CI == -1) ? mul_c(a.im) : mul_s(a.im);
-    const T sr = CR > 0 ? (T)1 : (T)-1, si = (CI > 0 ? (T)1 : (T)-1) * (T)SIGN;
+    using S = scalar_t<T>;
+    const S sr = CR > 0 ? (S)1 : (S)-1, si = (CI > 0 ? (S)1 : (S)-1) * (S)SIGN;
     return mk<T>(sr * rr - si * ii, sr * ir + si * ri);
 }
 
 template <int SIGN, typename T> SSF_HD void dft8(cx<T> *v) {   // v[0..7]
+    constexpr scalar_t<T> kS = (scalar_t<T>)SIGN;
     cx<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
     cx<T> o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
     dft4<SIGN>(e0, e1, e2, e3);
     dft4<SIGN>(o0, o1, o2, o3);
     // o_s *= W8^s
-    o1 = mk<T>(mul_h(o1.re - SIGN * o1.im), mul_h(o1.im + SIGN * o1.re));           // (1 + SIGN j)/sqrt2
+    o1 = mk<T>(mul_h(o1.re - kS * o1.im), mul_h(o1.im + kS * o1.re));           // (1 + SIGN j)/sqrt2
     o2 = mulj<SIGN>(o2);
-    o3 = mk<T>(mul_h(-o3.re - SIGN * o3.im), mul_h(-o3.im + SIGN * o3.re));         // (-1 + SIGN j)/sqrt2
+    o3 = mk<T>(mul_h(-o3.re - kS * o3.im), mul_h(-o3.im + kS * o3.re));         // (-1 + SIGN j)/sqrt2
     v[0] = e0 + o0; v[4] = e0 - o0;
     v[1] = e1 + o1; v[5] = e1 - o1;
     v[2] = e2 + o2; v[6] = e2 - o2;
     v[3] = e3 + o3; v[7] = e3 - o3;
 }
 template <int SIGN, typename T> SSF_HD void dft16(cx<T> *v) {  // v[0..15]
+    constexpr scalar_t<T> kS = (scalar_t<T>)SIGN;
     cx<T> e[8], o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -245,11 +349,11 @@ template <int SIGN, typename T> SSF_HD void dft16(cx<T> *v) {  // v[0..15]
     dft8<SIGN>(o);
     // o_s *= W16^s = cis(SIGN * pi s / 8)
     o[1] = rot16<SIGN, +1, +2>(o[1]);                                                  // ( c, SIGN s)
-    o[2] = mk<T>(mul_h(o[2].re - SIGN * o[2].im), mul_h(o[2].im + SIGN * o[2].re));
+    o[2] = mk<T>(mul_h(o[2].re - kS * o[2].im), mul_h(o[2].im + kS * o[2].re));
     o[3] = rot16<SIGN, +2, +1>(o[3]);                                                  // ( s, SIGN c)
     o[4] = mulj<SIGN>(o[4]);
     o[5] = rot16<SIGN, -2, +1>(o[5]);                                                  // (-s, SIGN c)
-    o[6] = mk<T>(mul_h(-o[6].re - SIGN * o[6].im), mul_h(-o[6].im + SIGN * o[6].re));
+    o[6] = mk<T>(mul_h(-o[6].re - kS * o[6].im), mul_h(-o[6].im + kS * o[6].re));
     o[7] = rot16<SIGN, -1, +2>(o[7]);                                                  // (-c, SIGN s)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

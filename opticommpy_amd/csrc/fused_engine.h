@@ -9,7 +9,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "fused_kernels.h"
@@ -90,9 +92,14 @@ inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
     return false;
 }
 
+// T = double / float: one complex row per polarisation (nrows rows);  T = pf2: the packed pair of the complex64
+// Manakov path (fused_core.h), nrows = number of polarisation PAIRS, 16-byte elements -- created and driven by the
+// float core (run_manakov_packed), only its Manakov span loop is used.
 template <typename T, class Backend> class FusedCore {
   public:
     using C = cx<T>;
+    using S = scalar_t<T>;
+    static constexpr bool kPacked = sizeof(T) != sizeof(S);
     Backend &be;
     int64_t N;
     int nrows, log2N;
@@ -103,7 +110,10 @@ template <typename T, class Backend> class FusedCore {
     cx<double> *wtab = nullptr;  // cis(-2 pi k / N2mix)
     size_t field_bytes;
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
-    T *P = nullptr, *Theta = nullptr;
+    S *P = nullptr, *Theta = nullptr;
+    bool own_G = true;           // the packed core works in the float core's exchange buffer
+    std::unique_ptr<FusedCore<pf2, Backend>> pk;     // float core: the packed-pair Manakov pipeline (created on first use)
+    bool use_packed = true;      // SSF_C64_PACKED=0: complex64 Manakov on the one-row-per-polarisation kernels (A/B runs)
     bool lim0_bound = true;       // SSF_LIM0_BOUND=0: always evaluate lim_0 on all samples (A/B runs)
     Ctrl *ctrl = nullptr;        // [2]
     LinOp *linops = nullptr;     // [2]
@@ -120,7 +130,12 @@ template <typename T, class Backend> class FusedCore {
     size_t row_lds, col_lds_mk, col_lds_1;
     std::string err;
 
-    FusedCore(Backend &b, int64_t N_, int nrows_, int precision) : be(b), N(N_), nrows(nrows_) {
+    int npairs() const { return kPacked ? nrows : std::max(nrows / 2, 1); }
+    FusedCore(Backend &b, int64_t N_, int nrows_, int precision, void *borrowed_G = nullptr) : be(b), N(N_), nrows(nrows_) {
+        if (borrowed_G) {
+            G = (C *)borrowed_G;
+            own_G = false;
+        }
         log2N = 0;
         while ((1ll << log2N) < N) ++log2N;
         if ((N & (N - 1)) == 0) {
@@ -188,14 +203,13 @@ template <typename T, class Backend> class FusedCore {
             row_grid = (int)(nfft / fpw);
             row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 16 + 2048);
         }
-        col_geometry(std::max(nrows / 2, 1), 2, &col_block_mk, &col_grid_mk, &col_lds_mk);
+        if (const char *e = std::getenv("SSF_C64_PACKED")) use_packed = std::atoi(e) != 0;
+        col_geometry(npairs(), kPacked ? 1 : 2, &col_block_mk, &col_grid_mk, &col_lds_mk);
         col_geometry(nrows, 1, &col_block_1, &col_grid_1, &col_lds_1);
         npart_max = std::max(col_grid_mk, col_grid_1);
-        void **ptrs[] = {(void **)&G, (void **)&T0, (void **)&T1, (void **)&Ehd};
-        for (auto pp : ptrs)
-            if (!(*pp = be.alloc(field_bytes))) return oom();
-        if (!(P = (T *)be.alloc(2 * sizeof(T) * (size_t)N * (size_t)((nrows + 1) / 2)))) return oom();   // two Pch buffers
-        if (!(Theta = (T *)be.alloc(sizeof(T) * (size_t)N * (size_t)((nrows + 1) / 2)))) return oom();
+        if (own_G && !(G = (C *)be.alloc(field_bytes))) return oom();
+        if (!(T0 = (C *)be.alloc(field_bytes))) return oom();
+        if (kPacked && mk_buffers()) return SSF_ERR_OOM;      // (the other cores allocate them when a Manakov run needs them)
         if (!(ctrl = (Ctrl *)be.alloc(2 * sizeof(Ctrl)))) return oom();
         if (!(linops = (LinOp *)be.alloc(2 * sizeof(LinOp)))) return oom();
         if (!(part = (double *)be.alloc(sizeof(double) * 5 * (size_t)npart_max))) return oom();
@@ -212,11 +226,20 @@ template <typename T, class Backend> class FusedCore {
         be.prepare(row_lds, std::max(col_lds_mk, col_lds_1));
         return SSF_OK;
     }
+    // second time-domain field, E_hd, Pch (two buffers) and the phase array: only the Manakov pipeline uses them
+    int mk_buffers() {
+        if (T1) return SSF_OK;
+        if (!(T1 = (C *)be.alloc(field_bytes)) || !(Ehd = (C *)be.alloc(field_bytes))) return oom();
+        if (!(P = (S *)be.alloc(2 * sizeof(S) * (size_t)N * (size_t)npairs()))) return oom();
+        if (!(Theta = (S *)be.alloc(sizeof(S) * (size_t)N * (size_t)npairs()))) return oom();
+        return SSF_OK;
+    }
     int oom() {
         err = "out of memory allocating fused-engine buffers: " + be.last_error();
         return SSF_ERR_OOM;
     }
     ~FusedCore() {
+        if (!own_G) G = nullptr;
         for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)Theta, (void *)ctrl, (void *)linops,
                         (void *)part, (void *)wtab, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
             if (p) be.free(p);
@@ -226,6 +249,7 @@ template <typename T, class Backend> class FusedCore {
     C *Tcur() { return cur ? T1 : T0; }
 
     int upload(const void *field, bool aos) {
+        if constexpr (kPacked) return SSF_ERR_UNSUPPORTED;
         cur = 0;
         be.h2d_big(aos ? G : T0, field, field_bytes);
         if (aos) be.aos_to_soa(T0, G, N, nrows);
@@ -234,6 +258,7 @@ template <typename T, class Backend> class FusedCore {
         return be.ok() ? SSF_OK : hiperr();
     }
     int download(void *field, int which, bool aos) {
+        if constexpr (kPacked) return SSF_ERR_UNSUPPORTED;
         const C *src = which < 0 ? Tcur() : snaps[(size_t)which];
         if (aos) {
             be.soa_to_aos(G, src, N, nrows);
@@ -276,7 +301,7 @@ template <typename T, class Backend> class FusedCore {
         a.N = N;
         a.npol = npol;
         a.mode = mode;
-        a.ngroups = std::max(nrows / 2, 1);
+        a.ngroups = npairs();
         a.pmax = part;
         a.pnum = part + npart_max;
         a.pden = part + 2 * (size_t)npart_max;
@@ -290,24 +315,27 @@ template <typename T, class Backend> class FusedCore {
         a.lin = lin;
         be.launch_row(a, row_grid, row_block, row_lds);
     }
-    void launch_col_plain(int mode, C *timebuf, T g_hz) {
+    void launch_col_plain(int mode, C *timebuf, S g_hz) {
+        if constexpr (kPacked) return;
         ColArgs<T> a = col_args(1, mode);
         a.T0 = timebuf;
         a.g_hz = g_hz;
         a.npart = col_grid_1;
         be.launch_col(a, col_grid_1, col_block_1, col_lds_1);
     }
-    void launch_amp(C *E, T gain, const C *noise, double sigma = 0.0, unsigned long long seed = 0, unsigned span = 0) {
-        AmpArgs<T> a{};
-        a.E = E;
-        a.noise = noise;
-        a.total = (long long)N * nrows;
-        a.N = N;
-        a.gain = gain;
-        a.sigma = sigma;
-        a.seed = seed;
-        a.span = span;
-        be.launch_amp(a, 1024, 256);
+    void launch_amp(C *E, S gain, const C *noise, double sigma = 0.0, unsigned long long seed = 0, unsigned span = 0) {
+        if constexpr (!kPacked) {
+            AmpArgs<S> a{};
+            a.E = E;
+            a.noise = noise;
+            a.total = (long long)N * nrows;
+            a.N = N;
+            a.gain = gain;
+            a.sigma = sigma;
+            a.seed = seed;
+            a.span = span;
+            be.launch_amp(a, 1024, 256);
+        }
     }
     int snapshot() {
         C *s = (C *)be.alloc(field_bytes);
@@ -330,16 +358,17 @@ template <typename T, class Backend> class FusedCore {
                 nz = noise_d;
             }
             const bool dev_noise = !noise && p.rng_seed != 0;                     // devices.py:723-726
-            launch_amp(Tcur(), (T)std::sqrt(d.G_lin), nz, dev_noise ? std::sqrt(d.p_noise / 2) : 0.0,
+            launch_amp(Tcur(), (S)std::sqrt(d.G_lin), nz, dev_noise ? std::sqrt(d.p_noise / 2) : 0.0,
                        (unsigned long long)p.rng_seed, (unsigned)span);
         } else if (p.amp == SSF_AMP_IDEAL) {
-            launch_amp(Tcur(), (T)ideal_gain, nullptr);
+            launch_amp(Tcur(), (S)ideal_gain, nullptr);
         }
         return SSF_OK;
     }
 
     // ---------------------------------------------------------------- scalar NLSE
     int run_nlse(const ssf_params &p, const Derived &d, int s0, int s1, const void *noise, ssf_stats *st) {
+        if constexpr (kPacked) return SSF_ERR_UNSUPPORTED;
         const int nsteps = (int)std::floor(p.Lspan / p.hz);
         const double w2 = (d.w_scale / (double)N) * (d.w_scale / (double)N);
         LinOp lo[2];
@@ -349,15 +378,15 @@ template <typename T, class Backend> class FusedCore {
         for (int span = s0; span <= s1; ++span) {
             C *E = Tcur();
             if (nsteps >= 1) {
-                launch_col_plain(CM_NLSE_FIRST, E, (T)0);                              // channels.py:216
+                launch_col_plain(CM_NLSE_FIRST, E, (S)0);                              // channels.py:216
                 launch_row_lin(linops + 0);
                 for (int s = 1; s < nsteps; ++s) {
-                    launch_col_plain(CM_NLSE_STEP, E, (T)(p.gamma * p.hz));
+                    launch_col_plain(CM_NLSE_STEP, E, (S)(p.gamma * p.hz));
                     launch_row_lin(linops + 1);
                 }
-                launch_col_plain(CM_NLSE_STEP, E, (T)(p.gamma * p.hz));
+                launch_col_plain(CM_NLSE_STEP, E, (S)(p.gamma * p.hz));
                 launch_row_lin(linops + 0);
-                launch_col_plain(CM_NLSE_LAST, E, (T)0);                               // channels.py:232
+                launch_col_plain(CM_NLSE_LAST, E, (S)0);                               // channels.py:232
             }
             int rc = amp_fwd(p, d, span, span - s0, noise, std::exp(d.alpha_lin / 2 * nsteps * p.hz));
             if (rc) return rc;
@@ -408,7 +437,7 @@ template <typename T, class Backend> class FusedCore {
         ++seq;
     }
     void launch_mk_col(const MkConst &k, int mode) {
-        ColArgs<T> a = col_args(2, mode);
+        ColArgs<T> a = col_args(kPacked ? 1 : 2, mode);
         a.cin = ctrl + (seq & 1);
         a.cout = ctrl + ((seq + 1) & 1);
         a.k = k;
@@ -437,77 +466,137 @@ template <typename T, class Backend> class FusedCore {
         return SSF_OK;
     }
 
-    int run_manakov(const ssf_params &p, const Derived &d, int s0, int s1, const void *noise, ssf_stats *st,
-                    ssf_trace *trace) {
-        int rc = prepare_trace(trace, p.maxIter);
-        if (rc) return rc;
-        MkConst k = mk_const(p, d);
-        if (!trace) k.trace_cap = 0;
-        if (k.trace_cap > 0) k.exact_lim0 = 1;
-        Ctrl c{};
+    // One span on the device: the field is in T[cur] on entry and in T[cur] (updated) on exit.  The host enqueues
+    // Col, [Row, Col]* in chunks and reads the control block between chunks (a synchronising 300-byte read).
+    struct SpanRun {
         long long trace_n = 0;
         double avg_it = 3.0;
-        for (int span = s0; span <= s1; ++span) {
-            if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))      // equalization.py:1090-1092
-                launch_amp(Tcur(), (T)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);
-            std::memset(&c, 0, sizeof(c));
-            c.state = ST_NEED_S;
-            c.cur = cur;
-            c.trace_n = trace_n;
-            be.h2d(ctrl + (seq & 1), &c, sizeof(Ctrl));
-            launch_mk_col(k, CM_MK);                                                       // first step start
-            int guard = 0;
-            for (;;) {
-                // estimate the [Row, Col] pairs still needed for this span
-                double steps_rem;
-                if (c.steps == 0 && c.state == ST_NEED_S)
-                    steps_rem = p.nlprMethod ? 8.0 : std::ceil(p.Lspan / p.hz);
-                else
-                    steps_rem = std::max(1.0, std::ceil((p.Lspan - c.z) / (c.hz > 0 ? c.hz : p.hz)));
-                double est = steps_rem * (1.0 + avg_it) * (p.nlprMethod ? 0.6 : 0.95);
-                int chunk = (int)std::min(512.0, std::max(2.0, est));
-                for (int i = 0; i < chunk; ++i) {
-                    launch_mk_row(k);
-                    launch_mk_col(k, CM_MK);
-                }
-                be.d2h(&c, ctrl + (seq & 1), sizeof(Ctrl));                               // synchronising read
-                if (!be.ok()) return hiperr();
-                if (c.steps > 0) avg_it = (double)c.iterations / (double)c.steps;
-                if (c.state == ST_SPAN_DONE && !c.pend0) break;
-                if (++guard > (1 << 22)) {
-                    err = "fused engine: span did not terminate";
-                    return SSF_ERR_STATE;
-                }
+    };
+    int run_span(const ssf_params &p, const MkConst &k, SpanRun &sr, ssf_stats *st) {
+        Ctrl c{};
+        c.state = ST_NEED_S;
+        c.cur = cur;
+        c.trace_n = sr.trace_n;
+        be.h2d(ctrl + (seq & 1), &c, sizeof(Ctrl));
+        launch_mk_col(k, CM_MK);                                                       // first step start
+        int guard = 0;
+        for (;;) {
+            // estimate the [Row, Col] pairs still needed for this span
+            double steps_rem;
+            if (c.steps == 0 && c.state == ST_NEED_S)
+                steps_rem = p.nlprMethod ? 8.0 : std::ceil(p.Lspan / p.hz);
+            else
+                steps_rem = std::max(1.0, std::ceil((p.Lspan - c.z) / (c.hz > 0 ? c.hz : p.hz)));
+            double est = steps_rem * (1.0 + sr.avg_it) * (p.nlprMethod ? 0.6 : 0.95);
+            int chunk = (int)std::min(512.0, std::max(2.0, est));
+            for (int i = 0; i < chunk; ++i) {
+                launch_mk_row(k);
+                launch_mk_col(k, CM_MK);
             }
-            cur = c.cur;
-            trace_n = c.trace_n;
-            st->steps += c.steps;
-            st->iterations += c.iterations;
-            st->nonconverged_steps += c.nonconv;
-            st->decided_ahead += c.n_ahead;
-            st->rebuilt_iterates += c.n_rebuilt;
-            st->transforms += (int64_t)nrows * (2 * c.steps + 2 * c.iterations);
-            if (p.direction >= 0 && (rc = amp_fwd(p, d, span, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
-            if (wants_snapshot(p, span) && (rc = snapshot())) return rc;
+            be.d2h(&c, ctrl + (seq & 1), sizeof(Ctrl));                               // synchronising read
+            if (!be.ok()) return hiperr();
+            if (c.steps > 0) sr.avg_it = (double)c.iterations / (double)c.steps;
+            if (c.state == ST_SPAN_DONE && !c.pend0) break;
+            if (++guard > (1 << 22)) {
+                err = "fused engine: span did not terminate";
+                return SSF_ERR_STATE;
+            }
         }
-        be.sync();
-        if (!be.ok()) return hiperr();
+        cur = c.cur;
+        sr.trace_n = c.trace_n;
+        st->steps += c.steps;
+        st->iterations += c.iterations;
+        st->nonconverged_steps += c.nonconv;
+        st->decided_ahead += c.n_ahead;
+        st->rebuilt_iterates += c.n_rebuilt;
+        st->transforms += (int64_t)(kPacked ? 2 * nrows : nrows) * (2 * c.steps + 2 * c.iterations);
+        return SSF_OK;
+    }
+    int fetch_trace(ssf_trace *trace, long long trace_n, int maxIter) {
         if (trace) {
             trace->count = trace_n;
             const long long n = std::min(trace_n, (long long)trace->capacity);
             if (n > 0) {
                 if (trace->hz) be.d2h(trace->hz, tr_hz, sizeof(double) * (size_t)n);
                 if (trace->iters) be.d2h(trace->iters, tr_it, sizeof(int) * (size_t)n);
-                if (trace->lims) be.d2h(trace->lims, tr_lim, sizeof(double) * (size_t)n * (size_t)p.maxIter);
+                if (trace->lims) be.d2h(trace->lims, tr_lim, sizeof(double) * (size_t)n * (size_t)maxIter);
             }
         }
         return be.ok() ? SSF_OK : hiperr();
+    }
+    MkConst mk_const_for(const ssf_params &p, const Derived &d, ssf_trace *trace) const {
+        MkConst k = mk_const(p, d);
+        if (!trace) k.trace_cap = 0;
+        if (k.trace_cap > 0) k.exact_lim0 = 1;
+        return k;
+    }
+
+    int run_manakov(const ssf_params &p, const Derived &d, int s0, int s1, const void *noise, ssf_stats *st,
+                    ssf_trace *trace) {
+        if constexpr (kPacked) return SSF_ERR_UNSUPPORTED;
+        int rc = mk_buffers();
+        if (rc) return rc;
+        if ((rc = prepare_trace(trace, p.maxIter))) return rc;
+        const MkConst k = mk_const_for(p, d, trace);
+        SpanRun sr;
+        for (int span = s0; span <= s1; ++span) {
+            if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))      // equalization.py:1090-1092
+                launch_amp(Tcur(), (S)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);
+            if ((rc = run_span(p, k, sr, st))) return rc;
+            if (p.direction >= 0 && (rc = amp_fwd(p, d, span, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
+            if (wants_snapshot(p, span) && (rc = snapshot())) return rc;
+        }
+        be.sync();
+        if (!be.ok()) return hiperr();
+        return fetch_trace(trace, sr.trace_n, p.maxIter);
+    }
+
+    // complex64 Manakov on the packed-pair pipeline: per span the rows of T[cur] are packed into the pair core's field
+    // (one pass), propagated there, and unpacked again for the amplifier / snapshot stage (one pass): two extra passes
+    // over the field per SPAN against (2 + 2 nIter) per STEP.
+    bool packed_ok() const { return std::is_same<T, float>::value && use_packed && !N2mix && (nrows % 2) == 0; }
+    int run_manakov_packed(const ssf_params &p, const Derived &d, int s0, int s1, const void *noise, ssf_stats *st,
+                           ssf_trace *trace) {
+        if constexpr (!std::is_same<T, float>::value) return SSF_ERR_UNSUPPORTED;
+        else {
+            int rc;
+            if (!pk) {
+                pk.reset(new FusedCore<pf2, Backend>(be, N, nrows / 2, SSF_C128, (void *)G));
+                if ((rc = pk->init())) {
+                    err = pk->err;
+                    pk.reset();
+                    return rc;
+                }
+            }
+            if ((rc = pk->prepare_trace(trace, p.maxIter))) return rc;
+            const MkConst k = pk->mk_const_for(p, d, trace);
+            typename FusedCore<pf2, Backend>::SpanRun sr;
+            for (int span = s0; span <= s1; ++span) {
+                if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))
+                    launch_amp(Tcur(), (S)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);
+                pk->cur = 0;
+                be.launch_repack(RepackArgs{Tcur(), pk->T0, (long long)N, nrows / 2, 1}, 1024, 256);
+                if ((rc = pk->run_span(p, k, sr, st))) {
+                    err = pk->err;
+                    return rc;
+                }
+                be.launch_repack(RepackArgs{Tcur(), pk->Tcur(), (long long)N, nrows / 2, 0}, 1024, 256);
+                if (p.direction >= 0 && (rc = amp_fwd(p, d, span, span - s0, noise, std::exp(d.alpha_lin / 2 * p.Lspan)))) return rc;
+                if (wants_snapshot(p, span) && (rc = snapshot())) return rc;
+            }
+            be.sync();
+            if (!be.ok()) return hiperr();
+            if ((rc = pk->fetch_trace(trace, sr.trace_n, p.maxIter))) err = pk->err;
+            return rc;
+        }
     }
 
     int execute(const ssf_params &p, int s0, int s1, const void *noise, ssf_stats *st, ssf_trace *trace) {
         const Derived d = derive(p);
         be.time_begin();
-        int rc = p.model == SSF_MODEL_NLSE ? run_nlse(p, d, s0, s1, noise, st) : run_manakov(p, d, s0, s1, noise, st, trace);
+        int rc = p.model == SSF_MODEL_NLSE ? run_nlse(p, d, s0, s1, noise, st)
+                 : packed_ok()             ? run_manakov_packed(p, d, s0, s1, noise, st, trace)
+                                           : run_manakov(p, d, s0, s1, noise, st, trace);
         if (rc) return rc;
         st->device_ms += be.time_end();
         st->n_snapshots = (int32_t)snaps.size();
@@ -516,15 +605,16 @@ template <typename T, class Backend> class FusedCore {
 
     // Eo = ifft(fft(Ei) * exp(-alpha/2 L + j beta2/2 w^2 L))     (channels.py:97)
     int linear_channel(double Fs, double Fc, double alpha, double D, double L) {
+        if constexpr (kPacked) return SSF_ERR_UNSUPPORTED;
         ssf_params p{};
         p.Fs = Fs; p.Fc = Fc; p.alpha = alpha; p.D = D; p.direction = 1; p.Lspan = 1; p.NF = 4.5;
         const Derived d = derive(p);
         const double w2 = (d.w_scale / (double)N) * (d.w_scale / (double)N);
         LinOp lo = make_linop(L, d.lin_a, d.lin_b, w2, 1.0 / (double)N, log2N);
         be.h2d(linops, &lo, sizeof(lo));
-        launch_col_plain(CM_PLAIN_FWD, Tcur(), (T)0);
+        launch_col_plain(CM_PLAIN_FWD, Tcur(), (S)0);
         launch_row_lin(linops);
-        launch_col_plain(CM_PLAIN_INV, Tcur(), (T)0);
+        launch_col_plain(CM_PLAIN_INV, Tcur(), (S)0);
         be.sync();
         return be.ok() ? SSF_OK : hiperr();
     }

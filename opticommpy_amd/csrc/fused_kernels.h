@@ -111,15 +111,39 @@ SSF_HD double pick_hz(const MkConst &k, double z, double maxphi) {
 }
 
 // ------------------------------------------------------------------------ thread-level FFT
+// Single precision, packed pair: apply unit factors (twiddles, operator) as hi + lo float pairs.  A factor rounded to
+// one float is off by up to 3e-8 in magnitude and phase, and it is the SAME error at every step (the twiddle of a given
+// butterfly never changes), so over 10^4 steps the errors add up coherently: -1.2e-7 of power per step and a spectral
+// ripple of 1e-3 after BASELINE config 3's 10 010 steps (the reference's own complex64 path, pocketfft with float
+// twiddles, drifts by 5e-4 there).  With the low part the effective factor is exact to 1e-15 and only the random
+// rounding of the products is left, which grows with the square root of the step count.
+#ifndef SSF_C64_HILO
+#define SSF_C64_HILO 1
+#endif
+// v * h for a factor given in double precision
+template <typename T> SSF_HD cx<T> mul_by_d(cx<T> v, cx<double> h) {
+    using S = scalar_t<T>;
+    if constexpr (sizeof(T) == sizeof(S)) {
+        return v * mk<T>((T)h.re, (T)h.im);
+    } else if constexpr (SSF_C64_HILO) {
+        const S hr = (S)h.re, hi = (S)h.im;
+        const S lr = (S)(h.re - (double)hr), li = (S)(h.im - (double)hi);
+        const T cr = fma_s<T>(v.re, lr, -(v.im * splat<T>(li)));            // v.re lr - v.im li
+        const T ci = fma_s<T>(v.re, li, v.im * splat<T>(lr));               // v.re li + v.im lr
+        return mk<T>(fma_s<T>(v.re, hr, fma_s<T>(-v.im, hi, cr)), fma_s<T>(v.re, hi, fma_s<T>(v.im, hr, ci)));
+    } else {
+        return tmul(v, mk<S>((S)h.re, (S)h.im));
+    }
+}
+
 // w[s] = cis(sign * 2 pi j s / 2^lgL), s = 0..R-1.  The power tree always runs in double and is
-// rounded once at the end: in single precision a float tree gives every twiddle a magnitude error
+// rounded once, where it is applied: in single precision a float tree gives every twiddle a magnitude error
 // that is the same at every step (w^s inherits s times the rounding of w), and those errors add up
 // coherently over thousands of steps (measured -0.26 % power after 2000 steps with a float tree).
-template <int R, typename T> SSF_HD void tw_powers(int sign, int j, int lgL, cx<T> *w) {
+template <int R> SSF_HD void tw_powers(int sign, int j, int lgL, cx<double> *p) {
     double c, s;
     cis2pi_d(scale_pow2((double)(sign * j), lgL), c, s);
     const cx<double> w1 = mk<double>(c, s);
-    cx<double> p[R];
     p[0] = mk<double>(1.0, 0.0);
     p[1] = w1;
     if (R > 2) {
@@ -137,8 +161,6 @@ template <int R, typename T> SSF_HD void tw_powers(int sign, int j, int lgL, cx<
 #pragma unroll
         for (int s2 = 9; s2 < 16; ++s2) p[s2 < R ? s2 : 0] = p[8] * p[s2 - 8];
     }
-#pragma unroll
-    for (int s2 = 0; s2 < R; ++s2) w[s2] = mk<T>((T)p[s2].re, (T)p[s2].im);
 }
 
 // butterflies of pass i for thread b (values v[u*r + q]); DIF: DFT then twiddle w^s
@@ -149,10 +171,10 @@ template <int SIGN, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, i
     case 4: {
         dft16<SIGN>(v);
         if (tw) {
-            cx<T> w[16];
+            cx<double> w[16];
             tw_powers<16>(SIGN, pass_j(p, i, b), lgLi, w);
 #pragma unroll
-            for (int s = 1; s < 16; ++s) v[s] = v[s] * w[s];
+            for (int s = 1; s < 16; ++s) v[s] = mul_by_d(v[s], w[s]);
         }
     } break;
     case 3:
@@ -160,10 +182,10 @@ template <int SIGN, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, i
         for (int u = 0; u < 2; ++u) {
             dft8<SIGN>(v + 8 * u);
             if (tw) {
-                cx<T> w[8];
+                cx<double> w[8];
                 tw_powers<8>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
 #pragma unroll
-                for (int s = 1; s < 8; ++s) v[8 * u + s] = v[8 * u + s] * w[s];
+                for (int s = 1; s < 8; ++s) v[8 * u + s] = mul_by_d(v[8 * u + s], w[s]);
             }
         }
         break;
@@ -172,10 +194,10 @@ template <int SIGN, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, i
         for (int u = 0; u < 4; ++u) {
             dft4<SIGN>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
             if (tw) {
-                cx<T> w[4];
+                cx<double> w[4];
                 tw_powers<4>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
 #pragma unroll
-                for (int s = 1; s < 4; ++s) v[4 * u + s] = v[4 * u + s] * w[s];
+                for (int s = 1; s < 4; ++s) v[4 * u + s] = mul_by_d(v[4 * u + s], w[s]);
             }
         }
         break;
@@ -184,9 +206,9 @@ template <int SIGN, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, i
         for (int u = 0; u < 8; ++u) {
             dft2<SIGN>(v[2 * u], v[2 * u + 1]);
             if (tw) {
-                cx<T> w[2];
+                cx<double> w[2];
                 tw_powers<2>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
-                v[2 * u + 1] = v[2 * u + 1] * w[1];
+                v[2 * u + 1] = mul_by_d(v[2 * u + 1], w[1]);
             }
         }
         break;
@@ -200,10 +222,10 @@ template <int SIGN, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, i
     switch (p.lg(i)) {
     case 4: {
         if (tw) {
-            cx<T> w[16];
+            cx<double> w[16];
             tw_powers<16>(SIGN, pass_j(p, i, b), lgLi, w);
 #pragma unroll
-            for (int s = 1; s < 16; ++s) v[s] = v[s] * w[s];
+            for (int s = 1; s < 16; ++s) v[s] = mul_by_d(v[s], w[s]);
         }
         dft16<SIGN>(v);
     } break;
@@ -211,10 +233,10 @@ template <int SIGN, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, i
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (tw) {
-                cx<T> w[8];
+                cx<double> w[8];
                 tw_powers<8>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
 #pragma unroll
-                for (int s = 1; s < 8; ++s) v[8 * u + s] = v[8 * u + s] * w[s];
+                for (int s = 1; s < 8; ++s) v[8 * u + s] = mul_by_d(v[8 * u + s], w[s]);
             }
             dft8<SIGN>(v + 8 * u);
         }
@@ -223,10 +245,10 @@ template <int SIGN, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, i
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (tw) {
-                cx<T> w[4];
+                cx<double> w[4];
                 tw_powers<4>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
 #pragma unroll
-                for (int s = 1; s < 4; ++s) v[4 * u + s] = v[4 * u + s] * w[s];
+                for (int s = 1; s < 4; ++s) v[4 * u + s] = mul_by_d(v[4 * u + s], w[s]);
             }
             dft4<SIGN>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
         }
@@ -235,9 +257,9 @@ template <int SIGN, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, i
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (tw) {
-                cx<T> w[2];
+                cx<double> w[2];
                 tw_powers<2>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
-                v[2 * u + 1] = v[2 * u + 1] * w[1];
+                v[2 * u + 1] = mul_by_d(v[2 * u + 1], w[1]);
             }
             dft2<SIGN>(v[2 * u], v[2 * u + 1]);
         }
@@ -430,16 +452,16 @@ SSF_HD void apply_lin16(const LinOp &lo, long long k0, int log2N, cx<T> *v) {
         const int m = q < 8 ? q : 16 - q;                       // |q'|, q' = q (q<8) or q-16
         const cx<double> bq = q < 8 ? Bp[m] : conj(Bp[m]);
         const cx<double> h = A * bq * mk<double>(lo.Cre[m], lo.Cim[m]);
-        v[q] = v[q] * mk<T>((T)h.re, (T)h.im);
+        v[q] = mul_by_d(v[q], h);
     }
 }
 // general (slow) form for short rows whose last radix is not 16
-template <typename T> SSF_HD cx<T> lin_at(const LinOp &lo, long long k, int log2N) {
+SSF_HD cx<double> lin_at(const LinOp &lo, long long k, int log2N) {
     const long long N = 1ll << log2N;
     const double kk = (double)(k < N / 2 ? k : k - N);
     double s, c;
     cis_rad_d(lo.cth * kk * kk, c, s);
-    return mk<T>((T)(lo.mag * c), (T)(lo.mag * s));
+    return mk<double>(lo.mag * c, lo.mag * s);
 }
 
 // Forward nwords 8-byte words of the control block (lead thread).  Eight words are fetched before any is stored:
@@ -675,7 +697,7 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
         ctx.issue_fence();
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = g[b + p.tpf * q];
+    for (int q = 0; q < 16; ++q) v[q] = ld_pol<1>(g + b + p.tpf * q);
     if (a.use_ctrl) {
         ctx.issue_fence();
         if (!row_ctrl(ctx, a, part, lo)) return;
@@ -697,14 +719,14 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
 #pragma unroll
         for (int idx = 0; idx < 16; ++idx) {
             const long long k = k1 + ((long long)rev_pos(p, reg_pos(p, last, b, idx)) << a.log2N1);
-            v[idx] = v[idx] * lin_at<T>(lo, k, log2N);
+            v[idx] = mul_by_d(v[idx], lin_at(lo, k, log2N));
         }
     }
     ctx.mark(3);
     fft_dit<+1>(ctx, p, b, v, l);
     ctx.mark(4);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) g[b + p.tpf * q] = v[q];
+    for (int q = 0; q < 16; ++q) st_pol<0>(g + b + p.tpf * q, v[q]);
     ctx.mark(5);
     ctx.flush(0);
 }
@@ -723,11 +745,11 @@ template <typename T> struct ColArgs {
     cx<T> *G;                 // (nrows, N1, N2)
     cx<T> *T0, *T1;           // time-domain fields, (nrows, N); Manakov: field at the step start / end (ping-pong)
     cx<T> *Ehd;               // (nrows, N)
-    T *P;                     // (2, K, N): Pch of the current / next step
-    T *Theta;                 // (K, N): phase shz * phi of the latest rotation
+    scalar_t<T> *P;           // (2, K, N): Pch of the current / next step
+    scalar_t<T> *Theta;       // (K, N): phase shz * phi of the latest rotation
     int log2N1, log2N2, npol, mode;
     int ngroups;              // Manakov: polarisation pairs K (P holds 2 x K x N values: two buffers)
-    T g_hz;                   // NLSE: gamma * hz
+    scalar_t<T> g_hz;         // NLSE: gamma * hz
     const Ctrl *cin;
     Ctrl *cout;
     MkConst k;
@@ -787,6 +809,14 @@ template <typename T, int LG, class Ctx, bool RAGGED = false> struct ColGeom {
     template <typename V> SSF_HD void st(V *ptr, long long i, V x) const {
         if (!RAGGED || valid) ptr[i] = x;
     }
+    // the same with a streaming policy bit (fused_core.h: SSF_MEMPOL)
+    template <int BIT, typename U> SSF_HD cx<U> ldp(const cx<U> *ptr, long long i) const {
+        if (RAGGED && !valid) return cx<U>{};
+        return ld_pol<BIT>(ptr + i);
+    }
+    template <int BIT, typename U> SSF_HD void stp(cx<U> *ptr, long long i, cx<U> x) const {
+        if (!RAGGED || valid) st_pol<BIT>(ptr + i, x);
+    }
 };
 
 // inter-pass twiddle of the N = N1*N2 decomposition, applied on the frequency side of the
@@ -806,8 +836,7 @@ template <int SIGN, bool RAGGED, typename T, class G> SSF_HD void global_twiddle
     powers16(ws, w);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const cx<double> t = w0 * w[q];
-        v[q] = v[q] * mk<T>((T)t.re, (T)t.im);
+        v[q] = mul_by_d(v[q], w0 * w[q]);
     }
 }
 
@@ -929,7 +958,7 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
 #define SSF_EHD_EARLY 8
 #endif
 #pragma unroll
-    for (int idx = 0; idx < SSF_EHD_EARLY; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
+    for (int idx = 0; idx < SSF_EHD_EARLY; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const long long t = own_time_off(g, j);
@@ -942,7 +971,7 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     }
     ctx.mark(7);
 #pragma unroll
-    for (int idx = SSF_EHD_EARLY; idx < 16; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
+    for (int idx = SSF_EHD_EARLY; idx < 16; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
     ctx.sync();
 #pragma unroll
     for (int idx = 0; idx < 16; ++idx) {
@@ -953,6 +982,105 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
         v[idx] = e * shC[(size_t)idx * g.half + g.t];
     }
     ctx.sync();
+}
+
+// What a Manakov column launch does, decided from the control block; the lead thread forwards the block with the
+// state advanced.  op: 0 = S (span start), 1 = H, 2 = I, 3 = rebuild of iterate 0, -1 = nothing to do.
+struct MkColStage {
+    bool do_inv = false, do_fwd = false, final_ = false, more = false, exact0 = true;
+    int op = -1;
+    struct { int state, it, cur, pcur; double z, hz; } c{};
+};
+template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &a, MkColStage &st) {
+    bool &do_inv = st.do_inv, &do_fwd = st.do_fwd, &final_ = st.final_, &more = st.more, &exact0 = st.exact0;
+    int &op = st.op;
+    auto &c = st.c;
+    // only scalars are taken from the control block (a private copy of the struct would live
+    // in scratch memory and cost real HBM traffic on every launch)
+    c.state = a.cin->state;
+    c.it = a.cin->it;
+    c.cur = a.cin->cur;
+    c.pcur = a.cin->pcur;
+    c.z = a.cin->z;
+    c.hz = a.cin->hz;
+    final_ = a.cin->final_ != 0;
+    exact0 = a.k.exact_lim0 || a.cin->exact0 != 0;
+    if (c.state == ST_NEED_S) {
+        op = 0;
+        do_fwd = true;
+    } else if (c.state == ST_NEED_H) {
+        op = 1;
+        do_inv = do_fwd = true;
+    } else if (c.state == ST_NEED_I) {
+        op = 2;
+        do_inv = true;
+        more = c.z + c.hz < a.k.Lspan;                                // channels.py:441, 387
+        do_fwd = final_ ? more : true;
+    } else if (c.state == ST_REDO0) {
+        op = 3;
+        do_fwd = true;
+    }
+    if (ctx.bid == 0 && ctx.tid == 0) {                               // forward the control block
+        ctrl_forward(a.cin, a.cout, (int)(sizeof(Ctrl) / 8));
+        Ctrl *n = a.cout;
+        if (op == 0) {
+            n->state = ST_AFTER_S;
+            n->hz_valid = 0;
+        } else if (op == 1) {
+            n->state = ST_ROW_ITER;
+            n->it = 0;
+            n->final_ = a.k.maxIter == 1;
+            n->pend0 = n->pendn = 0;
+        } else if (op == 3) {
+            n->state = ST_ROW_ITER;
+            n->it = 0;
+            n->final_ = a.cin->exact0 ? 0 : 1;                        // (exact0: rebuilt to measure lim_0, not as final)
+            n->redo_ = a.cin->exact0 ? 0 : 1;
+            n->pend0 = n->pendn = 0;
+            n->n_rebuilt = a.cin->n_rebuilt + 1;
+        } else if (op == 2 && !final_) {
+            n->state = ST_ROW_ITER;
+            n->it = c.it + 1;
+            n->pendn = 1;
+            if (c.it == 0) {
+                n->pend0 = 1;
+                n->pend0_idx = a.cin->trace_n;
+                n->bound0 = exact0 ? 0 : 1;
+                n->exact0 = 0;
+            }
+        } else if (op == 2) {                                         // the step ends here
+            const long long tn = a.cin->trace_n;
+            if (tn < a.k.trace_cap) {
+                if (a.k.tr_hz) a.k.tr_hz[tn] = c.hz;
+                if (a.k.tr_it) a.k.tr_it[tn] = c.it + 1;
+            }
+            n->trace_n = tn + 1;
+            n->steps = a.cin->steps + 1;
+            n->iterations = a.cin->iterations + c.it + 1;
+            n->z = c.z + c.hz;
+            n->cur = c.cur ^ 1;
+            n->it = 0;
+            n->final_ = 0;
+            if (c.it == 0) {
+                n->pend0 = 1;
+                n->pend0_idx = tn;
+                n->cap0 = a.cin->redo_ ? 0 : 1;
+                n->bound0 = exact0 ? 0 : 1;      // (only recorded in a trace, and a trace makes it exact)
+                n->exact0 = 0;
+            }
+            n->redo_ = 0;
+            if (more) {
+                n->state = ST_AFTER_S;
+                n->pcur = c.pcur ^ 1;
+                if (a.k.adaptive) n->hz_valid = 0;
+                else {
+                    const double hz = pick_hz(a.k, c.z + c.hz, 0.0);
+                    if (hz != c.hz) n->hz_valid = 0;
+                    n->hz = hz;
+                }
+            } else n->state = ST_SPAN_DONE;
+        }
+    }
 }
 
 // MODE is one of CM_*; the Manakov mode picks its stage from the Ctrl state.
@@ -966,92 +1094,20 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
     double *red = (double *)ctx.lds;
     ctx.mark(0);
     if (kMk) {
-        // only scalars are taken from the control block (a private copy of the struct would live
-        // in scratch memory and cost real HBM traffic on every launch)
-        c.state = a.cin->state;
-        c.it = a.cin->it;
-        c.cur = a.cin->cur;
-        c.pcur = a.cin->pcur;
-        c.z = a.cin->z;
-        c.hz = a.cin->hz;
-        final_ = a.cin->final_ != 0;
-        exact0 = a.k.exact_lim0 || a.cin->exact0 != 0;
-        if (c.state == ST_NEED_S) {
-            op = 0;
-            do_fwd = true;
-        } else if (c.state == ST_NEED_H) {
-            op = 1;
-            do_inv = do_fwd = true;
-        } else if (c.state == ST_NEED_I) {
-            op = 2;
-            do_inv = true;
-            more = c.z + c.hz < a.k.Lspan;                                // channels.py:441, 387
-            do_fwd = final_ ? more : true;
-        } else if (c.state == ST_REDO0) {
-            op = 3;
-            do_fwd = true;
-        }
-        if (ctx.bid == 0 && ctx.tid == 0) {                               // forward the control block
-            ctrl_forward(a.cin, a.cout, (int)(sizeof(Ctrl) / 8));
-            Ctrl *n = a.cout;
-            if (op == 0) {
-                n->state = ST_AFTER_S;
-                n->hz_valid = 0;
-            } else if (op == 1) {
-                n->state = ST_ROW_ITER;
-                n->it = 0;
-                n->final_ = a.k.maxIter == 1;
-                n->pend0 = n->pendn = 0;
-            } else if (op == 3) {
-                n->state = ST_ROW_ITER;
-                n->it = 0;
-                n->final_ = a.cin->exact0 ? 0 : 1;                        // (exact0: rebuilt to measure lim_0, not as final)
-                n->redo_ = a.cin->exact0 ? 0 : 1;
-                n->pend0 = n->pendn = 0;
-                n->n_rebuilt = a.cin->n_rebuilt + 1;
-            } else if (op == 2 && !final_) {
-                n->state = ST_ROW_ITER;
-                n->it = c.it + 1;
-                n->pendn = 1;
-                if (c.it == 0) {
-                    n->pend0 = 1;
-                    n->pend0_idx = a.cin->trace_n;
-                    n->bound0 = exact0 ? 0 : 1;
-                    n->exact0 = 0;
-                }
-            } else if (op == 2) {                                         // the step ends here
-                const long long tn = a.cin->trace_n;
-                if (tn < a.k.trace_cap) {
-                    if (a.k.tr_hz) a.k.tr_hz[tn] = c.hz;
-                    if (a.k.tr_it) a.k.tr_it[tn] = c.it + 1;
-                }
-                n->trace_n = tn + 1;
-                n->steps = a.cin->steps + 1;
-                n->iterations = a.cin->iterations + c.it + 1;
-                n->z = c.z + c.hz;
-                n->cur = c.cur ^ 1;
-                n->it = 0;
-                n->final_ = 0;
-                if (c.it == 0) {
-                    n->pend0 = 1;
-                    n->pend0_idx = tn;
-                    n->cap0 = a.cin->redo_ ? 0 : 1;
-                    n->bound0 = exact0 ? 0 : 1;      // (only recorded in a trace, and a trace makes it exact)
-                    n->exact0 = 0;
-                }
-                n->redo_ = 0;
-                if (more) {
-                    n->state = ST_AFTER_S;
-                    n->pcur = c.pcur ^ 1;
-                    if (a.k.adaptive) n->hz_valid = 0;
-                    else {
-                        const double hz = pick_hz(a.k, c.z + c.hz, 0.0);
-                        if (hz != c.hz) n->hz_valid = 0;
-                        n->hz = hz;
-                    }
-                } else n->state = ST_SPAN_DONE;
-            }
-        }
+        MkColStage st;
+        mk_col_stage(ctx, a, st);
+        do_inv = st.do_inv;
+        do_fwd = st.do_fwd;
+        final_ = st.final_;
+        more = st.more;
+        exact0 = st.exact0;
+        op = st.op;
+        c.state = st.c.state;
+        c.it = st.c.it;
+        c.cur = st.c.cur;
+        c.pcur = st.c.pcur;
+        c.z = st.c.z;
+        c.hz = st.c.hz;
         if (op < 0) return;
     } else {
         do_inv = MODE == CM_NLSE_STEP || MODE == CM_NLSE_LAST || MODE == CM_PLAIN_INV;
@@ -1077,7 +1133,7 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
     // ---- inverse column transform: G -> time samples in registers -------------------------
     if (do_inv) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+        for (int q = 0; q < 16; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
         ctx.mark(1);
         global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         fft_dif<+1>(ctx, p, g.b, v, lds);
@@ -1109,8 +1165,8 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) {
                 const long long t = g.time_off(idx);
-                if (op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
-                else v[idx] = g.ld(a.Ehd, g.rowbase + t);
+                if (op == 1) g.template stp<2>(a.Ehd, g.rowbase + t, v[idx]);
+                else v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + t);
             }
             cx<T> rot[16];
             ctx.sync();                              // inverse transform's LDS reads are done
@@ -1133,7 +1189,7 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
             }
             if (final_) {                            // the field after this step (channels.py:438-439)
 #pragma unroll
-                for (int idx = 0; idx < 16; ++idx) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
+                for (int idx = 0; idx < 16; ++idx) g.template stp<2>(Tnew, g.rowbase + g.time_off(idx), v[idx]);
             } else {
                 mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
                 if (!exact0) d0 = psum;              // exact denominator of the bound: sum Pch over the tile
@@ -1166,9 +1222,198 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
         global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) g.st(a.G, g.rowbase + g.freq_off(q), v[q]);
+        for (int q = 0; q < 16; ++q) g.template stp<0>(a.G, g.rowbase + g.freq_off(q), v[q]);
         ctx.mark(5);
         ctx.flush(do_inv ? 0 : 1);
+    }
+}
+
+// ------------------------------------------------------------- packed pair: complex64 Manakov
+// The complex64 Manakov path keeps both polarisations of a sample in one 16-byte element (fused_core.h: pf2), in
+// memory as (x.re, y.re, x.im, y.im).  The transforms are the ones above with T = pf2 (one packed instruction per
+// butterfly operation for both polarisations, twiddles and operator shared); the time-domain work below needs no
+// exchange between threads: |Ex|^2 + |Ey|^2, the phase and the rotation of a sample are local to its thread.
+// Same stages, same control block, same sums as the polarisation-split double-precision kernel (col_body).
+struct RepackArgs {
+    cx<float> *soa;       // (2 K, N): rows x0, y0, x1, y1, ...
+    cx<pf2> *pk;          // (K, N) packed pairs
+    long long N;
+    int npairs, to_pk;    // to_pk: soa -> pk, else pk -> soa
+};
+template <class Ctx> SSF_HD void repack_body(Ctx &ctx, const RepackArgs &a) {
+    const long long total = a.N * a.npairs;
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < total; i += (long long)ctx.nblocks * ctx.nthreads) {
+        const long long g = i / a.N, n = i - g * a.N;
+        cx<float> *x = a.soa + (2 * g) * a.N + n, *y = a.soa + (2 * g + 1) * a.N + n;
+        if (a.to_pk) {
+            const cx<float> ex = *x, ey = *y;
+            a.pk[i] = mk<pf2>(mk2(ex.re, ey.re), mk2(ex.im, ey.im));
+        } else {
+            const cx<pf2> e = a.pk[i];
+            *x = mk<float>(e.re[0], e.im[0]);
+            *y = mk<float>(e.re[1], e.im[1]);
+        }
+    }
+}
+
+// |Ex|^2 and |Ey|^2 of a packed sample
+SSF_HD void pair_pow(cx<pf2> e, float &ax, float &ay) {
+    const pf2 n = e.re * e.re + e.im * e.im;
+    ax = n[0];
+    ay = n[1];
+}
+// step start (channels.py:388-395): Pch = |Ex|^2 + |Ey|^2 -> Pbuf, block max of phi -> pmax.  Ends with a barrier.
+template <class Ctx, class G>
+SSF_HD void pk_step_start(Ctx &ctx, const G &g, const ColArgs<pf2> &a, const cx<pf2> *v, float *Pbuf) {
+    const float c8g = (float)a.k.c8g;
+    double m = -INFINITY;
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) {
+        float ax, ay;
+        pair_pow(v[idx], ax, ay);
+        const float pw = ax + ay;
+        g.st(Pbuf, g.pbase + g.time_off(idx), pw);
+        const float phi = c8g * (pw + ax + ay) / 2.0f;
+        m = (double)phi > m ? (double)phi : m;
+    }
+    if (a.k.adaptive) {
+        m = block_max(ctx, m, (double *)ctx.lds);
+        if (ctx.tid == 0) a.pmax[ctx.bid] = m;
+    }
+    ctx.sync();
+}
+
+template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2> &a) {
+    using T = pf2;
+    ctx.mark(0);
+    MkColStage st;
+    mk_col_stage(ctx, a, st);
+    if (st.op < 0) return;
+    const int op = st.op;
+    ColGeom<T, LG, Ctx, false> g(ctx, a);
+    const PassPlan &p = g.p;
+    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)g.c * lds_slots_per_fft(p.L);
+    double *red = (double *)ctx.lds;
+    cx<T> v[16];
+    cx<T> *Tcur = st.c.cur ? a.T1 : a.T0;                    // field at the step start
+    cx<T> *Tnew = st.c.cur ? a.T0 : a.T1;                    // receives the field at the step end
+    const long long psz = g.N * a.ngroups;
+    float *Pcur = a.P + (st.c.pcur ? psz : 0), *Palt = a.P + (st.c.pcur ? 0 : psz);
+
+    if (st.do_inv) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
+        ctx.mark(1);
+        global_twiddle<+1, false>(g, a.log2N1 + a.log2N2, v);
+        fft_dif<+1>(ctx, p, g.b, v, lds);
+        ctx.mark(2);
+    } else if (op != 3) {
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
+    }
+
+    const float shz = (float)(a.k.sgn * st.c.hz), c8g = (float)a.k.c8g;
+    if (op == 0) {                                           // span start: Pch into the current buffer
+        pk_step_start(ctx, g, a, v, Pcur);
+    } else if (op == 1 || op == 3) {                         // H (channels.py:409-417) | rebuild of iterate 0
+        float pw[16];
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) pw[idx] = g.ld(Pcur, g.pbase + g.time_off(idx));
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+            const long long t = g.time_off(idx);
+            if (op == 1) g.template stp<2>(a.Ehd, g.rowbase + t, v[idx]);
+            else v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + t);
+        }
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) v[idx] = tmul(v[idx], cis_t<float>(shz * (c8g * (pw[idx] + pw[idx]) / 2.0f)));
+        ctx.sync();                                          // the inverse transform's LDS reads are done
+    } else {                                                 // I: iterate `it` is in registers
+        double n0 = 0, d0 = 0, n1 = 0, d1 = 0, psum = 0;
+        const bool first = st.c.it == 0;
+        if (first) {                                         // lim_0 against the field at the step start
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) {
+                if (st.exact0 || idx == 0) {                 // (bound: one register in sixteen = one cache line in sixteen)
+                    const cx<T> e = g.ld(Tcur, g.rowbase + g.time_off(idx));
+#pragma unroll
+                    for (int l = 0; l < 2; ++l) {
+                        const double dr = (double)v[idx].re[l] - (double)e.re[l], di = (double)v[idx].im[l] - (double)e.im[l];
+                        n0 += dr * dr + di * di;
+                        d0 += (double)e.re[l] * e.re[l] + (double)e.im[l] * e.im[l];
+                    }
+                }
+            }
+        }
+        if (st.final_) {                                     // the field after this step (channels.py:438-439)
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) g.template stp<2>(Tnew, g.rowbase + g.time_off(idx), v[idx]);
+        } else {
+            // next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
+            // sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the note at the top of this file)
+            float pw[16], prev[16], pn[16];
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) {
+                const long long t = g.pbase + g.time_off(idx);
+                pw[idx] = g.ld(Pcur, t);
+                prev[idx] = first ? 0.0f : g.ld(a.Theta, t);
+            }
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) {
+                float ax, ay;
+                pair_pow(v[idx], ax, ay);
+                pn[idx] = shz * (c8g * (pw[idx] + ax + ay) / 2.0f);                    // the new phase
+                if (first) prev[idx] = shz * (c8g * (pw[idx] + pw[idx]) / 2.0f);
+                psum += (double)pw[idx];
+            }
+            ctx.mark(6);
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) g.st(a.Theta, g.pbase + g.time_off(idx), pn[idx]);
+            ctx.mark(7);
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) {
+                // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2)
+                const double sn = sin_half_angle((double)pn[idx] - (double)prev[idx]);
+                float ex, ey;
+                pair_pow(v[idx], ex, ey);
+                const double w = (double)ex + (double)ey;
+                n1 += w * (double)(float)(4.0 * sn * sn);
+                d1 += w;
+                v[idx] = tmul(v[idx], cis_t<float>(pn[idx]));
+            }
+            if (!st.exact0) d0 = psum;                       // exact denominator of the bound: sum Pch over the tile
+        }
+        if (first) {
+            block_sum2(ctx, n0, d0, red);
+            if (ctx.tid == 0) {
+                a.pnum0[ctx.bid] = n0;
+                a.pden0[ctx.bid] = d0;
+            }
+        }
+        if (!st.final_) {
+            block_sum2(ctx, n1, d1, red);
+            if (ctx.tid == 0) {
+                a.pnum[ctx.bid] = n1;
+                a.pden[ctx.bid] = d1;
+            }
+            ctx.sync();
+        } else if (st.more) {
+            ctx.sync();
+            pk_step_start(ctx, g, a, v, Palt);               // next step: Pch + forward transform
+        }
+    }
+
+    ctx.mark(3);
+    if (st.do_fwd) {
+        fft_dit<-1>(ctx, p, g.b, v, lds);
+        global_twiddle<-1, false>(g, a.log2N1 + a.log2N2, v);
+        ctx.mark(4);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) g.template stp<0>(a.G, g.rowbase + g.freq_off(q), v[q]);
+        ctx.mark(5);
+        ctx.flush(st.do_inv ? 0 : 1);
     }
 }
 

@@ -149,12 +149,25 @@ struct EmuBackend {
     double time_end() { return 0.0; }
     template <typename T> void launch_row(const ssf::fused::RowArgs<T> &a, int grid, int block, size_t lds) {
         ++launches;
-        if (a.mixed) run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_mixed_body<T>(c, a); });
-        else run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
+        if constexpr (!std::is_same<T, ssf::fused::pf2>::value) {
+            if (a.mixed) {
+                run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_mixed_body<T>(c, a); });
+                return;
+            }
+        }
+        run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
+    }
+    void launch_repack(const ssf::fused::RepackArgs &a, int grid, int block) {
+        ++launches;
+        run_grid(std::min(grid, 8), block, 64, [&](EmuCtx &c) { ssf::fused::repack_body(c, a); });
     }
     template <typename T> void launch_col(const ssf::fused::ColArgs<T> &a, int grid, int block, size_t lds) {
         ++launches;
         using namespace ssf::fused;
+        if constexpr (std::is_same<T, pf2>::value) {          // packed pair: only the Manakov stage exists
+            run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0>(c, a); });
+            return;
+        } else
         switch (a.mode) {
         case CM_NLSE_FIRST:
             if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST, true>(c, a); });

@@ -15,7 +15,12 @@ Output: tests/golden/<case>.npz, each holding
     margin    min |lim - tol| / tol over the run           (Manakov/DBP only)
     extra_*   case-specific extras (e.g. linear-channel output, edfa noise)
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|tx]
+    long_*    long runs (1001 steps of a lossy span and more): the input is NOT stored but regenerated from the
+              seeded recipe in cfg["synth"]; stored are the per-step iteration list, every lim value, the
+              output decimated by cfg["dec"], its per-column power and a seeded random projection of the full
+              output (so an error anywhere in the array shows), see long_vectors()
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|tx|long]
 """
 import json
 import os
@@ -23,6 +28,8 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):     # the BLAS thread pool makes scipy.linalg.norm
+    os.environ.setdefault(_v, "1")                                            # 40x slower on a busy box
 
 _nb = types.ModuleType("numba")
 
@@ -386,8 +393,79 @@ def tx_vectors():
         print(f"{name:36s} sig {sig.dtype}{sig.shape} symb {symb.shape}")
 
 
+def projection(out, seed=4242):
+    """(ncols,) complex: sum_n out[n, c] * r[n] with a seeded unit-variance complex vector r"""
+    rng = np.random.default_rng(seed)
+    r = (rng.normal(size=out.shape[0]) + 1j * rng.normal(size=out.shape[0])) / np.sqrt(2)
+    return out.astype(np.complex128).T @ r
+
+
+def run_long(name, func, synth, kw, dec=64):
+    """One long reference run; the input comes from synth_field(*synth)."""
+    import optic.dsp.equalization as ref_eq
+    import time
+    N, ncols, seed, p_dbm = synth
+    Ei = synth_field(N, ncols, seed, p_dbm, np.dtype(kw.get("prec", np.complex128)).type)
+    mod = ref_ch if func == "manakovSSF" else ref_eq
+    p = mk_param(**kw)
+    t0 = time.time()
+    with Tracer(mod) as tr:
+        out = ref_ch.manakovSSF(Ei, p) if func == "manakovSSF" else ref_dbp(Ei, p)
+    lims = np.array(tr.lims)
+    iters = np.array(split_iters(tr.lims, p.tol, p.maxIter), dtype=np.int8)
+    margin = float(np.min(np.abs(lims - p.tol) / p.tol))
+    cfg = json.loads(cfg_json(func, kw))
+    cfg["synth"], cfg["dec"] = list(synth), dec
+    o = out.astype(np.complex128)
+    sz = save(name, cfg=json.dumps(cfg), iters=iters, lims=lims, margin=margin, out_dec=out[::dec].copy(),
+              out_power=np.sum(np.abs(o) ** 2, axis=0), out_proj=projection(out))
+    changes = int(np.count_nonzero(np.diff(iters.astype(int))))
+    print(f"{name:26s} steps={len(iters):5d} iters={int(iters.sum()):6d} (min {iters.min()} max {iters.max()}, {changes} changes) "
+          f"margin={margin:.2e} {sz/1024:.0f} KiB  {time.time()-t0:.0f} s", flush=True)
+    return out
+
+
+def long_vectors():
+    """Long runs (identical per-step iteration counts across the 3 -> 2 crossover of a lossy span)."""
+    os.makedirs(OUT, exist_ok=True)
+    c2 = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False,
+              Ltotal=80, Lspan=80, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
+    run_long("long_c2_n14", "manakovSSF", (1 << 14, 2, 2, 8.4), dict(c2))
+    run_long("long_c2_n16", "manakovSSF", (1 << 16, 2, 2, 8.4), dict(c2))
+    run_long("long_adp_n14", "manakovSSF", (1 << 14, 2, 12, 8.4), dict(c2, nlprMethod=True, maxNlinPhaseRot=2e-2))
+    run_long("long_k2_n14", "manakovSSF", (1 << 14, 4, 13, 11.4), dict(c2))
+    run_long("long_dbp_n14", "manakovDBP", (1 << 14, 2, 14, 5.0), dict(c2, amp="edfa"))
+    run_long("long_n48000", "manakovSSF", (48000, 2, 15, 8.4), dict(c2, Ltotal=40, Lspan=40))
+    # the reference's own complex64 path against its complex128 result over BASELINE config 3's 10 spans
+    # (10 010 steps): the yardstick for the single-precision gate (both runs: complex64 input samples)
+    for lg in (14, 16):
+        synth = (1 << lg, 2, 3, 8.4)
+        kw = dict(c2, Ltotal=800, saveSpanN=[1, 2, 4, 10])
+        Ei = synth_field(*synth, np.complex64)
+        import time
+        t0 = time.time()
+        o128 = ref_ch.manakovSSF(Ei.astype(np.complex128), mk_param(**dict(kw, prec=np.complex128))).astype(np.complex128)
+        o64 = ref_ch.manakovSSF(Ei, mk_param(**dict(kw, prec=np.complex64)))
+        assert o64.dtype == np.complex64 and o128.shape == (1 << lg, 8)
+        dev, pr = [], []
+        for i in range(4):
+            a, b = o64[:, 2 * i:2 * i + 2].astype(np.complex128), o128[:, 2 * i:2 * i + 2]
+            dev.append(np.linalg.norm(a - b) / np.linalg.norm(b))
+            pr.append(np.sum(np.abs(a) ** 2) / np.sum(np.abs(b) ** 2))
+        cfg = json.loads(cfg_json("manakovSSF", kw))
+        cfg["synth"], cfg["dec"] = list(synth), 64
+        save(f"long_c64drift_n{lg}", cfg=json.dumps(cfg), spans=np.array([1, 2, 4, 10]), ref_c64_rel_l2=np.array(dev),
+             ref_c64_power_ratio=np.array(pr), out128_dec=o128[::64].copy(), out128_proj=projection(o128),
+             out128_power=np.sum(np.abs(o128) ** 2, axis=0))
+        print(f"long_c64drift_n{lg}: reference complex64 vs complex128 after 1/2/4/10 spans: rel-L2 "
+              + " ".join(f"{x:.2e}" for x in dev) + "  power ratio - 1 " + " ".join(f"{x-1:+.2e}" for x in pr)
+              + f"  {time.time()-t0:.0f} s", flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "tx":      # only the transmitter vectors
+    if len(sys.argv) > 1 and sys.argv[1] == "long":    # only the long-run vectors
+        long_vectors()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tx":      # only the transmitter vectors
         os.makedirs(OUT, exist_ok=True)
         tx_vectors()
     elif len(sys.argv) > 1 and sys.argv[1] == "rx":    # only the receiver-side vectors
