@@ -1,27 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- SSFM steps/s on MI355X for BASELINE.json's headline configuration.
+"""bench.py -- SSFM steps/s on MI355X for BASELINE.json's configurations.
 
-Workload (config 2, SURVEY.md 8d "C2"): dual-pol manakovSSF, N = 2^20 complex128
-samples, Fs 512 GS/s, 8.4 dBm band-limited Gaussian field (seed 2), alpha 0.2,
-D 16, gamma 1.3, hz 0.08 km fixed step, maxIter 10, tol 1e-5, amp 'ideal',
-saveSpanN = [].  One "step" = one pass of `while z_current < Lspan`
-(reference optic/models/channels.py:387).  The timed region runs EXACTLY K
-steps with the field already resident in HBM (upload before, download after).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config auto|1|2|3|4|5]
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+One "step" = one pass of `while z_current < Lspan` (reference optic/models/channels.py:387; the inner `for` of
+ssfm, :219).  The timed region runs EXACTLY K steps per unit with every input already resident in HBM (uploads
+before, downloads after), bracketed by a barrier on both sides; the time is the MAX over ranks.
 
-N > 1 is launched by the driver through torch.distributed.run, one rank per GPU;
-every rank propagates its own independent field (weak scaling, no data-path
-collective -- SURVEY.md 8e); torch.distributed (RCCL) is used only for the
-barriers and the max-over-ranks reduction of the elapsed time.
+  config 2 (default at N = 1, BASELINE's headline): manakovSSF, 2-pol, N = 2^20 complex128, hz 0.08, 8.4 dBm, seed 2
+  config 1: ssfm, N = 2^16 complex128, hz 0.5, 0 dBm, seed 1
+  config 3: manakovSSF, N = 2^22 complex64 (+ prec complex64), hz 0.08, 8.4 dBm, seed 3
+  config 4 (default at N > 1): 16 independent config-2 units, seeds 100..115, launch powers 8.4 + arange(-8, 0, 0.5) dB,
+            split in contiguous blocks over the ranks (16 / 8 / 4 / 2 units per GPU): strong scaling
+  config 5: 8 units (seeds 200..207): forward config-2 leg, then manakovDBP over the same span chained on the
+            device (--dbp-hz, default 0.08 km: the bandwidth-relevant setting; the notebook's is 10 km)
 
-Prints ONE JSON line on rank 0.
+N > 1: the driver starts one process per GPU (torchrun is only the process launcher); the ranks meet through RCCL bound
+inside libssf_hip.so (opticommpy_amd.mgpu.RcclComm): the parameter block is broadcast from rank 0, rank 0 synthesises the
+inputs of ALL units and scatters them (ncclSend / ncclRecv), barriers and the max-over-ranks time are all-reduces, the
+per-unit output checksums are all-gathered.  No per-step communication.  Units of a rank run on two
+lanes (plan + stream + host thread each) so that one unit's row launches overlap the other's column launches.
+
+Prints ONE JSON line on rank 0; exits non-zero if the in-run parity check against the CPU oracle fails.
 """
 import argparse
 import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,9 +38,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FS = 512e9
 
 
 def synth_field(N, ncols, seed, p_dbm, dtype=np.complex128):
+    """SURVEY.md 8d input recipe: band-limited complex Gaussian, each column P/2."""
     rng = np.random.default_rng(seed)
     E = (rng.normal(size=(N, ncols)) + 1j * rng.normal(size=(N, ncols))) / np.sqrt(2)
     F = np.fft.fft(E, axis=0)
@@ -44,15 +53,73 @@ def synth_field(N, ncols, seed, p_dbm, dtype=np.complex128):
     return E.astype(dtype)
 
 
-def make_params(lib_mod, steps, hz, prec_fs=512e9):
+def workload(cfg, log2n, prec, world):
+    """-> dict(model, log2n, prec, hz, units=[(seed, dBm)], dbp, scaling, text)"""
+    w = dict(model="manakov", log2n=20, prec="c128", hz=0.08, dbp=False, scaling="weak")
+    if cfg == 1:
+        w.update(model="nlse", log2n=16, hz=0.5, units=[(1 + r, 0.0) for r in range(world)],
+                 text="ssfm config-1: 1-pol N=2^16 complex128, hz=0.5 km, 0 dBm, amp=None, 1 independent field per GPU")
+    elif cfg == 2:
+        w.update(units=[(2 + r, 8.4) for r in range(world)],
+                 text="manakovSSF config-2: 2-pol N=2^20 complex128, hz=0.08 km fixed, 8.4 dBm, amp=ideal, 1 independent field per GPU")
+    elif cfg == 3:
+        w.update(log2n=22, prec="c64", units=[(3 + r, 8.4) for r in range(world)],
+                 text="manakovSSF config-3 shape: 2-pol N=2^22 complex64 (prec complex64), hz=0.08 km fixed, 8.4 dBm, amp=ideal, "
+                      "K steps of one span (the full configuration is 10 spans x 1001 steps), 1 independent field per GPU")
+    elif cfg == 4:
+        w.update(units=[(100 + u, 8.4 - 8.0 + 0.5 * u) for u in range(16)], scaling="strong",
+                 text="manakovSSF config-4: 16 independent 2-pol N=2^20 complex128 units (seeds 100..115, launch powers "
+                      "0.4..7.9 dBm in 0.5 dB steps), hz=0.08 km, amp=ideal, contiguous blocks of 16/G units per GPU, two lanes per GPU")
+    elif cfg == 5:
+        w.update(units=[(200 + u, 8.4) for u in range(8)], scaling="strong", dbp=True,
+                 text="config-5: 8 independent 2-pol N=2^20 complex128 units (seeds 200..207, 8.4 dBm): manakovSSF forward "
+                      "(hz 0.08, amp=ideal) then manakovDBP over the same span, chained in device memory, 8/G units per GPU")
+    else:
+        raise SystemExit("unknown --config")
+    if log2n:
+        w["log2n"] = log2n
+        w["text"] += " [--log2n %d]" % log2n
+    if prec:
+        w["prec"] = prec
+        w["text"] += " [--prec %s]" % prec
+    return w
+
+
+def make_params(lib_mod, w, steps, direction=1, hz=None):
     cp = lib_mod.Params()
-    cp.model, cp.direction = lib_mod.MODEL_MANAKOV, 1
-    cp.Fs, cp.Fc, cp.alpha, cp.D, cp.gamma = prec_fs, 193.1e12, 0.2, 16.0, 1.3
-    cp.Lspan = (steps - 0.5) * hz          # exactly `steps` passes of the while loop (last one is half a step)
+    hz = hz or w["hz"]
+    cp.model = lib_mod.MODEL_NLSE if w["model"] == "nlse" else lib_mod.MODEL_MANAKOV
+    cp.direction = direction
+    cp.Fs, cp.Fc, cp.alpha, cp.D, cp.gamma = FS, 193.1e12, 0.2, 16.0, 1.3
+    if w["model"] == "nlse":
+        cp.Lspan = steps * hz                    # floor(Lspan / hz) passes of the inner loop (channels.py:213)
+        cp.amp = lib_mod.AMP_NONE
+    else:
+        cp.Lspan = (steps - 0.5) * w["hz"]       # exactly `steps` passes of the while loop (the last one is half a step)
+        cp.amp = lib_mod.AMP_IDEAL
     cp.Nspans, cp.hz, cp.maxIter, cp.tol = 1, hz, 10, 1e-5
-    cp.nlprMethod, cp.maxNlinPhaseRot, cp.amp, cp.NF = 0, 2e-2, lib_mod.AMP_IDEAL, 4.5
+    cp.nlprMethod, cp.maxNlinPhaseRot, cp.NF = 0, 2e-2, 4.5
     cp.n_save, cp.save_spans = 0, None
     return cp
+
+
+def oracle_run(w, E, n, dtype):
+    from oracle import ssf_oracle as orc
+    p = orc.parameters()
+    p.Fs, p.Fc, p.alpha, p.D, p.gamma = FS, 193.1e12, 0.2, 16, 1.3
+    p.prgsBar, p.prec = False, dtype
+    tr = {}
+    t0 = time.perf_counter()
+    if w["model"] == "nlse":
+        p.Ltotal = p.Lspan = n * w["hz"]
+        p.hz, p.amp = w["hz"], None
+        ref = orc.ssfm(E[:, 0].copy(), p, trace=tr).reshape(-1, 1)
+        tr["iterations"] = 0
+    else:
+        p.Ltotal = p.Lspan = (n - 0.5) * w["hz"]
+        p.hz, p.maxIter, p.tol, p.nlprMethod, p.amp, p.saveSpanN = w["hz"], 10, 1e-5, False, "ideal", []
+        ref = orc.manakovSSF(E, p, trace=tr)
+    return ref, time.perf_counter() - t0, tr
 
 
 def main():
@@ -60,189 +127,263 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--log2n", type=int, default=20)
-    ap.add_argument("--prec", default="c128", choices=["c128", "c64"])
+    ap.add_argument("--config", default="auto", help="auto (2 at one GPU, 4 at several) | 1 | 2 | 3 | 4 | 5")
+    ap.add_argument("--log2n", type=int, default=0, help="experiments: override the configuration's length")
+    ap.add_argument("--prec", default="", choices=["", "c128", "c64"], help="experiments: override the precision")
+    ap.add_argument("--dbp-hz", type=float, default=0.08)
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("SSF_MGPU_LANES", "2")))
     ap.add_argument("--engine", default=os.environ.get("SSF_ENGINE", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU oracle leg (0: sized for ~10-20 s)")
     ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel HIP-event pass")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or os.environ.get("SSF_BENCH_FORCE_DIST"):      # (the env var exercises the RCCL path on one GPU)
-        import torch
-        import torch.distributed as dist
-        # (test knobs: SSF_BENCH_BACKEND=gloo + SSF_BENCH_DEVICE=0 run several ranks against one GPU, which RCCL
-        # refuses; the driver's runs use neither)
-        backend = os.environ.get("SSF_BENCH_BACKEND", "nccl")
-        if "SSF_BENCH_DEVICE" in os.environ:
-            local_rank = int(os.environ["SSF_BENCH_DEVICE"])
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        tdev = "cuda" if backend == "nccl" else "cpu"
+    if "SSF_BENCH_DEVICE" in os.environ:                       # (test knob: several ranks against one GPU)
+        local_rank = int(os.environ["SSF_BENCH_DEVICE"])
 
-    from opticommpy_amd import _lib
+    from opticommpy_amd import _lib, mgpu
     lib = _lib.load()
     if lib.ssf_device_count() <= 0:
         raise SystemExit("bench.py needs a GPU: no HIP device visible (there is no CPU fallback)")
 
-    N = 1 << args.log2n
-    dtype = np.complex128 if args.prec == "c128" else np.complex64
-    prec = _lib.SSF_C128 if args.prec == "c128" else _lib.SSF_C64
+    comm, comm_name = None, "none (single process)"
+    if world > 1 or os.environ.get("SSF_BENCH_FORCE_COMM"):    # (the env var exercises the RCCL path on one GPU)
+        try:
+            comm = mgpu.RcclComm.from_env(device=local_rank)
+            comm_name = "RCCL via libssf_hip.so (ssf_comm_*)"
+        except Exception as e:                                  # safety net for the scaling run only: never silent
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from comm_gloo import GlooComm
+            comm = GlooComm()
+            comm_name = "torch.distributed gloo stand-in (RCCL binding failed: %s)" % e
+
+    cfg = (2 if world == 1 else 4) if args.config == "auto" else int(args.config)
+    w = workload(cfg, args.log2n, args.prec, world)
+    w = mgpu.bcast_object(comm, w, 0)                           # "broadcast of the parameter block"
+    N = 1 << w["log2n"]
+    dtype = np.complex128 if w["prec"] == "c128" else np.complex64
+    prec = _lib.SSF_C128 if w["prec"] == "c128" else _lib.SSF_C64
+    s = 16 if w["prec"] == "c128" else 8
+    ncols = 1 if w["model"] == "nlse" else 2
     engine = {"auto": 0, "rocfft": 1, "fused": 2}[args.engine]
-    E = synth_field(N, 2, 2 + rank, 8.4, dtype)
-    soa = np.ascontiguousarray(E.T)
+    U = len(w["units"])
+    mine = list(mgpu.shard_range(U, world, rank))
 
-    h = C.c_void_p()
-    _lib.raise_for(lib, None, lib.ssf_plan_create(local_rank, N, 2, prec, engine, C.byref(h)))
+    # ---- inputs: rank 0 synthesises every unit and scatters (weak-scaling configs: every rank makes its own field)
+    fields = {}
+    if w["scaling"] == "strong" and comm is not None and world > 1:
+        for r in range(world):
+            for u in mgpu.shard_range(U, world, r):
+                if rank == 0:
+                    E = np.ascontiguousarray(synth_field(N, ncols, *w["units"][u], dtype).T)
+                    if r == 0:
+                        fields[u] = E
+                    else:
+                        comm.send(E, r)
+                elif rank == r:
+                    fields[u] = comm.recv(np.empty((ncols, N), dtype=dtype), 0)
+    else:
+        for u in mine:
+            fields[u] = np.ascontiguousarray(synth_field(N, ncols, *w["units"][u], dtype).T)
 
-    def run(steps, field, sync=True):
-        # sync: every rank makes this call (the timed run and its warm-up); the rank-0-only passes further down
-        # must not enter a barrier the other ranks never reach
+    # ---- one plan per unit (its field stays resident in HBM), units dealt to the lanes alternately
+    plans = {}
+    for u in mine:
+        h = C.c_void_p()
+        _lib.raise_for(lib, None, lib.ssf_plan_create(local_rank, N, ncols, prec, engine, C.byref(h)))
+        plans[u] = h
+    lanes = max(1, min(args.lanes, len(mine)))
+    lane_units = [mine[i::lanes] for i in range(lanes)]
+
+    def run_unit(u, steps, stats):
+        h = plans[u]
         st = _lib.Stats()
-        cp = make_params(_lib, steps, 0.08)
-        _lib.raise_for(lib, h, lib.ssf_upload(h, field.ctypes.data_as(C.c_void_p)))      # field resident in HBM
-        if dist is not None and sync:
-            dist.barrier()
-        t0 = time.perf_counter()
+        cp = make_params(_lib, w, steps)
         rc = lib.ssf_execute(h, C.byref(cp), 1, 1, None, C.byref(st), None)              # synchronous at return
+        if rc == 0 and w["dbp"]:
+            cpb = make_params(_lib, w, steps, direction=-1, hz=args.dbp_hz)
+            rc = lib.ssf_execute(h, C.byref(cpb), 1, 1, None, C.byref(st), None)         # chained: the field never leaves HBM
+        stats[u] = (rc, st)
+
+    def run_all(steps, sync=True):
+        for u in mine:
+            _lib.raise_for(lib, plans[u], lib.ssf_upload(plans[u], fields[u].ctypes.data_as(C.c_void_p)))
+        stats = {}
+        if comm is not None and sync:
+            comm.barrier()
+        t0 = time.perf_counter()
+        if lanes == 1:
+            for u in mine:
+                run_unit(u, steps, stats)
+        else:
+            th = [threading.Thread(target=lambda us=us: [run_unit(u, steps, stats) for u in us]) for us in lane_units]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
         t1 = time.perf_counter()
-        _lib.raise_for(lib, h, rc)
-        return t1 - t0, st
+        for u in mine:
+            _lib.raise_for(lib, plans[u], stats[u][0])
+        return t1 - t0, {u: stats[u][1] for u in mine}
 
     if args.warmup > 0:
-        run(args.warmup, soa)
-    dt, st = run(args.steps, soa)
-    assert st.steps == args.steps, (st.steps, args.steps)
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        dist.barrier()
+        run_all(args.warmup)
+    dt_local, sts = run_all(args.steps)
+    steps_local = sum(int(st.steps) for st in sts.values())
+    fwd_steps = args.steps * len(mine)
+    assert steps_local >= fwd_steps and (w["dbp"] or steps_local == fwd_steps), (steps_local, fwd_steps)
+    dt = dt_local
+    steps_total = steps_local
+    if comm is not None:
+        dt = float(comm.allreduce(np.array([dt_local]), "max")[0])
+        steps_total = int(round(comm.allreduce(np.array([float(steps_local)]), "sum")[0]))
+        comm.barrier()
 
-    out_soa = np.empty_like(soa)
-    _lib.raise_for(lib, h, lib.ssf_download(h, out_soa.ctypes.data_as(C.c_void_p)))
-    if dist is not None:
-        # "gather of results only" (SURVEY.md 8e): one RCCL all-gather of a per-rank checksum
-        import torch
-        cs = torch.tensor([float(np.sum(np.abs(out_soa) ** 2))], dtype=torch.float64, device=tdev)
-        allcs = [torch.zeros_like(cs) for _ in range(world)]
-        dist.all_gather(allcs, cs)
-        checksums = [float(x.item()) for x in allcs]
+    # results: per-unit checksum, all-gathered ("gather of results only")
+    outs = {}
+    for u in mine:
+        o = np.empty_like(fields[u])
+        _lib.raise_for(lib, plans[u], lib.ssf_download(plans[u], o.ctypes.data_as(C.c_void_p)))
+        outs[u] = o
+    per = max(len(mgpu.shard_range(U, world, r)) for r in range(world))
+    cs = np.zeros(per)
+    for i, u in enumerate(mine):
+        cs[i] = float(np.sum(np.abs(outs[u].astype(np.complex128)) ** 2))
+    if comm is not None:
+        allcs = comm.allgather(cs)
+        checksums = [float(allcs[r][i]) for r in range(world) for i in range(len(mgpu.shard_range(U, world, r)))]
+    else:
+        checksums = [float(x) for x in cs[:len(mine)]]
 
-    # per-kernel timing pass (HIP events around every launch on the plan stream; separate from the
-    # headline run because the events themselves cost a few microseconds per launch)
-    kernels = None
-    if rank == 0 and not args.no_kernel_times and lib.ssf_set_profiling(h, 1) == 0:
-        nprof = min(args.steps, 200)
-        _, stp = run(nprof, soa, sync=False)
-        kt = _lib.KernelTimes()
-        lib.ssf_get_kernel_times(h, C.byref(kt))
-        lib.ssf_set_profiling(h, 0)
-        bytes_per_launch = 2 * (16 if args.prec == "c128" else 8) * N * 2       # one transform-equivalent per row
-        kernels = {}
-        for name, ms, n in (("row (decision + FFT.H.IFFT of rows)", kt.row_ms, kt.row_n),
-                            ("col (Manakov column stage: S | H | I)", kt.col_ms, kt.col_n)):
-            if n:
-                avg_us = ms / n * 1e3
-                kernels[name] = {"launches": int(n), "avg_us": avg_us}
-                if name.startswith("row"):
-                    kernels[name].update(algorithmic_bytes_per_launch=bytes_per_launch,
-                                         achieved_GBs=bytes_per_launch / (avg_us * 1e-6) / 1e9,
-                                         frac=bytes_per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
-        kernels["profiled_steps"] = int(stp.steps)
-
+    rec = None
+    ok = True
     if rank == 0:
-        s = 16 if args.prec == "c128" else 8
-        steps_total = args.steps * world
-        value = steps_total / dt
-        dev_s = st.device_ms * 1e-3
-        achieved = st.bytes_algorithmic / dev_s / 1e9
+        u0 = mine[0]
+        st0 = sts[u0]
+        bytes_local = sum(float(st.bytes_algorithmic) for st in sts.values())
+        if len(mine) == 1:                                      # HIP events on the plan stream around the K timed steps
+            dev_s = st0.device_ms * 1e-3
+            timing = "HIP events around the K timed steps on the plan stream"
+        else:                                                   # several units on concurrent lanes: wall time of the rank
+            dev_s = dt_local
+            timing = "wall time of rank 0's timed region (its %d units run on %d concurrent lanes)" % (len(mine), lanes)
+        achieved = bytes_local / dev_s / 1e9
+        it_step = sum(int(st.iterations) for st in sts.values()) / max(steps_local, 1)
         rec = {
-            "metric": "SSFM steps/sec (2-pol, 2^%d samples)" % args.log2n, "value": value, "unit": "steps/s",
+            "metric": "SSFM steps/sec (%d-pol, 2^%d samples)" % (ncols, w["log2n"]), "value": steps_total / dt, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if args.prec == "c128" else "f32", "data": "synthetic",
-            "config": {"workload": "manakovSSF config-2: 2-pol N=2^%d %s, hz=0.08 km fixed, 8.4 dBm, amp=ideal, "
-                                   "1 independent field per GPU" % (args.log2n, "complex128" if s == 16 else "complex64"),
-                       "engine": _lib.ENGINE_NAMES[st.engine], "fields_per_gpu": 1,
-                       "iterations_per_step": st.iterations / st.steps,
-                       "transforms_per_step": st.transforms / st.steps},
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": w["scaling"],
+            "vs_baseline": None, "dtype": "f64" if s == 16 else "f32", "data": "synthetic",
+            "config": {"workload": w["text"], "baseline_config": cfg, "engine": _lib.ENGINE_NAMES[st0.engine],
+                       "units_total": U, "units_per_gpu": len(mine), "lanes_per_gpu": lanes,
+                       "unit_steps_total": steps_total, "iterations_per_step": it_step,
+                       "transforms_per_step": sum(int(st.transforms) for st in sts.values()) / max(steps_local, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "whole step pipeline (HIP events around the K timed steps on the plan stream)",
-                         "algorithmic_bytes_per_step": st.bytes_algorithmic / st.steps,
-                         "device_ms_per_step": st.device_ms / st.steps,
-                         "kernels": kernels},
+                         "kernel": "whole step pipeline of one GPU (rank 0): " + timing,
+                         "algorithmic_bytes_per_step": bytes_local / max(steps_local, 1),
+                         "device_ms_per_step": dev_s * 1e3 / max(steps_local, 1),
+                         "note": "the working set of a 2^20 complex128 field (184 MiB) fits the 256 MiB Infinity Cache: the "
+                                 "'HBM' figure of config 2 is partly an Infinity-Cache figure; configs with N >= 2^21 "
+                                 "(complex128) / 2^22 run out of it"},
+            "comm": comm_name, "rccl_ranks": world if comm is not None and comm_name.startswith("RCCL") else 0,
+            "unit_checksums": checksums,
         }
-        # measured memory ceiling on this box: a kernel with the row stage's memory shape and no arithmetic
-        # (32 MiB in + 32 MiB out per launch at N = 2^20 c128), SURVEY.md 8d
+
+        # per-kernel timing pass (HIP events around every launch; separate from the headline run because the events
+        # themselves cost a few microseconds per launch)
+        if not args.no_kernel_times and w["model"] == "manakov" and lib.ssf_set_profiling(plans[u0], 1) == 0:
+            nprof = min(args.steps, 200)
+            _lib.raise_for(lib, plans[u0], lib.ssf_upload(plans[u0], fields[u0].ctypes.data_as(C.c_void_p)))
+            stp = {}
+            run_unit(u0, nprof, stp)
+            kt = _lib.KernelTimes()
+            lib.ssf_get_kernel_times(plans[u0], C.byref(kt))
+            lib.ssf_set_profiling(plans[u0], 0)
+            bytes_per_launch = 2 * s * N * ncols                 # one transform-equivalent per row
+            kernels = {}
+            for name, ms, n in (("row", kt.row_ms, kt.row_n), ("col", kt.col_ms, kt.col_n)):
+                if n:
+                    avg_us = ms / n * 1e3
+                    gbs = bytes_per_launch / (avg_us * 1e-6) / 1e9
+                    kernels[name] = {"launches": int(n), "avg_us": avg_us, "algorithmic_bytes_per_launch": bytes_per_launch,
+                                     "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
+            kernels["what"] = {"row": "convergence decision + FFT.H.IFFT of the rows", "col": "Manakov column stage S | H | I "
+                               "(inverse + forward column transforms around the time-domain work)"}
+            kernels["profiled_steps"] = int(stp[u0][1].steps)
+            rec["roofline"]["kernels"] = kernels
+        # measured memory ceiling on this box: a kernel with the row stage's memory shape and no arithmetic (SURVEY.md 8d)
         probe = C.c_double(0.0)
         probe_bytes = max(65536, (2 * s * N) // 65536 * 65536)
         if lib.ssf_device_copy_bandwidth(local_rank, probe_bytes, 50, C.byref(probe)) == 0:
             rec["roofline"]["measured_copy_GBs"] = probe.value
             rec["roofline"]["frac_of_measured_copy"] = achieved / probe.value
-            rec["roofline"]["measured_copy_note"] = ("burst copy kernel, %d MiB read + %d MiB written per launch, "
-                                                     "no arithmetic" % (probe_bytes >> 20, probe_bytes >> 20))
-        if dist is not None:
-            rec["rank_checksums"] = checksums
+            rec["roofline"]["measured_copy_note"] = ("burst copy kernel, %d MiB read + %d MiB written per launch, no arithmetic"
+                                                     % (probe_bytes >> 20, probe_bytes >> 20))
         traffic_file = os.path.join(ROOT, "profiles", "traffic_bytes_per_step.json")
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file) and cfg in (2, 4) and not args.log2n and not args.prec:
             try:
-                t = json.load(open(traffic_file)).get(_lib.ENGINE_NAMES[st.engine])
-                if t and args.log2n == 20 and args.prec == "c128":
-                    # PMC-measured HBM-side bytes per step (separate rocprofv3 passes, see profiles/), scaled from
-                    # the profiled iteration count to this run's: traffic is linear in (1 + iterations/step)
-                    scale = (1.0 + st.iterations / st.steps) / (1.0 + t["iterations_per_step"])
-                    rec["roofline"]["traffic"] = t["bytes_per_step"] * scale
-                    rec["roofline"]["traffic_source"] = "profiles/traffic_bytes_per_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %d steps at %.2f it/step)" % (t["steps"], t["iterations_per_step"])
+                t = json.load(open(traffic_file)).get(_lib.ENGINE_NAMES[st0.engine])
+                if t:
+                    # PMC-measured HBM-side bytes per step (separate rocprofv3 passes, see profiles/), NOT measured in this
+                    # run: scaled from the profiled iteration count to this run's (linear in 1 + iterations/step)
+                    scale = (1.0 + it_step) / (1.0 + t["iterations_per_step"])
+                    rec["roofline"]["traffic_profiled"] = t["bytes_per_step"] * scale
+                    rec["roofline"]["traffic_ratio"] = t["bytes_per_step"] * scale / (bytes_local / max(steps_local, 1))
+                    rec["roofline"]["traffic_source"] = ("profiles/traffic_bytes_per_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                                         "%d steps at %.2f it/step)" % (t["steps"], t["iterations_per_step"]))
             except Exception:
                 pass
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import ssf_oracle as orc
-            n = max(2, args.cpu_steps)
-            p = orc.parameters()
-            p.Fs, p.Fc, p.alpha, p.D, p.gamma = 512e9, 193.1e12, 0.2, 16, 1.3
-            p.Ltotal = p.Lspan = (n - 0.5) * 0.08
-            p.hz, p.maxIter, p.tol, p.nlprMethod, p.amp, p.saveSpanN, p.prgsBar = 0.08, 10, 1e-5, False, "ideal", [], False
-            p.prec = dtype
-            tr = {}
-            t0 = time.perf_counter()
-            ref = orc.manakovSSF(E, p, trace=tr)
-            tc = time.perf_counter() - t0
-            # same n steps on the GPU for the in-run parity gate
-            _, stp = run(n, soa, sync=False)
-            got = np.empty_like(soa)
-            _lib.raise_for(lib, h, lib.ssf_download(h, got.ctypes.data_as(C.c_void_p)))
+
+        # ---- CPU oracle leg: in-run parity gate (always) and cpu_baseline (one GPU only)
+        if not args.no_cpu_baseline:
+            n = args.cpu_steps or {16: 100, 20: 16, 22: 6}.get(w["log2n"], 8)
+            if world > 1:
+                n = min(n, 4)
+            n = max(2, n)
+            E0 = np.ascontiguousarray(fields[u0].T)
+            ref, tc, tr = oracle_run(w, E0, n, dtype)
+            was_dbp, w["dbp"] = w["dbp"], False
+            _lib.raise_for(lib, plans[u0], lib.ssf_upload(plans[u0], fields[u0].ctypes.data_as(C.c_void_p)))
+            stp = {}
+            run_unit(u0, n, stp)
+            w["dbp"] = was_dbp
+            got = np.empty_like(fields[u0])
+            _lib.raise_for(lib, plans[u0], lib.ssf_download(plans[u0], got.ctypes.data_as(C.c_void_p)))
             err = float(np.linalg.norm(got.T.astype(np.complex128) - ref) / np.linalg.norm(ref))
-            cpu_model = "unknown"
-            try:
-                for line in open("/proc/cpuinfo"):
-                    if line.startswith("model name"):
-                        cpu_model = line.split(":", 1)[1].strip()
-                        break
-            except OSError:
-                pass
-            rec["cpu_baseline"] = {"value": n / tc, "unit": "steps/s", "cores": 1, "kind": "port",
-                                   "sample": "%d steps of the same config-2 field (numpy oracle, single thread; "
-                                             "%d cores available; %s; numpy %s)" % (n, os.cpu_count(), cpu_model, np.__version__),
-                                   "iterations_per_step": tr["iterations"] / tr["steps"]}
-            rec["parity"] = {"rel_l2_vs_oracle": err, "steps": n,
-                             "iterations_gpu": int(stp.iterations), "iterations_oracle": int(tr["iterations"]),
-                             "gate": 1e-10 if s == 16 else 5e-4, "ok": bool(err <= (1e-10 if s == 16 else 5e-4))}
-            rec["speedup_vs_cpu"] = value / (n / tc)
+            gate = 1e-10 if s == 16 else 5e-4
+            it_gpu, it_cpu = int(stp[u0][1].iterations), int(tr.get("iterations", 0))
+            ok = bool(err <= gate) and (s != 16 or it_gpu == it_cpu)
+            rec["parity"] = {"rel_l2_vs_oracle": err, "steps": n, "iterations_gpu": it_gpu, "iterations_oracle": it_cpu,
+                             "gate": gate, "ok": ok}
+            if world == 1:
+                cpu_model = "unknown"
+                try:
+                    for line in open("/proc/cpuinfo"):
+                        if line.startswith("model name"):
+                            cpu_model = line.split(":", 1)[1].strip()
+                            break
+                except OSError:
+                    pass
+                rec["cpu_baseline"] = {"value": n / tc, "unit": "steps/s", "cores": 1, "kind": "port",
+                                       "sample": "%d steps of unit 0's field (numpy oracle, single thread; %d cores available; %s; numpy %s)"
+                                                 % (n, os.cpu_count(), cpu_model, np.__version__),
+                                       "iterations_per_step": it_cpu / n}
+                rec["speedup_vs_cpu"] = rec["value"] / (n / tc)
+            if not ok:
+                rec["value"] = None                              # a wrong result is not a benchmark result
         print(json.dumps(rec))
-    lib.ssf_plan_destroy(h)
-    if dist is not None:
-        dist.barrier()                      # rank 0 arrives after its extra passes; nobody tears the group down early
-        dist.destroy_process_group()
+    for h in plans.values():
+        lib.ssf_plan_destroy(h)
+    if comm is not None:
+        flag = comm.allreduce(np.array([0.0 if ok else 1.0]), "max")     # rank 0 arrives after its extra passes
+        ok = flag[0] == 0.0
+        comm.close()
+    if not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

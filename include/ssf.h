@@ -20,6 +20,9 @@
  *   ssf_run                              one whole reference call (upload+execute+download)
  *   ssf_mgpu_run                         (no reference equivalent) independent fields
  *                                        sharded over the GPUs of one node, SURVEY.md 8e
+ *   ssf_comm_*                           (no reference equivalent) one process per GPU: RCCL
+ *                                        broadcast / scatter / gather of parameters, inputs and
+ *                                        results of independent units, SURVEY.md 8e
  *   ssf_linear_channel                   linearFiberChannel               channels.py:30-109
  *   ssf_overlap_save                     blockwiseFFTConv as used by edc  optic/dsp/core.py:973-1046,
  *                                                                          optic/dsp/equalization.py:113-117
@@ -61,7 +64,8 @@ typedef enum {
     SSF_ERR_FFT = -4,
     SSF_ERR_NO_DEVICE = -5,
     SSF_ERR_UNSUPPORTED = -6,
-    SSF_ERR_STATE = -7
+    SSF_ERR_STATE = -7,
+    SSF_ERR_COMM = -8          /* RCCL: library missing or a collective failed                */
 } ssf_status;
 
 enum { SSF_C64 = 0, SSF_C128 = 1 };                       /* field precision            */
@@ -177,6 +181,36 @@ int  ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_
                   int32_t rows_per_unit, int32_t precision, int32_t engine,
                   const ssf_params *params, const void *fields_in, void *fields_out,
                   ssf_stats *stats);
+
+/* ---- multi-GPU, one process per GPU: RCCL over xGMI ------------------------------------------
+ * The same partitioning as ssf_mgpu_run (unit u of U belongs to rank u*G/U ... contiguous blocks), for launchers that
+ * start one process per GPU (torchrun, mpirun, srun).  Only inputs and results of INDEPENDENT units and the
+ * parameter block cross the links; there is no per-step communication.  librccl.so is opened with
+ * dlopen by the first ssf_comm_get_id / ssf_comm_create call; without it these calls return SSF_ERR_COMM and
+ * everything else keeps working.  Every buffer may be a host pointer (staged through device memory inside the
+ * library) or a device pointer of ssf_device_malloc.  All calls are collective where RCCL's are, blocking at return.
+ *   ssf_comm_get_id     rank 0 draws the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other
+ *                       ranks by any out-of-band means (opticommpy_amd.mgpu: a file next to the launcher's port)
+ *   ssf_comm_create     ncclCommInitRank on `device`
+ *   ssf_comm_bcast      parameter block / launch powers                      (ncclBroadcast, in place)
+ *   ssf_comm_send/recv  inputs from the root to the owner of a unit, results back   (ncclSend / ncclRecv)
+ *   ssf_comm_allgather  results of every rank's block to every rank          (ncclAllGather)
+ *   ssf_comm_allreduce  op 0 = sum, 1 = max, in place: timings and checksums (ncclAllReduce)
+ *   ssf_comm_barrier    an 8-byte all-reduce */
+typedef struct ssf_comm ssf_comm;
+#define SSF_COMM_ID_BYTES 128
+int  ssf_comm_get_id(void *id);
+int  ssf_comm_create(int device, int32_t nranks, int32_t rank, const void *id, ssf_comm **out);
+int  ssf_comm_destroy(ssf_comm *comm);
+int  ssf_comm_rank(const ssf_comm *comm);
+int  ssf_comm_size(const ssf_comm *comm);
+int  ssf_comm_barrier(ssf_comm *comm);
+int  ssf_comm_allreduce(ssf_comm *comm, double *values, int32_t n, int32_t op);
+int  ssf_comm_bcast(ssf_comm *comm, void *buf, int64_t bytes, int32_t root);
+int  ssf_comm_send(ssf_comm *comm, const void *buf, int64_t bytes, int32_t peer);
+int  ssf_comm_recv(ssf_comm *comm, void *buf, int64_t bytes, int32_t peer);
+int  ssf_comm_allgather(ssf_comm *comm, const void *send, void *recv, int64_t bytes_per_rank);
+const char *ssf_comm_last_error(const ssf_comm *comm);       /* never NULL; comm may be NULL */
 
 /* ---- per-kernel timing (measurement aid; fused engine only) ------------------------------ */
 /* With profiling enabled every kernel launch of ssf_execute is bracketed by HIP events on the

@@ -14,7 +14,7 @@ ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_FUSED = 0, 1, 2
 ENGINE_NAMES = {ENGINE_AUTO: "auto", ENGINE_ROCFFT: "rocfft", ENGINE_FUSED: "fused"}
 
 STATUS = {0: "OK", -1: "bad argument", -2: "HIP error", -3: "out of device memory", -4: "FFT error",
-          -5: "no device", -6: "unsupported", -7: "bad call order"}
+          -5: "no device", -6: "unsupported", -7: "bad call order", -8: "RCCL error"}
 
 
 class Params(C.Structure):
@@ -109,7 +109,20 @@ SYMBOLS = {
     "ssf_device_copy_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     "ssf_linear_channel": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p, C.c_void_p]),
+    "ssf_comm_get_id": (C.c_int, [C.c_void_p]),
+    "ssf_comm_create": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ssf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ssf_comm_rank": (C.c_int, [C.c_void_p]),
+    "ssf_comm_size": (C.c_int, [C.c_void_p]),
+    "ssf_comm_barrier": (C.c_int, [C.c_void_p]),
+    "ssf_comm_allreduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32]),
+    "ssf_comm_bcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "ssf_comm_send": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "ssf_comm_recv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "ssf_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "ssf_comm_last_error": (C.c_char_p, [C.c_void_p]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 

@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const 
     SSF_DEV_CTX(1);
     col_body<T, LG, MODE, true>(ctx, a);
 }
-// complex64 Manakov: packed polarisation pairs (fused_kernels.h: col_pk_body), 256 threads = 16 columns of 256
-template <int LG> __global__ void __launch_bounds__(256, 2) k_col_pk(const ColArgs<pf2> a) {
+// complex64 Manakov: packed polarisation pairs (fused_kernels.h: col_pk_body); up to 512 threads (8 columns of 1024)
+template <int LG> __global__ void __launch_bounds__(512) k_col_pk(const ColArgs<pf2> a) {
     SSF_DEV_CTX(1);
     col_pk_body<LG>(ctx, a);
 }

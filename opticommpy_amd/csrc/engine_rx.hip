@@ -111,10 +111,16 @@ struct HipRxBackend {
         return p;
     }
     void free(void *p) { (void)hipFree(p); }
-    void h2d(void *d, const void *h, size_t n) {      // small, pageable source: synchronous copy
-        chk(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D");
+    // small copies go on the SAME stream as their consumers (a non-blocking stream has no implicit ordering with
+    // the null stream a plain hipMemcpy uses) and are waited for: the source may be a temporary
+    void h2d(void *d, const void *h, size_t n) {
+        chk(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, st), "hipMemcpyAsync H2D");
+        chk(hipStreamSynchronize(st), "hipStreamSynchronize");
     }
-    void d2h(void *h, const void *d, size_t n) { chk(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+    void d2h(void *h, const void *d, size_t n) {
+        chk(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, st), "hipMemcpyAsync D2H");
+        chk(hipStreamSynchronize(st), "hipStreamSynchronize");
+    }
     void h2d_big(void *d, const void *h, size_t n) { chk(stg.h2d(d, h, n, st), "staged upload"); }
     void d2h_big(void *h, const void *d, size_t n) { chk(stg.d2h(h, d, n, st), "staged download"); }
     void sync() { chk(hipStreamSynchronize(st), "hipStreamSynchronize"); }

@@ -155,6 +155,8 @@ template <typename T, class Backend> class FusedCore {
             const int h = std::atoi(e);
             if (h >= tpf && h <= 512 && (h & (h - 1)) == 0) half = h;
         }
+        if (kPacked && !std::getenv("SSF_COL_HALF"))          // packed pairs: one row per tile, keep its segments >= 128 B wide
+            while ((half / tpf) * sizeof(C) < 128 && half < 512) half <<= 1;
         while (half / tpf > N2 && half > tpf) half >>= 1;    // (a power of two also when N2 is not)
         // a grid that only just covers the 256 CUs leaves every CU with one lock-stepped workgroup:
         // prefer two smaller independent ones (measured +3 % at N = 2^20) while rows stay >= 128 B wide
@@ -198,6 +200,7 @@ template <typename T, class Backend> class FusedCore {
         } else {
             const int tpf2 = (1 << sp.l2) / 16;
             int fpw = tpf2 >= 256 ? 1 : 256 / tpf2;           // row transforms per workgroup
+            if (const char *e = std::getenv("SSF_ROW_FPW")) fpw = std::max(1, std::min(fpw, std::atoi(e)));   // tuning knob
             while (nfft % fpw) fpw >>= 1;                      // (nrows need not be a power of two)
             row_block = fpw * tpf2;
             row_grid = (int)(nfft / fpw);

@@ -1,4 +1,6 @@
 // ssf_api.hip -- the extern "C" boundary declared in include/ssf.h.
+#include <map>
+#include <memory>
 #include <thread>
 
 #include "ssf_internal.h"
@@ -334,19 +336,23 @@ int ssf_device_memcpy(int device, void *dst, const void *src, int64_t bytes) {
     if (dst_dev != src_dev && bytes >= (1 << 20)) {
         // large host <-> device copies of pageable memory go through the pinned double buffer (a plain
         // hipMemcpy of pageable memory runs at a fraction of the link rate)
+        // one lane (stream + pinned double buffer + events) per device and host thread: events and streams belong to
+        // the device they were created on
         struct Lane {
             hipStream_t st = nullptr;
             ssf::Stager stg;
-            int dev = -1;
         };
-        thread_local Lane lane;
-        if (lane.dev != device) {
-            if (lane.st) (void)hipStreamDestroy(lane.st);
-            lane.st = nullptr;
-            if (hipStreamCreateWithFlags(&lane.st, hipStreamNonBlocking) != hipSuccess) return set_err(SSF_ERR_HIP, "hipStreamCreate failed");
-            if (lane.dev < 0) (void)lane.stg.init();
-            lane.dev = device;
+        thread_local std::map<int, std::unique_ptr<Lane>> lanes;
+        std::unique_ptr<Lane> &slot = lanes[device];
+        if (!slot) {
+            slot.reset(new Lane());
+            if (hipStreamCreateWithFlags(&slot->st, hipStreamNonBlocking) != hipSuccess) {
+                slot.reset();
+                return set_err(SSF_ERR_HIP, "hipStreamCreate failed");
+            }
+            (void)slot->stg.init();            // (current device = `device`; falls back to plain copies without pinned memory)
         }
+        Lane &lane = *slot;
         e = dst_dev ? lane.stg.h2d(dst, src, (size_t)bytes, lane.st) : lane.stg.d2h(dst, src, (size_t)bytes, lane.st);
     } else {
         e = hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault);

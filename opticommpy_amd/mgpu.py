@@ -4,19 +4,26 @@ A single (N, 2) field is one global FFT per transform and is never split.  What 
 is a batch of independent units -- WDM channels simulated separately, launch-power sweep
 points (examples/test_NLC_withDBP_WDM_transmission.ipynb:660-675), Monte-Carlo fibre
 realisations: unit u of U goes to rank u*G//U (contiguous blocks), there is no per-step
-communication, and the only collective is the final gather of results.
+communication; the parameter block is broadcast, the inputs are scattered from the root and
+the results gathered, all through RCCL (xGMI inside a node) bound inside libssf_hip.so
+(include/ssf.h: ssf_comm_*).  No torch, no mpi4py.
 
 Two ways to use the GPUs of one node:
 
-* one process per GPU (``torchrun`` / ``python -m torch.distributed.run``), each rank calling
-  :func:`run_sharded`: torch.distributed ("nccl" = RCCL over xGMI on ROCm, "gloo" on CPU-only
-  test boxes) is used ONLY for the final all-gather of the outputs;
-* one process, one host thread per device, through the C entry point ``ssf_mgpu_run``:
-  :func:`run_threads` (what a one-node notebook user needs; no torch involved).
+* one process per GPU (``torchrun`` / ``mpirun`` / ``srun`` only as the process launcher): every rank
+  builds ``comm = RcclComm.from_env()`` and calls :func:`run_sharded`;
+* one process, host threads per device, through the C entry point ``ssf_mgpu_run``:
+  :func:`run_threads` (what a one-node notebook user needs).
+
+:func:`run_sharded` only needs an object with the small interface of :class:`RcclComm` (rank, world,
+barrier, bcast, send, recv, allgather, allreduce): the CPU tests drive it with a gloo-backed stand-in.
 """
 import copy
 import ctypes as C
 import os
+import pickle
+import tempfile
+import time
 
 import numpy as np
 
@@ -35,14 +42,137 @@ def owner_of(unit, n_units, world):
     raise IndexError(unit)
 
 
-def _dist():
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist
-    except ImportError:
-        pass
-    return None
+def _ptr(a):
+    """(address, nbytes, keepalive) of a contiguous numpy array or a DeviceArray"""
+    from . import device as _dev
+    if _dev.is_device(a):
+        return C.c_void_p(a.ptr.value if hasattr(a.ptr, "value") else a.ptr), a.nbytes, a
+    if not (isinstance(a, np.ndarray) and a.flags.c_contiguous):
+        raise ValueError("communication buffers must be C-contiguous numpy arrays or DeviceArrays")
+    return a.ctypes.data_as(C.c_void_p), a.nbytes, a
+
+
+class RcclComm:
+    """One RCCL communicator over the processes of a launcher (one process per GPU), through libssf_hip.so."""
+
+    def __init__(self, device, world, rank, comm_id):
+        self.lib = _lib.load()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        h = C.c_void_p()
+        rc = self.lib.ssf_comm_create(self.device, self.world, self.rank, comm_id, C.byref(h))
+        if rc:
+            msg = self.lib.ssf_comm_last_error(None)
+            raise RuntimeError("RCCL communicator: %s" % (msg.decode(errors="replace") if msg else _lib.STATUS.get(rc, rc)))
+        self.h = h
+
+    # -- rendezvous -------------------------------------------------------------------------------------------
+    @staticmethod
+    def id_path():
+        """Where rank 0 leaves the 128-byte rendezvous id: keyed by the launcher's port and the launcher process
+        (all workers of one node share their parent), $SSF_RCCL_ID_FILE overrides."""
+        p = os.environ.get("SSF_RCCL_ID_FILE")
+        if p:
+            return p
+        return os.path.join(tempfile.gettempdir(), "ssf_rccl_%s_%d.id" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+
+    @classmethod
+    def from_env(cls, device=None, timeout=180.0):
+        """RANK / WORLD_SIZE / LOCAL_RANK as torchrun, mpirun (OMPI_COMM_WORLD_*) or srun (SLURM_*) export them."""
+        env = os.environ
+        rank = int(env.get("RANK", env.get("OMPI_COMM_WORLD_RANK", env.get("SLURM_PROCID", "0"))))
+        world = int(env.get("WORLD_SIZE", env.get("OMPI_COMM_WORLD_SIZE", env.get("SLURM_NTASKS", "1"))))
+        local = int(env.get("LOCAL_RANK", env.get("OMPI_COMM_WORLD_LOCAL_RANK", env.get("SLURM_LOCALID", str(rank)))))
+        lib = _lib.load()
+        path = cls.id_path()
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        if rank == 0:
+            rc = lib.ssf_comm_get_id(buf)
+            if rc:
+                msg = lib.ssf_comm_last_error(None)
+                raise RuntimeError("RCCL: %s" % (msg.decode(errors="replace") if msg else rc))
+            if world > 1:
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                with open(tmp, "wb") as f:
+                    f.write(buf.raw)
+                os.replace(tmp, path)                          # atomic: readers never see a partial id
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        raw = f.read()
+                    if len(raw) == _lib.COMM_ID_BYTES:
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > timeout:
+                    raise TimeoutError("RCCL rendezvous: %s did not appear within %.0f s" % (path, timeout))
+                time.sleep(0.02)
+            buf = C.create_string_buffer(raw, _lib.COMM_ID_BYTES)
+        comm = cls(local if device is None else device, world, rank, buf)     # (collective: returns on every rank together)
+        if rank == 0 and world > 1:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+        return comm
+
+    # -- collectives ----------------------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc:
+            msg = self.lib.ssf_comm_last_error(self.h)
+            raise RuntimeError("RCCL: %s" % (msg.decode(errors="replace") if msg else _lib.STATUS.get(rc, rc)))
+
+    def barrier(self):
+        self._chk(self.lib.ssf_comm_barrier(self.h))
+
+    def allreduce(self, values, op="sum"):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._chk(self.lib.ssf_comm_allreduce(self.h, v.ctypes.data_as(C.POINTER(C.c_double)), v.size, {"sum": 0, "max": 1}[op]))
+        return v
+
+    def bcast(self, arr, root=0):
+        p, n, _k = _ptr(arr)
+        self._chk(self.lib.ssf_comm_bcast(self.h, p, n, root))
+        return arr
+
+    def send(self, arr, peer):
+        p, n, _k = _ptr(arr)
+        self._chk(self.lib.ssf_comm_send(self.h, p, n, peer))
+
+    def recv(self, arr, peer):
+        p, n, _k = _ptr(arr)
+        self._chk(self.lib.ssf_comm_recv(self.h, p, n, peer))
+        return arr
+
+    def allgather(self, arr):
+        a = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + a.shape, dtype=a.dtype)
+        self._chk(self.lib.ssf_comm_allgather(self.h, a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), a.nbytes))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ssf_comm_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def bcast_object(comm, obj, root=0):
+    """Broadcast a small picklable object (the parameter block, launch powers): 8-byte length, then the bytes."""
+    if comm is None or comm.world == 1:
+        return obj
+    raw = pickle.dumps(obj) if comm.rank == root else b""
+    n = np.array([len(raw)], dtype=np.int64)
+    comm.bcast(n, root)
+    buf = np.frombuffer(raw, dtype=np.uint8).copy() if comm.rank == root else np.empty(int(n[0]), dtype=np.uint8)
+    comm.bcast(buf, root)
+    return obj if comm.rank == root else pickle.loads(buf.tobytes())
 
 
 _LANES = {}
@@ -57,23 +187,43 @@ def _lane_pool(lanes):
     return pool
 
 
-def run_sharded(fields, param, compute=None, gather=True):
-    """Propagate a list of independent fields, sharded over the ranks of the initialised
-    torch.distributed group (or all of them locally when there is no group).
+def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
+    """Propagate a list of independent fields, sharded over the ranks of `comm` (all of them locally when comm is None).
 
-    fields : sequence of (N, 2K) arrays, identical shape/dtype on every rank
-    param  : parameters object (deep-copied per unit, so defaults written back by one unit
-             never leak into another)
+    fields : sequence of U arrays (N, 2K).  root=None: identical on every rank (each rank takes its block);
+             root=r: only rank r needs to hold them -- shape, dtype, the parameter block and the launch data are
+             broadcast and every other rank receives the inputs of its block from r (`fields` may be None there)
+    param  : parameters object (deep-copied per unit, so defaults written back by one unit never leak into another)
     compute: callable(Ei, param) -> Eout; default opticommpy_amd.manakovSSF (GPU)
-    gather : all-gather the outputs so every rank returns the full list (else: own units, None elsewhere)
+    gather : True: every rank returns the full list (one all-gather); "root": only `root` (or rank 0) does, the
+             others get None in the slots they do not own; False: own units only
     """
     if compute is None:
         from .models import manakovSSF as compute
-    dist = _dist()
-    world = dist.get_world_size() if dist else 1
-    rank = dist.get_rank() if dist else 0
-    n = len(fields)
-    mine = shard_range(n, world, rank)
+    world = comm.world if comm is not None else 1
+    rank = comm.rank if comm is not None else 0
+    if root is not None and world > 1:
+        meta = None
+        if rank == root:
+            f0 = np.asarray(fields[0])
+            meta = (len(fields), f0.shape, f0.dtype.str, param)
+        n, shape, dt, param = bcast_object(comm, meta, root)
+        dt = np.dtype(dt)
+        mine = shard_range(n, world, rank)
+        local = {}
+        for r in range(world):                                  # inputs: root -> owner, unit by unit
+            for u in shard_range(n, world, r):
+                if r == root:
+                    if rank == root:
+                        local[u] = np.ascontiguousarray(fields[u], dtype=dt)
+                elif rank == root:
+                    comm.send(np.ascontiguousarray(fields[u], dtype=dt), r)
+                elif rank == r:
+                    local[u] = comm.recv(np.empty(shape, dtype=dt), root)
+    else:
+        n = len(fields)
+        mine = shard_range(n, world, rank)
+        local = {u: fields[u] for u in mine}
     outs = [None] * n
     # Two lanes per GPU: the rank's units are taken by two host threads (each with its own plan and stream; ctypes
     # releases the GIL inside the library), so that one unit's transfers overlap the other's kernels and the kernels of
@@ -81,7 +231,7 @@ def run_sharded(fields, param, compute=None, gather=True):
     lanes = max(1, min(int(os.environ.get("SSF_MGPU_LANES", "2")), len(mine)))
 
     def one(u):
-        return u, np.asarray(compute(fields[u], copy.deepcopy(param)))
+        return u, np.asarray(compute(local[u], copy.deepcopy(param)))
 
     if lanes > 1:
         for u, o in _lane_pool(lanes).map(one, mine):
@@ -89,34 +239,36 @@ def run_sharded(fields, param, compute=None, gather=True):
     else:
         for u in mine:
             outs[u] = one(u)[1]
-    if not (dist and gather and world > 1):
+    if not (comm is not None and gather and world > 1):
         return outs
-    import torch
-    on_gpu = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    # equal-sized payload per rank: pad to the largest block
-    per = max(len(shard_range(n, world, r)) for r in range(world))
     probe = outs[mine[0]] if len(mine) else None
-    meta = [None] * world
-    dist.all_gather_object(meta, None if probe is None else (probe.shape, probe.dtype.str))
-    shape, dt = next(m for m in meta if m is not None)
-    dt = np.dtype(dt)
-    buf = np.zeros((per,) + tuple(shape), dtype=dt)
+    metas = [bcast_object(comm, None if probe is None else (probe.shape, probe.dtype.str), r) for r in range(world)]
+    oshape, odt = next(m for m in metas if m is not None)
+    odt = np.dtype(odt)
+    if gather == "root":
+        dst = 0 if root is None else root
+        for r in range(world):
+            for u in shard_range(n, world, r):
+                if r == dst:
+                    continue
+                if rank == r:
+                    comm.send(np.ascontiguousarray(outs[u], dtype=odt), dst)
+                elif rank == dst:
+                    outs[u] = comm.recv(np.empty(oshape, dtype=odt), r)
+        return outs
+    per = max(len(shard_range(n, world, r)) for r in range(world))      # equal-sized payload per rank: pad to the largest block
+    buf = np.zeros((per,) + tuple(oshape), dtype=odt)
     for i, u in enumerate(mine):
         buf[i] = outs[u]
-    t = torch.view_as_real(torch.from_numpy(buf)).to(dev) if np.iscomplexobj(buf) else torch.from_numpy(buf).to(dev)
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t)                       # the one collective of the data path
+    parts = comm.allgather(buf)                                      # the one collective of the data path
     for r in range(world):
-        arr = parts[r].cpu()
-        arr = torch.view_as_complex(arr).numpy() if np.iscomplexobj(buf) else arr.numpy()
         for i, u in enumerate(shard_range(n, world, r)):
-            outs[u] = arr[i].astype(dt, copy=False)
+            outs[u] = parts[r][i].astype(odt, copy=False)
     return outs
 
 
 def run_threads(fields, cparams, devices, precision=np.complex128, engine="auto"):
-    """Single-process multi-GPU: one host thread per device inside libssf_hip.so
+    """Single-process multi-GPU: host threads per device inside libssf_hip.so
     (ssf_mgpu_run).  `fields`: (U, rows, N) SoA array; `cparams`: a filled _lib.Params.
     Returns (outputs (U, rows, N), [stats dict per unit])."""
     lib = _lib.load()

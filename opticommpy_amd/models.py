@@ -526,6 +526,16 @@ def edc(sigIn, param):
         raise ValueError("FFT size is smaller than filter length")
     logg.info("Running CD compensation...")
     logg.info(f"CD filter length: {K} taps, FFT size: {Nfft}")
+    # The block size of an overlap-save evaluation does not change the linear convolution it computes: the device
+    # kernel takes powers of two in [16, 8192], so any other request of the reference (Nfft = 2 for a 1 km link,
+    # a non power of two, > 8192) is served with the smallest supported block that leaves >= 3/4 of each transform as
+    # output.  Filters longer than 8192 taps do not fit one LDS transform.
+    if Nfft < 16 or Nfft > 8192 or (Nfft & (Nfft - 1)):
+        if K > 8192:
+            raise ValueError(f"edc: {K} filter taps exceed the 8192-point blocks of the device kernel (reduce Fs/Rs or L)")
+        Nfft = 16
+        while Nfft < min(4 * K, 8192) or Nfft < K:
+            Nfft *= 2
     # core.py:1015-1020: centred impulse response, zero-padded to the FFT size, back to frequency
     h = np.pad(np.fft.fftshift(np.fft.ifft(Hf)), (0, Nfft - K), mode="constant")
     H = np.ascontiguousarray(np.fft.fft(h), dtype=np.complex128)

@@ -265,6 +265,13 @@ def iqMixing(sig, param):
     return _rx(_MODE["iqMixing"], len(sig), 1, p, sig.reshape(-1), None, None, (len(sig),), np.complex128, 0)
 
 
+def _same_fs(pd_fs, fe_fs):
+    """ssf_rx_params carries one sampling rate: the reference takes paramPD.Fs for the photodiode noise / low-pass and
+    paramFE.Fs for IQ mixing and skew (devices.py:562-571), which only coincide when both objects agree."""
+    if pd_fs and abs(pd_fs - fe_fs) > 1e-9 * abs(fe_fs):
+        raise ValueError(f"paramPD.Fs ({pd_fs}) differs from paramFE.Fs ({fe_fs}): the device front-end runs at one sampling rate")
+
+
 def coherentReceiver(Es, Elo, paramFE=None, paramPD=None, _unit_normals=None):
     """Single-polarisation coherent front-end (optic/models/devices.py:503-571): 2x4 hybrid, two
     balanced photodiode pairs, IQ impairments."""
@@ -276,6 +283,7 @@ def coherentReceiver(Es, Elo, paramFE=None, paramPD=None, _unit_normals=None):
         paramPD = parameters()
         paramPD.Fs = Fs
     p = _pd_fields(_lib.RxParams(), paramPD)
+    _same_fs(p.Fs, Fs)
     p.Fs = Fs
     _iq_fields(p, 0, paramFE)
     return _rx(_MODE["coherentReceiver"], len(Es), 1, p, Es, Elo, _unit_normals, (len(Es),), np.complex128, 4)
@@ -295,6 +303,7 @@ def pdmCoherentReceiver(Es, Elo, paramFE, paramPD=None, _unit_normals=None):
         paramPD = parameters()
         paramPD.Fs = Fs
     p = _pd_fields(_lib.RxParams(), paramPD)
+    _same_fs(p.Fs, Fs)
     p.Fs = Fs
     p.polRotation = getattr(paramFE, "polRotation", 0)
     p.pdl = getattr(paramFE, "pdl", 0)

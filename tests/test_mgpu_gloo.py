@@ -1,7 +1,8 @@
-"""world_size-2 test of the N > 1 path on CPU (gloo): the sharding rule, the independence of
-units and the final all-gather.  The propagation itself is stubbed by the CPU oracle here
-(`compute=`) -- this test is about the host-side distribution logic; the HIP path is covered
-by the -m gpu tests."""
+"""world_size-2 test of the N > 1 path on CPU: the sharding rule, the independence of units, the broadcast of the
+parameter block, the scatter of the inputs from the root and the gather of the results.  The product's
+communicator is RCCL inside libssf_hip.so (mgpu.RcclComm); here a gloo-backed stand-in with the same interface
+(tests/comm_gloo.py) carries the messages and the CPU oracle stands in for the propagation (`compute=`) -- this test
+is about the host-side distribution logic; the HIP path is covered by the -m gpu tests."""
 import os
 import socket
 import subprocess
@@ -17,12 +18,12 @@ WORKER = r'''
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ["SSF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SSF_ROOT"], "tests"))
-import torch.distributed as dist
 from opticommpy_amd import mgpu
 from oracle import ssf_oracle as orc
 from helpers import synth_field
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
+from comm_gloo import GlooComm
+comm = GlooComm()
+rank, world = comm.rank, comm.world
 U = 5
 fields = [synth_field(256, 2, 100 + u, 8.4 - 0.5 * u) for u in range(U)]
 p = orc.parameters()
@@ -31,12 +32,26 @@ calls = []
 def compute(E, q):
     calls.append(1)
     return orc.manakovSSF(E, q)
-outs = mgpu.run_sharded(fields, p, compute=compute)
+outs = mgpu.run_sharded(fields, p, compute=compute, comm=comm)
 assert len(calls) == len(mgpu.shard_range(U, world, rank)), (rank, len(calls))
 assert not hasattr(p, "maxIter")            # the caller's param object is untouched (deep copies per unit)
 np.save(os.path.join(os.environ["SSF_OUT"], f"out_rank{rank}.npy"), np.stack(outs))
-dist.barrier()
-dist.destroy_process_group()
+# root mode: only rank 0 holds fields and parameters; everything else arrives through the communicator
+comm.calls.clear()
+outs2 = mgpu.run_sharded(fields if rank == 0 else None, p if rank == 0 else None, compute=compute, comm=comm, root=0,
+                         gather="root")
+if rank == 0:
+    assert all(np.array_equal(a, b) for a, b in zip(outs, outs2))
+    sent = [c for c in comm.calls if c[0] == "send"]
+    assert len(sent) == len(mgpu.shard_range(U, world, 1)) and all(c[1] == 1 for c in sent)      # inputs of rank 1's block only
+else:
+    mine = list(mgpu.shard_range(U, world, rank))
+    assert all((outs2[u] is not None) == (u in mine) for u in range(U))
+    assert sum(1 for c in comm.calls if c[0] == "recv") == len(mine)
+t = comm.allreduce(np.array([float(rank + 1)]), "max")
+assert t[0] == world
+assert mgpu.bcast_object(comm, {"powers": [1.5, 2.5]} if rank == 0 else None, 0) == {"powers": [1.5, 2.5]}
+comm.close()
 '''
 
 

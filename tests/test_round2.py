@@ -1,0 +1,83 @@
+"""Round-2 additions: advisor findings (argument handling on the host side) and the new entry points."""
+import numpy as np
+import pytest
+
+import opticommpy_amd as oa
+from helpers import make_param, rel_l2, synth_field
+from oracle import ssf_oracle as orc
+
+
+def test_receiver_rejects_two_different_sampling_rates():
+    """ssf_rx_params carries one Fs; the reference uses paramPD.Fs for the photodiodes and paramFE.Fs for IQ mixing."""
+    E = np.ones(64, complex)
+    fe, pd = oa.parameters(), oa.parameters()
+    fe.Fs, pd.Fs, pd.B = 64e9, 128e9, 20e9
+    with pytest.raises(ValueError, match="differs from paramFE.Fs"):
+        oa.coherentReceiver(E, E, fe, pd)
+    with pytest.raises(ValueError, match="differs from paramFE.Fs"):
+        oa.pdmCoherentReceiver(np.ones((64, 2), complex), E, fe, pd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,Nfft", [(1.0, None), (50.0, 100), (400.0, None)])
+def test_edc_block_size_is_the_devices_choice(L, Nfft):
+    """A 1 km link gives NfilterCoeffs = Nfft = 2 in the reference, an explicit Nfft need not be a power of two: the
+    device block size is chosen independently (same linear convolution)."""
+    E = synth_field(1 << 14, 2, 91, 0.0)
+    kw = dict(L=L, D=16, Fc=193.1e12, Fs=64e9, Rs=32e9)
+    if Nfft:
+        kw.update(Nfft=Nfft, NfilterCoeffs=45)
+    ref = orc.edc(E, make_param(orc.parameters, kw))
+    out = oa.edc(E, make_param(oa.parameters, kw))
+    assert rel_l2(out, ref) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_with_one_rank(tmp_path, monkeypatch):
+    """The RCCL binding of libssf_hip.so end to end on one GPU (more ranks need more GPUs: RCCL refuses two ranks on
+    one device): rendezvous id, communicator, every collective the sharded driver uses, host and device buffers."""
+    from opticommpy_amd import mgpu
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    with mgpu.RcclComm.from_env() as comm:
+        assert (comm.rank, comm.world) == (0, 1)
+        comm.barrier()
+        assert comm.allreduce(np.array([1.5, -2.0]), "sum").tolist() == [1.5, -2.0]
+        assert comm.allreduce(np.array([3.0]), "max").tolist() == [3.0]
+        a = np.arange(1000, dtype=np.complex128)
+        assert np.array_equal(comm.bcast(a.copy(), 0), a)
+        assert np.array_equal(comm.allgather(a)[0], a)
+        d = oa.to_device(a)
+        comm.bcast(d, 0)
+        assert np.array_equal(d.get(), a)
+        fields = [synth_field(1 << 12, 2, 5 + u, 3.0) for u in range(3)]
+        p = make_param(oa.parameters, dict(Fs=512e9, Ltotal=2, Lspan=1, hz=0.25, amp="ideal", nlprMethod=False, prgsBar=False, saveSpanN=[]))
+        outs = mgpu.run_sharded(fields, p, comm=comm, root=0)
+        for E, o in zip(fields, outs):
+            assert rel_l2(o, orc.manakovSSF(E, make_param(orc.parameters, dict(Fs=512e9, Ltotal=2, Lspan=1, hz=0.25, amp="ideal",
+                                                                                 nlprMethod=False, prgsBar=False, saveSpanN=[])))) <= 1e-10
+
+
+@pytest.mark.gpu
+def test_packed_c64_pipeline_matches_the_unpacked_one_and_the_oracle(monkeypatch):
+    """complex64 Manakov runs on packed polarisation pairs (SSF_C64_PACKED=0 selects the one-row-per-polarisation
+    kernels): same iteration counts, both within the single-precision gate of the oracle, K = 1 and K = 3 pairs,
+    adaptive and fixed step, forward and backward."""
+    from opticommpy_amd import models
+    for ncols, adaptive, func in ((2, False, "manakovSSF"), (6, True, "manakovSSF"), (2, False, "manakovDBP")):
+        N = 1 << 13
+        E = synth_field(N, ncols, 77, 9.0, np.complex64)
+        cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=4, Lspan=2,
+                   hz=0.1, nlprMethod=adaptive, amp="ideal", saveSpanN=[], prec="complex64")
+        ref = getattr(orc, func)(E.astype(np.complex128), make_param(orc.parameters, dict(cfg, prec="complex128")))
+        res = {}
+        for packed in ("1", "0"):
+            monkeypatch.setenv("SSF_C64_PACKED", packed)
+            models.release_plans()
+            res[packed] = (getattr(oa, func)(E, make_param(oa.parameters, cfg)), models.last_run["iterations"])
+        monkeypatch.delenv("SSF_C64_PACKED")
+        models.release_plans()
+        assert res["1"][1] == res["0"][1]
+        assert rel_l2(res["1"][0], ref) <= 5e-5 and rel_l2(res["0"][0], ref) <= 5e-4
+        assert rel_l2(res["1"][0], res["0"][0]) <= 5e-4

@@ -432,7 +432,7 @@ def long_vectors():
               Ltotal=80, Lspan=80, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
     run_long("long_c2_n14", "manakovSSF", (1 << 14, 2, 2, 8.4), dict(c2))
     run_long("long_c2_n16", "manakovSSF", (1 << 16, 2, 2, 8.4), dict(c2))
-    run_long("long_adp_n14", "manakovSSF", (1 << 14, 2, 12, 8.4), dict(c2, nlprMethod=True, maxNlinPhaseRot=2e-2))
+    run_long("long_adp_n14", "manakovSSF", (1 << 14, 2, 12, 8.4), dict(c2, nlprMethod=True, maxNlinPhaseRot=2e-3))
     run_long("long_k2_n14", "manakovSSF", (1 << 14, 4, 13, 11.4), dict(c2))
     run_long("long_dbp_n14", "manakovDBP", (1 << 14, 2, 14, 5.0), dict(c2, amp="edfa"))
     run_long("long_n48000", "manakovSSF", (48000, 2, 15, 8.4), dict(c2, Ltotal=40, Lspan=40))
