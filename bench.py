@@ -375,13 +375,20 @@ def main():
                 rec["speedup_vs_cpu"] = rec["value"] / (n / tc)
             if not ok:
                 rec["value"] = None                              # a wrong result is not a benchmark result
-        print(json.dumps(rec))
     for h in plans.values():
         lib.ssf_plan_destroy(h)
     if comm is not None:
         flag = comm.allreduce(np.array([0.0 if ok else 1.0]), "max")     # rank 0 arrives after its extra passes
         ok = flag[0] == 0.0
         comm.close()
+    if rec is not None:
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which would
+        # otherwise be flushed after it at exit
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(rec), flush=True)
     if not ok:
         sys.exit(1)
 

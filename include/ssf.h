@@ -17,6 +17,7 @@
  *   ssf_execute  (model MANAKOV, -1)     manakovDBP                       modelsGPU.py:564-772
  *                                        == optic/dsp/equalization.py:1087-1160
  *   ssf_download                         cp.asnumpy(...)                  modelsGPU.py:271,501-509
+ *   ssf_set_snapshot_sink / ssf_sync_snapshots   Ech_spans[:, 2*indRecSpan:...] = ...   channels.py:453-456
  *   ssf_run                              one whole reference call (upload+execute+download)
  *   ssf_mgpu_run                         (no reference equivalent) independent fields
  *                                        sharded over the GPUs of one node, SURVEY.md 8e
@@ -162,6 +163,15 @@ int  ssf_execute(ssf_plan *plan, const ssf_params *params, int32_t span_first,
                  int32_t span_last, const void *noise, ssf_stats *stats, ssf_trace *trace);
 int  ssf_download(ssf_plan *plan, void *field_soa);         /* (nrows, N) complex        */
 int  ssf_download_snapshots(ssf_plan *plan, void *snap_soa);/* (n_snapshots, nrows, N)   */
+/* Streamed snapshots.  With a sink set, the snapshots of the following ssf_execute calls are
+ * not kept in device memory: capture number i (i = first_index, first_index + 1, ... in capture order) of the
+ * (nrows, N) field is written to columns [i * nrows, (i + 1) * nrows) of the row-major (N, ld) complex array at
+ * `dst` -- the reference's Ech_spans[:, 2 * indRecSpan : 2 * indRecSpan + 2] (optic/models/channels.py:453-456,
+ * modelsGPU.py:497-498).  dst on the device: written in place by the conversion kernel.  dst on the host: moved by
+ * a copy thread on its own stream while the next span propagates; ssf_sync_snapshots returns when every captured
+ * snapshot has arrived (ssf_execute does not wait for them).  dst = NULL detaches the sink (and waits). */
+int  ssf_set_snapshot_sink(ssf_plan *plan, void *dst, int64_t ld, int32_t first_index);
+int  ssf_sync_snapshots(ssf_plan *plan);
 /* Same transfers in the reference's own array layout: (N, nrows) row-major, i.e. the C-contiguous
  * numpy field with columns [x0, y0, x1, y1, ...]; the AoS <-> SoA conversion runs on the device
  * (Ei_[:, 0::2].T / Ech[:, 0::2] = Ech_x.T in the reference, modelsGPU.py:406-407, 506-509).

@@ -82,6 +82,8 @@ SYMBOLS = {
                               C.POINTER(Stats), C.POINTER(Trace)]),
     "ssf_download": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ssf_download_snapshots": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ssf_set_snapshot_sink": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "ssf_sync_snapshots": (C.c_int, [C.c_void_p]),
     "ssf_upload_aos": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ssf_download_aos": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ssf_run": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -300,6 +300,10 @@ struct HipBackend {
             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         armed.push_back(f);
     }
+    bool sink_active() const { return pl->sink.active(); }
+    template <typename C> void sink_capture(const C *soa, long long N, int nrows) {
+        chk(pl->sink.capture(soa, N, nrows, pl->stream), "snapshot sink");
+    }
     void launch_repack(const RepackArgs &a, int grid, int block) {
         k_repack<<<grid, block, 0, pl->stream>>>(a);
         chk(hipGetLastError(), "launch k_repack");

@@ -291,6 +291,7 @@ template <typename T> class RocfftEngine final : public Engine {
         }
         for (C *s : snaps) (void)hipFree(s);
         snaps.clear();
+        n_sunk = 0;
         return SSF_OK;
     }
     int n_snapshots() const override { return (int)snaps.size(); }
@@ -328,7 +329,13 @@ template <typename T> class RocfftEngine final : public Engine {
         SSF_HIP(pl, hipStreamSynchronize(pl->stream));
         return SSF_OK;
     }
+    int n_sunk = 0;              // snapshots handed to the plan's sink since the last upload
     int snapshot() {
+        if (pl->sink.active()) {                     // streamed out (ssf_snapshots.h), not kept
+            SSF_HIP(pl, pl->sink.capture(E, (long long)pl->N, pl->nrows, pl->stream));
+            ++n_sunk;
+            return SSF_OK;
+        }
         C *s = nullptr;
         SSF_HIP(pl, hipMalloc(&s, field_bytes));
         snaps.push_back(s);
@@ -457,7 +464,7 @@ template <typename T> class RocfftEngine final : public Engine {
         float ms = 0;
         SSF_HIP(pl, hipEventElapsedTime(&ms, ev0, ev1));
         st->device_ms += ms;
-        st->n_snapshots = (int32_t)snaps.size();
+        st->n_snapshots = (int32_t)snaps.size() + n_sunk;
         return SSF_OK;
     }
 

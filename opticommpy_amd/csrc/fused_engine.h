@@ -26,7 +26,7 @@ struct Split {
 
 // How N = 2^m is split.  Columns want >= 256 B contiguous per row of a tile
 // (C = 4096/N1 columns x sizeof(complex)); rows are bounded by the 160 KiB LDS.
-inline bool choose_split(int log2N, int precision, Split *s) {
+inline bool choose_split(int log2N, int precision, Split *s, bool packed = false) {
     if (log2N < 8) return false;
     if (const char *e = std::getenv("SSF_SPLIT_L1")) {        // tuning knob: force log2 N1
         const int l1 = std::atoi(e);
@@ -40,6 +40,11 @@ inline bool choose_split(int log2N, int precision, Split *s) {
     const int l1pref = 8, l2max = dbl ? 13 : 14;     // (measured: 8 is best for both precisions at 2^20)
     int l1 = std::min(l1pref, log2N / 2);
     int l2 = log2N - l1;
+    if (packed && l2 > 12 && log2N - 12 <= 10) {     // packed pairs (16-byte elements): rows of 4096 are three radix-16 passes and
+        s->l1 = log2N - 12;                           // two workgroups per CU, rows of 8192 four passes and one: measured at 2^22
+        s->l2 = 12;                                   // row launch 59 -> 46 us, column launch (1024 long, 64-B segments) 60 -> 63 us
+        return true;
+    }
     const int l2soft = l2max - 1;          // prefer two workgroups per CU
     if (l2 > l2soft) {
         l1 = std::min(log2N - l2soft, l1pref + 1);
@@ -139,7 +144,7 @@ template <typename T, class Backend> class FusedCore {
         log2N = 0;
         while ((1ll << log2N) < N) ++log2N;
         if ((N & (N - 1)) == 0) {
-            choose_split(log2N, precision, &sp);
+            choose_split(log2N, precision, &sp, kPacked);
         } else {
             choose_mixed_split(N, precision, &sp.l1, &N2mix);
             sp.l2 = 0;
@@ -155,8 +160,8 @@ template <typename T, class Backend> class FusedCore {
             const int h = std::atoi(e);
             if (h >= tpf && h <= 512 && (h & (h - 1)) == 0) half = h;
         }
-        if (kPacked && !std::getenv("SSF_COL_HALF"))          // packed pairs: one row per tile, keep its segments >= 128 B wide
-            while ((half / tpf) * sizeof(C) < 128 && half < 512) half <<= 1;
+        // (packed pairs, columns of 1024: 512-thread workgroups with 128-B row segments measured slower than 256 threads with
+        //  64-B segments: column launch 67.5 vs 63.2 us at 2^22 -- one 139 KiB workgroup per CU against two of 70 KiB)
         while (half / tpf > N2 && half > tpf) half >>= 1;    // (a power of two also when N2 is not)
         // a grid that only just covers the 256 CUs leaves every CU with one lock-stepped workgroup:
         // prefer two smaller independent ones (measured +3 % at N = 2^20) while rows stay >= 128 B wide
@@ -258,6 +263,7 @@ template <typename T, class Backend> class FusedCore {
         if (aos) be.aos_to_soa(T0, G, N, nrows);
         for (C *s : snaps) be.free(s);
         snaps.clear();
+        n_sunk = 0;
         return be.ok() ? SSF_OK : hiperr();
     }
     int download(void *field, int which, bool aos) {
@@ -340,7 +346,13 @@ template <typename T, class Backend> class FusedCore {
             be.launch_amp(a, 1024, 256);
         }
     }
+    int n_sunk = 0;              // snapshots handed to the plan's sink since the last upload
     int snapshot() {
+        if (be.sink_active()) {                      // streamed out (ssf_snapshots.h), not kept
+            be.sink_capture(Tcur(), (long long)N, nrows);
+            ++n_sunk;
+            return be.ok() ? SSF_OK : hiperr();
+        }
         C *s = (C *)be.alloc(field_bytes);
         if (!s) return oom();
         snaps.push_back(s);
@@ -602,7 +614,7 @@ template <typename T, class Backend> class FusedCore {
                                            : run_manakov(p, d, s0, s1, noise, st, trace);
         if (rc) return rc;
         st->device_ms += be.time_end();
-        st->n_snapshots = (int32_t)snaps.size();
+        st->n_snapshots = (int32_t)snaps.size() + n_sunk;
         return SSF_OK;
     }
 

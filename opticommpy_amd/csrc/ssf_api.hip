@@ -105,6 +105,7 @@ int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int
 int ssf_plan_destroy(ssf_plan *plan) {
     if (!plan) return SSF_OK;
     (void)hipSetDevice(plan->device);
+    (void)plan->sink.sync();
     delete plan->engine;
     if (plan->stream) (void)hipStreamDestroy(plan->stream);
     delete plan;
@@ -162,6 +163,22 @@ int ssf_download_snapshots(ssf_plan *plan, void *snap_soa) {
         int rc = download_common(plan, (char *)snap_soa + (size_t)i * fb, i, false);
         if (rc) return rc;
     }
+    return SSF_OK;
+}
+
+int ssf_set_snapshot_sink(ssf_plan *plan, void *dst, int64_t ld, int32_t first_index) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    if (dst && (ld < plan->nrows || first_index < 0)) return fail(plan, SSF_ERR_BAD_ARG, "ssf_set_snapshot_sink: ld < nrows or negative index");
+    SSF_HIP(plan, hipSetDevice(plan->device));
+    SSF_HIP(plan, plan->sink.set(plan->device, dst, ld, first_index, plan->precision == SSF_C128 ? 16 : 8));
+    return SSF_OK;
+}
+
+int ssf_sync_snapshots(ssf_plan *plan) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    SSF_HIP(plan, hipSetDevice(plan->device));
+    SSF_HIP(plan, hipStreamSynchronize(plan->stream));        // device destinations: ordered on the plan's stream
+    SSF_HIP(plan, plan->sink.sync());
     return SSF_OK;
 }
 

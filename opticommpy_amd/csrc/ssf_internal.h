@@ -12,6 +12,7 @@
 #include "ssf.h"
 #include "ssf_copy.h"
 #include "ssf_derived.h"
+#include "ssf_snapshots.h"
 
 namespace ssf {
 
@@ -64,6 +65,7 @@ struct ssf_plan {
     std::string err;
     bool has_field = false;
     ssf::Stager stager;
+    ssf::SnapshotSink sink;      // destination of streamed snapshots (ssf_set_snapshot_sink), inactive by default
 };
 
 namespace ssf {

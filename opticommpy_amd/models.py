@@ -236,6 +236,29 @@ def _execute(pl, cp, Nspans, save, prgs, noise_fn, want_trace, max_steps_hint):
     return st
 
 
+def _open_sink(pl, on_dev, N, ncols, nblk, n_captured):
+    """Result array of a run with saveSpanN: (N, ncols * nblk), the captured spans streamed into their columns while
+    the following span propagates (ssf_set_snapshot_sink); spans that are never reached stay zero (channels.py:375-377)."""
+    shape = (N, ncols * nblk)
+    if on_dev:
+        out = _dev.empty(True, shape, pl.dtype)
+        if n_captured < nblk:
+            out.set(np.zeros(shape, dtype=pl.dtype))
+    else:
+        out = np.zeros(shape, dtype=pl.dtype) if n_captured < nblk else np.empty(shape, dtype=pl.dtype)
+    if n_captured:
+        pl.check(pl.lib.ssf_set_snapshot_sink(pl.h, _dev.out_ptr(out), ncols * nblk, 0))
+    return out
+
+
+def _close_sink(pl, n_captured):
+    if n_captured:
+        try:
+            pl.check(pl.lib.ssf_sync_snapshots(pl.h))
+        finally:
+            pl.lib.ssf_set_snapshot_sink(pl.h, None, 0, 0)
+
+
 def _fill_params(model, direction, param, Fs, Nspans, save_arr):
     cp = _lib.Params()
     cp.model, cp.direction = model, direction
@@ -305,24 +328,18 @@ def ssfm(Ei, param=None, _trace=False, _cpu_seed_policy=False):
 
     pl.check(pl.lib.ssf_upload(pl.h, in_ptr))
     nsteps = int(np.floor(param.Lspan / param.hz))
-    st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, nsteps + 1)
+    sink = _open_sink(pl, on_dev, N, 1, len(save_list), len(captured)) if save_list else None
+    try:
+        st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, nsteps + 1)
+    finally:
+        if sink is not None:
+            _close_sink(pl, len(captured))
 
-    if on_dev:                                          # device in -> device out (one field: last saved span / final)
-        if len(save_list) > 1:
-            raise NotImplementedError("device-resident ssfm returns one field: set param.saveSpanN to one span or []")
+    if save_list:                                       # device in -> device out, numpy in -> numpy out
+        out = sink.reshape(N) if len(save_list) == 1 else sink
+    elif on_dev:
         out = _dev.empty(True, (N,), pl.dtype)
-        if save_list and not st.n_snapshots:
-            out.set(np.zeros(N, dtype=pl.dtype))
-        else:
-            pl.check(pl.lib.ssf_download(pl.h, out.ptr) if not save_list else pl.lib.ssf_download_snapshots(pl.h, out.ptr))
-    elif save_list:
-        out = np.zeros((N, len(save_list)), dtype=pl.dtype)
-        if st.n_snapshots:
-            snaps = np.empty((st.n_snapshots, 1, N), dtype=pl.dtype)
-            pl.check(pl.lib.ssf_download_snapshots(pl.h, snaps.ctypes.data_as(C.c_void_p)))
-            out[:, : st.n_snapshots] = snaps[:, 0, :].T
-        if out.shape[1] == 1:
-            out = out.reshape(N)
+        pl.check(pl.lib.ssf_download(pl.h, out.ptr))
     else:
         res = np.empty((1, N), dtype=pl.dtype)
         pl.check(pl.lib.ssf_download(pl.h, res.ctypes.data_as(C.c_void_p)))
@@ -393,29 +410,20 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
         hint = 1 << 16
     else:
         hint = int(np.ceil(param.Lspan / param.hz)) + 1
-    st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, hint)
+    sink = _open_sink(pl, on_dev, N, ncols, len(save_list), len(captured)) if save_list else None
+    try:
+        st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, hint)
+    finally:
+        if sink is not None:
+            _close_sink(pl, len(captured))
     for _ in range(int(st.nonconverged_steps)):
         logg.warning(NONCONV_WARNING.format(param.maxIter))
 
-    if on_dev:                                          # device in -> device out
-        if len(save_list) > 1:
-            raise NotImplementedError("device-resident runs return one field: set param.saveSpanN to one span or []")
+    if save_list:                                       # (N, 2 len(saveSpanN)), on the device when the input was
+        out = sink
+    elif on_dev:
         out = _dev.empty(True, (N, ncols), pl.dtype)
-        if save_list and not st.n_snapshots:
-            out.set(np.zeros((N, ncols), dtype=pl.dtype))
-        else:
-            pl.check(pl.lib.ssf_download_aos(pl.h, 0 if save_list else -1, out.ptr))
-    elif save_list:
-        nblk = len(save_list)
-        if nblk == 1 and st.n_snapshots == 1:
-            out = np.empty((N, ncols), dtype=pl.dtype)
-            pl.check(pl.lib.ssf_download_aos(pl.h, 0, out.ctypes.data_as(C.c_void_p)))
-        else:
-            out = np.zeros((N, ncols * nblk), dtype=pl.dtype)
-            tmp = np.empty((N, ncols), dtype=pl.dtype)
-            for i in range(st.n_snapshots):
-                pl.check(pl.lib.ssf_download_aos(pl.h, i, tmp.ctypes.data_as(C.c_void_p)))
-                out[:, 2 * i: 2 * i + 2] = tmp
+        pl.check(pl.lib.ssf_download_aos(pl.h, -1, out.ptr))
     else:
         res = np.empty((N, ncols), dtype=pl.dtype)
         pl.check(pl.lib.ssf_download_aos(pl.h, -1, res.ctypes.data_as(C.c_void_p)))

@@ -157,6 +157,8 @@ struct EmuBackend {
         }
         run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
     }
+    bool sink_active() const { return false; }
+    template <typename C> void sink_capture(const C *, long long, int) {}
     void launch_repack(const ssf::fused::RepackArgs &a, int grid, int block) {
         ++launches;
         run_grid(std::min(grid, 8), block, 64, [&](EmuCtx &c) { ssf::fused::repack_body(c, a); });

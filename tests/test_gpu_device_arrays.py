@@ -46,8 +46,14 @@ def test_every_entry_point_matches_its_numpy_call():
     s = dict(Fs=512e9, Ltotal=4, Lspan=2, hz=0.5, amp=None, prgsBar=False)
     a = oa.ssfm(E[:, 0].copy(), bag(**s))
     assert np.array_equal(a, oa.ssfm(oa.to_device(E[:, 0].copy()), bag(**s)).get())
-    with pytest.raises(NotImplementedError):
-        oa.manakovSSF(oa.to_device(E), bag(saveSpanN=[1, 2], **ch))
+    # several snapshots: (N, 2 len(saveSpanN)) on the device as on the host, spans never reached stay zero
+    for save in ([1, 2], [2, 1, 7]):
+        a = oa.manakovSSF(E, bag(saveSpanN=save, **ch))
+        b = oa.manakovSSF(oa.to_device(E), bag(saveSpanN=save, **ch))
+        assert isinstance(b, oa.DeviceArray) and b.shape == (N, 2 * len(save)) and np.array_equal(a, b.get())
+    a = oa.ssfm(E[:, 0].copy(), bag(saveSpanN=[1, 2], **s))
+    b = oa.ssfm(oa.to_device(E[:, 0].copy()), bag(saveSpanN=[1, 2], **s))
+    assert a.shape == (N, 2) and np.array_equal(a, b.get())
     Elo = np.full(N, np.sqrt(5e-3), dtype=complex)
     fe, pd = bag(Fs=512e9, polRotation=0.3, timeSkewX=1e-13), bag(Fs=512e9, B=100e9, seed=3)
     a = oa.pdmCoherentReceiver(E, Elo, fe, pd)

@@ -59,9 +59,10 @@ def test_oracle_reproduces_the_reference_over_a_full_span():
     tr = {}
     out = orc.manakovSSF(_input(cfg), make_param(orc.parameters, _run_cfg(cfg)), trace=tr)
     assert tr["iters"] == list(d["iters"])
-    assert np.array_equal(np.concatenate([np.asarray(r, dtype=float) for r in tr["lims"]]), d["lims"])
+    # (the norms are BLAS nrm2 calls: their last bit depends on the BLAS thread count, the field does not)
+    np.testing.assert_allclose(np.concatenate([np.asarray(r, dtype=float) for r in tr["lims"]]), d["lims"], rtol=1e-12)
     assert np.array_equal(out[:: int(cfg["dec"])], d["out_dec"])
-    assert np.array_equal(projection(out), d["out_proj"])
+    np.testing.assert_allclose(projection(out), d["out_proj"], rtol=1e-12)          # (a BLAS product: see above)
 
 
 @pytest.mark.gpu

@@ -81,3 +81,28 @@ def test_packed_c64_pipeline_matches_the_unpacked_one_and_the_oracle(monkeypatch
         assert res["1"][1] == res["0"][1]
         assert rel_l2(res["1"][0], ref) <= 5e-5 and rel_l2(res["0"][0], ref) <= 5e-4
         assert rel_l2(res["1"][0], res["0"][0]) <= 5e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["complex128", "complex64"])
+def test_snapshots_are_streamed_into_the_result_array(prec):
+    """saveSpanN with several spans: every captured span goes straight to its columns of the (N, 2 len(saveSpanN))
+    result (host: a copy thread while the next span runs; device: in place) and equals the same run stopped there."""
+    N = 1 << 16
+    E = synth_field(N, 2, 17, 5.0, np.dtype(prec).type)
+    cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Lspan=2, hz=0.1,
+               nlprMethod=False, amp="ideal", prec=prec)
+    save = [1, 2, 3, 5]
+    full = oa.manakovSSF(E, make_param(oa.parameters, dict(cfg, Ltotal=10, saveSpanN=save)))
+    assert full.shape == (N, 8) and full.dtype == np.dtype(prec)
+    for i, sp in enumerate(save):
+        part = oa.manakovSSF(E, make_param(oa.parameters, dict(cfg, Ltotal=2 * sp, saveSpanN=[])))
+        assert np.array_equal(full[:, 2 * i:2 * i + 2], part), sp
+    dev = oa.manakovSSF(oa.to_device(E), make_param(oa.parameters, dict(cfg, Ltotal=10, saveSpanN=save)))
+    assert np.array_equal(dev.get(), full)
+    # with the per-span progress bar the library is called span by span: same result
+    bar = oa.manakovSSF(E, make_param(oa.parameters, dict(cfg, Ltotal=10, saveSpanN=save, prgsBar=True)))
+    assert np.array_equal(bar, full)
+    if prec == "complex128":
+        ref = orc.manakovSSF(E, make_param(orc.parameters, dict(cfg, Ltotal=10, saveSpanN=save)))
+        assert rel_l2(full, ref) <= 1e-10
