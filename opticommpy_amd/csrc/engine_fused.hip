@@ -350,7 +350,75 @@ template <typename T> class FusedEngine final : public Engine {
     void reset_times() { be.kt = ssf_kernel_times{}; }
 };
 
+template <typename T> class FusedConvImpl final : public FusedConv {
+    using Cc = cx<T>;
+    ssf_plan *pl;
+    HipBackend be;
+    FusedCore<T, HipBackend> core;
+    Cc *hk[2] = {nullptr, nullptr};
+    int64_t M;
+    std::string err_;
+
+  public:
+    FusedConvImpl(ssf_plan *p, int64_t M_, int nrows) : pl(p), be(p), core(be, M_, nrows, p->precision), M(M_) {}
+    ~FusedConvImpl() override {
+        for (Cc *h : hk)
+            if (h) (void)hipFree(h);
+    }
+    int init() {
+        if (core.N2mix) {
+            err_ = "convolution length must be a power of two";
+            return SSF_ERR_BAD_ARG;
+        }
+        int rc = core.init();
+        if (rc) err_ = core.err;
+        return rc;
+    }
+    std::string error() const override { return err_.empty() ? be.last_error() : err_; }
+    void *work() override { return core.T0; }
+    int set_kernel(int which, const void *b_host) override {
+        if (which < 0 || which > 1) return SSF_ERR_BAD_ARG;
+        if (!hk[which] && hipMalloc(&hk[which], sizeof(Cc) * (size_t)M) != hipSuccess) {
+            err_ = "out of memory (convolution kernel)";
+            return SSF_ERR_OOM;
+        }
+        be.memset(core.T0, 0, core.field_bytes);                       // the kernel goes into row 0, the other rows are idle
+        be.h2d(core.T0, b_host, sizeof(Cc) * (size_t)M);
+        core.launch_col_plain(CM_PLAIN_FWD, core.T0, (T)0);
+        core.launch_row_conv(nullptr, 1);                              // spectrum in the row kernel's own order -> G
+        be.d2d(hk[which], core.G, sizeof(Cc) * (size_t)M);
+        be.sync();
+        return be.ok() ? SSF_OK : SSF_ERR_HIP;
+    }
+    int run(int which) override {
+        core.launch_col_plain(CM_PLAIN_FWD, core.T0, (T)0);
+        core.launch_row_conv(hk[which], 0);
+        core.launch_col_plain(CM_PLAIN_INV, core.T0, (T)0);
+        return be.ok() ? SSF_OK : SSF_ERR_HIP;
+    }
+};
+
 }  // namespace
+
+FusedConv *make_fused_conv(ssf_plan *plan, int64_t M, int nrows) {
+    int rc;
+    FusedConv *c;
+    if (plan->precision == SSF_C128) {
+        auto *x = new FusedConvImpl<double>(plan, M, nrows);
+        rc = x->init();
+        c = x;
+    } else {
+        auto *x = new FusedConvImpl<float>(plan, M, nrows);
+        rc = x->init();
+        c = x;
+    }
+    if (rc != SSF_OK) {
+        plan->err = c->error();
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
 
 namespace {
 template <typename T>

@@ -1,8 +1,15 @@
-// engine_rocfft.hip -- general-length engine: rocFFT transforms + fused elementwise HIP
+// engine_rocfft.hip -- general-length engine: batched length-N transforms + fused elementwise HIP
 // kernels.  Handles every N (the reference accepts any length; typical notebooks use
 // N = SpS * Nsymbols, not a power of two).  Host drives the data-dependent control flow
 // (one 16-byte read-back per fixed-point iteration), so this engine is the generality /
 // cross-check path; the roofline engine is engine_fused.hip.
+//
+// Two transform providers:
+//   * Bluestein on the fused kernels (product path for the lengths the fused pipeline does not take natively: a prime
+//     factor above 5, too few factors of two, ...): X[k] = w[k] sum_n (x[n] w[n]) conj(w)[k - n], w[n] = exp(-j pi n^2 / N),
+//     i.e. one circular convolution of length M = 2^m >= 2N - 1 with a fixed kernel = FusedConv (engine_fused.hip):
+//     chirp-multiply + zero-pad, column FWD, row FFT . B . IFFT, column INV, chirp-multiply: five launches per transform;
+//   * rocFFT (SSF_ENGINE_ROCFFT on request): the independent on-GPU cross-check of all hand-written transforms.
 //
 // Reference semantics followed: optic/models/channels.py:215-238 (ssfm),
 // :380-456 (manakovSSF), optic/dsp/equalization.py:1087-1160 (manakovDBP).
@@ -207,6 +214,41 @@ __global__ void k_amp(typename Cx<T>::type *E, int64_t total, T gain, const type
     }
 }
 
+// Bluestein: wk[r][n] = in[r][n] * ch[n] (conj(ch) for the inverse) for n < N, zero up to M
+template <typename T>
+__global__ void k_blue_pre(const typename Cx<T>::type *in, typename Cx<T>::type *wk, const double2 *ch, int64_t N, int64_t M,
+                           int nrows, int inverse) {
+    const int64_t total = M * nrows;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / M, n = i - r * M;
+        typename Cx<T>::type o;
+        o.x = 0;
+        o.y = 0;
+        if (n < N) {
+            const auto e = in[r * N + n];
+            const double c = ch[n].x, sn = inverse ? -ch[n].y : ch[n].y;
+            o.x = (T)((double)e.x * c - (double)e.y * sn);
+            o.y = (T)((double)e.x * sn + (double)e.y * c);
+        }
+        wk[i] = o;
+    }
+}
+// out[r][k] = wk[r][k] * ch[k] (conj for the inverse), k < N
+template <typename T>
+__global__ void k_blue_post(const typename Cx<T>::type *wk, typename Cx<T>::type *out, const double2 *ch, int64_t N, int64_t M,
+                            int nrows, int inverse) {
+    const int64_t total = N * nrows;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / N, k = i - r * N;
+        const auto e = wk[r * M + k];
+        const double c = ch[k].x, sn = inverse ? -ch[k].y : ch[k].y;
+        typename Cx<T>::type o;
+        o.x = (T)((double)e.x * c - (double)e.y * sn);
+        o.y = (T)((double)e.x * sn + (double)e.y * c);
+        out[i] = o;
+    }
+}
+
 std::once_flag g_rocfft_once;
 
 template <typename T> class RocfftEngine final : public Engine {
@@ -219,23 +261,64 @@ template <typename T> class RocfftEngine final : public Engine {
     T *P = nullptr;
     double *part = nullptr;   // 3 * kMaxPartials partials + 4 results
     double *res_h = nullptr;  // pinned host, 4 doubles
-    rocfft_plan fwd = nullptr, inv = nullptr;
+    rocfft_plan fwd = nullptr, inv = nullptr;     // (the two plans double as the direction tags of fft())
     rocfft_execution_info info = nullptr;
     void *work = nullptr;
+    const bool blue;                              // transforms by Bluestein on the fused kernels instead of rocFFT
+    int64_t M = 0;
+    FusedConv *conv = nullptr;
+    double2 *chirp = nullptr;                     // exp(-j pi n^2 / N), n < N
     std::vector<C *> snaps;
     C *E = nullptr;           // current field (points at bufA or bufB)
     double lin_hz = NAN, lin_scale = NAN, lin_a = NAN, lin_b = NAN, lin_w = NAN;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
   public:
-    explicit RocfftEngine(ssf_plan *p) : pl(p), N(p->N), nrows(p->nrows) {
+    RocfftEngine(ssf_plan *p, bool bluestein) : pl(p), N(p->N), nrows(p->nrows), blue(bluestein) {
         row_bytes = sizeof(C) * (size_t)N;
         field_bytes = row_bytes * (size_t)nrows;
     }
-    int id() const override { return SSF_ENGINE_ROCFFT; }
+    // (with Bluestein every transform runs on the fused kernels: reported as the fused engine)
+    int id() const override { return blue ? SSF_ENGINE_FUSED : SSF_ENGINE_ROCFFT; }
+
+    static int64_t bluestein_length(int64_t n) {
+        int64_t m = 256;
+        while (m < 2 * n - 1) m *= 2;
+        return m;
+    }
+    int init_bluestein() {
+        M = bluestein_length(N);
+        conv = make_fused_conv(pl, M, nrows);
+        if (!conv) return pl->err.find("out of memory") != std::string::npos ? SSF_ERR_OOM : SSF_ERR_UNSUPPORTED;
+        // chirp with the exact quadratic residue: n^2 mod 2N in integers, angle = -pi r / N
+        std::vector<double2> ch((size_t)N);
+        for (int64_t n = 0; n < N; ++n) {
+            const int64_t r = (int64_t)(((unsigned __int128)n * (unsigned __int128)n) % (unsigned __int128)(2 * N));
+            const double a = -3.14159265358979323846 * ((double)r / (double)N);
+            ch[(size_t)n].x = std::cos(a);
+            ch[(size_t)n].y = std::sin(a);
+        }
+        SSF_HIP(pl, hipMalloc(&chirp, sizeof(double2) * (size_t)N));
+        SSF_HIP(pl, hipMemcpy(chirp, ch.data(), sizeof(double2) * (size_t)N, hipMemcpyHostToDevice));
+        // convolution kernels: forward b[m] = conj(w)[|m|] / M, inverse conj of it, |m| < N, wrapped into length M
+        std::vector<C> b((size_t)M);
+        for (int which = 0; which < 2; ++which) {
+            std::fill(b.begin(), b.end(), C{0, 0});
+            for (int64_t m = 0; m < N; ++m) {
+                C v;
+                v.x = (T)(ch[(size_t)m].x / (double)M);
+                v.y = (T)((which == 0 ? -ch[(size_t)m].y : ch[(size_t)m].y) / (double)M);
+                b[(size_t)m] = v;
+                if (m) b[(size_t)(M - m)] = v;
+            }
+            int rc = conv->set_kernel(which, b.data());
+            if (rc) return fail(pl, rc, "Bluestein kernel: " + conv->error());
+        }
+        return SSF_OK;
+    }
 
     int init() {
-        std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+        if (!blue) std::call_once(g_rocfft_once, [] { rocfft_setup(); });
         SSF_HIP(pl, hipMalloc(&bufA, field_bytes));
         SSF_HIP(pl, hipMalloc(&bufB, field_bytes));
         SSF_HIP(pl, hipMalloc(&Ehd, field_bytes));
@@ -246,6 +329,12 @@ template <typename T> class RocfftEngine final : public Engine {
         SSF_HIP(pl, hipHostMalloc(&res_h, 4 * sizeof(double)));
         SSF_HIP(pl, hipEventCreate(&ev0));
         SSF_HIP(pl, hipEventCreate(&ev1));
+        E = bufA;
+        if (blue) {
+            fwd = (rocfft_plan)(void *)this;             // direction tags only (never dereferenced)
+            inv = (rocfft_plan)(void *)&M;
+            return init_bluestein();
+        }
         const size_t len = (size_t)N;
         const rocfft_precision pr = sizeof(T) == 8 ? rocfft_precision_double : rocfft_precision_single;
         if (rocfft_plan_create(&fwd, rocfft_placement_notinplace, rocfft_transform_type_complex_forward, pr, 1, &len,
@@ -269,9 +358,11 @@ template <typename T> class RocfftEngine final : public Engine {
     }
 
     ~RocfftEngine() override {
-        if (fwd) rocfft_plan_destroy(fwd);
-        if (inv) rocfft_plan_destroy(inv);
+        if (fwd && !blue) rocfft_plan_destroy(fwd);
+        if (inv && !blue) rocfft_plan_destroy(inv);
         if (info) rocfft_execution_info_destroy(info);
+        delete conv;
+        if (chirp) (void)hipFree(chirp);
         for (void *p : {(void *)bufA, (void *)bufB, (void *)Ehd, (void *)F, (void *)lin, (void *)P, (void *)part,
                         (void *)work, (void *)noise_d})
             if (p) (void)hipFree(p);
@@ -308,6 +399,14 @@ template <typename T> class RocfftEngine final : public Engine {
 
   private:
     int fft(rocfft_plan p, C *in, C *out) {
+        if (blue) {
+            const int inverse = p == inv ? 1 : 0;
+            C *wk = (C *)conv->work();
+            k_blue_pre<T><<<grid_for(M * nrows), kBlock, 0, pl->stream>>>(in, wk, chirp, N, M, nrows, inverse);
+            if (int rc = conv->run(inverse)) return fail(pl, rc, "Bluestein convolution: " + conv->error());
+            k_blue_post<T><<<grid_for(N * nrows), kBlock, 0, pl->stream>>>(wk, out, chirp, N, M, nrows, inverse);
+            return SSF_OK;
+        }
         void *ib[1] = {in}, *ob[1] = {out};
         if (rocfft_execute(p, ib, ob, info) != rocfft_status_success) return fail(pl, SSF_ERR_FFT, "rocfft_execute failed");
         return SSF_OK;
@@ -485,15 +584,15 @@ template <typename T> class RocfftEngine final : public Engine {
 
 }  // namespace
 
-Engine *make_rocfft_engine(ssf_plan *plan) {
+static Engine *make_general(ssf_plan *plan, bool bluestein) {
     int rc;
     Engine *e;
     if (plan->precision == SSF_C128) {
-        auto *x = new RocfftEngine<double>(plan);
+        auto *x = new RocfftEngine<double>(plan, bluestein);
         rc = x->init();
         e = x;
     } else {
-        auto *x = new RocfftEngine<float>(plan);
+        auto *x = new RocfftEngine<float>(plan, bluestein);
         rc = x->init();
         e = x;
     }
@@ -502,6 +601,15 @@ Engine *make_rocfft_engine(ssf_plan *plan) {
         return nullptr;
     }
     return e;
+}
+Engine *make_rocfft_engine(ssf_plan *plan) { return make_general(plan, false); }
+Engine *make_general_engine(ssf_plan *plan) { return make_general(plan, true); }
+
+bool general_supports(int64_t N, int nrows, int precision) {
+    if (N < 2 || nrows < 1) return false;
+    int64_t m = 256;
+    while (m < 2 * N - 1) m *= 2;
+    return fused_supports(m, nrows, precision);
 }
 
 }  // namespace ssf

@@ -324,6 +324,15 @@ template <typename T, class Backend> class FusedCore {
         a.lin = lin;
         be.launch_row(a, row_grid, row_block, row_lds);
     }
+    // fixed-kernel convolution (FusedConv): forward-only row stage / multiplier-array row stage
+    void launch_row_conv(const C *harr, int fwd_only) {
+        RowArgs<T> a = row_args();
+        a.use_ctrl = 0;
+        a.lin = nullptr;
+        a.harr = harr;
+        a.fwd_only = fwd_only;
+        be.launch_row(a, row_grid, row_block, row_lds);
+    }
     void launch_col_plain(int mode, C *timebuf, S g_hz) {
         if constexpr (kPacked) return;
         ColArgs<T> a = col_args(1, mode);

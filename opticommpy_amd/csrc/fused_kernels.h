@@ -426,6 +426,10 @@ template <typename T> struct RowArgs {
     MixPlan plan;             // its pass plan
     const cx<double> *wtab;   // cis(-2 pi k / N2), k < N2
     int rows_per_wg;          // rows a workgroup handles side by side (nthreads / rows_per_wg threads each)
+    // convolution with a fixed kernel (Bluestein transforms of the general-length path, conv_engine): the multiplier is
+    // an array in the row kernel's own spectrum order, [k1][position after the forward passes], the same for every field row
+    const cx<T> *harr;        // use_ctrl == 0 and lin == nullptr: spectrum *= harr[(rr mod N1) * N2 + position]
+    int fwd_only;             // 1: stop after the forward row transform and store the spectrum in that order (makes harr)
 };
 
 // linear operator for the 16 registers of a last-radix-16 butterfly: bins k0 + (N/16) q
@@ -701,7 +705,7 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     if (a.use_ctrl) {
         ctx.issue_fence();
         if (!row_ctrl(ctx, a, part, lo)) return;
-    } else {
+    } else if (a.lin) {
         lo = *a.lin;
     }
     const int N1 = 1 << a.log2N1, log2N = a.log2N1 + a.log2N2;
@@ -712,7 +716,16 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     ctx.mark(2);
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
     const int last = p.npass - 1;
-    if (p.lg(last) == 4) {
+    if (!a.use_ctrl && !a.lin) {                 // fixed-kernel convolution: multiplier array in this kernel's spectrum order
+        if (a.fwd_only) {
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) g[reg_pos(p, last, b, idx)] = v[idx];
+            return;
+        }
+        const cx<T> *h = a.harr + ((size_t)k1 << a.log2N2);
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * h[reg_pos(p, last, b, idx)];
+    } else if (p.lg(last) == 4) {
         const long long k0 = k1 + ((long long)rev_pos(p, reg_pos(p, last, b, 0)) << a.log2N1);
         apply_lin16(lo, k0, log2N, v);
     } else {

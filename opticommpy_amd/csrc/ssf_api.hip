@@ -82,14 +82,18 @@ int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int
         return set_err(SSF_ERR_HIP, "hipStreamCreate failed");
     }
     (void)pl->stager.init();          // falls back to plain copies if pinned memory is unavailable
+    // SSF_ENGINE_FUSED / AUTO: the fused pipeline when it takes N natively, otherwise the general-length engine with its
+    // transforms built from the fused kernels (Bluestein); rocFFT only on request (the on-GPU cross-check) or, under AUTO,
+    // for lengths beyond the Bluestein range (2N - 1 > 2^22 complex128 / 2^23 complex64)
+    const bool native = fused_supports(N, nrows, precision), general = !native && general_supports(N, nrows, precision);
     int want = engine;
-    if (want == SSF_ENGINE_AUTO) want = fused_supports(N, nrows, precision) ? SSF_ENGINE_FUSED : SSF_ENGINE_ROCFFT;
-    if (want == SSF_ENGINE_FUSED && !fused_supports(N, nrows, precision)) {
+    if (want == SSF_ENGINE_AUTO) want = (native || general) ? SSF_ENGINE_FUSED : SSF_ENGINE_ROCFFT;
+    if (want == SSF_ENGINE_FUSED && !native && !general) {
         (void)hipStreamDestroy(pl->stream);
         delete pl;
-        return set_err(SSF_ERR_UNSUPPORTED, "fused engine needs N = 2^m within its supported range");
+        return set_err(SSF_ERR_UNSUPPORTED, "fused engine: N beyond the range of its transforms (use SSF_ENGINE_ROCFFT)");
     }
-    pl->engine = want == SSF_ENGINE_FUSED ? make_fused_engine(pl) : make_rocfft_engine(pl);
+    pl->engine = want == SSF_ENGINE_ROCFFT ? make_rocfft_engine(pl) : native ? make_fused_engine(pl) : make_general_engine(pl);
     if (!pl->engine) {
         const int code = pl->err.find("out of memory") != std::string::npos ? SSF_ERR_OOM : SSF_ERR_HIP;
         set_err(code, pl->err.empty() ? "engine creation failed" : pl->err);

@@ -78,6 +78,22 @@ bool fused_supports(int64_t N, int nrows, int precision);
 int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int log2nfft, int K, const void *Hfft,
                         const void *in, void *out, std::string *err);
 
+// Circular convolution of every row of an (nrows, M) block with one of two fixed kernels, M = 2^m, on the fused kernels
+// (column FWD, row FFT . multiplier-array . IFFT, column INV: three launches on the plan's stream).  The general-length
+// engine builds its length-N transforms from it (Bluestein): any N the reference accepts runs on the hand-written kernels.
+class FusedConv {
+  public:
+    virtual ~FusedConv() {}
+    virtual void *work() = 0;                                        // the (nrows, M) block, convolved in place
+    virtual int set_kernel(int which, const void *b_host) = 0;       // M complex values (already scaled by 1 / M)
+    virtual int run(int which) = 0;
+    virtual std::string error() const = 0;
+};
+FusedConv *make_fused_conv(ssf_plan *plan, int64_t M, int nrows);
+// general-length engine with its transforms on the fused kernels (Bluestein) instead of rocFFT; nullptr if N is out of range
+Engine *make_general_engine(ssf_plan *plan);
+bool general_supports(int64_t N, int nrows, int precision);
+
 // receiver front-end (engine_rx.hip)
 int rx_run(int device, int mode, int64_t N, int nmodes, const ssf_rx_params *p, const void *in0, const void *lo,
            const double *un, void *out, std::string *err);

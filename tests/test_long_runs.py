@@ -38,7 +38,7 @@ def _run_cfg(cfg):
 def _check(d, cfg, out, iters, lims, tol=1e-10):
     assert list(iters) == list(d["iters"])                                   # every step, crossovers included
     flat = np.concatenate([np.asarray(r, dtype=float) for r in lims]) if len(lims) and np.ndim(lims[0]) else np.asarray(lims)
-    np.testing.assert_allclose(flat, d["lims"], rtol=1e-6)
+    np.testing.assert_allclose(flat, d["lims"], rtol=1e-6, atol=1e-15)       # (atol: the last, rounding-sized step's lim is ~4e-12)
     dec = int(cfg["dec"])
     assert rel_l2(out[::dec], d["out_dec"]) <= tol
     np.testing.assert_allclose(np.sum(np.abs(out) ** 2, axis=0), d["out_power"], rtol=1e-9)

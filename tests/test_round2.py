@@ -106,3 +106,34 @@ def test_snapshots_are_streamed_into_the_result_array(prec):
     if prec == "complex128":
         ref = orc.manakovSSF(E, make_param(orc.parameters, dict(cfg, Ltotal=10, saveSpanN=save)))
         assert rel_l2(full, ref) <= 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,prec", [(97, "complex128"), (1500, "complex128"), (3000, "complex128"), (12000, "complex128"),
+                                    (2 * 3 * 7 * 11 * 13, "complex128"), (10007, "complex64"), (31, "complex128")])
+def test_any_length_runs_on_the_fused_kernels(N, prec):
+    """Lengths the fused pipeline does not take natively (a prime factor above 5, fewer than seven factors of two, tiny
+    N) run on the general-length engine with Bluestein transforms built from the fused kernels: engine='fused' accepts
+    every N the reference accepts, rocFFT is only the cross-check.  Same gates as everywhere: 1e-10 / identical iteration
+    counts in double precision, 5e-4 in single."""
+    from opticommpy_amd import models
+    E = synth_field(N, 2, 3 + N % 7, 8.4, np.dtype(prec).type)
+    cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=4, Lspan=2, hz=0.1,
+               nlprMethod=False, amp="ideal", saveSpanN=[], prec=prec)
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+    oa.set_engine("fused")
+    try:
+        out = oa.manakovSSF(E, make_param(oa.parameters, cfg), _trace=True)
+        run = dict(models.last_run)
+        s1 = oa.ssfm(E[:, 0].copy(), make_param(oa.parameters, dict(cfg, hz=0.5)))
+        back = oa.manakovDBP(out, make_param(oa.parameters, cfg))
+    finally:
+        oa.set_engine("auto")
+    assert run["engine"] == "fused"
+    c64 = prec == "complex64"
+    assert rel_l2(out, ref) <= (5e-4 if c64 else 1e-10)
+    if not c64:
+        assert list(run["iters"]) == tr["iters"]
+    assert rel_l2(s1, orc.ssfm(E[:, 0].copy(), make_param(orc.parameters, dict(cfg, hz=0.5)))) <= (5e-4 if c64 else 1e-10)
+    assert rel_l2(back, orc.manakovDBP(ref, make_param(orc.parameters, cfg))) <= (1e-3 if c64 else 1e-9)
