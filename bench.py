@@ -144,6 +144,9 @@ def main():
     if "SSF_BENCH_DEVICE" in os.environ:                       # (test knob: several ranks against one GPU)
         local_rank = int(os.environ["SSF_BENCH_DEVICE"])
 
+    if rank > 0:                                               # only rank 0 reports: nothing of the other ranks (RCCL's
+        devnull = os.open(os.devnull, os.O_WRONLY)             # version banner comes through C stdio at exit) may follow
+        os.dup2(devnull, 1)                                    # rank 0's JSON line on the launcher's merged stdout
     from opticommpy_amd import _lib, mgpu
     lib = _lib.load()
     if lib.ssf_device_count() <= 0:

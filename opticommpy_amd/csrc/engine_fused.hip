@@ -93,6 +93,76 @@ template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT) k_ols(co
     ols_body<T>(ctx, a);
 }
 
+// ---- persistent span kernel (scalar NLSE): every stage of a span in ONE launch ----------------------------------------
+// For small N a launch is one latency chain (dispatch -> loads -> transform -> stores -> end-of-kernel write-back),
+// ~10 us whatever the size, and a span is 2 * nsteps + 1 of them.  Here the stages run inside one launch of <= 256
+// co-resident workgroups (one per CU at most) with a grid barrier in between: arrival counter + generation word,
+// agent-scope release before / acquire after (the L2s of the eight XCDs are not coherent with each other, so the stage's
+// output is written back and the readers' lines invalidated), bounded spin (a barrier that cannot complete sets the abort
+// word and the host reports it instead of hanging).  The stage bodies are the ones of the per-stage kernels, called with
+// virtual workgroup numbers.  Reference loop: optic/models/channels.py:215-232.
+__device__ __forceinline__ bool grid_sync(unsigned *bar, unsigned nwg) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                          // release: this workgroup's stores, device-wide
+        const unsigned g = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned spins = 0;
+            while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == g) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24) || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __threadfence();
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // every wave: no stale L1 / L2 lines of the previous stage
+    return __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+template <typename T, int LGR, int LGC> __global__ void __launch_bounds__(256) k_nlse_span(const SpanNlseArgs<T> a) {
+    SSF_DEV_CTX(0);
+    const int me = (int)blockIdx.x, nwg = (int)gridDim.x;
+    auto col_stage = [&](int mode) {
+        for (int vb = me; vb < a.col_grid; vb += nwg) {
+            ctx.bid = vb;
+            if (mode == CM_NLSE_FIRST) col_body<T, LGC, CM_NLSE_FIRST, false>(ctx, a.col);
+            else if (mode == CM_NLSE_STEP) col_body<T, LGC, CM_NLSE_STEP, false>(ctx, a.col);
+            else col_body<T, LGC, CM_NLSE_LAST, false>(ctx, a.col);
+            __syncthreads();
+        }
+    };
+    auto row_stage = [&](const LinOp *lin) {
+        RowArgs<T> ra = a.row;
+        ra.lin = lin;
+        for (int vb = me; vb < a.row_grid; vb += nwg) {
+            ctx.bid = vb;
+            row_body<T, LGR>(ctx, ra);
+            __syncthreads();
+        }
+    };
+    col_stage(CM_NLSE_FIRST);                                     // channels.py:216
+    if (!grid_sync(a.bar, nwg)) return;
+    row_stage(a.lin_half);
+    if (!grid_sync(a.bar, nwg)) return;
+    for (int s = 1; s < a.nsteps; ++s) {
+        col_stage(CM_NLSE_STEP);
+        if (!grid_sync(a.bar, nwg)) return;
+        row_stage(a.lin_full);                                    // lin * lin: second half of one step, first half of the next
+        if (!grid_sync(a.bar, nwg)) return;
+    }
+    col_stage(CM_NLSE_STEP);
+    if (!grid_sync(a.bar, nwg)) return;
+    row_stage(a.lin_half);
+    if (!grid_sync(a.bar, nwg)) return;
+    col_stage(CM_NLSE_LAST);                                      // channels.py:232
+}
+
 template <typename T> using RowFn = void (*)(const RowArgs<T>);
 template <typename T> using ColFn = void (*)(const ColArgs<T>);
 
@@ -299,6 +369,34 @@ struct HipBackend {
         chk(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         armed.push_back(f);
+    }
+    // persistent span kernel: grid <= CUs (every workgroup resident), 256 threads, any supported power-of-two split.
+    // OFF by default: measured slower than one launch per stage at every size (MI355X, ssfm, steps/s, launches vs
+    // persistent: 2^12 41.1k / 31.6k, 2^14 43.6k / 28.7k, 2^16 51.2k / 49.0k, 2^18 49.6k / 25.6k, 2^20 33.1k / 7.6k;
+    // gpurun_out/r2e) -- an agent-scope release + acquire around a grid barrier costs more than the 1.5-2 us of a kernel
+    // boundary (the micro-architecture guide's price list says the same: 4-7 us per barrier), and a stage's ~10 us is one
+    // wave's ~2000 dependent FP64 instructions, not launch overhead.  SSF_PERSIST=<largest grid> turns it on.
+    static constexpr bool kCanPersist = true;
+    int persist_limit() {
+        if (const char *e = getenv("SSF_PERSIST")) return atoi(e);
+        return 0;
+    }
+    template <typename T> int launch_nlse_span(const SpanNlseArgs<T> &a, int grid, size_t lds) {
+        void (*f)(const SpanNlseArgs<T>);
+        if constexpr (std::is_same<T, pf2>::value) return SSF_ERR_UNSUPPORTED;
+        else {
+            if (a.row.log2N2 == 8 && a.col.log2N1 == 8) f = k_nlse_span<T, 8, 8>;
+            else if (a.row.log2N2 == 10 && a.col.log2N1 == 8) f = k_nlse_span<T, 10, 8>;
+            else if (a.row.log2N2 == 12 && a.col.log2N1 == 8) f = k_nlse_span<T, 12, 8>;
+            else f = k_nlse_span<T, 0, 0>;
+            arm((const void *)f);
+            chk(hipMemsetAsync(a.bar, 0, 3 * sizeof(unsigned), pl->stream), "hipMemsetAsync(barrier)");
+            stamp_begin(3);
+            f<<<grid, 256, lds, pl->stream>>>(a);
+            stamp_end();
+            chk(hipGetLastError(), "launch k_nlse_span");
+            return ok() ? SSF_OK : SSF_ERR_HIP;
+        }
     }
     bool sink_active() const { return pl->sink.active(); }
     template <typename C> void sink_capture(const C *soa, long long N, int nrows) {

@@ -122,6 +122,7 @@ template <typename T, class Backend> class FusedCore {
     bool lim0_bound = true;       // SSF_LIM0_BOUND=0: always evaluate lim_0 on all samples (A/B runs)
     Ctrl *ctrl = nullptr;        // [2]
     LinOp *linops = nullptr;     // [2]
+    unsigned *gbar = nullptr;    // persistent span kernel: arrivals, generation, abort
     double *part = nullptr;      // 3 * npart_max
     double *tr_hz = nullptr, *tr_lim = nullptr;
     int *tr_it = nullptr;
@@ -220,6 +221,7 @@ template <typename T, class Backend> class FusedCore {
         if (kPacked && mk_buffers()) return SSF_ERR_OOM;      // (the other cores allocate them when a Manakov run needs them)
         if (!(ctrl = (Ctrl *)be.alloc(2 * sizeof(Ctrl)))) return oom();
         if (!(linops = (LinOp *)be.alloc(2 * sizeof(LinOp)))) return oom();
+        if (!(gbar = (unsigned *)be.alloc(4 * sizeof(unsigned)))) return oom();
         if (!(part = (double *)be.alloc(sizeof(double) * 5 * (size_t)npart_max))) return oom();
         if (N2mix) {
             if (!(wtab = (cx<double> *)be.alloc(sizeof(cx<double>) * (size_t)N2mix))) return oom();
@@ -248,7 +250,7 @@ template <typename T, class Backend> class FusedCore {
     }
     ~FusedCore() {
         if (!own_G) G = nullptr;
-        for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)Theta, (void *)ctrl, (void *)linops,
+        for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)Theta, (void *)ctrl, (void *)linops, (void *)gbar,
                         (void *)part, (void *)wtab, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
             if (p) be.free(p);
         for (C *s : snaps) be.free(s);
@@ -399,9 +401,47 @@ template <typename T, class Backend> class FusedCore {
         lo[0] = make_linop(p.hz / 2, d.lin_a, d.lin_b, w2, 1.0 / (double)N, log2N);
         lo[1] = make_linop(p.hz, d.lin_a, d.lin_b, w2, 1.0 / (double)N, log2N);     // lin * lin
         be.h2d(linops, lo, sizeof(lo));
+        // small N: the whole span in one persistent launch (engine_fused.hip: k_nlse_span) when both stage grids fit the
+        // CUs with 256-thread workgroups
+        int pgrid = 0, prow = 0, pcol = 0;
+        size_t plds = 0;
+        if constexpr (Backend::kCanPersist && !kPacked) {
+            const int tpf1 = (1 << sp.l1) / 16, tpf2 = (1 << sp.l2) / 16, lim = be.persist_limit();
+            if (!N2mix && tpf1 <= 256 && tpf2 <= 256 && nsteps >= 1) {
+                const int fpw = 256 / tpf2, Cc = 256 / tpf1;
+                const int64_t nfft = (int64_t)nrows << sp.l1;
+                if (nfft % fpw == 0 && (1 << sp.l2) % Cc == 0) {
+                    prow = (int)(nfft / fpw);
+                    pcol = nrows * ((1 << sp.l2) / Cc);
+                    if (std::max(prow, pcol) <= lim) {
+                        pgrid = std::max(prow, pcol);
+                        plds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2), (size_t)Cc * lds_slots_per_fft(1 << sp.l1)) * sizeof(C);
+                        plds = std::max(plds, (size_t)256 * 16 + 2048);
+                    }
+                }
+            }
+        }
         for (int span = s0; span <= s1; ++span) {
             C *E = Tcur();
-            if (nsteps >= 1) {
+            if (pgrid > 0) {
+                if constexpr (Backend::kCanPersist && !kPacked) {
+                    SpanNlseArgs<T> a{};
+                    a.row = row_args();
+                    a.row.use_ctrl = 0;
+                    a.col = col_args(1, CM_NLSE_STEP);
+                    a.col.T0 = E;
+                    a.col.g_hz = (S)(p.gamma * p.hz);
+                    a.col.npart = pcol;
+                    a.lin_half = linops + 0;
+                    a.lin_full = linops + 1;
+                    a.nsteps = nsteps;
+                    a.row_grid = prow;
+                    a.col_grid = pcol;
+                    a.bar = gbar;
+                    int rc = be.launch_nlse_span(a, pgrid, plds);
+                    if (rc) return hiperr();
+                }
+            } else if (nsteps >= 1) {
                 launch_col_plain(CM_NLSE_FIRST, E, (S)0);                              // channels.py:216
                 launch_row_lin(linops + 0);
                 for (int s = 1; s < nsteps; ++s) {
@@ -419,6 +459,14 @@ template <typename T, class Backend> class FusedCore {
             st->transforms += (int64_t)nrows * (2 * (int64_t)nsteps + 2);
         }
         be.sync();
+        if (pgrid > 0) {                                               // a barrier that could not complete set the abort word
+            unsigned flags[3] = {0, 0, 0};
+            be.d2h(flags, gbar, sizeof(flags));
+            if (flags[2]) {
+                err = "persistent span kernel: grid barrier timed out (workgroups not co-resident?)";
+                return SSF_ERR_STATE;
+            }
+        }
         return be.ok() ? SSF_OK : hiperr();
     }
 

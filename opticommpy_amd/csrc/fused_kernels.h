@@ -1430,6 +1430,15 @@ template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2
     }
 }
 
+// arguments of the persistent span kernel (engine_fused.hip: k_nlse_span): every stage of a scalar-NLSE span in one launch
+template <typename T> struct SpanNlseArgs {
+    RowArgs<T> row;
+    ColArgs<T> col;
+    const LinOp *lin_half, *lin_full;
+    int nsteps, row_grid, col_grid;
+    unsigned *bar;            // [0] arrivals, [1] generation, [2] abort
+};
+
 // --------------------------------------------------------------------- elementwise helpers
 template <typename T> struct AmpArgs {
     cx<T> *E;

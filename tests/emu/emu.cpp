@@ -157,6 +157,7 @@ struct EmuBackend {
         }
         run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
     }
+    static constexpr bool kCanPersist = false;         // (no grid barrier between the emulator's sequential workgroups)
     bool sink_active() const { return false; }
     template <typename C> void sink_capture(const C *, long long, int) {}
     void launch_repack(const ssf::fused::RepackArgs &a, int grid, int block) {
