@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- SSFM steps/s on MI355X for BASELINE.json's configurations.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config auto|1|2|3|4|5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4|5]
 
 One "step" = one pass of `while z_current < Lspan` (reference optic/models/channels.py:387; the inner `for` of
 ssfm, :219).  The timed region runs EXACTLY K steps per unit with every input already resident in HBM (uploads
 before, downloads after), bracketed by a barrier on both sides; the time is the MAX over ranks.
 
-  config 2 (default at N = 1, BASELINE's headline): manakovSSF, 2-pol, N = 2^20 complex128, hz 0.08, 8.4 dBm, seed 2
+  config 2 (default, BASELINE's headline; at N > 1 one independent field per GPU, seeds 2, 3, ...: weak scaling):
+            manakovSSF, 2-pol, N = 2^20 complex128, hz 0.08, 8.4 dBm
   config 1: ssfm, N = 2^16 complex128, hz 0.5, 0 dBm, seed 1
   config 3: manakovSSF, N = 2^22 complex64 (+ prec complex64), hz 0.08, 8.4 dBm, seed 3
-  config 4 (default at N > 1): 16 independent config-2 units, seeds 100..115, launch powers 8.4 + arange(-8, 0, 0.5) dB,
-            split in contiguous blocks over the ranks (16 / 8 / 4 / 2 units per GPU): strong scaling
+  config 4: 16 independent config-2 units, seeds 100..115, launch powers 8.4 + arange(-8, 0, 0.5) dB, split in
+            contiguous blocks over the ranks (16 / 8 / 4 / 2 units per GPU): strong scaling (--config 4 or
+            SSF_BENCH_CONFIG=4; not the default because the driver's scaling curve needs the N = 1 workload at every N)
   config 5: 8 units (seeds 200..207): forward config-2 leg, then manakovDBP over the same span chained on the
             device (--dbp-hz, default 0.08 km: the bandwidth-relevant setting; the notebook's is 10 km)
 
@@ -127,7 +129,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default="auto", help="auto (2 at one GPU, 4 at several) | 1 | 2 | 3 | 4 | 5")
+    ap.add_argument("--config", default=os.environ.get("SSF_BENCH_CONFIG", "2"), help="1 | 2 (default) | 3 | 4 | 5")
     ap.add_argument("--log2n", type=int, default=0, help="experiments: override the configuration's length")
     ap.add_argument("--prec", default="", choices=["", "c128", "c64"], help="experiments: override the precision")
     ap.add_argument("--dbp-hz", type=float, default=0.08)
@@ -163,7 +165,7 @@ def main():
             comm = GlooComm()
             comm_name = "torch.distributed gloo stand-in (RCCL binding failed: %s)" % e
 
-    cfg = (2 if world == 1 else 4) if args.config == "auto" else int(args.config)
+    cfg = int(args.config)
     w = workload(cfg, args.log2n, args.prec, world)
     w = mgpu.bcast_object(comm, w, 0)                           # "broadcast of the parameter block"
     N = 1 << w["log2n"]

@@ -140,9 +140,10 @@ def test_any_length_runs_on_the_fused_kernels(N, prec):
 
 
 @pytest.mark.gpu
-def test_persistent_span_kernel_is_bit_identical_to_the_launch_sequence(monkeypatch):
+def test_persistent_span_kernel_matches_the_launch_sequence(monkeypatch):
     """ssfm with every stage of a span in one persistent launch (grid barrier between stages; off by default because it
-    measured slower, SSF_PERSIST=<grid> turns it on): same kernels bodies, same results to the bit."""
+    measured slower, SSF_PERSIST=<grid> turns it on): same kernel bodies (other tile widths, so rounding-level
+    differences only)."""
     from opticommpy_amd import models
     E = synth_field(1 << 16, 1, 1, 0.0).reshape(-1) * np.sqrt(2)
     cfg = dict(Fs=512e9, Ltotal=100, Lspan=50, hz=0.5, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, amp="ideal", prgsBar=False, saveSpanN=[])
@@ -153,5 +154,5 @@ def test_persistent_span_kernel_is_bit_identical_to_the_launch_sequence(monkeypa
         out[mode] = oa.ssfm(E, make_param(oa.parameters, cfg))
     monkeypatch.delenv("SSF_PERSIST")
     models.release_plans()
-    assert np.array_equal(out["0"], out["256"])
+    assert rel_l2(out["256"], out["0"]) <= 1e-12
     assert rel_l2(out["256"], orc.ssfm(E, make_param(orc.parameters, cfg))) <= 1e-10
