@@ -111,7 +111,7 @@ SSF_HD double pick_hz(const MkConst &k, double z, double maxphi) {
 }
 
 // ------------------------------------------------------------------------ thread-level FFT
-// Single precision, packed pair: apply unit factors (twiddles, operator) as hi + lo float pairs.  A factor rounded to
+// Single precision (one row per polarisation and packed pairs): apply unit factors (twiddles, operator) as hi + lo float pairs.  A factor rounded to
 // one float is off by up to 3e-8 in magnitude and phase, and it is the SAME error at every step (the twiddle of a given
 // butterfly never changes), so over 10^4 steps the errors add up coherently: -1.2e-7 of power per step and a spectral
 // ripple of 1e-3 after BASELINE config 3's 10 010 steps (the reference's own complex64 path, pocketfft with float
@@ -123,9 +123,9 @@ SSF_HD double pick_hz(const MkConst &k, double z, double maxphi) {
 // v * h for a factor given in double precision
 template <typename T> SSF_HD cx<T> mul_by_d(cx<T> v, cx<double> h) {
     using S = scalar_t<T>;
-    if constexpr (sizeof(T) == sizeof(S)) {
+    if constexpr (sizeof(S) == 8) {
         return v * mk<T>((T)h.re, (T)h.im);
-    } else if constexpr (SSF_C64_HILO) {
+    } else if constexpr (SSF_C64_HILO) {                                    // float and packed float pairs alike
         const S hr = (S)h.re, hi = (S)h.im;
         const S lr = (S)(h.re - (double)hr), li = (S)(h.im - (double)hi);
         const T cr = fma_s<T>(v.re, lr, -(v.im * splat<T>(li)));            // v.re lr - v.im li
@@ -135,6 +135,8 @@ template <typename T> SSF_HD cx<T> mul_by_d(cx<T> v, cx<double> h) {
         return tmul(v, mk<S>((S)h.re, (S)h.im));
     }
 }
+// (the mixed-radix rows of mixed_fft.h -- lengths 2^a 3^b 5^c -- still round their factors and butterfly constants to
+//  one float: complex64 at those lengths behaves like the reference's own complex64 path)
 
 // w[s] = cis(sign * 2 pi j s / 2^lgL), s = 0..R-1.  The power tree always runs in double and is
 // rounded once, where it is applied: in single precision a float tree gives every twiddle a magnitude error
