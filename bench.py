@@ -157,6 +157,8 @@ def main():
     comm, comm_name = None, "none (single process)"
     if world > 1 or os.environ.get("SSF_BENCH_FORCE_COMM"):    # (the env var exercises the RCCL path on one GPU)
         try:
+            if os.environ.get("SSF_BENCH_COMM") == "gloo":      # (test knob: the control flow of N ranks on one GPU)
+                raise RuntimeError("SSF_BENCH_COMM=gloo")
             comm = mgpu.RcclComm.from_env(device=local_rank)
             comm_name = "RCCL via libssf_hip.so (ssf_comm_*)"
         except Exception as e:                                  # safety net for the scaling run only: never silent
