@@ -552,22 +552,29 @@ template <typename T, class Backend> class FusedCore {
         be.h2d(ctrl + (seq & 1), &c, sizeof(Ctrl));
         launch_mk_col(k, CM_MK);                                                       // first step start
         int guard = 0;
+        long long prev_steps = 0, prev_iters = 0;
         for (;;) {
-            // estimate the [Row, Col] pairs still needed for this span
+            // [Row, Col] pairs still needed for this span: (1 + nIter) per step.  A surplus pair is a no-op launch
+            // (~10 us); a chunk that ends short of the span costs a synchronising read and an idle stream (~100-150 us),
+            // so the estimate is rounded up, not down: fixed step = remaining steps x (1 + recent iterations per step)
+            // + a few pairs (the 20-step driver run needed three rounds with the old 0.95 x estimate: -10 % steps/s)
             double steps_rem;
             if (c.steps == 0 && c.state == ST_NEED_S)
                 steps_rem = p.nlprMethod ? 8.0 : std::ceil(p.Lspan / p.hz);
             else
                 steps_rem = std::max(1.0, std::ceil((p.Lspan - c.z) / (c.hz > 0 ? c.hz : p.hz)));
-            double est = steps_rem * (1.0 + sr.avg_it) * (p.nlprMethod ? 0.6 : 0.95);
-            int chunk = (int)std::min(512.0, std::max(2.0, est));
+            double est = p.nlprMethod ? steps_rem * (1.0 + sr.avg_it) * 0.6 : steps_rem * (1.0 + sr.avg_it) + 3.0;
+            int chunk = (int)std::min(512.0, std::max(2.0, std::ceil(est)));
             for (int i = 0; i < chunk; ++i) {
                 launch_mk_row(k);
                 launch_mk_col(k, CM_MK);
             }
             be.d2h(&c, ctrl + (seq & 1), sizeof(Ctrl));                               // synchronising read
             if (!be.ok()) return hiperr();
-            if (c.steps > 0) sr.avg_it = (double)c.iterations / (double)c.steps;
+            if (c.steps > prev_steps)                                                 // iterations per step of the last chunk
+                sr.avg_it = (double)(c.iterations - prev_iters) / (double)(c.steps - prev_steps);
+            prev_steps = c.steps;
+            prev_iters = c.iterations;
             if (c.state == ST_SPAN_DONE && !c.pend0) break;
             if (++guard > (1 << 22)) {
                 err = "fused engine: span did not terminate";
