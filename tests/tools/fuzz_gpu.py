@@ -28,11 +28,12 @@ def main():
         N = 1 << lg
         pick = rng.integers(0, 5)
         if pick == 0:
-            N = int(rng.choice([1500, 3000, 6000, 10000]))          # rocFFT engine only
+            N = int(rng.choice([1500, 3000, 6000, 10000, 97, 1009, 1234, 6006, 31]))   # general-length engine (Bluestein on the fused kernels)
         elif pick == 1:                                             # fused engine, mixed-radix rows
             N = int(rng.choice([128 * 75, 128 * 81, 128 * 125, 256 * 45, 512 * 27, 1024 * 15, 128 * 225, 256 * 135,
                                 48000, 128 * 405, 512 * 125, 1024 * 75]))
         K = int(rng.choice([1, 1, 1, 2, 3]))
+        c64 = bool(rng.integers(0, 4) == 0) and pick >= 2        # complex64: packed polarisation pairs (power-of-two lengths)
         func = str(rng.choice(["manakovSSF", "manakovSSF", "manakovDBP", "ssfm"]))
         p_dbm = float(rng.choice([-20, -5, 0, 6, 10, 14]))
         adaptive = bool(rng.integers(0, 2)) and func != "ssfm"
@@ -51,8 +52,16 @@ def main():
         else:
             E = synth_field(N, 2 * K, case, p_dbm)
         tr = {}
-        with np.errstate(all="ignore"):
-            ref = ORC[func](E, make_param(orc.parameters, cfg), trace=tr)
+        gate = 1e-9
+        if c64:                                                   # single-precision run against the double-precision oracle
+            gate = 5e-4
+            with np.errstate(all="ignore"):
+                ref = ORC[func](E, make_param(orc.parameters, cfg), trace=tr)
+            cfg = dict(cfg, prec="complex64")
+            E = E.astype(np.complex64)
+        else:
+            with np.errstate(all="ignore"):
+                ref = ORC[func](E, make_param(orc.parameters, cfg), trace=tr)
         engines = ["rocfft"] + (["fused"] if models.engine_supported("fused", N) else [])
         for eng in engines:
             oa.set_engine(eng)
@@ -60,8 +69,8 @@ def main():
             run = dict(models.last_run)
             out2 = FUNCS[func](E, make_param(oa.parameters, cfg))
             run2 = dict(models.last_run)
-            ok = np.all(np.isfinite(ref)) and rel_l2(out, ref) <= 1e-9 and np.array_equal(out, out2) if eng == "fused" else rel_l2(out, ref) <= 1e-9 and rel_l2(out2, ref) <= 1e-9
-            if func != "ssfm":
+            ok = np.all(np.isfinite(ref)) and rel_l2(out, ref) <= gate and np.array_equal(out, out2) if eng == "fused" else rel_l2(out, ref) <= max(gate, 2e-3 if c64 else 0) and rel_l2(out2, ref) <= max(gate, 2e-3 if c64 else 0)
+            if func != "ssfm" and not c64:
                 ok = ok and list(run["iters"]) == tr["iters"] and run2["iterations"] == run["iterations"]
             if not ok:
                 bad += 1
