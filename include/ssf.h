@@ -21,6 +21,8 @@
  *   ssf_run                              one whole reference call (upload+execute+download)
  *   ssf_mgpu_run                         (no reference equivalent) independent fields
  *                                        sharded over the GPUs of one node, SURVEY.md 8e
+ *   ssf_set_coupling                     np.max(phiRot) / scipy.linalg.norm over ALL rows of a K > 1 batch
+ *                                        (channels.py:394, 517-519) when the rows live in several plans
  *   ssf_comm_*                           (no reference equivalent) one process per GPU: RCCL
  *                                        broadcast / scatter / gather of parameters, inputs and
  *                                        results of independent units, SURVEY.md 8e
@@ -221,6 +223,18 @@ int  ssf_comm_send(ssf_comm *comm, const void *buf, int64_t bytes, int32_t peer)
 int  ssf_comm_recv(ssf_comm *comm, void *buf, int64_t bytes, int32_t peer);
 int  ssf_comm_allgather(ssf_comm *comm, const void *send, void *recv, int64_t bytes_per_rank);
 const char *ssf_comm_last_error(const ssf_comm *comm);       /* never NULL; comm may be NULL */
+
+/* ---- coupled batch across plans (the caveat row) ------------------------------------------------
+ * A (N, 2K) batch passed to ONE reference call is coupled: the adaptive step uses max(phi) over ALL rows
+ * (optic/models/channels.py:394) and convergenceCondition the Frobenius norms over ALL rows (channels.py:517-519).  To
+ * reproduce that call with the pairs spread over several plans (GPUs, processes), give each plan a reducer: the
+ * general-length engine (host-driven control flow: plans created with SSF_ENGINE_ROCFFT) hands it the partial results it
+ * is about to use -- op 0: values[0..n) are sums (sum |E_fd - E_conv|^2, sum |E_conv|^2), op 1: maxima (max phi) -- and
+ * continues with what the reducer leaves in `values`: with an all-reduce over the participating plans every plan takes
+ * the step sizes and iteration counts of the single coupled call.  reduce = NULL detaches.  Returns SSF_ERR_UNSUPPORTED
+ * on the fused engine (its control flow lives on the device; independent units need no coupling). */
+typedef int (*ssf_reduce_fn)(void *ctx, double *values, int32_t n, int32_t op);
+int  ssf_set_coupling(ssf_plan *plan, ssf_reduce_fn reduce, void *ctx);
 
 /* ---- per-kernel timing (measurement aid; fused engine only) ------------------------------ */
 /* With profiling enabled every kernel launch of ssf_execute is bracketed by HIP events on the

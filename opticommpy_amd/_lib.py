@@ -90,6 +90,7 @@ SYMBOLS = {
                           C.POINTER(Stats), C.POINTER(Trace)]),
     "ssf_mgpu_run": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    "ssf_set_coupling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ssf_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "ssf_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "ssf_overlap_save": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -125,6 +126,7 @@ SYMBOLS = {
     "ssf_comm_last_error": (C.c_char_p, [C.c_void_p]),
 }
 COMM_ID_BYTES = 128
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32)     # ssf_reduce_fn
 
 _lib = None
 

@@ -272,8 +272,21 @@ template <typename T> class RocfftEngine final : public Engine {
     C *E = nullptr;           // current field (points at bufA or bufB)
     double lin_hz = NAN, lin_scale = NAN, lin_a = NAN, lin_b = NAN, lin_w = NAN;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ssf_reduce_fn reduce = nullptr;               // coupled batch across plans (ssf_set_coupling)
+    void *reduce_ctx = nullptr;
+
+    int coupled(double *values, int n, int op) {
+        if (!reduce) return SSF_OK;
+        const int rc = reduce(reduce_ctx, values, n, op);
+        return rc ? fail(pl, SSF_ERR_COMM, "coupling reducer failed") : SSF_OK;
+    }
 
   public:
+    int set_coupling(ssf_reduce_fn f, void *ctx) override {
+        reduce = f;
+        reduce_ctx = ctx;
+        return SSF_OK;
+    }
     RocfftEngine(ssf_plan *p, bool bluestein) : pl(p), N(p->N), nrows(p->nrows), blue(bluestein) {
         row_bytes = sizeof(C) * (size_t)N;
         field_bytes = row_bytes * (size_t)nrows;
@@ -514,6 +527,7 @@ template <typename T> class RocfftEngine final : public Engine {
                 if (p.nlprMethod) {                             // channels.py:392-397
                     k_finish<<<1, kBlock, 0, pl->stream>>>(nullptr, nullptr, pmax, gp, res);
                     if ((rc = read_results())) return rc;
+                    if ((rc = coupled(res_h + 2, 1, 1))) return rc;                     // max over the rows of every plan
                     const double cand = p.maxNlinPhaseRot / res_h[2];
                     hz_ = (p.Lspan - z >= cand) ? cand : p.Lspan - z;
                 } else if (p.Lspan - z < p.hz) {
@@ -530,6 +544,7 @@ template <typename T> class RocfftEngine final : public Engine {
                     k_conv<T><<<gc, kBlock, 0, pl->stream>>>(X, Ec, total, pnum, pden);
                     k_finish<<<1, kBlock, 0, pl->stream>>>(pnum, pden, nullptr, gc, res);
                     if ((rc = read_results())) return rc;
+                    if ((rc = coupled(res_h, 2, 0))) return rc;                         // norms over the rows of every plan
                     const double lim = std::sqrt(res_h[0]) / std::sqrt(res_h[1]);        // channels.py:517-519
                     lims[(size_t)it] = lim;
                     std::swap(Ec, X);                                                    // E_conv = E_fd

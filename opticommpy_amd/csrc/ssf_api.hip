@@ -197,6 +197,12 @@ int ssf_run(ssf_plan *plan, const ssf_params *params, const void *in, void *out,
     return SSF_OK;
 }
 
+int ssf_set_coupling(ssf_plan *plan, ssf_reduce_fn reduce, void *ctx) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    int rc = plan->engine->set_coupling(reduce, ctx);
+    return rc ? fail(plan, rc, "coupled batches need the general-length engine (create the plan with SSF_ENGINE_ROCFFT)") : SSF_OK;
+}
+
 int ssf_set_profiling(ssf_plan *plan, int32_t enable) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     int rc = plan->engine->set_profiling(enable);

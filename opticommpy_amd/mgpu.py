@@ -267,6 +267,22 @@ def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
     return outs
 
 
+def run_coupled(Ei_block, param, comm):
+    """One reference call on a (N, 2K) batch whose polarisation pairs are spread over the ranks of `comm`.
+
+    A K > 1 batch in ONE `manakovSSF` call is coupled through max(phi) over all rows (adaptive step, reference
+    optic/models/channels.py:394) and the all-row norms of convergenceCondition (channels.py:517-519).  Every rank
+    passes ITS columns `Ei_block` (N, 2 K_local) and the same `param`; the engine's partial sums and maxima are
+    all-reduced over `comm` before they are used (ssf_set_coupling), so every rank takes the step sizes and
+    iteration counts of the single coupled call and returns its block of that call's result.  Host-driven control
+    flow (general-length engine): an 8-byte all-reduce per step and a 16-byte one per iteration.  Independent units do
+    not need this -- use run_sharded."""
+    from .models import manakovSSF
+    if comm is None or comm.world == 1:
+        return manakovSSF(Ei_block, param)
+    return manakovSSF(Ei_block, param, _coupling=comm)
+
+
 def run_threads(fields, cparams, devices, precision=np.complex128, engine="auto"):
     """Single-process multi-GPU: host threads per device inside libssf_hip.so
     (ssf_mgpu_run).  `fields`: (U, rows, N) SoA array; `cparams`: a filled _lib.Params.

@@ -350,7 +350,7 @@ def ssfm(Ei, param=None, _trace=False, _cpu_seed_policy=False):
 # ----------------------------------------------------------------------------
 # manakovSSF / manakovDBP
 # ----------------------------------------------------------------------------
-def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
+def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=None):
     Fs = _require_fs(param)
     defaults = [("Ltotal", 400), ("Lspan", 80), ("hz", 0.5), ("alpha", 0.2), ("D", 16), ("gamma", 1.3),
                 ("Fc", 193.1e12), ("prec", np.complex128), ("amp", "edfa")]
@@ -379,7 +379,14 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
                          "with more than one polarisation pair set param.saveSpanN = []")
     Nspans = int(np.floor(param.Ltotal / param.Lspan))
     prec = _prec_code(param.prec)
-    pl = _get_plan(N, ncols, prec)
+    if _coupling is not None:                 # rows of ONE reference call spread over several processes (mgpu.run_coupled):
+        saved_engine, _state["engine"] = _state["engine"], _lib.ENGINE_ROCFFT      # host-driven control flow
+        try:
+            pl = _get_plan(N, ncols, prec)
+        finally:
+            _state["engine"] = saved_engine
+    else:
+        pl = _get_plan(N, ncols, prec)
     # the reference's own layout goes over the bus; the (N, 2K) -> (2K, N) conversion runs on the GPU
     in_ptr, _keep = _dev.arg(Ei, pl.dtype)
 
@@ -411,9 +418,22 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
     else:
         hint = int(np.ceil(param.Lspan / param.hz)) + 1
     sink = _open_sink(pl, on_dev, N, ncols, len(save_list), len(captured)) if save_list else None
+    reducer = None
+    if _coupling is not None:
+        def _reduce(_ctx, vals, n, op):       # called by the engine with the partial sums / maxima it is about to use
+            try:
+                a = np.ctypeslib.as_array(vals, shape=(n,))
+                a[:] = _coupling.allreduce(a.copy(), "max" if op else "sum")
+                return 0
+            except Exception:                 # (never let an exception cross the C boundary)
+                return 1
+        reducer = _lib.REDUCE_FN(_reduce)
+        pl.check(pl.lib.ssf_set_coupling(pl.h, C.cast(reducer, C.c_void_p), None))
     try:
         st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, hint)
     finally:
+        if reducer is not None:
+            pl.lib.ssf_set_coupling(pl.h, None, None)
         if sink is not None:
             _close_sink(pl, len(captured))
     for _ in range(int(st.nonconverged_steps)):
@@ -431,7 +451,7 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise):
     return (out, param) if param.returnParameters else out
 
 
-def manakovSSF(Ei, param, _trace=False, _cpu_seed_policy=False, _noise=None):
+def manakovSSF(Ei, param, _trace=False, _cpu_seed_policy=False, _noise=None, _coupling=None):
     """Manakov split-step Fourier model (symmetric, dual-pol.) on the GPU.
 
     Reference: optic/models/modelsGPU.py:281-511 == optic/models/channels.py:252-468.
@@ -441,7 +461,7 @@ def manakovSSF(Ei, param, _trace=False, _cpu_seed_policy=False, _noise=None):
     [10], tol [1e-5], nlprMethod [True], maxNlinPhaseRot [2e-2], prgsBar [True],
     saveSpanN [[Ltotal // Lspan]], seed [None], returnParameters [False].
     """
-    return _manakov(Ei, param, +1, _trace, _cpu_seed_policy, _noise)
+    return _manakov(Ei, param, +1, _trace, _cpu_seed_policy, _noise, _coupling)
 
 
 def manakovDBP(Ei, param, _trace=False):

@@ -1,0 +1,68 @@
+"""A K > 1 batch of ONE reference call spread over two processes (mgpu.run_coupled / ssf_set_coupling): every process
+holds one polarisation pair, the engine's max(phi) and norm sums are all-reduced before they are used, and each process
+returns its columns of the single coupled call (reference optic/models/channels.py:394, 517-519).  Both processes share
+GPU 0 here (the product's communicator, RCCL, refuses two ranks on one device, so the gloo stand-in carries the 8- and
+16-byte all-reduces)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SSF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SSF_ROOT"], "tests"))
+import opticommpy_amd as oa
+from opticommpy_amd import mgpu, models
+from helpers import synth_field, make_param
+from comm_gloo import GlooComm
+comm = GlooComm()
+oa.set_device(0)
+E = np.concatenate([synth_field(4096, 2, 11, 3.0), synth_field(4096, 2, 12, 12.0)], axis=1)      # two pairs, 9 dB apart
+cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=8, Lspan=4, hz=0.5,
+           nlprMethod=True, maxNlinPhaseRot=1e-2, amp="ideal", saveSpanN=[])
+blk = np.ascontiguousarray(E[:, 2 * comm.rank: 2 * comm.rank + 2])
+out = mgpu.run_coupled(blk, make_param(oa.parameters, cfg), comm)
+np.save(os.path.join(os.environ["SSF_OUT"], f"coupled_rank{comm.rank}.npy"), out)
+np.save(os.path.join(os.environ["SSF_OUT"], f"steps_rank{comm.rank}.npy"), np.array([models.last_run["steps"], models.last_run["iterations"]]))
+comm.close()
+'''
+
+
+def test_two_processes_reproduce_the_single_coupled_call(tmp_path):
+    import opticommpy_amd as oa
+    from helpers import make_param, rel_l2, synth_field
+    from opticommpy_amd import models
+    from oracle import ssf_oracle as orc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SSF_ROOT=ROOT, SSF_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out.decode()[-3000:]
+    got = np.concatenate([np.load(tmp_path / f"coupled_rank{r}.npy") for r in range(2)], axis=1)
+    steps = [np.load(tmp_path / f"steps_rank{r}.npy") for r in range(2)]
+    E = np.concatenate([synth_field(4096, 2, 11, 3.0), synth_field(4096, 2, 12, 12.0)], axis=1)
+    cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=8, Lspan=4, hz=0.5,
+               nlprMethod=True, maxNlinPhaseRot=1e-2, amp="ideal", saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)                 # the single coupled call
+    assert rel_l2(got, ref) <= 1e-10
+    assert all(int(s[0]) == tr["steps"] and int(s[1]) == tr["iterations"] for s in steps)       # both ranks: the coupled step sequence
+    # ... which is not what the pairs do on their own: the weak pair alone takes far fewer (longer) steps
+    alone = orc.manakovSSF(E[:, :2].copy(), make_param(orc.parameters, cfg), trace=(tr0 := {}))
+    assert tr0["steps"] < tr["steps"] and rel_l2(got[:, :2], alone) > 1e-6
