@@ -451,6 +451,20 @@ SSF_HD int rev_pos(const PassPlan &p, int pos) {
 // LDS slot of transform-local position pos (pad one slot per 16 to spread banks)
 SSF_HD int lds_slot(int pos) { return pos + (pos >> 4); }
 SSF_HD int lds_slots_per_fft(int L) { return L + (L >> 4) + 1; }
+// Column kernels: C transforms side by side in LDS, lane l of a wave works on column l % C, butterfly l / C.  A 16-lane
+// group of a 16-byte LDS access then touches (16 / C) consecutive slots of each of C columns: they fall into 16 different
+// 16-byte bank groups when the column stride is 16 / C slots modulo 16 (with the "+ 1" stride above, C = 8 columns leave
+// 9 distinct groups for 16 lanes, C = 4 only 7: SQ_LDS_BANK_CONFLICT 2.3 x SQ_ACTIVE_INST_LDS in k_col_pk<10>).
+// Measured (same box, A/B): C = 4 (packed pairs, columns of 1024) column launch 62.0 -> 61.0 us, +1 % steps/s at config 3;
+// C = 8 (complex128 Manakov) no gain within the noise (5 768 vs 5 672 steps/s the other way): applied to C <= 4 only.
+#ifndef SSF_COLPAD
+#define SSF_COLPAD 1
+#endif
+SSF_HD int lds_col_stride(int L, int C, int elem_bytes) {
+    if (!SSF_COLPAD || elem_bytes != 16 || C > 4 || C < 2) return lds_slots_per_fft(L);
+    const int want = 16 / C, s = L + (L >> 4);
+    return s + ((want - s) & 15);
+}
 
 }  // namespace fused
 }  // namespace ssf

@@ -172,7 +172,7 @@ template <typename T, class Backend> class FusedCore {
         const int Cc = half / tpf;
         *block = half * npol;
         *grid = groups * ((N2 + Cc - 1) / Cc);
-        *lds = std::max((size_t)npol * Cc * lds_slots_per_fft(1 << sp.l1) * sizeof(C), (size_t)half * npol * 16 + 1024);
+        *lds = std::max((size_t)npol * Cc * lds_col_stride(1 << sp.l1, Cc, (int)sizeof(C)) * sizeof(C), (size_t)half * npol * 16 + 1024);
     }
 
     int init() {
@@ -415,7 +415,7 @@ template <typename T, class Backend> class FusedCore {
                     pcol = nrows * ((1 << sp.l2) / Cc);
                     if (std::max(prow, pcol) <= lim) {
                         pgrid = std::max(prow, pcol);
-                        plds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2), (size_t)Cc * lds_slots_per_fft(1 << sp.l1)) * sizeof(C);
+                        plds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2), (size_t)Cc * lds_col_stride(1 << sp.l1, Cc, (int)sizeof(C))) * sizeof(C);
                         plds = std::max(plds, (size_t)256 * 16 + 2048);
                     }
                 }

@@ -1131,7 +1131,7 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
 
     ColGeom<T, LG, Ctx, RAGGED> g(ctx, a);
     const PassPlan &p = g.p;
-    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_slots_per_fft(p.L);
+    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
     cx<T> v[16];
 
     // buffers by role (Manakov)
@@ -1307,7 +1307,7 @@ template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2
     const int op = st.op;
     ColGeom<T, LG, Ctx, false> g(ctx, a);
     const PassPlan &p = g.p;
-    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)g.c * lds_slots_per_fft(p.L);
+    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)g.c * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
     double *red = (double *)ctx.lds;
     cx<T> v[16];
     cx<T> *Tcur = st.c.cur ? a.T1 : a.T0;                    // field at the step start

@@ -18,7 +18,8 @@ def main(argv):
              "where (end-start) > ? group by kernel_name, counter_name order by kernel_name, counter_name")
         print(f"# {path}  (dispatches longer than {min_us} us)")
         for name, ctr, n, avg, dur in cur.execute(q, (min_us * 1e3,)):
-            short = name.split("(")[0].replace("void ssf::(anonymous namespace)::", "")
+            short = name.replace("void ssf::(anonymous namespace)::", "").replace("ssf::(anonymous namespace)::", "").replace("ssf::fused::", "")
+            short = short.split("(")[0]
             print(f"{short:42s} {ctr:24s} n={n:5d} avg={avg:14.4f} avg_dur_us={dur/1e3:8.2f}")
 
 
