@@ -40,10 +40,10 @@ inline bool choose_split(int log2N, int precision, Split *s, bool packed = false
     const int l1pref = 8, l2max = dbl ? 13 : 14;     // (measured: 8 is best for both precisions at 2^20)
     int l1 = std::min(l1pref, log2N / 2);
     int l2 = log2N - l1;
-    if (packed && l2 > 12 && log2N - 12 <= 10) {     // packed pairs (16-byte elements): rows of 4096 are three radix-16 passes and
-        s->l1 = log2N - 12;                           // two workgroups per CU, rows of 8192 four passes and one: measured at 2^22
-        s->l2 = 12;                                   // row launch 59 -> 46 us, column launch (1024 long, 64-B segments) 60 -> 63 us
-        return true;
+    if (packed && l2 > 12) {                          // packed pairs (16-byte elements): rows of 4096 are three radix-16 passes and
+        s->l1 = std::min(log2N - 12, 10);             // two workgroups per CU, rows of 8192 four passes and one: measured at 2^22
+        s->l2 = log2N - s->l1;                        // row launch 59 -> 46 us, column launch (1024 long, 64-B segments) 60 -> 63 us
+        return s->l2 <= 13;                           // (2^23: 1024 x 8192; beyond that the pairs do not fit the LDS rows)
     }
     const int l2soft = l2max - 1;          // prefer two workgroups per CU
     if (l2 > l2soft) {
@@ -633,7 +633,10 @@ template <typename T, class Backend> class FusedCore {
     // complex64 Manakov on the packed-pair pipeline: per span the rows of T[cur] are packed into the pair core's field
     // (one pass), propagated there, and unpacked again for the amplifier / snapshot stage (one pass): two extra passes
     // over the field per SPAN against (2 + 2 nIter) per STEP.
-    bool packed_ok() const { return std::is_same<T, float>::value && use_packed && !N2mix && (nrows % 2) == 0; }
+    bool packed_ok() const {
+        Split t;
+        return std::is_same<T, float>::value && use_packed && !N2mix && (nrows % 2) == 0 && choose_split(log2N, SSF_C128, &t, true);
+    }
     int run_manakov_packed(const ssf_params &p, const Derived &d, int s0, int s1, const void *noise, ssf_stats *st,
                            ssf_trace *trace) {
         if constexpr (!std::is_same<T, float>::value) return SSF_ERR_UNSUPPORTED;

@@ -156,3 +156,17 @@ def test_persistent_span_kernel_matches_the_launch_sequence(monkeypatch):
     models.release_plans()
     assert rel_l2(out["256"], out["0"]) <= 1e-12
     assert rel_l2(out["256"], orc.ssfm(E, make_param(orc.parameters, cfg))) <= 1e-10
+
+
+@pytest.mark.gpu
+def test_largest_complex64_length_runs_on_packed_pairs():
+    """N = 2^23 complex64 (the largest fused length): packed pairs with a 1024 x 8192 split; two steps against the oracle."""
+    from opticommpy_amd import models
+    N = 1 << 23
+    E = synth_field(N, 2, 9, 8.4, np.complex64)
+    cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=0.12, Lspan=0.12,
+               hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[], prec="complex64")
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg))
+    out = oa.manakovSSF(E, make_param(oa.parameters, cfg))
+    assert models.last_run["engine"] == "fused" and models.last_run["steps"] == 2
+    assert rel_l2(out, ref) <= 5e-5
