@@ -1389,12 +1389,14 @@ template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2
             ctx.mark(7);
 #pragma unroll
             for (int idx = 0; idx < 16; ++idx) {
-                // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2)
-                const double sn = sin_half_angle((double)pn[idx] - (double)prev[idx]);
+                // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2); the two phases agree to a few digits, so
+                // their single-precision difference is exact (Sterbenz) and small: the float kernel is enough
+                const float dth = pn[idx] - prev[idx];
+                const float sn = fabsf(dth) <= 1.5f ? ksin_f(0.5f * dth) : (float)sin_half_angle((double)dth);
                 float ex, ey;
                 pair_pow(v[idx], ex, ey);
                 const double w = (double)ex + (double)ey;
-                n1 += w * (double)(float)(4.0 * sn * sn);
+                n1 += w * (double)(4.0f * sn * sn);
                 d1 += w;
                 v[idx] = tmul(v[idx], cis_t<float>(pn[idx]));
             }
