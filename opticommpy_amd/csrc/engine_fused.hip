@@ -1,586 +1,27 @@
-// engine_fused.hip -- HIP backend of the fused radix-2^n engine: __global__ wrappers around
-// the kernel bodies of fused_kernels.h plus the Backend that FusedCore (fused_engine.h)
-// drives.  All launches go to the plan's stream; nothing here synchronises inside a step.
-#include <cstdlib>
+// engine_fused.hip -- entry points of the fused engine: dispatch on the field precision to the two translation units
+// that hold the kernels (engine_fused_f64.hip, engine_fused_f32.hip: engine_fused_impl.h compiled once per precision, in
+// parallel), and the length rule.
 #include <vector>
 
-#include "dev_ctx.h"
 #include "fused_engine.h"
 #include "ssf_internal.h"
 
 namespace ssf {
-namespace {
 
-using namespace fused;
+Engine *make_fused_engine_f64(ssf_plan *plan);
+Engine *make_fused_engine_f32(ssf_plan *plan);
+FusedConv *make_fused_conv_f64(ssf_plan *plan, int64_t M, int nrows);
+FusedConv *make_fused_conv_f32(ssf_plan *plan, int64_t M, int nrows);
+int fused_overlap_save_f64(int64_t sigLen, int nrows, int log2nfft, int K, const void *Hfft, const void *in, void *out, std::string *err);
+int fused_overlap_save_f32(int64_t sigLen, int nrows, int log2nfft, int K, const void *Hfft, const void *in, void *out, std::string *err);
 
-// Phase timing (diagnostic builds only, make PHASE=1): mark(i) drains the memory counters and
-// stores the 100 MHz wall clock for the lead thread of every workgroup; the product build
-// compiles mark() to nothing.
-#ifdef SSF_PHASE_TIMING
-__device__ unsigned long long g_marks[4][4096][8];
-#endif
-
-struct DevCtx : DevCtxCore {
-#ifdef SSF_PHASE_TIMING
-    int kind;
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // stamps stay in registers; flush(set) stores the complete record of this launch, so a
-    // launch of another kind (early return, no forward transform) never mixes into it
-    __device__ __forceinline__ void mark(int i) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        ts[i] = wall_clock64();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __device__ __forceinline__ void flush(int set) {
-        if (tid == 0 && bid < 4096)
-            for (int i = 0; i < 8; ++i) g_marks[kind + 2 * set][bid][i] = ts[i];
-    }
-#else
-    __device__ __forceinline__ void mark(int) {}
-    __device__ __forceinline__ void flush(int) {}
-#endif
-};
-
-#ifdef SSF_PHASE_TIMING
-#define SSF_CTX_KIND(k) , k
-#else
-#define SSF_CTX_KIND(k)
-#endif
-#define SSF_DEV_CTX(k)                                                        \
-    extern __shared__ __attribute__((aligned(16))) char ssf_smem[];           \
-    DevCtx ctx{{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, ssf_smem} SSF_CTX_KIND(k)}
-
-// OCC = minimum waves per SIMD the register allocator must leave room for: 1 = up to 512
-// registers per lane and no spills (one 256-thread workgroup per CU), 2 = 256 registers
-// (two workgroups per CU).  LG = compile-time log2 of the transform length (0 = runtime).
-template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds__(MAXT, OCC) k_row(const RowArgs<T> a) {
-    SSF_DEV_CTX(0);
-    row_body<T, LG>(ctx, a);
+Engine *make_fused_engine(ssf_plan *plan) {
+    return plan->precision == SSF_C128 ? make_fused_engine_f64(plan) : make_fused_engine_f32(plan);
 }
-// Manakov column kernels run 512 threads (x half | y half); the single-row modes run 256
-template <typename T, int LG, int MODE>
-__global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs<T> a) {
-    SSF_DEV_CTX(1);
-    col_body<T, LG, MODE, false>(ctx, a);
-}
-// row lengths with factors 3 / 5 (mixed_fft.h): mixed-radix row stage, column stage with ragged last tiles
-template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT, MAXT <= 256 ? 2 : 1) k_row_mixed(const RowArgs<T> a) {
-    SSF_DEV_CTX(0);
-    row_mixed_body<T>(ctx, a);
-}
-template <typename T, int LG, int MODE>
-__global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const ColArgs<T> a) {
-    SSF_DEV_CTX(1);
-    col_body<T, LG, MODE, true>(ctx, a);
-}
-// complex64 Manakov: packed polarisation pairs (fused_kernels.h: col_pk_body); up to 512 threads (8 columns of 1024)
-template <int LG> __global__ void __launch_bounds__(512) k_col_pk(const ColArgs<pf2> a) {
-    SSF_DEV_CTX(1);
-    col_pk_body<LG>(ctx, a);
-}
-__global__ void __launch_bounds__(256) k_repack(const RepackArgs a) {
-    SSF_DEV_CTX(1);
-    repack_body(ctx, a);
-}
-template <typename T> __global__ void __launch_bounds__(256) k_amp(const AmpArgs<T> a) {
-    SSF_DEV_CTX(1);
-    amp_body<T>(ctx, a);
-}
-
-template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT) k_ols(const OlsArgs<T> a) {
-    SSF_DEV_CTX(1);
-    ols_body<T>(ctx, a);
-}
-
-// ---- persistent span kernel (scalar NLSE): every stage of a span in ONE launch ----------------------------------------
-// For small N a launch is one latency chain (dispatch -> loads -> transform -> stores -> end-of-kernel write-back),
-// ~10 us whatever the size, and a span is 2 * nsteps + 1 of them.  Here the stages run inside one launch of <= 256
-// co-resident workgroups (one per CU at most) with a grid barrier in between: arrival counter + generation word,
-// agent-scope release before / acquire after (the L2s of the eight XCDs are not coherent with each other, so the stage's
-// output is written back and the readers' lines invalidated), bounded spin (a barrier that cannot complete sets the abort
-// word and the host reports it instead of hanging).  The stage bodies are the ones of the per-stage kernels, called with
-// virtual workgroup numbers.  Reference loop: optic/models/channels.py:215-232.
-__device__ __forceinline__ bool grid_sync(unsigned *bar, unsigned nwg) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();                                          // release: this workgroup's stores, device-wide
-        const unsigned g = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
-            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            unsigned spins = 0;
-            while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == g) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24) || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __threadfence();
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // every wave: no stale L1 / L2 lines of the previous stage
-    return __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-}
-template <typename T, int LGR, int LGC> __global__ void __launch_bounds__(256) k_nlse_span(const SpanNlseArgs<T> a) {
-    SSF_DEV_CTX(0);
-    const int me = (int)blockIdx.x, nwg = (int)gridDim.x;
-    auto col_stage = [&](int mode) {
-        for (int vb = me; vb < a.col_grid; vb += nwg) {
-            ctx.bid = vb;
-            if (mode == CM_NLSE_FIRST) col_body<T, LGC, CM_NLSE_FIRST, false>(ctx, a.col);
-            else if (mode == CM_NLSE_STEP) col_body<T, LGC, CM_NLSE_STEP, false>(ctx, a.col);
-            else col_body<T, LGC, CM_NLSE_LAST, false>(ctx, a.col);
-            __syncthreads();
-        }
-    };
-    auto row_stage = [&](const LinOp *lin) {
-        RowArgs<T> ra = a.row;
-        ra.lin = lin;
-        for (int vb = me; vb < a.row_grid; vb += nwg) {
-            ctx.bid = vb;
-            row_body<T, LGR>(ctx, ra);
-            __syncthreads();
-        }
-    };
-    col_stage(CM_NLSE_FIRST);                                     // channels.py:216
-    if (!grid_sync(a.bar, nwg)) return;
-    row_stage(a.lin_half);
-    if (!grid_sync(a.bar, nwg)) return;
-    for (int s = 1; s < a.nsteps; ++s) {
-        col_stage(CM_NLSE_STEP);
-        if (!grid_sync(a.bar, nwg)) return;
-        row_stage(a.lin_full);                                    // lin * lin: second half of one step, first half of the next
-        if (!grid_sync(a.bar, nwg)) return;
-    }
-    col_stage(CM_NLSE_STEP);
-    if (!grid_sync(a.bar, nwg)) return;
-    row_stage(a.lin_half);
-    if (!grid_sync(a.bar, nwg)) return;
-    col_stage(CM_NLSE_LAST);                                      // channels.py:232
-}
-
-template <typename T> using RowFn = void (*)(const RowArgs<T>);
-template <typename T> using ColFn = void (*)(const ColArgs<T>);
-
-// kernel selection: specialised lengths for the sizes that matter, generic otherwise
-template <typename T> RowFn<T> pick_row(int lg2, int block, int occ) {
-    if (block <= 256) {
-        if (occ == 2) {
-            switch (lg2) {
-            case 10: return k_row<T, 256, 2, 10>;
-            case 11: return k_row<T, 256, 2, 11>;
-            case 12: return k_row<T, 256, 2, 12>;
-            default: return k_row<T, 256, 2, 0>;
-            }
-        }
-        switch (lg2) {
-        case 10: return k_row<T, 256, 1, 10>;
-        case 11: return k_row<T, 256, 1, 11>;
-        case 12: return k_row<T, 256, 1, 12>;
-        default: return k_row<T, 256, 1, 0>;
-        }
-    }
-    if (block <= 512) return lg2 == 13 ? k_row<T, 512, 1, 13> : k_row<T, 512, 1, 0>;
-    return lg2 == 14 ? k_row<T, 1024, 1, 14> : k_row<T, 1024, 1, 0>;
-}
-template <typename T, int LG> ColFn<T> pick_col_mode(int mode) {
-    switch (mode) {
-    case CM_NLSE_FIRST: return k_col<T, LG, CM_NLSE_FIRST>;
-    case CM_NLSE_STEP: return k_col<T, LG, CM_NLSE_STEP>;
-    case CM_NLSE_LAST: return k_col<T, LG, CM_NLSE_LAST>;
-    case CM_MK: return k_col<T, LG, CM_MK>;
-    case CM_PLAIN_FWD: return k_col<T, LG, CM_PLAIN_FWD>;
-    default: return k_col<T, LG, CM_PLAIN_INV>;
-    }
-}
-template <typename T> ColFn<T> pick_col_ragged(int lg1, int mode) {
-    if (mode == CM_MK) {                      // the Manakov stage is worth its specialised lengths
-        switch (lg1) {
-        case 7: return k_col_ragged<T, 7, CM_MK>;
-        case 8: return k_col_ragged<T, 8, CM_MK>;
-        case 9: return k_col_ragged<T, 9, CM_MK>;
-        default: return k_col_ragged<T, 0, CM_MK>;
-        }
-    }
-    switch (mode) {
-    case CM_NLSE_FIRST: return k_col_ragged<T, 0, CM_NLSE_FIRST>;
-    case CM_NLSE_STEP: return k_col_ragged<T, 0, CM_NLSE_STEP>;
-    case CM_NLSE_LAST: return k_col_ragged<T, 0, CM_NLSE_LAST>;
-    case CM_PLAIN_FWD: return k_col_ragged<T, 0, CM_PLAIN_FWD>;
-    default: return k_col_ragged<T, 0, CM_PLAIN_INV>;
-    }
-}
-template <typename T> ColFn<T> pick_col(int lg1, int mode) {
-    switch (lg1) {
-    case 7: return pick_col_mode<T, 7>(mode);
-    case 8: return pick_col_mode<T, 8>(mode);
-    case 9: return pick_col_mode<T, 9>(mode);
-    default: return pick_col_mode<T, 0>(mode);
-    }
-}
-
-struct HipBackend {
-    ssf_plan *pl;
-    hipError_t first_err = hipSuccess;
-    std::string where;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-    int row_occ = 2;
-    // optional per-launch event timing (ssf_set_profiling)
-    bool profiling = false;
-    struct Stamp { hipEvent_t a, b; int cat; };
-    std::vector<Stamp> stamps;
-    std::vector<hipEvent_t> pool;
-    ssf_kernel_times kt{};
-    hipEvent_t get_event() {
-        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
-        hipEvent_t e = nullptr;
-        chk(hipEventCreate(&e), "hipEventCreate");
-        return e;
-    }
-    void stamp_begin(int cat) {
-        if (!profiling) return;
-        Stamp s{get_event(), get_event(), cat};
-        chk(hipEventRecord(s.a, pl->stream), "hipEventRecord");
-        stamps.push_back(s);
-    }
-    void stamp_end() {
-        if (!profiling) return;
-        chk(hipEventRecord(stamps.back().b, pl->stream), "hipEventRecord");
-    }
-    void collect() {        // call after a stream synchronise
-        for (auto &s : stamps) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-                double *t = s.cat == 0 ? &kt.row_ms : s.cat == 1 ? &kt.col_ms : &kt.other_ms;
-                int64_t *n = s.cat == 0 ? &kt.row_n : s.cat == 1 ? &kt.col_n : &kt.other_n;
-                *t += ms;
-                *n += 1;
-            }
-            pool.push_back(s.a);
-            pool.push_back(s.b);
-        }
-        stamps.clear();
-    }
-    explicit HipBackend(ssf_plan *p) : pl(p) {
-        if (const char *s = getenv("SSF_FUSED_ROW_OCC")) row_occ = atoi(s) == 1 ? 1 : 2;
-        chk(hipEventCreate(&ev0), "hipEventCreate");
-        chk(hipEventCreate(&ev1), "hipEventCreate");
-    }
-    ~HipBackend() {
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        for (auto &s : stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
-        for (auto e : pool) (void)hipEventDestroy(e);
-    }
-    void chk(hipError_t e, const char *what) {
-        if (e != hipSuccess && first_err == hipSuccess) {
-            first_err = e;
-            where = what;
-        }
-    }
-    bool ok() const { return first_err == hipSuccess; }
-    std::string last_error() const {
-        return first_err == hipSuccess ? std::string() : where + ": " + hipGetErrorString(first_err);
-    }
-    void *alloc(size_t n) {
-        void *p = nullptr;
-        chk(hipMalloc(&p, n ? n : 16), "hipMalloc");
-        return p;
-    }
-    void free(void *p) { (void)hipFree(p); }
-    void h2d(void *d, const void *h, size_t n) {
-        chk(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, pl->stream), "hipMemcpyAsync H2D");
-        chk(hipStreamSynchronize(pl->stream), "hipStreamSynchronize");
-    }
-    void d2h(void *h, const void *d, size_t n) {
-        chk(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, pl->stream), "hipMemcpyAsync D2H");
-        chk(hipStreamSynchronize(pl->stream), "hipStreamSynchronize");
-    }
-    void h2d_big(void *d, const void *h, size_t n) { chk(pl->stager.h2d(d, h, n, pl->stream), "staged H2D"); }
-    void d2h_big(void *h, const void *d, size_t n) { chk(pl->stager.d2h(h, d, n, pl->stream), "staged D2H"); }
-    template <typename C> void aos_to_soa(C *soa, const C *aos, long long N, int nrows) {
-        k_aos_to_soa<C><<<1024, 256, 0, pl->stream>>>(aos, soa, N, nrows);
-        chk(hipStreamSynchronize(pl->stream), "aos_to_soa");
-    }
-    template <typename C> void soa_to_aos(C *aos, const C *soa, long long N, int nrows) {
-        k_soa_to_aos<C><<<1024, 256, 0, pl->stream>>>(soa, aos, N, nrows);
-        chk(hipGetLastError(), "soa_to_aos");
-    }
-    void d2d(void *d, const void *s, size_t n) {
-        chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, pl->stream), "hipMemcpyAsync D2D");
-    }
-    void memset(void *d, int v, size_t n) { chk(hipMemsetAsync(d, v, n, pl->stream), "hipMemsetAsync"); }
-    void sync() { chk(hipStreamSynchronize(pl->stream), "hipStreamSynchronize"); }
-    void time_begin() { chk(hipEventRecord(ev0, pl->stream), "hipEventRecord"); }
-    double time_end() {
-        chk(hipEventRecord(ev1, pl->stream), "hipEventRecord");
-        chk(hipStreamSynchronize(pl->stream), "hipStreamSynchronize");
-        float ms = 0;
-        chk(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
-        collect();
-        return ms;
-    }
-    size_t row_lds_max = 0, col_lds_max = 0;
-    void prepare(size_t row_lds, size_t col_lds) {
-        row_lds_max = row_lds;
-        col_lds_max = col_lds;
-    }
-    template <typename T> void launch_row(const RowArgs<T> &a, int grid, int block, size_t lds) {
-        RowFn<T> f;
-        if constexpr (std::is_same<T, pf2>::value) f = pick_row<T>(a.log2N2, block, row_occ);     // (no mixed-radix rows there)
-        else
-            f = !a.mixed ? pick_row<T>(a.log2N2, block, row_occ)
-                : block <= 256 ? (RowFn<T>)k_row_mixed<T, 256> : block <= 512 ? (RowFn<T>)k_row_mixed<T, 512> : (RowFn<T>)k_row_mixed<T, 1024>;
-        arm((const void *)f);
-        stamp_begin(0);
-        f<<<grid, block, lds, pl->stream>>>(a);
-        stamp_end();
-        chk(hipGetLastError(), "launch k_row");
-    }
-    template <typename T> void launch_col(const ColArgs<T> &a, int grid, int block, size_t lds) {
-        ColFn<T> f;
-        if constexpr (std::is_same<T, pf2>::value) {
-            switch (a.log2N1) {
-            case 7: f = k_col_pk<7>; break;
-            case 8: f = k_col_pk<8>; break;
-            case 9: f = k_col_pk<9>; break;
-            case 10: f = k_col_pk<10>; break;
-            default: f = k_col_pk<0>; break;
-            }
-        } else
-            f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
-        arm((const void *)f);
-        stamp_begin(a.mode == CM_MK ? 1 : 3);
-        f<<<grid, block, lds, pl->stream>>>(a);
-        stamp_end();
-        chk(hipGetLastError(), "launch k_col");
-    }
-    // raise the dynamic-LDS cap of a kernel the first time THIS backend (= this plan, hence this
-    // device) launches it; the attribute is per device, so the record must not be shared
-    std::vector<const void *> armed;
-    void arm(const void *f) {
-        for (const void *g : armed)
-            if (g == f) return;
-        chk(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        armed.push_back(f);
-    }
-    // persistent span kernel: grid <= CUs (every workgroup resident), 256 threads, any supported power-of-two split.
-    // OFF by default: measured slower than one launch per stage at every size (MI355X, ssfm, steps/s, launches vs
-    // persistent: 2^12 41.1k / 31.6k, 2^14 43.6k / 28.7k, 2^16 51.2k / 49.0k, 2^18 49.6k / 25.6k, 2^20 33.1k / 7.6k;
-    // gpurun_out/r2e) -- an agent-scope release + acquire around a grid barrier costs more than the 1.5-2 us of a kernel
-    // boundary (the micro-architecture guide's price list says the same: 4-7 us per barrier), and a stage's ~10 us is one
-    // wave's ~2000 dependent FP64 instructions, not launch overhead.  SSF_PERSIST=<largest grid> turns it on.
-    static constexpr bool kCanPersist = true;
-    int persist_limit() {
-        if (const char *e = getenv("SSF_PERSIST")) return atoi(e);
-        return 0;
-    }
-    template <typename T> int launch_nlse_span(const SpanNlseArgs<T> &a, int grid, size_t lds) {
-        void (*f)(const SpanNlseArgs<T>);
-        if constexpr (std::is_same<T, pf2>::value) return SSF_ERR_UNSUPPORTED;
-        else {
-            if (a.row.log2N2 == 8 && a.col.log2N1 == 8) f = k_nlse_span<T, 8, 8>;
-            else if (a.row.log2N2 == 10 && a.col.log2N1 == 8) f = k_nlse_span<T, 10, 8>;
-            else if (a.row.log2N2 == 12 && a.col.log2N1 == 8) f = k_nlse_span<T, 12, 8>;
-            else f = k_nlse_span<T, 0, 0>;
-            arm((const void *)f);
-            chk(hipMemsetAsync(a.bar, 0, 3 * sizeof(unsigned), pl->stream), "hipMemsetAsync(barrier)");
-            stamp_begin(3);
-            f<<<grid, 256, lds, pl->stream>>>(a);
-            stamp_end();
-            chk(hipGetLastError(), "launch k_nlse_span");
-            return ok() ? SSF_OK : SSF_ERR_HIP;
-        }
-    }
-    bool sink_active() const { return pl->sink.active(); }
-    template <typename C> void sink_capture(const C *soa, long long N, int nrows) {
-        chk(pl->sink.capture(soa, N, nrows, pl->stream), "snapshot sink");
-    }
-    void launch_repack(const RepackArgs &a, int grid, int block) {
-        k_repack<<<grid, block, 0, pl->stream>>>(a);
-        chk(hipGetLastError(), "launch k_repack");
-    }
-    template <typename T> void launch_amp(const AmpArgs<T> &a, int grid, int block) {
-        k_amp<T><<<grid, block, 0, pl->stream>>>(a);
-        chk(hipGetLastError(), "launch k_amp");
-    }
-};
-
-template <typename T> class FusedEngine final : public Engine {
-    ssf_plan *pl;
-    HipBackend be;
-    FusedCore<T, HipBackend> core;
-
-  public:
-    explicit FusedEngine(ssf_plan *p) : pl(p), be(p), core(be, p->N, p->nrows, p->precision) {}
-    int id() const override { return SSF_ENGINE_FUSED; }
-    int ret(int rc) {
-        if (rc != SSF_OK) pl->err = core.err.empty() ? be.last_error() : core.err;
-        return rc;
-    }
-    int init() { return ret(core.init()); }
-    int upload(const void *field, bool aos) override {
-        be.kt = ssf_kernel_times{};
-        return ret(core.upload(field, aos));
-    }
-    int download(void *field, int which, bool aos) override { return ret(core.download(field, which, aos)); }
-    int n_snapshots() const override { return (int)core.snaps.size(); }
-    int execute(const ssf_params &p, int s0, int s1, const void *noise, ssf_stats *st, ssf_trace *tr) override {
-        return ret(core.execute(p, s0, s1, noise, st, tr));
-    }
-    int linear_channel(double Fs, double Fc, double alpha, double D, double L) override {
-        return ret(core.linear_channel(Fs, Fc, alpha, D, L));
-    }
-    int set_profiling(int on) override {
-        be.profiling = on != 0;
-        return SSF_OK;
-    }
-    int kernel_times(ssf_kernel_times *out) override {
-        *out = be.kt;
-        return SSF_OK;
-    }
-    void reset_times() { be.kt = ssf_kernel_times{}; }
-};
-
-template <typename T> class FusedConvImpl final : public FusedConv {
-    using Cc = cx<T>;
-    ssf_plan *pl;
-    HipBackend be;
-    FusedCore<T, HipBackend> core;
-    Cc *hk[2] = {nullptr, nullptr};
-    int64_t M;
-    std::string err_;
-
-  public:
-    FusedConvImpl(ssf_plan *p, int64_t M_, int nrows) : pl(p), be(p), core(be, M_, nrows, p->precision), M(M_) {}
-    ~FusedConvImpl() override {
-        for (Cc *h : hk)
-            if (h) (void)hipFree(h);
-    }
-    int init() {
-        if (core.N2mix) {
-            err_ = "convolution length must be a power of two";
-            return SSF_ERR_BAD_ARG;
-        }
-        int rc = core.init();
-        if (rc) err_ = core.err;
-        return rc;
-    }
-    std::string error() const override { return err_.empty() ? be.last_error() : err_; }
-    void *work() override { return core.T0; }
-    int set_kernel(int which, const void *b_host) override {
-        if (which < 0 || which > 1) return SSF_ERR_BAD_ARG;
-        if (!hk[which] && hipMalloc(&hk[which], sizeof(Cc) * (size_t)M) != hipSuccess) {
-            err_ = "out of memory (convolution kernel)";
-            return SSF_ERR_OOM;
-        }
-        be.memset(core.T0, 0, core.field_bytes);                       // the kernel goes into row 0, the other rows are idle
-        be.h2d(core.T0, b_host, sizeof(Cc) * (size_t)M);
-        core.launch_col_plain(CM_PLAIN_FWD, core.T0, (T)0);
-        core.launch_row_conv(nullptr, 1);                              // spectrum in the row kernel's own order -> G
-        be.d2d(hk[which], core.G, sizeof(Cc) * (size_t)M);
-        be.sync();
-        return be.ok() ? SSF_OK : SSF_ERR_HIP;
-    }
-    int run(int which) override {
-        core.launch_col_plain(CM_PLAIN_FWD, core.T0, (T)0);
-        core.launch_row_conv(hk[which], 0);
-        core.launch_col_plain(CM_PLAIN_INV, core.T0, (T)0);
-        return be.ok() ? SSF_OK : SSF_ERR_HIP;
-    }
-};
-
-}  // namespace
 
 FusedConv *make_fused_conv(ssf_plan *plan, int64_t M, int nrows) {
-    int rc;
-    FusedConv *c;
-    if (plan->precision == SSF_C128) {
-        auto *x = new FusedConvImpl<double>(plan, M, nrows);
-        rc = x->init();
-        c = x;
-    } else {
-        auto *x = new FusedConvImpl<float>(plan, M, nrows);
-        rc = x->init();
-        c = x;
-    }
-    if (rc != SSF_OK) {
-        plan->err = c->error();
-        delete c;
-        return nullptr;
-    }
-    return c;
+    return plan->precision == SSF_C128 ? make_fused_conv_f64(plan, M, nrows) : make_fused_conv_f32(plan, M, nrows);
 }
-
-namespace {
-template <typename T>
-int overlap_save_t(int64_t sigLen, int nrows, int lg, int K, const void *Hfft, const void *in, void *out, std::string *err) {
-    using Cc = cx<T>;
-    const int nfft = 1 << lg, d = nfft - K + 1, discard = K - 1, D = (K - 1) / 2;
-    const long long numBlocks = (sigLen + K - 1 + d - 1) / d;                       // core.py:1023-1025
-    const size_t sig_bytes = sizeof(Cc) * (size_t)sigLen * (size_t)nrows;
-    hipStream_t st = nullptr;
-    Cc *din = nullptr, *dout = nullptr, *dH = nullptr;
-    auto fail_ = [&](const char *what, hipError_t e) {
-        *err = std::string(what) + ": " + hipGetErrorString(e);
-        if (din) (void)hipFree(din);
-        if (dout) (void)hipFree(dout);
-        if (dH) (void)hipFree(dH);
-        if (st) (void)hipStreamDestroy(st);
-        return e == hipErrorOutOfMemory ? SSF_ERR_OOM : SSF_ERR_HIP;
-    };
-    hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail_("hipStreamCreate", e);
-    if ((e = hipMalloc(&din, sig_bytes)) != hipSuccess) return fail_("hipMalloc", e);
-    if ((e = hipMalloc(&dout, sig_bytes)) != hipSuccess) return fail_("hipMalloc", e);
-    if ((e = hipMalloc(&dH, sizeof(Cc) * (size_t)nfft)) != hipSuccess) return fail_("hipMalloc", e);
-    std::vector<Cc> Hs((size_t)nfft);                                                // fold the 1/NFFT of the ifft into H
-    for (int i = 0; i < nfft; ++i) {
-        Hs[(size_t)i].re = ((const Cc *)Hfft)[i].re / (T)nfft;
-        Hs[(size_t)i].im = ((const Cc *)Hfft)[i].im / (T)nfft;
-    }
-    Stager stg;
-    (void)stg.init();
-    if ((e = stg.h2d(din, in, sig_bytes, st)) != hipSuccess) return fail_("upload", e);
-    if ((e = hipMemcpyAsync(dH, Hs.data(), sizeof(Cc) * (size_t)nfft, hipMemcpyHostToDevice, st)) != hipSuccess) return fail_("upload H", e);
-    OlsArgs<T> a{};
-    a.in = din;
-    a.out = dout;
-    a.H = dH;
-    a.sigLen = sigLen;
-    a.njobs = numBlocks * nrows;
-    a.nrows = nrows;
-    a.log2nfft = lg;
-    a.d = d;
-    a.discard = discard;
-    a.D = D;
-    ols_defaults(a);
-    const int tpf = nfft / 16;
-    const int block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
-    const long long grid = (a.njobs + fpw - 1) / fpw;
-    const size_t lds = (size_t)fpw * lds_slots_per_fft(nfft) * sizeof(Cc);
-    if (block <= 256) {
-        (void)hipFuncSetAttribute((const void *)k_ols<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        k_ols<T, 256><<<(unsigned)grid, block, lds, st>>>(a);
-    } else {
-        (void)hipFuncSetAttribute((const void *)k_ols<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        k_ols<T, 1024><<<(unsigned)grid, block, lds, st>>>(a);
-    }
-    if ((e = hipGetLastError()) != hipSuccess) return fail_("launch k_ols", e);
-    if ((e = stg.d2h(out, dout, sig_bytes, st)) != hipSuccess) return fail_("download", e);
-    (void)hipFree(din);
-    (void)hipFree(dout);
-    (void)hipFree(dH);
-    (void)hipStreamDestroy(st);
-    return SSF_OK;
-}
-}  // namespace
 
 int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int log2nfft, int K, const void *Hfft,
                        const void *in, void *out, std::string *err) {
@@ -589,8 +30,8 @@ int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int
         *err = std::string("hipSetDevice: ") + hipGetErrorString(e);
         return SSF_ERR_HIP;
     }
-    return precision == SSF_C128 ? overlap_save_t<double>(sigLen, nrows, log2nfft, K, Hfft, in, out, err)
-                                 : overlap_save_t<float>(sigLen, nrows, log2nfft, K, Hfft, in, out, err);
+    return precision == SSF_C128 ? fused_overlap_save_f64(sigLen, nrows, log2nfft, K, Hfft, in, out, err)
+                                 : fused_overlap_save_f32(sigLen, nrows, log2nfft, K, Hfft, in, out, err);
 }
 
 bool fused_supports(int64_t N, int nrows, int precision) {
@@ -605,29 +46,18 @@ bool fused_supports(int64_t N, int nrows, int precision) {
     return fused::choose_split(l, precision, &s);
 }
 
-Engine *make_fused_engine(ssf_plan *plan) {
-    int rc;
-    Engine *e;
-    if (plan->precision == SSF_C128) {
-        auto *x = new FusedEngine<double>(plan);
-        rc = x->init();
-        e = x;
-    } else {
-        auto *x = new FusedEngine<float>(plan);
-        rc = x->init();
-        e = x;
-    }
-    if (rc != SSF_OK) {
-        delete e;
-        return nullptr;
-    }
-    return e;
-}
-
 }  // namespace ssf
 
 #ifdef SSF_PHASE_TIMING
+// phase stamps of the last launches (diagnostic build): the unit that ran has non-zero stamps
+extern "C" int ssf_debug_marks_f64(unsigned long long *out);
+extern "C" int ssf_debug_marks_f32(unsigned long long *out);
 extern "C" int ssf_debug_marks(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssf::g_marks), sizeof(unsigned long long) * 4 * 4096 * 8);
+    const size_t n = (size_t)4 * 4096 * 8;
+    std::vector<unsigned long long> a(n), b(n);
+    int rc = ssf_debug_marks_f64(a.data());
+    if (!rc) rc = ssf_debug_marks_f32(b.data());
+    for (size_t i = 0; i < n; ++i) out[i] = a[i] > b[i] ? a[i] : b[i];
+    return rc;
 }
 #endif

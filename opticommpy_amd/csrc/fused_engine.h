@@ -1,5 +1,5 @@
 // fused_engine.h -- host side of the fused radix-2^n engine, templated on a Backend so the
-// same control code drives real HIP launches (engine_fused.hip) and the CPU emulator
+// same control code drives real HIP launches (engine_fused_impl.h) and the CPU emulator
 // (tests/emu).  No host<->device synchronisation inside a step: the data-dependent control
 // flow (iteration count, adaptive step, span end) lives in a device-resident Ctrl block that
 // every launch reads and forwards; the host only enqueues a uniform launch sequence
@@ -401,7 +401,7 @@ template <typename T, class Backend> class FusedCore {
         lo[0] = make_linop(p.hz / 2, d.lin_a, d.lin_b, w2, 1.0 / (double)N, log2N);
         lo[1] = make_linop(p.hz, d.lin_a, d.lin_b, w2, 1.0 / (double)N, log2N);     // lin * lin
         be.h2d(linops, lo, sizeof(lo));
-        // small N: the whole span in one persistent launch (engine_fused.hip: k_nlse_span) when both stage grids fit the
+        // small N: the whole span in one persistent launch (engine_fused_impl.h: k_nlse_span) when both stage grids fit the
         // CUs with 256-thread workgroups
         int pgrid = 0, prow = 0, pcol = 0;
         size_t plds = 0;

@@ -1,6 +1,6 @@
 // fused_kernels.h -- kernel bodies of the fused pipeline, written against an execution
 // context `Ctx` (tid / bid / nthreads / nblocks / lds / sync()) so that the same source is
-// launched as HIP kernels on gfx950 (engine_fused.hip) and stepped by the CPU emulator in
+// launched as HIP kernels on gfx950 (engine_fused_impl.h) and stepped by the CPU emulator in
 // tests/emu (fibers; sync() yields).  No wave intrinsics: block reductions go through LDS.
 //
 // Decomposition of one length-N transform of a row (N = N1*N2, n = n1*N2 + n2,
@@ -1434,7 +1434,7 @@ template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2
     }
 }
 
-// arguments of the persistent span kernel (engine_fused.hip: k_nlse_span): every stage of a scalar-NLSE span in one launch
+// arguments of the persistent span kernel (engine_fused_impl.h: k_nlse_span): every stage of a scalar-NLSE span in one launch
 template <typename T> struct SpanNlseArgs {
     RowArgs<T> row;
     ColArgs<T> col;

@@ -129,7 +129,7 @@ inline int fir_nfft(int K) {
     while (nfft < K) nfft <<= 1;
     return nfft;
 }
-constexpr int kMaxNfft = 8192;            // c128 rows of the LDS transform (engine_fused.hip: k_ols)
+constexpr int kMaxNfft = 8192;            // c128 rows of the LDS transform (engine_fused_impl.h: k_ols)
 
 template <class Backend> struct RxCore {
     Backend &be;

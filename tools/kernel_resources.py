@@ -12,14 +12,16 @@ CSRC = os.path.join(ROOT, "opticommpy_amd", "csrc")
 
 
 def main():
-    keep = os.environ.get("SSF_KEEP_ASM")                      # path: keep / reuse the assembly listing
+    keep = os.environ.get("SSF_KEEP_ASM")                      # path prefix: keep / reuse the assembly listings
+    txt = ""
     with tempfile.TemporaryDirectory() as td:
-        asm = keep or os.path.join(td, "engine_fused.s")
-        if not (keep and os.path.exists(keep)):
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                               "-I" + CSRC, "-Wno-pass-failed", "--cuda-device-only", "-S"] + sys.argv[1:] +
-                                  [os.path.join(CSRC, "engine_fused.hip"), "-o", asm], stderr=subprocess.DEVNULL)
-        txt = open(asm).read()
+        for unit in ("engine_fused_f64", "engine_fused_f32"):  # the two translation units that hold the kernels
+            asm = (keep + "." + unit + ".s") if keep else os.path.join(td, unit + ".s")
+            if not (keep and os.path.exists(asm)):
+                subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                                       "-I" + CSRC, "-Wno-pass-failed", "--cuda-device-only", "-S"] + sys.argv[1:] +
+                                      [os.path.join(CSRC, unit + ".hip"), "-o", asm], stderr=subprocess.DEVNULL)
+            txt += open(asm).read()
     rows = []
     for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", txt, re.S):
         blk = m.group(0)
