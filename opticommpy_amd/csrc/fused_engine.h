@@ -57,7 +57,7 @@ inline bool choose_split(int log2N, int precision, Split *s, bool packed = false
 }
 
 // Lengths with factors 3 and 5 (N = 2^a * m, m odd and 5-smooth -- notebook lengths are SpS x Nsymbols):
-// the column length stays a power of two (2^8 if possible, else 2^9, 2^7, 2^10 out of the 2^a), the rest is the row length, transformed
+// the column length stays a power of two (2^8 if possible, else 2^9, 2^7, 2^10, 2^6 ... 2^4 out of the 2^a), the rest is the row length, transformed
 // by the mixed-radix row kernel (mixed_fft.h).  Rows of up to 8192 values (16 per thread, 512 threads, one row per workgroup:
 // 132 KiB of LDS in double precision).
 constexpr int64_t kMixMaxRow = 8192;
@@ -73,18 +73,20 @@ inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
     int64_t rest = m;
     for (int q : {3, 5})
         while (rest % q == 0) rest /= q;
-    if (rest != 1 || a < 7) return false;
+    if (rest != 1 || a < 4) return false;
     if (const char *e = std::getenv("SSF_MIX_L1")) {               // tuning knob: force log2 N1
         const int l = std::atoi(e);
         const int64_t n2 = N >> l;
         MixPlan mp;
-        if (l >= 7 && l <= std::min(a, 10) && n2 >= 64 && n2 <= kMixMaxRow && mix_make_plan((int)n2, &mp)) {
+        if (l >= 4 && l <= std::min(a, 10) && n2 >= 64 && n2 <= kMixMaxRow && mix_make_plan((int)n2, &mp)) {
             *l1 = l;
             *N2 = (int)n2;
             return true;
         }
     }
-    for (int l : {8, 9, 7, 10}) {      // measured (tools/exp/mix_split_sweep.py): 2^8 columns beat 2^9 by 8-13 %, 2^10 loses 15-25 %
+    // 8, 9, 7, 10: measured (tools/exp/mix_split_sweep.py): 2^8 columns beat 2^9 by 8-13 %, 2^10 loses 15-25 %; 6, 5, 4: lengths with
+    // few factors of two (12 000 = 2^5 x 375, 6000 = 2^4 x 375): short columns, still far cheaper than a Bluestein transform
+    for (int l : {8, 9, 7, 10, 6, 5, 4}) {
         if (l > a) continue;
         const int64_t n2 = N >> l;
         MixPlan mp;
