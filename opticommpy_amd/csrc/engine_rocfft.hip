@@ -17,6 +17,9 @@
 
 #include <mutex>
 
+#include "dev_ctx.h"
+#include "fused_kernels.h"
+#include "rx_pipeline.h"
 #include "ssf_internal.h"
 #include "ssf_rng.h"
 
@@ -249,6 +252,53 @@ __global__ void k_blue_post(const typename Cx<T>::type *wk, typename Cx<T>::type
     }
 }
 
+// Bluestein for M <= 8192 (N <= 4096): the whole transform in ONE launch -- chirp-multiply and zero-pad on load, M-point
+// forward transform in LDS, x B (natural-order spectrum of the chirp kernel, 1 / M folded in), inverse transform, chirp-multiply
+// on store: the overlap-save kernel's structure (fused_kernels.h: ols_body) with one block per row.  The three-launch
+// FusedConv path costs five launches per transform, and at these sizes every launch is a latency chain.
+template <typename T> struct BlueArgs {
+    const fused::cx<T> *in;
+    fused::cx<T> *out;
+    const double2 *ch;
+    const fused::cx<T> *Bhat;       // M values
+    long long N, njobs;
+    int log2M, inverse;
+};
+template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT) k_blue(const BlueArgs<T> a) {
+    using namespace fused;
+    extern __shared__ __attribute__((aligned(16))) char blue_smem[];
+    DevCtxCore ctx{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, blue_smem};
+    const PassPlan p = make_plan(a.log2M);
+    const int fpw = ctx.nthreads / p.tpf, f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
+    const long long job = (long long)ctx.bid * fpw + f;
+    const bool live = job < a.njobs;                       // idle threads still take part in the barriers
+    cx<T> *l = (cx<T> *)ctx.lds + (size_t)f * lds_slots_per_fft(p.L);
+    cx<T> v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const long long n = b + p.tpf * q;
+        v[q] = mk<T>((T)0, (T)0);
+        if (live && n < a.N) {
+            const cx<T> e = a.in[job * a.N + n];
+            const double c = a.ch[n].x, sn = a.inverse ? -a.ch[n].y : a.ch[n].y;
+            v[q] = mk<T>((T)((double)e.re * c - (double)e.im * sn), (T)((double)e.re * sn + (double)e.im * c));
+        }
+    }
+    fft_dif<-1>(ctx, p, b, v, l);
+    const int last = p.npass - 1;
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * a.Bhat[rev_pos(p, reg_pos(p, last, b, idx))];
+    fft_dit<+1>(ctx, p, b, v, l);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const long long k = b + p.tpf * q;
+        if (live && k < a.N) {
+            const double c = a.ch[k].x, sn = a.inverse ? -a.ch[k].y : a.ch[k].y;
+            a.out[job * a.N + k] = mk<T>((T)((double)v[q].re * c - (double)v[q].im * sn), (T)((double)v[q].re * sn + (double)v[q].im * c));
+        }
+    }
+}
+
 std::once_flag g_rocfft_once;
 
 template <typename T> class RocfftEngine final : public Engine {
@@ -266,7 +316,8 @@ template <typename T> class RocfftEngine final : public Engine {
     void *work = nullptr;
     const bool blue;                              // transforms by Bluestein on the fused kernels instead of rocFFT
     int64_t M = 0;
-    FusedConv *conv = nullptr;
+    FusedConv *conv = nullptr;                    // M > 8192: three fused launches per convolution
+    fused::cx<T> *Bhat[2] = {nullptr, nullptr};   // M <= 8192: spectra of the two chirp kernels for the one-launch transform
     double2 *chirp = nullptr;                     // exp(-j pi n^2 / N), n < N
     std::vector<C *> snaps;
     C *E = nullptr;           // current field (points at bufA or bufB)
@@ -301,8 +352,11 @@ template <typename T> class RocfftEngine final : public Engine {
     }
     int init_bluestein() {
         M = bluestein_length(N);
-        conv = make_fused_conv(pl, M, nrows);
-        if (!conv) return pl->err.find("out of memory") != std::string::npos ? SSF_ERR_OOM : SSF_ERR_UNSUPPORTED;
+        const bool one_launch = M <= 8192;
+        if (!one_launch) {
+            conv = make_fused_conv(pl, M, nrows);
+            if (!conv) return pl->err.find("out of memory") != std::string::npos ? SSF_ERR_OOM : SSF_ERR_UNSUPPORTED;
+        }
         // chirp with the exact quadratic residue: n^2 mod 2N in integers, angle = -pi r / N
         std::vector<double2> ch((size_t)N);
         for (int64_t n = 0; n < N; ++n) {
@@ -323,6 +377,23 @@ template <typename T> class RocfftEngine final : public Engine {
                 v.y = (T)((which == 0 ? -ch[(size_t)m].y : ch[(size_t)m].y) / (double)M);
                 b[(size_t)m] = v;
                 if (m) b[(size_t)(M - m)] = v;
+            }
+            if (one_launch) {                        // natural-order spectrum of the kernel, computed on the host in double
+                std::vector<rx::zc> hb((size_t)M, rx::zc(0.0, 0.0));      // (from the exact chirp, not from its rounded copy)
+                for (int64_t m = 0; m < N; ++m) {
+                    const rx::zc v(ch[(size_t)m].x / (double)M, (which == 0 ? -ch[(size_t)m].y : ch[(size_t)m].y) / (double)M);
+                    hb[(size_t)m] = v;
+                    if (m) hb[(size_t)(M - m)] = v;
+                }
+                rx::host_fft(hb, -1);
+                std::vector<fused::cx<T>> hs((size_t)M);
+                for (int64_t m = 0; m < M; ++m) {
+                    hs[(size_t)m].re = (T)hb[(size_t)m].real();
+                    hs[(size_t)m].im = (T)hb[(size_t)m].imag();
+                }
+                SSF_HIP(pl, hipMalloc(&Bhat[which], sizeof(fused::cx<T>) * (size_t)M));
+                SSF_HIP(pl, hipMemcpy(Bhat[which], hs.data(), sizeof(fused::cx<T>) * (size_t)M, hipMemcpyHostToDevice));
+                continue;
             }
             int rc = conv->set_kernel(which, b.data());
             if (rc) return fail(pl, rc, "Bluestein kernel: " + conv->error());
@@ -375,6 +446,8 @@ template <typename T> class RocfftEngine final : public Engine {
         if (inv && !blue) rocfft_plan_destroy(inv);
         if (info) rocfft_execution_info_destroy(info);
         delete conv;
+        for (auto *q : Bhat)
+            if (q) (void)hipFree(q);
         if (chirp) (void)hipFree(chirp);
         for (void *p : {(void *)bufA, (void *)bufB, (void *)Ehd, (void *)F, (void *)lin, (void *)P, (void *)part,
                         (void *)work, (void *)noise_d})
@@ -412,6 +485,24 @@ template <typename T> class RocfftEngine final : public Engine {
 
   private:
     int fft(rocfft_plan p, C *in, C *out) {
+        if (blue && !conv) {                         // M <= 8192: one launch per batched transform
+            const int inverse = p == inv ? 1 : 0;
+            int lg = 0;
+            while ((1ll << lg) < M) ++lg;
+            BlueArgs<T> a{(const fused::cx<T> *)in, (fused::cx<T> *)out, chirp, Bhat[inverse], (long long)N, (long long)nrows, lg, inverse};
+            const int tpf = (int)(M / 16), block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
+            const int grid = (nrows + fpw - 1) / fpw;
+            const size_t lds = (size_t)fpw * fused::lds_slots_per_fft((int)M) * sizeof(fused::cx<T>);
+            if (block <= 256) {
+                (void)hipFuncSetAttribute((const void *)k_blue<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                k_blue<T, 256><<<grid, block, lds, pl->stream>>>(a);
+            } else {
+                (void)hipFuncSetAttribute((const void *)k_blue<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                k_blue<T, 512><<<grid, block, lds, pl->stream>>>(a);
+            }
+            SSF_HIP(pl, hipGetLastError());
+            return SSF_OK;
+        }
         if (blue) {
             const int inverse = p == inv ? 1 : 0;
             C *wk = (C *)conv->work();
