@@ -124,6 +124,74 @@ def oracle_run(w, E, n, dtype):
     return ref, time.perf_counter() - t0, tr
 
 
+def unit_checksum(out, seed=4242):
+    """(power, projection) of one unit's output (rows, N): sum |E|^2 and |sum_rn E[r, n] q[r, n]| with a seeded
+    unit-variance complex vector q -- the power alone cannot tell two units of equal launch power apart."""
+    o = out.astype(np.complex128)
+    rng = np.random.default_rng(seed)
+    q = (rng.normal(size=o.shape) + 1j * rng.normal(size=o.shape)) / np.sqrt(2)
+    return float(np.sum(np.abs(o) ** 2)), float(np.abs(np.vdot(q, o)))
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """--gpus N without a launcher: start the N ranks ourselves (one process per GPU, the environment torchrun would
+    export, a fresh private directory for the RCCL rendezvous file) and relay rank 0's JSON line."""
+    import shutil
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="ssf_bench_")
+    port = str(free_port())
+    procs = []
+
+    def die_with_parent():                                      # a killed launcher must not leave ranks behind
+        try:
+            C.CDLL("libc.so.6").prctl(1, 9)                      # PR_SET_PDEATHSIG, SIGKILL
+        except Exception:
+            pass
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SSF_RCCL_ID_FILE=os.path.join(tmp, "rccl.id"),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, preexec_fn=die_with_parent))
+        chunks = []
+        rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        rd.start()
+        failed_at = None
+        while any(p.poll() is None for p in procs):             # a rank that dies leaves the others in a collective:
+            if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+                failed_at = time.time()
+            if failed_at is not None and time.time() - failed_at > 10.0:
+                break                                           # ... give them ten seconds, then end the run
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        rcs = [p.wait() for p in procs]
+        rd.join(5.0)
+        out0 = b"".join(chunks).decode(errors="replace")
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(tmp, ignore_errors=True)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc]
+    if bad:
+        sys.stderr.write("bench.py --gpus %d: rank(s) failed: %s\n" % (n, bad))
+        sys.exit(1)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +207,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU oracle leg (0: sized for ~10-20 s)")
     ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel HIP-event pass")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher: be one (a launcher's environment wins)
+        self_launch(args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -156,16 +227,14 @@ def main():
 
     comm, comm_name = None, "none (single process)"
     if world > 1 or os.environ.get("SSF_BENCH_FORCE_COMM"):    # (the env var exercises the RCCL path on one GPU)
-        try:
-            if os.environ.get("SSF_BENCH_COMM") == "gloo":      # (test knob: the control flow of N ranks on one GPU)
-                raise RuntimeError("SSF_BENCH_COMM=gloo")
-            comm = mgpu.RcclComm.from_env(device=local_rank)
-            comm_name = "RCCL via libssf_hip.so (ssf_comm_*)"
-        except Exception as e:                                  # safety net for the scaling run only: never silent
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
+        if os.environ.get("SSF_BENCH_COMM") == "gloo":          # (explicit opt-in, tests: N ranks against one GPU,
+            sys.path.insert(0, os.path.join(ROOT, "tests"))     #  which RCCL refuses)
             from comm_gloo import GlooComm
             comm = GlooComm()
-            comm_name = "torch.distributed gloo stand-in (RCCL binding failed: %s)" % e
+            comm_name = "torch.distributed gloo stand-in (SSF_BENCH_COMM=gloo)"
+        else:                                                   # RCCL or nothing: a failure here fails the run
+            comm = mgpu.RcclComm.from_env(device=local_rank)
+            comm_name = "RCCL via libssf_hip.so (ssf_comm_*)"
 
     cfg = int(args.config)
     w = workload(cfg, args.log2n, args.prec, world)
@@ -256,14 +325,14 @@ def main():
         _lib.raise_for(lib, plans[u], lib.ssf_download(plans[u], o.ctypes.data_as(C.c_void_p)))
         outs[u] = o
     per = max(len(mgpu.shard_range(U, world, r)) for r in range(world))
-    cs = np.zeros(per)
+    cs = np.zeros((per, 2))
     for i, u in enumerate(mine):
-        cs[i] = float(np.sum(np.abs(outs[u].astype(np.complex128)) ** 2))
+        cs[i] = unit_checksum(outs[u])
     if comm is not None:
         allcs = comm.allgather(cs)
-        checksums = [float(allcs[r][i]) for r in range(world) for i in range(len(mgpu.shard_range(U, world, r)))]
+        checksums = [[float(x) for x in allcs[r][i]] for r in range(world) for i in range(len(mgpu.shard_range(U, world, r)))]
     else:
-        checksums = [float(x) for x in cs[:len(mine)]]
+        checksums = [[float(x) for x in c] for c in cs[:len(mine)]]
 
     rec = None
     ok = True
@@ -297,7 +366,7 @@ def main():
                                  "'HBM' figure of config 2 is partly an Infinity-Cache figure; configs with N >= 2^21 "
                                  "(complex128) / 2^22 run out of it"},
             "comm": comm_name, "rccl_ranks": world if comm is not None and comm_name.startswith("RCCL") else 0,
-            "unit_checksums": checksums,
+            "unit_checksums": checksums,          # per unit: [sum |E|^2, |<q, E>|] with a seeded random vector q
         }
 
         # per-kernel timing pass (HIP events around every launch; separate from the headline run because the events

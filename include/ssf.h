@@ -98,11 +98,15 @@ typedef struct {
     double  maxNlinPhaseRot;  /* [rad]                                                   */
     double  NF;               /* EDFA noise figure [dB]                                  */
     int32_t n_save;           /* number of entries of save_spans (0 = final field only)  */
-    int32_t reserved;
+    int32_t rng_row_offset;   /* device ASE noise: row r of this plan draws stream row      */
+                              /* rng_row_offset + r (ranks holding parts of one coupled     */
+                              /* batch, Monte-Carlo units sharing a seed: distinct offsets  */
+                              /* give independent noise); 0 for a stand-alone call          */
     const int32_t *save_spans;/* 1-based span indexes to snapshot (reference saveSpanN)  */
     int64_t rng_seed;         /* amp == EDFA and no host noise given: != 0 -> ASE noise is */
                               /* generated on the device (Philox4x32-10 keyed by rng_seed, */
-                              /* counter = sample/row/span); 0 -> gain only                */
+                              /* counter = sample / rng_row_offset + row / span); 0 -> gain */
+                              /* only                                                       */
 } ssf_params;
 
 typedef struct {

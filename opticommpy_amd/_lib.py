@@ -22,7 +22,7 @@ class Params(C.Structure):
                 ("alpha", C.c_double), ("D", C.c_double), ("gamma", C.c_double), ("Lspan", C.c_double),
                 ("Nspans", C.c_int32), ("maxIter", C.c_int32), ("hz", C.c_double), ("tol", C.c_double),
                 ("nlprMethod", C.c_int32), ("amp", C.c_int32), ("maxNlinPhaseRot", C.c_double),
-                ("NF", C.c_double), ("n_save", C.c_int32), ("reserved", C.c_int32),
+                ("NF", C.c_double), ("n_save", C.c_int32), ("rng_row_offset", C.c_int32),
                 ("save_spans", C.POINTER(C.c_int32)), ("rng_seed", C.c_int64)]
 
 

@@ -12,6 +12,12 @@ struct DevCtxCore {
     __device__ __forceinline__ void sync() { __syncthreads(); }
     // keeps the instruction scheduler from moving memory operations across this point
     __device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
+    // idle for n * 64 clocks (s_sleep takes at most 127 ticks at a time)
+    __device__ __forceinline__ void sleep64(int n) {
+        for (; n >= 64; n -= 64) __builtin_amdgcn_s_sleep(64);
+        for (; n >= 8; n -= 8) __builtin_amdgcn_s_sleep(8);
+        for (; n >= 1; n -= 1) __builtin_amdgcn_s_sleep(1);
+    }
     // all-lanes butterfly over the 64-lane wave (every lane returns the same value)
     __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

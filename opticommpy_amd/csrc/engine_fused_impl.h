@@ -60,6 +60,11 @@ template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds
     SSF_DEV_CTX(0);
     row_body<T, LG>(ctx, a);
 }
+// eight values per thread: at most 128 registers, four waves per SIMD (two 512-thread workgroups, or one of 1024, per CU)
+template <typename T, int MAXT, int LG> __global__ void __launch_bounds__(MAXT, 4) k_row8(const RowArgs<T> a) {
+    SSF_DEV_CTX(0);
+    row_body<T, LG, 8>(ctx, a);
+}
 // Manakov column kernels run 512 threads (x half | y half); the single-row modes run 256
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs<T> a) {
@@ -169,7 +174,18 @@ template <typename T> using RowFn = void (*)(const RowArgs<T>);
 template <typename T> using ColFn = void (*)(const ColArgs<T>);
 
 // kernel selection: specialised lengths for the sizes that matter, generic otherwise
-template <typename T> RowFn<T> pick_row(int lg2, int block, int occ) {
+template <typename T> RowFn<T> pick_row(int lg2, int block, int occ, int vpt = 16) {
+    if (vpt == 8) {
+        if (block <= 512) {
+            switch (lg2) {
+            case 10: return k_row8<T, 512, 10>;
+            case 11: return k_row8<T, 512, 11>;
+            case 12: return k_row8<T, 512, 12>;
+            default: return k_row8<T, 512, 0>;
+            }
+        }
+        return lg2 == 13 ? k_row8<T, 1024, 13> : k_row8<T, 1024, 0>;
+    }
     if (block <= 256) {
         if (occ == 2) {
             switch (lg2) {
@@ -334,9 +350,9 @@ struct HipBackend {
     }
     template <typename T> void launch_row(const RowArgs<T> &a, int grid, int block, size_t lds) {
         RowFn<T> f;
-        if constexpr (std::is_same<T, pf2>::value) f = pick_row<T>(a.log2N2, block, row_occ);     // (no mixed-radix rows there)
+        if constexpr (std::is_same<T, pf2>::value) f = pick_row<T>(a.log2N2, block, row_occ, a.vpt);     // (no mixed-radix rows there)
         else
-            f = !a.mixed ? pick_row<T>(a.log2N2, block, row_occ)
+            f = !a.mixed ? pick_row<T>(a.log2N2, block, row_occ, a.vpt)
                 : block <= 256 ? (RowFn<T>)k_row_mixed<T, 256> : block <= 512 ? (RowFn<T>)k_row_mixed<T, 512> : (RowFn<T>)k_row_mixed<T, 1024>;
         arm((const void *)f);
         stamp_begin(0);

@@ -198,7 +198,7 @@ __global__ void k_finish(const double *a, const double *b, const double *c, int 
 // span epilogue: E = E*gain (+ noise)      (channels.py:443-451, devices.py:726)
 template <typename T>
 __global__ void k_amp(typename Cx<T>::type *E, int64_t total, T gain, const typename Cx<T>::type *noise,
-                      double sigma = 0.0, unsigned long long seed = 0, unsigned span = 0, int64_t N = 1) {
+                      double sigma = 0.0, unsigned long long seed = 0, unsigned span = 0, int64_t N = 1, unsigned row0 = 0) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         auto e = E[i];
         e.x *= gain;
@@ -209,7 +209,7 @@ __global__ void k_amp(typename Cx<T>::type *E, int64_t total, T gain, const type
         }
         if (sigma > 0) {       // device-generated ASE (same generator as the fused engine)
             double re, im;
-            gauss_pair((unsigned long long)(i % N), (unsigned)(i / N), span, seed, sigma, re, im);
+            gauss_pair((unsigned long long)(i % N), row0 + (unsigned)(i / N), span, seed, sigma, re, im);
             e.x += (T)re;
             e.y += (T)im;
         }
@@ -563,7 +563,7 @@ template <typename T> class RocfftEngine final : public Engine {
             const bool dev_noise = !noise && p.rng_seed != 0;
             k_amp<T><<<grid_for(total), kBlock, 0, pl->stream>>>(E, total, (T)std::sqrt(d.G_lin), nz,
                                                                   dev_noise ? std::sqrt(d.p_noise / 2) : 0.0,
-                                                                  (unsigned long long)p.rng_seed, (unsigned)span, N);
+                                                                  (unsigned long long)p.rng_seed, (unsigned)span, N, (unsigned)p.rng_row_offset);
         } else if (p.amp == SSF_AMP_IDEAL) {
             k_amp<T><<<grid_for(total), kBlock, 0, pl->stream>>>(E, total, (T)ideal_gain, nullptr);
         }

@@ -96,6 +96,8 @@ template <> SSF_HD pf2 fma_s<pf2>(pf2 x, float a, pf2 c) {
 // written by one launch and read by the next one, normally from another XCD: keeping them in the writer's L2 buys
 // nothing and leaves the whole output dirty until the end-of-kernel write-back.  A non-temporal access streams
 // through instead.  bit 0: G stores, bit 1: G loads, bit 2: field / E_hd stores, bit 3: field / E_hd loads.
+// SSF_WT bits (same numbering, stores only): write-through stores (sc0 sc1): the line leaves the L2 when it is stored
+// instead of waiting, dirty, for the end-of-kernel write-back (up to 32 MiB of L2 to flush before the next launch starts).
 #ifndef SSF_MEMPOL
 #define SSF_MEMPOL 0
 #endif
@@ -115,8 +117,25 @@ template <int BIT, typename T> SSF_HD cx<T> ld_pol(const cx<T> *p) {
 #endif
     return *p;
 }
+#ifndef SSF_WT
+#define SSF_WT 0
+#endif
 template <int BIT, typename T> SSF_HD void st_pol(cx<T> *p, cx<T> x) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr ((SSF_WT >> BIT) & 1) {
+        if constexpr (sizeof(cx<T>) == 16) {
+            typedef float vec4 __attribute__((ext_vector_type(4)));
+            vec4 v;
+            __builtin_memcpy(&v, &x, 16);
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        } else {
+            typedef float vec2 __attribute__((ext_vector_type(2)));
+            vec2 v;
+            __builtin_memcpy(&v, &x, 8);
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        }
+        return;
+    }
     if constexpr ((SSF_MEMPOL >> BIT) & 1) {
         if constexpr (sizeof(T) == sizeof(scalar_t<T>)) {
             typedef T vec2 __attribute__((ext_vector_type(2)));
@@ -383,9 +402,9 @@ template <typename T> SSF_HD void powers16(cx<T> w, cx<T> *p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Mixed-radix pass plan for one length-L transform (L = 2^m, 16 <= L <= 65536), 16 values
-// per thread, L/16 threads per transform.
-//   radices r_0..r_{p-1}:  [16, (2^rem), 16, 16, ...]   with rem = (m - 4) mod 4
+// Mixed-radix pass plan for one length-L transform (L = 2^m, 16 <= L <= 65536), V = 2^lgV values
+// per thread (16, or 8 for the 128-register kernels that run four waves per SIMD), L/V threads per transform.
+//   radices r_0..r_{p-1}:  [V, (2^rem), V, V, ...]   with rem = (m - lgV) mod lgV
 //   L_0 = L, L_{i+1} = L_i / r_i   (L_p = 1)
 // Pass i works in place on positions  block*L_i + j + L_{i+1}*q  (q = 0..r_i-1),
 // butterfly id bb = block*L_{i+1} + j  in [0, L / r_i).
@@ -393,7 +412,8 @@ template <typename T> SSF_HD void powers16(cx<T> w, cx<T> *p) {
 //   pos = sum_i s_i * L_{i+1},   k = sum_i s_i * (r_0 ... r_{i-1}).
 // ---------------------------------------------------------------------------------------
 struct PassPlan {
-    int L, log2L, npass, tpf;      // tpf = threads per transform = L/16
+    int L, log2L, npass, tpf;      // tpf = threads per transform = L/V
+    int lgV;                       // log2 of the values per thread
     unsigned lg_pk;                // 4 bits per pass: log2 r_i
     unsigned long long lgLn_pk;    // 8 bits per pass: log2 L_{i+1} (stride of pass i)
     // packed (not arrays) so that a runtime pass index never forces the plan into scratch memory
@@ -402,20 +422,21 @@ struct PassPlan {
     SSF_HD int lgLn(int i) const { return (int)((lgLn_pk >> (8 * i)) & 255ull); }
 };
 
-SSF_HD PassPlan make_plan(int log2L) {
+SSF_HD PassPlan make_plan(int log2L, int lgV = 4) {
     PassPlan p;
     p.L = 1 << log2L;
     p.log2L = log2L;
-    p.tpf = p.L >> 4;
+    p.lgV = lgV;
+    p.tpf = p.L >> lgV;
     p.lg_pk = 0;
     p.lgLn_pk = 0;
     int n = 0, left = log2L;
-    const int rem = (log2L - 4) & 3, n16 = (log2L - 4) >> 2;
+    const int rem = (log2L - lgV) % lgV, n16 = (log2L - lgV) / lgV;
     for (int i = 0; i < 2 + n16; ++i) {
         int lg;
-        if (i == 0) lg = 4;
+        if (i == 0) lg = lgV;
         else if (i == 1) lg = rem;
-        else lg = 4;
+        else lg = lgV;
         if (lg == 0) continue;
         left -= lg;
         p.lg_pk |= (unsigned)lg << (4 * n);

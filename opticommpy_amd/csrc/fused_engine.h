@@ -131,6 +131,8 @@ template <typename T, class Backend> class FusedCore {
     long long tr_cap = 0;
     int tr_maxIter = 0;
     std::vector<C *> snaps;
+    int row_v = 16;              // values per thread of the radix-2^n row kernel (SSF_ROW_V=8: 128-register kernels)
+    int row_stagger = 0;         // 64-clock ticks the second half of the row grid starts late (SSF_ROW_STAGGER)
     int cur = 0;                 // which of T0/T1 holds the current field
     unsigned seq = 0;
     // launch geometry
@@ -206,8 +208,11 @@ template <typename T, class Backend> class FusedCore {
                 if (mix_plan_from_radices(N2mix, r, n, &mp) && mp.r[mp.npass - 1] <= kMixMaxOpRadix) mix_plan = mp;
             }
         } else {
-            const int tpf2 = (1 << sp.l2) / 16;
-            int fpw = tpf2 >= 256 ? 1 : 256 / tpf2;           // row transforms per workgroup
+            if (const char *e = std::getenv("SSF_ROW_V")) row_v = std::atoi(e) == 8 ? 8 : 16;
+            if (const char *e = std::getenv("SSF_ROW_STAGGER")) row_stagger = std::max(0, std::atoi(e));
+            if (sp.l2 < 6) row_v = 16;
+            const int tpf2 = (1 << sp.l2) / row_v, wg = row_v == 8 ? 512 : 256;
+            int fpw = tpf2 >= wg ? 1 : wg / tpf2;             // row transforms per workgroup
             if (const char *e = std::getenv("SSF_ROW_FPW")) fpw = std::max(1, std::min(fpw, std::atoi(e)));   // tuning knob
             while (nfft % fpw) fpw >>= 1;                      // (nrows need not be a power of two)
             row_block = fpw * tpf2;
@@ -298,6 +303,8 @@ template <typename T, class Backend> class FusedCore {
         if (N2mix) a.plan = mix_plan;
         a.wtab = wtab;
         a.rows_per_wg = mix_rows;
+        a.vpt = row_v;
+        a.stagger = row_stagger;
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {
@@ -345,7 +352,8 @@ template <typename T, class Backend> class FusedCore {
         a.npart = col_grid_1;
         be.launch_col(a, col_grid_1, col_block_1, col_lds_1);
     }
-    void launch_amp(C *E, S gain, const C *noise, double sigma = 0.0, unsigned long long seed = 0, unsigned span = 0) {
+    void launch_amp(C *E, S gain, const C *noise, double sigma = 0.0, unsigned long long seed = 0, unsigned span = 0,
+                    unsigned row0 = 0) {
         if constexpr (!kPacked) {
             AmpArgs<S> a{};
             a.E = E;
@@ -356,6 +364,7 @@ template <typename T, class Backend> class FusedCore {
             a.sigma = sigma;
             a.seed = seed;
             a.span = span;
+            a.row0 = row0;
             be.launch_amp(a, 1024, 256);
         }
     }
@@ -387,7 +396,7 @@ template <typename T, class Backend> class FusedCore {
             }
             const bool dev_noise = !noise && p.rng_seed != 0;                     // devices.py:723-726
             launch_amp(Tcur(), (S)std::sqrt(d.G_lin), nz, dev_noise ? std::sqrt(d.p_noise / 2) : 0.0,
-                       (unsigned long long)p.rng_seed, (unsigned)span);
+                       (unsigned long long)p.rng_seed, (unsigned)span, (unsigned)p.rng_row_offset);
         } else if (p.amp == SSF_AMP_IDEAL) {
             launch_amp(Tcur(), (S)ideal_gain, nullptr);
         }
@@ -430,6 +439,8 @@ template <typename T, class Backend> class FusedCore {
                     SpanNlseArgs<T> a{};
                     a.row = row_args();
                     a.row.use_ctrl = 0;
+                    a.row.vpt = 16;
+                    a.row.stagger = 0;
                     a.col = col_args(1, CM_NLSE_STEP);
                     a.col.T0 = E;
                     a.col.g_hz = (S)(p.gamma * p.hz);

@@ -165,23 +165,26 @@ template <int R> SSF_HD void tw_powers(int sign, int j, int lgL, cx<double> *p) 
     }
 }
 
-// butterflies of pass i for thread b (values v[u*r + q]); DIF: DFT then twiddle w^s
-template <int SIGN, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, int b, cx<T> *v) {
+// butterflies of pass i for thread b (values v[u*r + q]); DIF: DFT then twiddle w^s.  V = values per thread (16, or 8 for
+// the 128-register kernels): a thread carries V / r butterflies of a radix-r pass.
+template <int SIGN, int V = 16, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, int b, cx<T> *v) {
     const int lgLi = pass_lgLi(p, i);
     const bool tw = p.lgLn(i) > 0;
     switch (p.lg(i)) {
-    case 4: {
-        dft16<SIGN>(v);
-        if (tw) {
-            cx<double> w[16];
-            tw_powers<16>(SIGN, pass_j(p, i, b), lgLi, w);
+    case 4:
+        if constexpr (V >= 16) {
+            dft16<SIGN>(v);
+            if (tw) {
+                cx<double> w[16];
+                tw_powers<16>(SIGN, pass_j(p, i, b), lgLi, w);
 #pragma unroll
-            for (int s = 1; s < 16; ++s) v[s] = mul_by_d(v[s], w[s]);
+                for (int s = 1; s < 16; ++s) v[s] = mul_by_d(v[s], w[s]);
+            }
         }
-    } break;
+        break;
     case 3:
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < V / 8; ++u) {
             dft8<SIGN>(v + 8 * u);
             if (tw) {
                 cx<double> w[8];
@@ -193,7 +196,7 @@ template <int SIGN, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, i
         break;
     case 2:
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < V / 4; ++u) {
             dft4<SIGN>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
             if (tw) {
                 cx<double> w[4];
@@ -205,7 +208,7 @@ template <int SIGN, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, i
         break;
     default:
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < V / 2; ++u) {
             dft2<SIGN>(v[2 * u], v[2 * u + 1]);
             if (tw) {
                 cx<double> w[2];
@@ -218,22 +221,24 @@ template <int SIGN, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, i
 }
 
 // DIT: twiddle w^s then DFT (exact mirror of dif_pass with the opposite SIGN)
-template <int SIGN, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, int b, cx<T> *v) {
+template <int SIGN, int V = 16, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, int b, cx<T> *v) {
     const int lgLi = pass_lgLi(p, i);
     const bool tw = p.lgLn(i) > 0;
     switch (p.lg(i)) {
-    case 4: {
-        if (tw) {
-            cx<double> w[16];
-            tw_powers<16>(SIGN, pass_j(p, i, b), lgLi, w);
+    case 4:
+        if constexpr (V >= 16) {
+            if (tw) {
+                cx<double> w[16];
+                tw_powers<16>(SIGN, pass_j(p, i, b), lgLi, w);
 #pragma unroll
-            for (int s = 1; s < 16; ++s) v[s] = mul_by_d(v[s], w[s]);
+                for (int s = 1; s < 16; ++s) v[s] = mul_by_d(v[s], w[s]);
+            }
+            dft16<SIGN>(v);
         }
-        dft16<SIGN>(v);
-    } break;
+        break;
     case 3:
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < V / 8; ++u) {
             if (tw) {
                 cx<double> w[8];
                 tw_powers<8>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
@@ -245,7 +250,7 @@ template <int SIGN, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, i
         break;
     case 2:
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < V / 4; ++u) {
             if (tw) {
                 cx<double> w[4];
                 tw_powers<4>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
@@ -257,7 +262,7 @@ template <int SIGN, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, i
         break;
     default:
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < V / 2; ++u) {
             if (tw) {
                 cx<double> w[2];
                 tw_powers<2>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
@@ -269,44 +274,44 @@ template <int SIGN, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, i
     }
 }
 
-// transform-local position of register idx (0..15) of thread b in pass i
+// transform-local position of register idx (0..V-1) of thread b in pass i
 SSF_HD int reg_pos(const PassPlan &p, int i, int b, int idx) {
     const int lg = p.lg(i);
     return pass_pos(p, i, b + p.tpf * (idx >> lg), idx & ((1 << lg) - 1));
 }
 
-template <typename T> SSF_HD void lds_put(const PassPlan &p, int i, int b, const cx<T> *v, cx<T> *lds) {
+template <int V = 16, typename T> SSF_HD void lds_put(const PassPlan &p, int i, int b, const cx<T> *v, cx<T> *lds) {
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) lds[lds_slot(reg_pos(p, i, b, idx))] = v[idx];
+    for (int idx = 0; idx < V; ++idx) lds[lds_slot(reg_pos(p, i, b, idx))] = v[idx];
 }
-template <typename T> SSF_HD void lds_get(const PassPlan &p, int i, int b, cx<T> *v, const cx<T> *lds) {
+template <int V = 16, typename T> SSF_HD void lds_get(const PassPlan &p, int i, int b, cx<T> *v, const cx<T> *lds) {
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) v[idx] = lds[lds_slot(reg_pos(p, i, b, idx))];
+    for (int idx = 0; idx < V; ++idx) v[idx] = lds[lds_slot(reg_pos(p, i, b, idx))];
 }
 
 // DIF transform: v holds pass-0 positions on entry, pass-(p-1) positions (digit-reversed) on exit
-template <int SIGN, typename T, class Ctx>
+template <int SIGN, int V = 16, typename T, class Ctx>
 SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
-    dif_pass<SIGN>(p, 0, b, v);
+    dif_pass<SIGN, V>(p, 0, b, v);
 #pragma unroll
     for (int i = 1; i < p.npass; ++i) {
-        lds_put(p, i - 1, b, v, lds);
+        lds_put<V>(p, i - 1, b, v, lds);
         ctx.sync();
-        lds_get(p, i, b, v, lds);
-        dif_pass<SIGN>(p, i, b, v);
+        lds_get<V>(p, i, b, v, lds);
+        dif_pass<SIGN, V>(p, i, b, v);
     }
 }
 // DIT transform: v holds pass-(p-1) positions on entry, pass-0 positions (natural) on exit
-template <int SIGN, typename T, class Ctx>
+template <int SIGN, int V = 16, typename T, class Ctx>
 SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
 #pragma unroll
     for (int i = p.npass - 1; i >= 1; --i) {
-        dit_pass<SIGN>(p, i, b, v);
-        lds_put(p, i, b, v, lds);
+        dit_pass<SIGN, V>(p, i, b, v);
+        lds_put<V>(p, i, b, v, lds);
         ctx.sync();
-        lds_get(p, i - 1, b, v, lds);
+        lds_get<V>(p, i - 1, b, v, lds);
     }
-    dit_pass<SIGN>(p, 0, b, v);
+    dit_pass<SIGN, V>(p, 0, b, v);
 }
 
 // ------------------------------------------------------------------------ block reductions
@@ -432,32 +437,39 @@ template <typename T> struct RowArgs {
     // an array in the row kernel's own spectrum order, [k1][position after the forward passes], the same for every field row
     const cx<T> *harr;        // use_ctrl == 0 and lin == nullptr: spectrum *= harr[(rr mod N1) * N2 + position]
     int fwd_only;             // 1: stop after the forward row transform and store the spectrum in that order (makes harr)
+    int vpt;                  // values per thread of the radix-2^n row kernel: 16 (0 = 16) or 8
+    int stagger;              // > 0: the second half of the grid starts this many 64-clock ticks late (co-resident workgroups
+                              // out of phase: one loads / stores while the other transforms)
 };
 
-// linear operator for the 16 registers of a last-radix-16 butterfly: bins k0 + (N/16) q
-template <typename T>
+// linear operator for the V registers of a last-radix-V butterfly (V = 16 | 8): bins k0 + (N/V) q, signed q' = q or q - V;
+// phase cth (k0 + dk q')^2 = A * B^q' * C_|q'| with C_m = cis(cth dk^2 m^2) = the control block's table at 16/V * m
+template <int V = 16, typename T>
 SSF_HD void apply_lin16(const LinOp &lo, long long k0, int log2N, cx<T> *v) {
-    const double dk = (double)(1ll << (log2N - 4));
+    constexpr int lgV = V == 16 ? 4 : 3, H = V / 2, CS = 16 / V;
+    const double dk = (double)(1ll << (log2N - lgV));
     const double k0d = (double)k0;
     double s, c;
     cis_rad_d(lo.cth * k0d * k0d, c, s);
     const cx<double> A = mk<double>(lo.mag * c, lo.mag * s);
     cis_rad_d(2.0 * lo.cth * k0d * dk, c, s);
-    cx<double> Bp[9];
+    cx<double> Bp[H + 1];
     Bp[0] = mk<double>(1.0, 0.0);
     Bp[1] = mk<double>(c, s);
     Bp[2] = Bp[1] * Bp[1];
     Bp[3] = Bp[2] * Bp[1];
     Bp[4] = Bp[2] * Bp[2];
-    Bp[5] = Bp[4] * Bp[1];
-    Bp[6] = Bp[3] * Bp[3];
-    Bp[7] = Bp[4] * Bp[3];
-    Bp[8] = Bp[4] * Bp[4];
+    if constexpr (V == 16) {
+        Bp[5] = Bp[4] * Bp[1];
+        Bp[6] = Bp[3] * Bp[3];
+        Bp[7] = Bp[4] * Bp[3];
+        Bp[8] = Bp[4] * Bp[4];
+    }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int m = q < 8 ? q : 16 - q;                       // |q'|, q' = q (q<8) or q-16
-        const cx<double> bq = q < 8 ? Bp[m] : conj(Bp[m]);
-        const cx<double> h = A * bq * mk<double>(lo.Cre[m], lo.Cim[m]);
+    for (int q = 0; q < V; ++q) {
+        const int m = q < H ? q : V - q;                        // |q'|, q' = q (q < V/2) or q - V
+        const cx<double> bq = q < H ? Bp[m] : conj(Bp[m]);
+        const cx<double> h = A * bq * mk<double>(lo.Cre[CS * m], lo.Cim[CS * m]);
         v[q] = mul_by_d(v[q], h);
     }
 }
@@ -671,15 +683,19 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
 }
 
 // LG > 0: row length fixed at compile time (index math folds to immediates); 0: runtime
-template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const RowArgs<T> &a) {
+// V = values per thread: 16 (256 registers, two waves per SIMD) or 8 (128 registers, four waves per SIMD: while the waves
+// of one workgroup wait for their row or for their stores to drain, the other workgroup of the CU has the SIMDs)
+template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &ctx, const RowArgs<T> &a) {
+    constexpr int lgV = V == 16 ? 4 : 3;
     cx<T> *lds = (cx<T> *)ctx.lds;
     LinOp lo;
-    const PassPlan p = make_plan(LG > 0 ? LG : a.log2N2);
+    const PassPlan p = make_plan(LG > 0 ? LG : a.log2N2, lgV);
     const int fpw = ctx.nthreads / p.tpf;                  // row transforms per workgroup
     const int f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
     const long long rr = (long long)ctx.bid * fpw + f;     // global row-transform index (grid is exact)
     cx<T> *g = a.G + (rr << a.log2N2);
-    cx<T> v[16];
+    cx<T> v[V];
+    if (a.stagger > 0 && ctx.bid >= (ctx.nblocks >> 1)) ctx.sleep64(a.stagger);
     ctx.mark(0);
     // Issue order matters (vmcnt retires in order): first the convergence sums the last column
     // stage may have left (fetched unconditionally, they are only used if the control block says
@@ -703,7 +719,7 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
         ctx.issue_fence();
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = ld_pol<1>(g + b + p.tpf * q);
+    for (int q = 0; q < V; ++q) v[q] = ld_pol<1>(g + b + p.tpf * q);
     if (a.use_ctrl) {
         ctx.issue_fence();
         if (!row_ctrl(ctx, a, part, lo)) return;
@@ -714,34 +730,34 @@ template <typename T, int LG, class Ctx> SSF_HD void row_body(Ctx &ctx, const Ro
     const int k1 = (int)(rr & (N1 - 1));
     cx<T> *l = lds + (size_t)f * lds_slots_per_fft(p.L);
     ctx.mark(1);
-    fft_dif<-1>(ctx, p, b, v, l);
+    fft_dif<-1, V>(ctx, p, b, v, l);
     ctx.mark(2);
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
     const int last = p.npass - 1;
     if (!a.use_ctrl && !a.lin) {                 // fixed-kernel convolution: multiplier array in this kernel's spectrum order
         if (a.fwd_only) {
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) g[reg_pos(p, last, b, idx)] = v[idx];
+            for (int idx = 0; idx < V; ++idx) g[reg_pos(p, last, b, idx)] = v[idx];
             return;
         }
         const cx<T> *h = a.harr + ((size_t)k1 << a.log2N2);
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * h[reg_pos(p, last, b, idx)];
-    } else if (p.lg(last) == 4) {
+        for (int idx = 0; idx < V; ++idx) v[idx] = v[idx] * h[reg_pos(p, last, b, idx)];
+    } else if (p.lg(last) == lgV) {
         const long long k0 = k1 + ((long long)rev_pos(p, reg_pos(p, last, b, 0)) << a.log2N1);
-        apply_lin16(lo, k0, log2N, v);
+        apply_lin16<V>(lo, k0, log2N, v);
     } else {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) {
+        for (int idx = 0; idx < V; ++idx) {
             const long long k = k1 + ((long long)rev_pos(p, reg_pos(p, last, b, idx)) << a.log2N1);
             v[idx] = mul_by_d(v[idx], lin_at(lo, k, log2N));
         }
     }
     ctx.mark(3);
-    fft_dit<+1>(ctx, p, b, v, l);
+    fft_dit<+1, V>(ctx, p, b, v, l);
     ctx.mark(4);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) st_pol<0>(g + b + p.tpf * q, v[q]);
+    for (int q = 0; q < V; ++q) st_pol<0>(g + b + p.tpf * q, v[q]);
     ctx.mark(5);
     ctx.flush(0);
 }
@@ -1452,6 +1468,7 @@ template <typename T> struct AmpArgs {
     double sigma;         // > 0: add device-generated ASE, sigma per quadrature
     unsigned long long seed;
     unsigned span;
+    unsigned row0;        // stream row of row 0 (ssf_params::rng_row_offset)
 };
 template <typename T, class Ctx> SSF_HD void amp_body(Ctx &ctx, const AmpArgs<T> &a) {
     for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < a.total; i += (long long)ctx.nblocks * ctx.nthreads) {
@@ -1459,7 +1476,7 @@ template <typename T, class Ctx> SSF_HD void amp_body(Ctx &ctx, const AmpArgs<T>
         if (a.noise) e = e + a.noise[i];
         if (a.sigma > 0) {
             double re, im;
-            gauss_pair((unsigned long long)(i % a.N), (unsigned)(i / a.N), a.span, a.seed, a.sigma, re, im);
+            gauss_pair((unsigned long long)(i % a.N), a.row0 + (unsigned)(i / a.N), a.span, a.seed, a.sigma, re, im);
             e = e + mk<T>((T)re, (T)im);
         }
         a.E[i] = e;

@@ -22,12 +22,25 @@ import copy
 import ctypes as C
 import os
 import pickle
+import stat
 import tempfile
 import time
 
 import numpy as np
 
 from . import _lib
+
+
+def _process_start_time():
+    """Wall-clock start of this process (seconds since the epoch); falls back to 'now'."""
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/stat") as f:
+            btime = next(float(ln.split()[1]) for ln in f if ln.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        return time.time()
 
 
 def shard_range(n_units, world, rank):
@@ -66,14 +79,57 @@ class RcclComm:
         self.h = h
 
     # -- rendezvous -------------------------------------------------------------------------------------------
+    # Rank 0 hands the 128-byte RCCL id to the other ranks through a file.  $SSF_RCCL_ID_FILE names it explicitly
+    # (bench.py --gpus N and any launcher that can export one variable to all ranks); otherwise it lives in a per-user
+    # 0700 directory and is keyed by what every rank of ONE job shares whatever started it: the rendezvous address and
+    # port plus the launcher's run / job id (torchrun, srun, mpirun) -- not the parent pid, which differs per rank under
+    # srun or mpirun with a daemon per rank.  The file is created with O_EXCL, mode 0600, and carries a magic word and
+    # its creation time: readers ignore anything written before their own job could have started (a file a crashed run
+    # left behind) and rank 0 unlinks it on every exit path.
+    _MAGIC = b"SSFRCCL1"
+    _STALE_S = 300.0
+
     @staticmethod
     def id_path():
-        """Where rank 0 leaves the 128-byte rendezvous id: keyed by the launcher's port and the launcher process
-        (all workers of one node share their parent), $SSF_RCCL_ID_FILE overrides."""
-        p = os.environ.get("SSF_RCCL_ID_FILE")
+        env = os.environ
+        p = env.get("SSF_RCCL_ID_FILE")
         if p:
             return p
-        return os.path.join(tempfile.gettempdir(), "ssf_rccl_%s_%d.id" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        d = os.path.join(tempfile.gettempdir(), "ssf_rccl_%d" % os.getuid())
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.lstat(d)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise RuntimeError("RCCL rendezvous: %s is not a private directory of this user" % d)
+        job = env.get("TORCHELASTIC_RUN_ID") or env.get("SLURM_JOB_ID") or env.get("OMPI_MCA_ess_base_jobid") \
+            or env.get("PMIX_NAMESPACE") or "ppid%d" % os.getppid()
+        key = "%s_%s_%s" % (env.get("MASTER_ADDR", "local"), env.get("MASTER_PORT", "0"), job)
+        return os.path.join(d, "".join(c if c.isalnum() or c in "._-" else "_" for c in key) + ".id")
+
+    @classmethod
+    def _publish_id(cls, path, raw):
+        try:
+            os.unlink(path)                                    # whatever is there is not from this run
+        except OSError:
+            pass
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(cls._MAGIC + np.array([time.time()], dtype=np.float64).tobytes() + raw)
+
+    @classmethod
+    def _read_id(cls, path, not_before):
+        try:
+            fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+        except OSError:
+            return None
+        with os.fdopen(fd, "rb") as f:
+            if os.fstat(f.fileno()).st_uid != os.getuid():
+                raise RuntimeError("RCCL rendezvous: %s belongs to another user" % path)
+            raw = f.read()
+        if len(raw) != 16 + _lib.COMM_ID_BYTES or raw[:8] != cls._MAGIC:
+            return None                                        # not complete yet (or not ours)
+        if float(np.frombuffer(raw[8:16], dtype=np.float64)[0]) < not_before:
+            return None                                        # left behind by an earlier run
+        return raw[16:]
 
     @classmethod
     def from_env(cls, device=None, timeout=180.0):
@@ -91,30 +147,26 @@ class RcclComm:
                 msg = lib.ssf_comm_last_error(None)
                 raise RuntimeError("RCCL: %s" % (msg.decode(errors="replace") if msg else rc))
             if world > 1:
-                tmp = "%s.%d.tmp" % (path, os.getpid())
-                with open(tmp, "wb") as f:
-                    f.write(buf.raw)
-                os.replace(tmp, path)                          # atomic: readers never see a partial id
+                cls._publish_id(path, buf.raw)
         else:
             t0 = time.time()
+            not_before = _process_start_time() - cls._STALE_S
             while True:
-                try:
-                    with open(path, "rb") as f:
-                        raw = f.read()
-                    if len(raw) == _lib.COMM_ID_BYTES:
-                        break
-                except OSError:
-                    pass
+                raw = cls._read_id(path, not_before)
+                if raw is not None:
+                    break
                 if time.time() - t0 > timeout:
-                    raise TimeoutError("RCCL rendezvous: %s did not appear within %.0f s" % (path, timeout))
+                    raise TimeoutError("RCCL rendezvous: no fresh id in %s within %.0f s" % (path, timeout))
                 time.sleep(0.02)
             buf = C.create_string_buffer(raw, _lib.COMM_ID_BYTES)
-        comm = cls(local if device is None else device, world, rank, buf)     # (collective: returns on every rank together)
-        if rank == 0 and world > 1:
-            try:
-                os.remove(path)
-            except OSError:
-                pass
+        try:
+            comm = cls(local if device is None else device, world, rank, buf)  # (collective: returns on every rank together)
+        finally:
+            if rank == 0 and world > 1:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
         return comm
 
     # -- collectives ----------------------------------------------------------------------------------------------
@@ -231,7 +283,16 @@ def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
     lanes = max(1, min(int(os.environ.get("SSF_MGPU_LANES", "2")), len(mine)))
 
     def one(u):
-        return u, np.asarray(compute(local[u], copy.deepcopy(param)))
+        p = copy.deepcopy(param)
+        # a fixed param.seed keys ONE noise stream: unit u draws its own rows of it (ssf_params::rng_row_offset), so the
+        # Monte-Carlo units of a seeded run get independent ASE noise, the same whatever the number of ranks
+        ncols = int(np.shape(local[u])[1]) if np.ndim(local[u]) > 1 else 1
+        try:
+            p._rng_row_offset = int(getattr(param, "_rng_row_offset", 0)) + u * ncols
+        except AttributeError:                                  # (a parameter object without settable attributes)
+            pass
+        out = np.asarray(compute(local[u], p))
+        return u, out
 
     if lanes > 1:
         for u, o in _lane_pool(lanes).map(one, mine):
@@ -280,7 +341,14 @@ def run_coupled(Ei_block, param, comm):
     from .models import manakovSSF
     if comm is None or comm.world == 1:
         return manakovSSF(Ei_block, param)
-    return manakovSSF(Ei_block, param, _coupling=comm)
+    # rows of the coupled batch held by the ranks before this one: with amp='edfa' and a fixed seed every rank keys the
+    # same Philox stream, and its pairs must draw THEIR rows of it (independent noise per column, like the single call)
+    counts = comm.allgather(np.array([float(np.shape(Ei_block)[1])]))
+    param._rng_row_offset = int(round(float(np.sum(counts[:comm.rank]))))
+    try:
+        return manakovSSF(Ei_block, param, _coupling=comm)
+    finally:
+        del param._rng_row_offset
 
 
 def run_threads(fields, cparams, devices, precision=np.complex128, engine="auto"):

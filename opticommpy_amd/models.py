@@ -271,6 +271,10 @@ def _fill_params(model, direction, param, Fs, Nspans, save_arr):
     cp.amp = _amp_code(param.amp)
     cp.NF = float(getattr(param, "NF", 4.5))
     cp.n_save = len(save_arr)
+    # device ASE noise: which rows of the seed's noise stream this call's rows are.  A stand-alone call starts at 0; the
+    # sharded / coupled drivers (mgpu.py) give every unit / rank its own block so that a shared param.seed does not
+    # repeat the same noise in every Monte-Carlo unit or correlate the pairs of a coupled batch across ranks
+    cp.rng_row_offset = int(getattr(param, "_rng_row_offset", 0))
     cp.save_spans = save_arr.ctypes.data_as(C.POINTER(C.c_int32)) if len(save_arr) else None
     return cp
 

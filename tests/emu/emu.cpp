@@ -32,6 +32,7 @@ struct EmuCtx {
     void mark(int) {}
     void flush(int) {}
     void issue_fence() {}
+    void sleep64(int) {}
     double wave_sum(double v) { return v; }
     double wave_max(double v) { return v; }
 };
@@ -155,7 +156,8 @@ struct EmuBackend {
                 return;
             }
         }
-        run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
+        if (a.vpt == 8) run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0, 8>(c, a); });
+        else run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
     }
     static constexpr bool kCanPersist = false;         // (no grid barrier between the emulator's sequential workgroups)
     bool sink_active() const { return false; }

@@ -31,6 +31,10 @@ blk = np.ascontiguousarray(E[:, 2 * comm.rank: 2 * comm.rank + 2])
 out = mgpu.run_coupled(blk, make_param(oa.parameters, cfg), comm)
 np.save(os.path.join(os.environ["SSF_OUT"], f"coupled_rank{comm.rank}.npy"), out)
 np.save(os.path.join(os.environ["SSF_OUT"], f"steps_rank{comm.rank}.npy"), np.array([models.last_run["steps"], models.last_run["iterations"]]))
+# EDFA with a fixed seed: every rank keys the same noise stream and must draw ITS rows of it
+cfg2 = dict(cfg, amp="edfa", NF=5.0, seed=9, nlprMethod=False, hz=1.0, gamma=0.0)
+out2 = mgpu.run_coupled(blk, make_param(oa.parameters, cfg2), comm)
+np.save(os.path.join(os.environ["SSF_OUT"], f"edfa_rank{comm.rank}.npy"), out2)
 comm.close()
 '''
 
@@ -66,3 +70,9 @@ def test_two_processes_reproduce_the_single_coupled_call(tmp_path):
     # ... which is not what the pairs do on their own: the weak pair alone takes far fewer (longer) steps
     alone = orc.manakovSSF(E[:, :2].copy(), make_param(orc.parameters, cfg), trace=(tr0 := {}))
     assert tr0["steps"] < tr["steps"] and rel_l2(got[:, :2], alone) > 1e-6
+    # amp='edfa' with a fixed seed: the two ranks' pairs get the noise rows of the single K = 2 call (gamma = 0: no coupling
+    # through the field), not the same rows twice (advisor, round 2)
+    cfg2 = dict(cfg, amp="edfa", NF=5.0, seed=9, nlprMethod=False, hz=1.0, gamma=0.0)
+    single = oa.manakovSSF(E, make_param(oa.parameters, cfg2))
+    got2 = np.concatenate([np.load(tmp_path / f"edfa_rank{r}.npy") for r in range(2)], axis=1)
+    assert rel_l2(got2, single) <= 1e-12

@@ -418,3 +418,28 @@ def test_mixed_radix_planner_covers_every_row_length_the_split_can_ask_for():
             rad = list(r[:n])
             assert 1 <= n <= 6 and int(np.prod(rad)) == L and set(rad) <= ok_radices and rad[-1] <= 16, (L, T, rad)
     assert e.emu_mix_plan(7 * 64, 128, r) == 0
+
+
+# ---- round 3: eight values per thread (128-register kernels, four waves per SIMD) ---------------------------------
+@pytest.mark.parametrize("N,prec", [(1 << 12, "complex128"), (1 << 14, "complex128"), (1 << 16, "complex128"),
+                                    (1 << 17, "complex128"), (1 << 14, "complex64")])
+def test_rows_with_eight_values_per_thread(monkeypatch, N, prec):
+    """SSF_ROW_V=8: radix-8 row passes (a fourth LDS exchange per 4096-point transform), operator on the eight bins
+    N/8 apart of a last-pass butterfly.  Same results as the oracle, same iteration counts; ssfm and the linear channel too."""
+    monkeypatch.setenv("SSF_ROW_V", "8")
+    dt = np.complex64 if prec == "complex64" else np.complex128
+    E = synth_field(N, 2, 41, 8.4).astype(dt)
+    cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5, prgsBar=False,
+               Ltotal=0.48, Lspan=0.24, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[], prec=prec)
+    tr = {}
+    q = make_param(orc.parameters, cfg)
+    q.prec = dt
+    ref = orc.manakovSSF(E, q, trace=tr)
+    out, info = eb.run("manakovSSF", E, cfg)
+    if prec == "complex128":
+        assert rel_l2(out.T, ref) <= TOL_C128 and list(info["iters"]) == tr["iters"]
+        p = orc.parameters()
+        p.Fs, p.L, p.alpha, p.D, p.Fc = 512e9, 3.0, 0.2, 16, 193.1e12
+        assert rel_l2(eb.linear_channel(E, 512e9, 193.1e12, 0.2, 16, 3.0), orc.linearFiberChannel(E, p)) < 1e-13
+    else:
+        assert rel_l2(out.T, ref) <= 5e-4

@@ -20,7 +20,7 @@ Output: tests/golden/<case>.npz, each holding
               output decimated by cfg["dec"], its per-column power and a seeded random projection of the full
               output (so an error anywhere in the array shows), see long_vectors()
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|tx|long]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|tx|long|long20]
 """
 import json
 import os
@@ -462,8 +462,18 @@ def long_vectors():
               + f"  {time.time()-t0:.0f} s", flush=True)
 
 
+def long20_vector():
+    """BASELINE config 2 at its full size: 2^20 samples, one 80 km span, 1001 steps (about 15 minutes of reference time)."""
+    os.makedirs(OUT, exist_ok=True)
+    c2 = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False,
+              Ltotal=80, Lspan=80, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
+    run_long("long_c2_n20", "manakovSSF", (1 << 20, 2, 2, 8.4), dict(c2), dec=512)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "long":    # only the long-run vectors
+    if len(sys.argv) > 1 and sys.argv[1] == "long20":  # only the full-size config-2 vector
+        long20_vector()
+    elif len(sys.argv) > 1 and sys.argv[1] == "long":    # only the long-run vectors
         long_vectors()
     elif len(sys.argv) > 1 and sys.argv[1] == "tx":      # only the transmitter vectors
         os.makedirs(OUT, exist_ok=True)
