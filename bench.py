@@ -364,7 +364,8 @@ def main():
                          "device_ms_per_step": dev_s * 1e3 / max(steps_local, 1),
                          "note": "the working set of a 2^20 complex128 field (184 MiB) fits the 256 MiB Infinity Cache: the "
                                  "'HBM' figure of config 2 is partly an Infinity-Cache figure; configs with N >= 2^21 "
-                                 "(complex128) / 2^22 run out of it"},
+                                 "(complex128) / 2^22 run out of it (out-of-cache fraction of the same complex128 kernels: "
+                                 "python bench.py --log2n 22, profiles/r3_c2_out_of_cache.json)"},
             "comm": comm_name, "rccl_ranks": world if comm is not None and comm_name.startswith("RCCL") else 0,
             "unit_checksums": checksums,          # per unit: [sum |E|^2, |<q, E>|] with a seeded random vector q
         }
@@ -400,17 +401,18 @@ def main():
             rec["roofline"]["measured_copy_note"] = ("burst copy kernel, %d MiB read + %d MiB written per launch, no arithmetic"
                                                      % (probe_bytes >> 20, probe_bytes >> 20))
         traffic_file = os.path.join(ROOT, "profiles", "traffic_bytes_per_step.json")
-        if os.path.exists(traffic_file) and cfg in (2, 4) and not args.log2n and not args.prec:
+        if os.path.exists(traffic_file) and not args.log2n and not args.prec:
             try:
-                t = json.load(open(traffic_file)).get(_lib.ENGINE_NAMES[st0.engine])
-                if t:
-                    # PMC-measured HBM-side bytes per step (separate rocprofv3 passes, see profiles/), NOT measured in this
+                t = json.load(open(traffic_file)).get("config%d" % cfg)
+                if t and t.get("engine") == _lib.ENGINE_NAMES[st0.engine]:
+                    # PMC-measured HBM-side bytes per unit-step (separate rocprofv3 passes, see profiles/), NOT measured in this
                     # run: scaled from the profiled iteration count to this run's (linear in 1 + iterations/step)
                     scale = (1.0 + it_step) / (1.0 + t["iterations_per_step"])
                     rec["roofline"]["traffic_profiled"] = t["bytes_per_step"] * scale
                     rec["roofline"]["traffic_ratio"] = t["bytes_per_step"] * scale / (bytes_local / max(steps_local, 1))
-                    rec["roofline"]["traffic_source"] = ("profiles/traffic_bytes_per_step.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                                         "%d steps at %.2f it/step)" % (t["steps"], t["iterations_per_step"]))
+                    rec["roofline"]["traffic_source"] = ("profiles/traffic_bytes_per_step.json[config%d] (%s: rocprofv3 --pmc FETCH_SIZE / "
+                                                         "WRITE_SIZE, %d unit-steps at %.2f it/step)"
+                                                         % (cfg, t.get("source", "?"), t["steps"], t["iterations_per_step"]))
             except Exception:
                 pass
 

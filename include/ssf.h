@@ -21,6 +21,7 @@
  *   ssf_run                              one whole reference call (upload+execute+download)
  *   ssf_mgpu_run                         (no reference equivalent) independent fields
  *                                        sharded over the GPUs of one node, SURVEY.md 8e
+ *   ssf_plan_set_units                   (no reference equivalent) several independent fields per launch
  *   ssf_set_coupling                     np.max(phiRot) / scipy.linalg.norm over ALL rows of a K > 1 batch
  *                                        (channels.py:394, 517-519) when the rows live in several plans
  *   ssf_comm_*                           (no reference equivalent) one process per GPU: RCCL
@@ -239,6 +240,19 @@ const char *ssf_comm_last_error(const ssf_comm *comm);       /* never NULL; comm
  * on the fused engine (its control flow lives on the device; independent units need no coupling). */
 typedef int (*ssf_reduce_fn)(void *ctx, double *values, int32_t n, int32_t op);
 int  ssf_set_coupling(ssf_plan *plan, ssf_reduce_fn reduce, void *ctx);
+
+/* ---- independent units in one plan (no reference equivalent: the reference runs one field per call) ----------------
+ * Small fields are latency-bound one at a time: a launch is one chain of load -> transform -> store of ~10 us whatever its
+ * size.  ssf_plan_set_units(plan, n) declares the plan's rows to be n independent fields ("units") of nrows / n rows each,
+ * rows [u * nrows / n, (u + 1) * nrows / n) = unit u (an even number of rows per unit for the Manakov models).  Every
+ * launch of ssf_execute then carries all units (grid.y = n), and every unit keeps its OWN device-resident control block,
+ * partial sums, step sizes and convergence decisions: the result is bit-equal to n separate plans, unlike one coupled
+ * K > 1 call (which shares max(phi) and the norms over all rows, channels.py:394, 517-519).  ssf_stats counts are sums
+ * over the units; traces are not recorded (SSF_ERR_BAD_ARG with a trace).  Device noise: row r draws stream row
+ * rng_row_offset + r, i.e. unit u sees what a stand-alone call with rng_row_offset + u * nrows / n would.  Call it before
+ * ssf_upload (the engine is rebuilt, an uploaded field is dropped).  Natively split lengths of the fused engine only
+ * (SSF_ERR_UNSUPPORTED otherwise: the caller falls back to one call per unit). */
+int  ssf_plan_set_units(ssf_plan *plan, int32_t n_units);
 
 /* ---- per-kernel timing (measurement aid; fused engine only) ------------------------------ */
 /* With profiling enabled every kernel launch of ssf_execute is bracketed by HIP events on the

@@ -76,6 +76,7 @@ SYMBOLS = {
     "ssf_version": (C.c_char_p, []),
     "ssf_plan_create": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "ssf_plan_destroy": (C.c_int, [C.c_void_p]),
+    "ssf_plan_set_units": (C.c_int, [C.c_void_p, C.c_int32]),
     "ssf_last_error": (C.c_char_p, [C.c_void_p]),
     "ssf_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ssf_execute": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_int32, C.c_void_p,

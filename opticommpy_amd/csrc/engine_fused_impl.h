@@ -30,7 +30,9 @@ struct DevCtx : DevCtxCore {
     // launch of another kind (early return, no forward transform) never mixes into it
     __device__ __forceinline__ void mark(int i) {
         __builtin_amdgcn_sched_barrier(0);
+#if SSF_PHASE_TIMING != 2                                          // (2: stamps only, phases overlap as in the product build)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         ts[i] = wall_clock64();
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -58,33 +60,42 @@ struct DevCtx : DevCtxCore {
 // (two workgroups per CU).  LG = compile-time log2 of the transform length (0 = runtime).
 template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds__(MAXT, OCC) k_row(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    row_body<T, LG>(ctx, a);
+    row_body<T, LG>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // eight values per thread: at most 128 registers, four waves per SIMD (two 512-thread workgroups, or one of 1024, per CU)
 template <typename T, int MAXT, int LG> __global__ void __launch_bounds__(MAXT, 4) k_row8(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    row_body<T, LG, 8>(ctx, a);
+    row_body<T, LG, 8>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // Manakov column kernels run 512 threads (x half | y half); the single-row modes run 256
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    col_body<T, LG, MODE, false>(ctx, a);
+    col_body<T, LG, MODE, false>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // row lengths with factors 3 / 5 (mixed_fft.h): mixed-radix row stage, column stage with ragged last tiles
 template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT, MAXT <= 256 ? 2 : 1) k_row_mixed(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    row_mixed_body<T>(ctx, a);
+    row_mixed_body<T>(ctx, unit_view(a, (int)blockIdx.y));
 }
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    col_body<T, LG, MODE, true>(ctx, a);
+    col_body<T, LG, MODE, true>(ctx, unit_view(a, (int)blockIdx.y));
+}
+// eight values per thread (at most 128 registers, four waves per SIMD): 512-thread workgroups, two per CU
+template <typename T, int LG, int MODE> __global__ void __launch_bounds__(512, 4) k_col8(const ColArgs<T> a) {
+    SSF_DEV_CTX(1);
+    col_body<T, LG, MODE, false, 8>(ctx, unit_view(a, (int)blockIdx.y));
+}
+template <int LG> __global__ void __launch_bounds__(512, 4) k_col_pk8(const ColArgs<pf2> a) {
+    SSF_DEV_CTX(1);
+    col_pk_body<LG, 8>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // complex64 Manakov: packed polarisation pairs (fused_kernels.h: col_pk_body); up to 512 threads (8 columns of 1024)
 template <int LG> __global__ void __launch_bounds__(512) k_col_pk(const ColArgs<pf2> a) {
     SSF_DEV_CTX(1);
-    col_pk_body<LG>(ctx, a);
+    col_pk_body<LG>(ctx, unit_view(a, (int)blockIdx.y));
 }
 __global__ void __launch_bounds__(256) k_repack(const RepackArgs a) {
     SSF_DEV_CTX(1);
@@ -232,6 +243,22 @@ template <typename T> ColFn<T> pick_col_ragged(int lg1, int mode) {
     default: return k_col_ragged<T, 0, CM_PLAIN_INV>;
     }
 }
+template <typename T, int LG> ColFn<T> pick_col8_mode(int mode) {
+    switch (mode) {
+    case CM_NLSE_FIRST: return k_col8<T, LG, CM_NLSE_FIRST>;
+    case CM_NLSE_STEP: return k_col8<T, LG, CM_NLSE_STEP>;
+    case CM_NLSE_LAST: return k_col8<T, LG, CM_NLSE_LAST>;
+    case CM_MK: return k_col8<T, LG, CM_MK>;
+    case CM_PLAIN_FWD: return k_col8<T, LG, CM_PLAIN_FWD>;
+    default: return k_col8<T, LG, CM_PLAIN_INV>;
+    }
+}
+template <typename T> ColFn<T> pick_col8(int lg1, int mode) {
+    switch (lg1) {
+    case 8: return pick_col8_mode<T, 8>(mode);
+    default: return pick_col8_mode<T, 0>(mode);
+    }
+}
 template <typename T> ColFn<T> pick_col(int lg1, int mode) {
     switch (lg1) {
     case 7: return pick_col_mode<T, 7>(mode);
@@ -348,7 +375,7 @@ struct HipBackend {
         row_lds_max = row_lds;
         col_lds_max = col_lds;
     }
-    template <typename T> void launch_row(const RowArgs<T> &a, int grid, int block, size_t lds) {
+    template <typename T> void launch_row(const RowArgs<T> &a, int grid, int block, size_t lds, int units = 1) {
         RowFn<T> f;
         if constexpr (std::is_same<T, pf2>::value) f = pick_row<T>(a.log2N2, block, row_occ, a.vpt);     // (no mixed-radix rows there)
         else
@@ -356,13 +383,20 @@ struct HipBackend {
                 : block <= 256 ? (RowFn<T>)k_row_mixed<T, 256> : block <= 512 ? (RowFn<T>)k_row_mixed<T, 512> : (RowFn<T>)k_row_mixed<T, 1024>;
         arm((const void *)f);
         stamp_begin(0);
-        f<<<grid, block, lds, pl->stream>>>(a);
+        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, pl->stream>>>(a);
         stamp_end();
         chk(hipGetLastError(), "launch k_row");
     }
-    template <typename T> void launch_col(const ColArgs<T> &a, int grid, int block, size_t lds) {
+    template <typename T> void launch_col(const ColArgs<T> &a, int grid, int block, size_t lds, int units = 1) {
         ColFn<T> f;
         if constexpr (std::is_same<T, pf2>::value) {
+            if (a.vpt == 8) {
+                switch (a.log2N1) {
+                case 8: f = k_col_pk8<8>; break;
+                case 10: f = k_col_pk8<10>; break;
+                default: f = k_col_pk8<0>; break;
+                }
+            } else
             switch (a.log2N1) {
             case 7: f = k_col_pk<7>; break;
             case 8: f = k_col_pk<8>; break;
@@ -371,10 +405,10 @@ struct HipBackend {
             default: f = k_col_pk<0>; break;
             }
         } else
-            f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
+            f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : a.vpt == 8 ? pick_col8<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
         arm((const void *)f);
         stamp_begin(a.mode == CM_MK ? 1 : 3);
-        f<<<grid, block, lds, pl->stream>>>(a);
+        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, pl->stream>>>(a);
         stamp_end();
         chk(hipGetLastError(), "launch k_col");
     }
@@ -434,7 +468,7 @@ template <typename T> class FusedEngine final : public Engine {
     FusedCore<T, HipBackend> core;
 
   public:
-    explicit FusedEngine(ssf_plan *p) : pl(p), be(p), core(be, p->N, p->nrows, p->precision) {}
+    explicit FusedEngine(ssf_plan *p) : pl(p), be(p), core(be, p->N, p->nrows, p->precision, nullptr, p->units) {}
     int id() const override { return SSF_ENGINE_FUSED; }
     int ret(int rc) {
         if (rc != SSF_OK) pl->err = core.err.empty() ? be.last_error() : core.err;

@@ -95,7 +95,8 @@ template <> SSF_HD pf2 fma_s<pf2>(pf2 x, float a, pf2 c) {
 // Streaming-memory policy (compile-time, SSF_MEMPOL bits): the exchange buffer G and the time-domain fields are
 // written by one launch and read by the next one, normally from another XCD: keeping them in the writer's L2 buys
 // nothing and leaves the whole output dirty until the end-of-kernel write-back.  A non-temporal access streams
-// through instead.  bit 0: G stores, bit 1: G loads, bit 2: field / E_hd stores, bit 3: field / E_hd loads.
+// through instead.  bit 0: G stores of the row stage, bit 1: G loads, bit 2: field / E_hd stores, bit 3: field / E_hd loads,
+// bit 4: G stores of the column stage.
 // SSF_WT bits (same numbering, stores only): write-through stores (sc0 sc1): the line leaves the L2 when it is stored
 // instead of waiting, dirty, for the end-of-kernel write-back (up to 32 MiB of L2 to flush before the next launch starts).
 #ifndef SSF_MEMPOL
@@ -159,8 +160,18 @@ template <int BIT, typename T> SSF_HD void st_pol(cx<T> *p, cx<T> x) {
 }
 
 // cis(2*pi*frac) evaluated in double (frac is exact: integer / power of two)
+// SSF_FAKE_TRIG (diagnostic builds only, wrong results): every sine / cosine costs two instructions -- what the launches would
+// take if the twiddle bases came for free
+#ifndef SSF_FAKE_TRIG
+#define SSF_FAKE_TRIG 0
+#endif
 SSF_HD void cis2pi_d(double frac, double &c, double &s) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (SSF_FAKE_TRIG) {
+        c = 1.0 - frac;
+        s = frac;
+        return;
+    }
     sincospi(2.0 * frac, &s, &c);
 #else
     const double a = kTwoPi * frac;
@@ -218,6 +229,11 @@ constexpr double kQuarterPi = 0.78539816339744830962;
 // sincos (whose Payne-Hanek path bloats the kernel); the reduction error |a| * 2^-53 is the
 // rounding a itself already carries
 SSF_HD void cis_rad_d(double a, double &c, double &s) {
+    if (SSF_FAKE_TRIG == 2) {
+        c = 1.0 - a;
+        s = a;
+        return;
+    }
     if (fabs(a) <= kQuarterPi) {
         s = ksin_d(a);
         c = kcos_d(a);

@@ -133,6 +133,7 @@ template <typename T, class Backend> class FusedCore {
     std::vector<C *> snaps;
     int row_v = 16;              // values per thread of the radix-2^n row kernel (SSF_ROW_V=8: 128-register kernels)
     int row_stagger = 0;         // 64-clock ticks the second half of the row grid starts late (SSF_ROW_STAGGER)
+    int col_v = 16;              // values per thread of the column kernels (SSF_COL_V=8)
     int cur = 0;                 // which of T0/T1 holds the current field
     unsigned seq = 0;
     // launch geometry
@@ -140,8 +141,13 @@ template <typename T, class Backend> class FusedCore {
     size_t row_lds, col_lds_mk, col_lds_1;
     std::string err;
 
+    int units = 1;               // the rows form `units` independent fields: own control block, partial sums, step sizes and
+                                 // convergence decisions per unit, every launch carries all of them (grid.y = units)
     int npairs() const { return kPacked ? nrows : std::max(nrows / 2, 1); }
-    FusedCore(Backend &b, int64_t N_, int nrows_, int precision, void *borrowed_G = nullptr) : be(b), N(N_), nrows(nrows_) {
+    int rows_u() const { return nrows / units; }                 // rows of one unit
+    int pairs_u() const { return std::max(npairs() / units, 1); }
+    FusedCore(Backend &b, int64_t N_, int nrows_, int precision, void *borrowed_G = nullptr, int units_ = 1)
+        : be(b), N(N_), nrows(nrows_), units(units_ > 0 ? units_ : 1) {
         if (borrowed_G) {
             G = (C *)borrowed_G;
             own_G = false;
@@ -159,8 +165,8 @@ template <typename T, class Backend> class FusedCore {
 
     // npol = 2: a workgroup carries both rows of a polarisation pair (x threads | y threads)
     void col_geometry(int groups, int npol, int *block, int *grid, size_t *lds) const {
-        const int tpf = (1 << sp.l1) / 16, N2 = N2mix ? N2mix : 1 << sp.l2;
-        int half = 256;
+        const int tpf = (1 << sp.l1) / col_v, N2 = N2mix ? N2mix : 1 << sp.l2;
+        int half = col_v == 8 ? 512 / npol : 256;              // (eight values per thread: 512-thread workgroups, two per CU)
         if (const char *e = std::getenv("SSF_COL_HALF")) {        // tuning knob: threads per polarisation row
             const int h = std::atoi(e);
             if (h >= tpf && h <= 512 && (h & (h - 1)) == 0) half = h;
@@ -181,7 +187,9 @@ template <typename T, class Backend> class FusedCore {
 
     int init() {
         if (const char *e = std::getenv("SSF_LIM0_BOUND")) lim0_bound = std::atoi(e) != 0;
-        const int64_t nfft = (int64_t)nrows << sp.l1;
+        if (const char *e = std::getenv("SSF_COL_V")) col_v = std::atoi(e) == 8 ? 8 : 16;
+        if (N2mix || sp.l1 < 6 || sp.l1 > 10) col_v = 16;      // (ragged tiles / very short or very long columns: 16-value kernels only)
+        const int64_t nfft = (int64_t)rows_u() << sp.l1;       // row transforms of one unit
         if (N2mix) {               // rows in LDS after 4 KiB of scratch; 128 threads per row while 16 values per thread suffice
             int tpr = 128;
             if (const char *e = std::getenv("SSF_MIX_TPR")) tpr = std::max(64, std::min(1024, std::atoi(e)));
@@ -220,16 +228,16 @@ template <typename T, class Backend> class FusedCore {
             row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 16 + 2048);
         }
         if (const char *e = std::getenv("SSF_C64_PACKED")) use_packed = std::atoi(e) != 0;
-        col_geometry(npairs(), kPacked ? 1 : 2, &col_block_mk, &col_grid_mk, &col_lds_mk);
-        col_geometry(nrows, 1, &col_block_1, &col_grid_1, &col_lds_1);
+        col_geometry(pairs_u(), kPacked ? 1 : 2, &col_block_mk, &col_grid_mk, &col_lds_mk);
+        col_geometry(rows_u(), 1, &col_block_1, &col_grid_1, &col_lds_1);
         npart_max = std::max(col_grid_mk, col_grid_1);
         if (own_G && !(G = (C *)be.alloc(field_bytes))) return oom();
         if (!(T0 = (C *)be.alloc(field_bytes))) return oom();
         if (kPacked && mk_buffers()) return SSF_ERR_OOM;      // (the other cores allocate them when a Manakov run needs them)
-        if (!(ctrl = (Ctrl *)be.alloc(2 * sizeof(Ctrl)))) return oom();
+        if (!(ctrl = (Ctrl *)be.alloc(2 * (size_t)units * sizeof(Ctrl)))) return oom();      // [launch parity][unit]
         if (!(linops = (LinOp *)be.alloc(2 * sizeof(LinOp)))) return oom();
         if (!(gbar = (unsigned *)be.alloc(4 * sizeof(unsigned)))) return oom();
-        if (!(part = (double *)be.alloc(sizeof(double) * 5 * (size_t)npart_max))) return oom();
+        if (!(part = (double *)be.alloc(sizeof(double) * 5 * (size_t)units * (size_t)npart_max))) return oom();   // [array][unit][npart_max]
         if (N2mix) {
             if (!(wtab = (cx<double> *)be.alloc(sizeof(cx<double>) * (size_t)N2mix))) return oom();
             std::vector<cx<double>> w((size_t)N2mix);
@@ -296,7 +304,9 @@ template <typename T, class Backend> class FusedCore {
         a.G = G;
         a.log2N1 = sp.l1;
         a.log2N2 = sp.l2;
-        a.nfft = (int)((int64_t)nrows << sp.l1);
+        a.nfft = (int)((int64_t)rows_u() << sp.l1);
+        a.u_elems = (long long)rows_u() * N;
+        a.u_part = npart_max;
         a.N2 = N2mix ? N2mix : 1 << sp.l2;
         a.N = N;
         a.mixed = N2mix ? 1 : 0;
@@ -321,19 +331,23 @@ template <typename T, class Backend> class FusedCore {
         a.N = N;
         a.npol = npol;
         a.mode = mode;
-        a.ngroups = npairs();
+        a.ngroups = pairs_u();
+        a.vpt = col_v;
+        a.u_elems = (long long)rows_u() * N;
+        a.u_part = npart_max;
+        const size_t ps = (size_t)units * (size_t)npart_max;       // one array of partial sums: [unit][npart_max]
         a.pmax = part;
-        a.pnum = part + npart_max;
-        a.pden = part + 2 * (size_t)npart_max;
-        a.pnum0 = part + 3 * (size_t)npart_max;
-        a.pden0 = part + 4 * (size_t)npart_max;
+        a.pnum = part + ps;
+        a.pden = part + 2 * ps;
+        a.pnum0 = part + 3 * ps;
+        a.pden0 = part + 4 * ps;
         return a;
     }
     void launch_row_lin(const LinOp *lin) {
         RowArgs<T> a = row_args();
         a.use_ctrl = 0;
         a.lin = lin;
-        be.launch_row(a, row_grid, row_block, row_lds);
+        be.launch_row(a, row_grid, row_block, row_lds, units);
     }
     // fixed-kernel convolution (FusedConv): forward-only row stage / multiplier-array row stage
     void launch_row_conv(const C *harr, int fwd_only) {
@@ -342,7 +356,7 @@ template <typename T, class Backend> class FusedCore {
         a.lin = nullptr;
         a.harr = harr;
         a.fwd_only = fwd_only;
-        be.launch_row(a, row_grid, row_block, row_lds);
+        be.launch_row(a, row_grid, row_block, row_lds, units);
     }
     void launch_col_plain(int mode, C *timebuf, S g_hz) {
         if constexpr (kPacked) return;
@@ -350,7 +364,7 @@ template <typename T, class Backend> class FusedCore {
         a.T0 = timebuf;
         a.g_hz = g_hz;
         a.npart = col_grid_1;
-        be.launch_col(a, col_grid_1, col_block_1, col_lds_1);
+        be.launch_col(a, col_grid_1, col_block_1, col_lds_1, units);
     }
     void launch_amp(C *E, S gain, const C *noise, double sigma = 0.0, unsigned long long seed = 0, unsigned span = 0,
                     unsigned row0 = 0) {
@@ -418,7 +432,7 @@ template <typename T, class Backend> class FusedCore {
         size_t plds = 0;
         if constexpr (Backend::kCanPersist && !kPacked) {
             const int tpf1 = (1 << sp.l1) / 16, tpf2 = (1 << sp.l2) / 16, lim = be.persist_limit();
-            if (!N2mix && tpf1 <= 256 && tpf2 <= 256 && nsteps >= 1) {
+            if (!N2mix && tpf1 <= 256 && tpf2 <= 256 && nsteps >= 1 && lim > 0 && units == 1) {
                 const int fpw = 256 / tpf2, Cc = 256 / tpf1;
                 const int64_t nfft = (int64_t)nrows << sp.l1;
                 if (nfft % fpw == 0 && (1 << sp.l2) % Cc == 0) {
@@ -442,6 +456,7 @@ template <typename T, class Backend> class FusedCore {
                     a.row.vpt = 16;
                     a.row.stagger = 0;
                     a.col = col_args(1, CM_NLSE_STEP);
+                    a.col.vpt = 16;
                     a.col.T0 = E;
                     a.col.g_hz = (S)(p.gamma * p.hz);
                     a.col.npart = pcol;
@@ -509,25 +524,26 @@ template <typename T, class Backend> class FusedCore {
     void launch_mk_row(const MkConst &k) {
         RowArgs<T> a = row_args();
         a.use_ctrl = 1;
-        a.cin = ctrl + (seq & 1);
-        a.cout = ctrl + ((seq + 1) & 1);
+        a.cin = ctrl + (size_t)(seq & 1) * units;
+        a.cout = ctrl + (size_t)((seq + 1) & 1) * units;
         a.k = k;
+        const size_t ps = (size_t)units * (size_t)npart_max;
         a.pmax = part;
-        a.pnum = part + npart_max;
-        a.pden = part + 2 * (size_t)npart_max;
-        a.pnum0 = part + 3 * (size_t)npart_max;
-        a.pden0 = part + 4 * (size_t)npart_max;
+        a.pnum = part + ps;
+        a.pden = part + 2 * ps;
+        a.pnum0 = part + 3 * ps;
+        a.pden0 = part + 4 * ps;
         a.npart = col_grid_mk;
-        be.launch_row(a, row_grid, row_block, row_lds);
+        be.launch_row(a, row_grid, row_block, row_lds, units);
         ++seq;
     }
     void launch_mk_col(const MkConst &k, int mode) {
         ColArgs<T> a = col_args(kPacked ? 1 : 2, mode);
-        a.cin = ctrl + (seq & 1);
-        a.cout = ctrl + ((seq + 1) & 1);
+        a.cin = ctrl + (size_t)(seq & 1) * units;
+        a.cout = ctrl + (size_t)((seq + 1) & 1) * units;
         a.k = k;
         a.npart = col_grid_mk;
-        be.launch_col(a, col_grid_mk, col_block_mk, col_lds_mk);
+        be.launch_col(a, col_grid_mk, col_block_mk, col_lds_mk, units);
         ++seq;
     }
     int prepare_trace(ssf_trace *trace, int maxIter) {
@@ -558,11 +574,15 @@ template <typename T, class Backend> class FusedCore {
         double avg_it = 3.0;
     };
     int run_span(const ssf_params &p, const MkConst &k, SpanRun &sr, ssf_stats *st) {
-        Ctrl c{};
-        c.state = ST_NEED_S;
-        c.cur = cur;
-        c.trace_n = sr.trace_n;
-        be.h2d(ctrl + (seq & 1), &c, sizeof(Ctrl));
+        std::vector<Ctrl> cs((size_t)units);
+        for (auto &c : cs) {
+            c = Ctrl{};
+            c.state = ST_NEED_S;
+            c.cur = cur;
+            c.trace_n = sr.trace_n;
+        }
+        const size_t cbytes = sizeof(Ctrl) * (size_t)units;
+        be.h2d(ctrl + (size_t)(seq & 1) * units, cs.data(), cbytes);
         launch_mk_col(k, CM_MK);                                                       // first step start
         int guard = 0;
         long long prev_steps = 0, prev_iters = 0;
@@ -570,38 +590,60 @@ template <typename T, class Backend> class FusedCore {
             // [Row, Col] pairs still needed for this span: (1 + nIter) per step.  A surplus pair is a no-op launch
             // (~10 us); a chunk that ends short of the span costs a synchronising read and an idle stream (~100-150 us),
             // so the estimate is rounded up, not down: fixed step = remaining steps x (1 + recent iterations per step)
-            // + a few pairs (the 20-step driver run needed three rounds with the old 0.95 x estimate: -10 % steps/s)
-            double steps_rem;
-            if (c.steps == 0 && c.state == ST_NEED_S)
-                steps_rem = p.nlprMethod ? 8.0 : std::ceil(p.Lspan / p.hz);
-            else
-                steps_rem = std::max(1.0, std::ceil((p.Lspan - c.z) / (c.hz > 0 ? c.hz : p.hz)));
+            // + a few pairs (the 20-step driver run needed three rounds with the old 0.95 x estimate: -10 % steps/s).
+            // Several units: the one with the most steps left decides (the others idle through their surplus launches).
+            double steps_rem = 0.0;
+            for (const Ctrl &c : cs) {
+                double r;
+                if (c.state == ST_SPAN_DONE && !c.pend0) r = 0.0;
+                else if (c.steps == 0 && c.state == ST_NEED_S) r = p.nlprMethod ? 8.0 : std::ceil(p.Lspan / p.hz);
+                else r = std::max(1.0, std::ceil((p.Lspan - c.z) / (c.hz > 0 ? c.hz : p.hz)));
+                steps_rem = std::max(steps_rem, r);
+            }
             double est = p.nlprMethod ? steps_rem * (1.0 + sr.avg_it) * 0.6 : steps_rem * (1.0 + sr.avg_it) + 3.0;
             int chunk = (int)std::min(512.0, std::max(2.0, std::ceil(est)));
             for (int i = 0; i < chunk; ++i) {
                 launch_mk_row(k);
                 launch_mk_col(k, CM_MK);
             }
-            be.d2h(&c, ctrl + (seq & 1), sizeof(Ctrl));                               // synchronising read
+            be.d2h(cs.data(), ctrl + (size_t)(seq & 1) * units, cbytes);              // synchronising read
             if (!be.ok()) return hiperr();
-            if (c.steps > prev_steps)                                                 // iterations per step of the last chunk
-                sr.avg_it = (double)(c.iterations - prev_iters) / (double)(c.steps - prev_steps);
-            prev_steps = c.steps;
-            prev_iters = c.iterations;
-            if (c.state == ST_SPAN_DONE && !c.pend0) break;
+            long long steps = 0, iters = 0;
+            bool done = true;
+            double worst = 0.0;
+            for (const Ctrl &c : cs) {
+                steps += c.steps;
+                iters += c.iterations;
+                done = done && c.state == ST_SPAN_DONE && !c.pend0;
+                if (c.steps > 0) worst = std::max(worst, (double)c.iterations / (double)c.steps);
+            }
+            if (steps > prev_steps)                                                   // iterations per step of the last chunk
+                sr.avg_it = units == 1 ? (double)(iters - prev_iters) / (double)(steps - prev_steps) : worst;
+            prev_steps = steps;
+            prev_iters = iters;
+            if (done) break;
             if (++guard > (1 << 22)) {
                 err = "fused engine: span did not terminate";
                 return SSF_ERR_STATE;
             }
         }
-        cur = c.cur;
-        sr.trace_n = c.trace_n;
-        st->steps += c.steps;
-        st->iterations += c.iterations;
-        st->nonconverged_steps += c.nonconv;
-        st->decided_ahead += c.n_ahead;
-        st->rebuilt_iterates += c.n_rebuilt;
-        st->transforms += (int64_t)(kPacked ? 2 * nrows : nrows) * (2 * c.steps + 2 * c.iterations);
+        if (units == 1) {
+            cur = cs[0].cur;
+        } else {                                   // units may have taken different numbers of steps (adaptive step): bring
+            const size_t ub = sizeof(C) * (size_t)rows_u() * (size_t)N;                // every field back into T[cur]
+            for (int u = 0; u < units; ++u)
+                if (cs[(size_t)u].cur != cur)
+                    be.d2d((char *)(cur ? T1 : T0) + (size_t)u * ub, (char *)(cur ? T0 : T1) + (size_t)u * ub, ub);
+        }
+        sr.trace_n = cs[0].trace_n;
+        for (const Ctrl &c : cs) {
+            st->steps += c.steps;
+            st->iterations += c.iterations;
+            st->nonconverged_steps += c.nonconv;
+            st->decided_ahead += c.n_ahead;
+            st->rebuilt_iterates += c.n_rebuilt;
+            st->transforms += (int64_t)(kPacked ? 2 * rows_u() : rows_u()) * (2 * c.steps + 2 * c.iterations);
+        }
         return SSF_OK;
     }
     int fetch_trace(ssf_trace *trace, long long trace_n, int maxIter) {
@@ -618,7 +660,7 @@ template <typename T, class Backend> class FusedCore {
     }
     MkConst mk_const_for(const ssf_params &p, const Derived &d, ssf_trace *trace) const {
         MkConst k = mk_const(p, d);
-        if (!trace) k.trace_cap = 0;
+        if (!trace || units > 1) k.trace_cap = 0;                     // (no per-unit traces)
         if (k.trace_cap > 0) k.exact_lim0 = 1;
         return k;
     }
@@ -656,7 +698,7 @@ template <typename T, class Backend> class FusedCore {
         else {
             int rc;
             if (!pk) {
-                pk.reset(new FusedCore<pf2, Backend>(be, N, nrows / 2, SSF_C128, (void *)G));
+                pk.reset(new FusedCore<pf2, Backend>(be, N, nrows / 2, SSF_C128, (void *)G, units));
                 if ((rc = pk->init())) {
                     err = pk->err;
                     pk.reset();
@@ -688,6 +730,10 @@ template <typename T, class Backend> class FusedCore {
 
     int execute(const ssf_params &p, int s0, int s1, const void *noise, ssf_stats *st, ssf_trace *trace) {
         const Derived d = derive(p);
+        if (units > 1 && (trace || (p.model != SSF_MODEL_NLSE && (rows_u() % 2)))) {
+            err = "independent units: an even number of rows per unit for the Manakov models, no trace";
+            return SSF_ERR_BAD_ARG;
+        }
         be.time_begin();
         int rc = p.model == SSF_MODEL_NLSE ? run_nlse(p, d, s0, s1, noise, st)
                  : packed_ok()             ? run_manakov_packed(p, d, s0, s1, noise, st, trace)

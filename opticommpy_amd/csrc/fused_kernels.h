@@ -290,15 +290,22 @@ template <int V = 16, typename T> SSF_HD void lds_get(const PassPlan &p, int i, 
 }
 
 // DIF transform: v holds pass-0 positions on entry, pass-(p-1) positions (digit-reversed) on exit
+// (SSF_ABL 3 / 4, diagnostic builds, wrong results: no LDS exchanges / no butterflies -- which pipe the transform phase waits for)
+#ifndef SSF_ABL
+#define SSF_ABL 0
+#endif
+#define SSF_ABL_NOMEM (SSF_ABL == 2 || SSF_ABL == 5 || SSF_ABL == 6)    /* 5 = 2 + 3: arithmetic only; 6 = 2 + 4: LDS only */
+#define SSF_ABL_NOLDS (SSF_ABL == 3 || SSF_ABL == 5)
+#define SSF_ABL_NOVALU (SSF_ABL == 4 || SSF_ABL == 6)
 template <int SIGN, int V = 16, typename T, class Ctx>
 SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
-    dif_pass<SIGN, V>(p, 0, b, v);
+    if (!SSF_ABL_NOVALU) dif_pass<SIGN, V>(p, 0, b, v);
 #pragma unroll
     for (int i = 1; i < p.npass; ++i) {
-        lds_put<V>(p, i - 1, b, v, lds);
+        if (!SSF_ABL_NOLDS) lds_put<V>(p, i - 1, b, v, lds);
         ctx.sync();
-        lds_get<V>(p, i, b, v, lds);
-        dif_pass<SIGN, V>(p, i, b, v);
+        if (!SSF_ABL_NOLDS) lds_get<V>(p, i, b, v, lds);
+        if (!SSF_ABL_NOVALU) dif_pass<SIGN, V>(p, i, b, v);
     }
 }
 // DIT transform: v holds pass-(p-1) positions on entry, pass-0 positions (natural) on exit
@@ -306,12 +313,12 @@ template <int SIGN, int V = 16, typename T, class Ctx>
 SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
 #pragma unroll
     for (int i = p.npass - 1; i >= 1; --i) {
-        dit_pass<SIGN, V>(p, i, b, v);
-        lds_put<V>(p, i, b, v, lds);
+        if (!SSF_ABL_NOVALU) dit_pass<SIGN, V>(p, i, b, v);
+        if (!SSF_ABL_NOLDS) lds_put<V>(p, i, b, v, lds);
         ctx.sync();
-        lds_get<V>(p, i - 1, b, v, lds);
+        if (!SSF_ABL_NOLDS) lds_get<V>(p, i - 1, b, v, lds);
     }
-    dit_pass<SIGN, V>(p, 0, b, v);
+    if (!SSF_ABL_NOVALU) dit_pass<SIGN, V>(p, 0, b, v);
 }
 
 // ------------------------------------------------------------------------ block reductions
@@ -438,6 +445,10 @@ template <typename T> struct RowArgs {
     const cx<T> *harr;        // use_ctrl == 0 and lin == nullptr: spectrum *= harr[(rr mod N1) * N2 + position]
     int fwd_only;             // 1: stop after the forward row transform and store the spectrum in that order (makes harr)
     int vpt;                  // values per thread of the radix-2^n row kernel: 16 (0 = 16) or 8
+    // independent units (grid.y = number of units): unit u works on G + u * u_elems with control blocks cin[u] / cout[u]
+    // and partial sums at + u * u_part of every array (unit_view below); 0 / unused for a single unit
+    long long u_elems;
+    int u_part;
     int stagger;              // > 0: the second half of the grid starts this many 64-clock ticks late (co-resident workgroups
                               // out of phase: one loads / stores while the other transforms)
 };
@@ -718,8 +729,13 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
         }
         ctx.issue_fence();
     }
+    // SSF_ABL (diagnostic builds): 1 = no transforms (the launch's memory phase alone), 2 = no row loads / stores (its
+    // arithmetic and LDS phase alone); results are garbage either way
 #pragma unroll
-    for (int q = 0; q < V; ++q) v[q] = ld_pol<1>(g + b + p.tpf * q);
+    for (int q = 0; q < V; ++q) {
+        if (SSF_ABL_NOMEM) v[q] = mk<T>(splat<T>((scalar_t<T>)(ctx.tid + q)), splat<T>((scalar_t<T>)(ctx.bid - q)));
+        else v[q] = ld_pol<1>(g + b + p.tpf * q);
+    }
     if (a.use_ctrl) {
         ctx.issue_fence();
         if (!row_ctrl(ctx, a, part, lo)) return;
@@ -730,7 +746,7 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     const int k1 = (int)(rr & (N1 - 1));
     cx<T> *l = lds + (size_t)f * lds_slots_per_fft(p.L);
     ctx.mark(1);
-    fft_dif<-1, V>(ctx, p, b, v, l);
+    if (SSF_ABL != 1) fft_dif<-1, V>(ctx, p, b, v, l);
     ctx.mark(2);
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
     const int last = p.npass - 1;
@@ -754,10 +770,12 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
         }
     }
     ctx.mark(3);
-    fft_dit<+1, V>(ctx, p, b, v, l);
+    if (SSF_ABL != 1) fft_dit<+1, V>(ctx, p, b, v, l);
     ctx.mark(4);
 #pragma unroll
-    for (int q = 0; q < V; ++q) st_pol<0>(g + b + p.tpf * q, v[q]);
+    for (int q = 0; q < V; ++q)
+        if (!SSF_ABL_NOMEM || a.nfft < 0) st_pol<0>(g + b + p.tpf * q, v[q]);
+    if (SSF_WT & 1) ctx.drain();
     ctx.mark(5);
     ctx.flush(0);
 }
@@ -788,14 +806,58 @@ template <typename T> struct ColArgs {
     int npart;                // number of column workgroups (partials per array)
     int N2;                   // row length when it is not 1 << log2N2 (mixed-radix rows), else 0
     long long N;              // N1 * N2 in that case
+    int vpt;                  // values per thread: 16 (0 = 16) or 8 (128-register kernels, four waves per SIMD)
+    long long u_elems;        // independent units (see RowArgs): field elements per unit; P / Theta advance by 2 / 1 x ngroups x N
+    int u_part;
 };
+
+// Arguments of unit u of a batch of independent units: every pointer moved to the unit's block.  The kernel bodies never
+// know: a unit has its own rows, control blocks, partial sums, step sizes and convergence decisions.
+template <typename T> SSF_HD RowArgs<T> unit_view(const RowArgs<T> &a, int u) {
+    RowArgs<T> b = a;
+    if (u > 0) {
+        b.G += (long long)u * a.u_elems;
+        if (a.cin) b.cin += u;
+        if (a.cout) b.cout += u;
+        const long long po = (long long)u * a.u_part;
+        if (a.pmax) b.pmax += po;
+        if (a.pnum) b.pnum += po;
+        if (a.pden) b.pden += po;
+        if (a.pnum0) b.pnum0 += po;
+        if (a.pden0) b.pden0 += po;
+    }
+    return b;
+}
+template <typename T> SSF_HD ColArgs<T> unit_view(const ColArgs<T> &a, int u) {
+    ColArgs<T> b = a;
+    if (u > 0) {
+        const long long fo = (long long)u * a.u_elems;
+        b.G += fo;
+        if (a.T0) b.T0 += fo;
+        if (a.T1) b.T1 += fo;
+        if (a.Ehd) b.Ehd += fo;
+        const long long N = a.N2 ? a.N : 1ll << (a.log2N1 + a.log2N2);
+        if (a.P) b.P += 2 * N * a.ngroups * (long long)u;
+        if (a.Theta) b.Theta += N * a.ngroups * (long long)u;
+        if (a.cin) b.cin += u;
+        if (a.cout) b.cout += u;
+        const long long po = (long long)u * a.u_part;
+        if (a.pmax) b.pmax += po;
+        if (a.pnum) b.pnum += po;
+        if (a.pden) b.pden += po;
+        if (a.pnum0) b.pnum0 += po;
+        if (a.pden0) b.pden0 += po;
+    }
+    return b;
+}
 
 // Thread geometry of the column kernel.  A workgroup owns C adjacent columns of one field
 // group (Manakov: one polarisation pair; the x row is handled by the first half of the
 // threads, the y row by the second half; NLSE: a single row, no split).
 // RAGGED: the row length N2 is not a power of two (mixed-radix rows); the last tile of a row is then
 // only partly filled, and its surplus threads (valid == false) load zeros and store nothing.
-template <typename T, int LG, class Ctx, bool RAGGED = false> struct ColGeom {
+template <typename T, int LG, class Ctx, bool RAGGED = false, int V = 16> struct ColGeom {
+    static constexpr int kV = V;
     PassPlan p;
     int half, pol, t, C, c, b, n2, N2;
     bool valid;
@@ -803,7 +865,7 @@ template <typename T, int LG, class Ctx, bool RAGGED = false> struct ColGeom {
     long long rowbase;        // element offset of this thread's row
     long long pbase;          // element offset of the pair's row in P
     SSF_HD ColGeom(Ctx &ctx, const ColArgs<T> &a) {
-        p = make_plan(LG > 0 ? LG : a.log2N1);
+        p = make_plan(LG > 0 ? LG : a.log2N1, V == 16 ? 4 : 3);
         half = ctx.nthreads / a.npol;
         pol = ctx.tid / half;
         t = ctx.tid - pol * half;
@@ -833,11 +895,11 @@ template <typename T, int LG, class Ctx, bool RAGGED = false> struct ColGeom {
         return (long long)rev_pos(p, reg_pos(p, p.npass - 1, b, idx)) * N2 + n2;
     }
     // guarded accesses (the guard disappears when the row length is a power of two)
-    template <typename V> SSF_HD V ld(const V *ptr, long long i) const {
-        if (RAGGED && !valid) return V{};
+    template <typename W> SSF_HD W ld(const W *ptr, long long i) const {
+        if (RAGGED && !valid) return W{};
         return ptr[i];
     }
-    template <typename V> SSF_HD void st(V *ptr, long long i, V x) const {
+    template <typename W> SSF_HD void st(W *ptr, long long i, W x) const {
         if (!RAGGED || valid) ptr[i] = x;
     }
     // the same with a streaming policy bit (fused_core.h: SSF_MEMPOL)
@@ -863,35 +925,48 @@ template <int SIGN, bool RAGGED, typename T, class G> SSF_HD void global_twiddle
         w0 = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.b) & (N - 1)), log2N));
         ws = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.p.tpf) & (N - 1)), log2N));
     }
+    constexpr int V = G::kV;
     cx<double> w[16];                        // (double tree, rounded once: see tw_powers)
-    powers16(ws, w);
+    if constexpr (V == 16) powers16(ws, w);
+    else {
+        w[0] = mk<double>(1.0, 0.0);
+        w[1] = ws;
+        w[2] = ws * ws;
+        w[3] = w[2] * ws;
+        w[4] = w[2] * w[2];
+        w[5] = w[4] * ws;
+        w[6] = w[3] * w[3];
+        w[7] = w[4] * w[3];
+    }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < V; ++q) {
         v[q] = mul_by_d(v[q], w0 * w[q]);
     }
 }
 
-// exchange 16 per-thread values with the partner thread (same column/butterfly, other
+// exchange V per-thread values with the partner thread (same column/butterfly, other
 // polarisation) through LDS scratch `sh` (2*16*half values); one barrier inside.
 // The caller guarantees (barrier) that `sh` is free on entry.
-template <typename V, class Ctx, class G> SSF_HD void pair_swap(Ctx &ctx, const G &g, const V *mine, V *other, V *sh) {
+template <typename U, class Ctx, class G> SSF_HD void pair_swap(Ctx &ctx, const G &g, const U *mine, U *other, U *sh) {
+    constexpr int V = G::kV;
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) sh[(size_t)(g.pol * 16 + idx) * g.half + g.t] = mine[idx];
+    for (int idx = 0; idx < V; ++idx) sh[(size_t)(g.pol * V + idx) * g.half + g.t] = mine[idx];
     ctx.sync();
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) other[idx] = sh[(size_t)((g.pol ^ 1) * 16 + idx) * g.half + g.t];
+    for (int idx = 0; idx < V; ++idx) other[idx] = sh[(size_t)((g.pol ^ 1) * V + idx) * g.half + g.t];
 }
 
 // The two threads of a polarisation pair hold the same 16 time samples (x row | y row).  Every
 // per-sample quantity that is common to both polarisations (phase, rotation, |d rot|^2) is
-// evaluated once, by the sample's owner: the x thread owns registers 0-7, the y thread 8-15.
+// evaluated once, by the sample's owner: the x thread owns registers 0 .. V/2-1, the y thread V/2 .. V-1.
 // own_idx(j) = register of this thread's j-th owned sample, oth_idx(j) = the partner's.
-template <class G> SSF_HD int own_idx(const G &g, int j) { return g.pol ? j + 8 : j; }
-template <class G> SSF_HD int oth_idx(const G &g, int j) { return g.pol ? j : j + 8; }
-template <class G> SSF_HD long long own_time_off(const G &g, int j) { return g.pol ? g.time_off(j + 8) : g.time_off(j); }
+template <class G> SSF_HD int own_idx(const G &g, int j) { return g.pol ? j + G::kV / 2 : j; }
+template <class G> SSF_HD int oth_idx(const G &g, int j) { return g.pol ? j : j + G::kV / 2; }
+template <class G> SSF_HD long long own_time_off(const G &g, int j) { return g.pol ? g.time_off(j + G::kV / 2) : g.time_off(j); }
 // pick, for register idx (compile-time), the owner's or the partner's value
-template <typename V, class G> SSF_HD V pick16(const G &g, int idx, const V *own, const V *oth) {
-    return ((idx >> 3) == g.pol) ? own[idx & 7] : oth[idx & 7];
+template <typename U, class G> SSF_HD U pick16(const G &g, int idx, const U *own, const U *oth) {
+    constexpr int H = G::kV / 2;
+    return ((idx / H) == g.pol) ? own[idx % H] : oth[idx % H];
 }
 
 // rot[idx] = cis(ang) for all 16 registers from the 8 phases this thread owns; the partners
@@ -899,33 +974,35 @@ template <typename V, class G> SSF_HD V pick16(const G &g, int idx, const V *own
 // guarantees `sh` is free on entry.
 template <typename T, class Ctx, class G>
 SSF_HD void pair_cis(Ctx &ctx, const G &g, const T *ang_own, cx<T> *rot, cx<T> *sh) {
-    cx<T> own[8], oth[8];
+    constexpr int V = G::kV, H = V / 2;
+    cx<T> own[H], oth[H];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < H; ++j) {
         own[j] = cis_t<T>(ang_own[j]);
         sh[(size_t)own_idx(g, j) * g.half + g.t] = own[j];
     }
     ctx.sync();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) oth[j] = sh[(size_t)oth_idx(g, j) * g.half + g.t];
+    for (int j = 0; j < H; ++j) oth[j] = sh[(size_t)oth_idx(g, j) * g.half + g.t];
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) rot[idx] = pick16(g, idx, own, oth);
+    for (int idx = 0; idx < V; ++idx) rot[idx] = pick16(g, idx, own, oth);
 }
 
 // ---- Manakov time-domain building blocks (registers v = this thread's 16 samples of its row) ----
 // step start (channels.py:388-395): Pch = |Ex|^2 + |Ey|^2 -> Pbuf, block max of phi -> pmax
 template <typename T, class Ctx, class G>
 SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T> *v, T *Pbuf, bool lds_busy) {
+    constexpr int V = G::kV;
     T *shT = (T *)ctx.lds;
-    T mine[16], oth[16];
+    T mine[V], oth[V];
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) mine[idx] = norm2(v[idx]);
+    for (int idx = 0; idx < V; ++idx) mine[idx] = norm2(v[idx]);
     if (lds_busy) ctx.sync();
     pair_swap(ctx, g, mine, oth, shT);
     const T c8g = (T)a.k.c8g;
     double m = -INFINITY;
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) {
+    for (int idx = 0; idx < V; ++idx) {
         const T ax = g.pol ? oth[idx] : mine[idx], ay = g.pol ? mine[idx] : oth[idx];
         const T pw = ax + ay;
         if (g.pol == 0) g.st(Pbuf, g.pbase + g.time_off(idx), pw);
@@ -944,35 +1021,36 @@ SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T>
 template <typename T, class Ctx, class G>
 SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, const T *Pbuf, T shz, bool first,
                        double &num, double &den, double &pch_sum) {
-    T *shN = (T *)ctx.lds;                                   // 16*half powers for the owners
-    cx<T> *shC = (cx<T> *)(shN + 16 * (size_t)g.half);       // 16*half rotations
-    T *shD = (T *)(shC + 16 * (size_t)g.half);               // 16*half |d rot|^2
-    T nown[8], noth[8];
+    constexpr int V = G::kV, H = V / 2;
+    T *shN = (T *)ctx.lds;                                   // V*half powers for the owners
+    cx<T> *shC = (cx<T> *)(shN + V * (size_t)g.half);        // V*half rotations
+    T *shD = (T *)(shC + V * (size_t)g.half);                // V*half |d rot|^2
+    T nown[H], noth[H];
     // The step-start powers and the last phases of the owned samples are fetched here, all at once, and arrive
     // while the partners swap their powers.  (Fetched inside the phase loop, each pair of loads waits for the
     // Theta store of the sample before it - the compiler has to assume they alias - and the loop pays eight
     // memory round trips in a row.)
-    T pw8[8], prev8[8];
+    T pw8[H], prev8[H];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < H; ++j) {
         const long long t = own_time_off(g, j);
         pw8[j] = g.ld(Pbuf, g.pbase + t);
         prev8[j] = first ? (T)0 : g.ld(a.Theta, g.pbase + t);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const T lo = norm2(v[j]), hi = norm2(v[j + 8]);
+    for (int j = 0; j < H; ++j) {
+        const T lo = norm2(v[j]), hi = norm2(v[j + H]);
         nown[j] = g.pol ? hi : lo;
         noth[j] = g.pol ? lo : hi;                           // goes to the partner, who owns that sample
     }
     ctx.sync();                                              // the inverse transform's LDS reads are done
 #pragma unroll
-    for (int j = 0; j < 8; ++j) shN[(size_t)oth_idx(g, j) * g.half + g.t] = noth[j];
+    for (int j = 0; j < H; ++j) shN[(size_t)oth_idx(g, j) * g.half + g.t] = noth[j];
     ctx.sync();
     const T c8g = (T)a.k.c8g;
-    T ang8[8];                                               // the new phases; prev8 <- the old ones
+    T ang8[H];                                               // the new phases; prev8 <- the old ones
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < H; ++j) {
         const T po = shN[(size_t)own_idx(g, j) * g.half + g.t];
         const T ax = g.pol ? po : nown[j], ay = g.pol ? nown[j] : po;
         const T pw = pw8[j];
@@ -986,12 +1064,12 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     // rotation and |d rot|^2 go to LDS and all sixteen come back from there (own and partner's alike) once the
     // partners have met.
 #ifndef SSF_EHD_EARLY
-#define SSF_EHD_EARLY 8
+#define SSF_EHD_EARLY (V / 2)
 #endif
 #pragma unroll
     for (int idx = 0; idx < SSF_EHD_EARLY; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < H; ++j) {
         const long long t = own_time_off(g, j);
         const T ang = ang8[j], prev = prev8[j];
         // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2)
@@ -1002,10 +1080,10 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     }
     ctx.mark(7);
 #pragma unroll
-    for (int idx = SSF_EHD_EARLY; idx < 16; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
+    for (int idx = SSF_EHD_EARLY; idx < V; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
     ctx.sync();
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) {
+    for (int idx = 0; idx < V; ++idx) {
         const cx<T> e = v[idx];
         const double w = (double)norm2(e);
         num += w * (double)shD[(size_t)idx * g.half + g.t];
@@ -1115,7 +1193,8 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
 }
 
 // MODE is one of CM_*; the Manakov mode picks its stage from the Ctrl state.
-template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
+template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
+    constexpr int H = V / 2;
     constexpr bool kMk = MODE == CM_MK;
     // ---- what does this launch do? ------------------------------------------------------
     bool do_inv = false, do_fwd = false;
@@ -1145,10 +1224,10 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
         do_fwd = MODE == CM_NLSE_STEP || MODE == CM_NLSE_FIRST || MODE == CM_PLAIN_FWD;
     }
 
-    ColGeom<T, LG, Ctx, RAGGED> g(ctx, a);
+    ColGeom<T, LG, Ctx, RAGGED, V> g(ctx, a);
     const PassPlan &p = g.p;
     cx<T> *lds = (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
-    cx<T> v[16];
+    cx<T> v[V];
 
     // buffers by role (Manakov)
     cx<T> *Tcur = a.T0, *Tnew = a.T1;
@@ -1164,53 +1243,53 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
     // ---- inverse column transform: G -> time samples in registers -------------------------
     if (do_inv) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
+        for (int q = 0; q < V; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
         ctx.mark(1);
         global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v);
-        fft_dif<+1>(ctx, p, g.b, v, lds);
+        fft_dif<+1, V>(ctx, p, g.b, v, lds);
         ctx.mark(2);
     } else if (!(kMk && op == 3)) {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
+        for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
     }
 
     // ---- time-domain work ---------------------------------------------------------------
     if (MODE == CM_NLSE_STEP) {                                          // channels.py:225
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * cis_t<T>(a.g_hz * norm2(v[idx]));
+        for (int idx = 0; idx < V; ++idx) v[idx] = v[idx] * cis_t<T>(a.g_hz * norm2(v[idx]));
     } else if (MODE == CM_NLSE_LAST || MODE == CM_PLAIN_INV) {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) g.st(a.T0, g.rowbase + g.time_off(idx), v[idx]);
+        for (int idx = 0; idx < V; ++idx) g.st(a.T0, g.rowbase + g.time_off(idx), v[idx]);
     } else if (kMk) {
         const T shz = (T)(a.k.sgn * c.hz), c8g = (T)a.k.c8g;
-        cx<T> *shC = (cx<T> *)(ctx.lds + 2 * 16 * (size_t)g.half * sizeof(T));
+        cx<T> *shC = (cx<T> *)(ctx.lds + 2 * V * (size_t)g.half * sizeof(T));
         if (op == 0) {                               // span start: Pch into the current buffer
             mk_step_start(ctx, g, a, v, Pcur, false);
         } else if (op == 1 || op == 3) {             // H (channels.py:409-417) | rebuild of iterate 0
-            T ang[8];
+            T ang[H];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < H; ++j) {
                 const T pw = g.ld(Pcur, g.pbase + own_time_off(g, j));
                 ang[j] = shz * (c8g * (pw + pw) / (T)2);
             }
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) {
+            for (int idx = 0; idx < V; ++idx) {
                 const long long t = g.time_off(idx);
                 if (op == 1) g.template stp<2>(a.Ehd, g.rowbase + t, v[idx]);
                 else v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + t);
             }
-            cx<T> rot[16];
+            cx<T> rot[V];
             ctx.sync();                              // inverse transform's LDS reads are done
             pair_cis(ctx, g, ang, rot, shC);
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * rot[idx];
+            for (int idx = 0; idx < V; ++idx) v[idx] = v[idx] * rot[idx];
             ctx.sync();
         } else {                                     // I: iterate `it` is in registers
             double n0 = 0, d0 = 0, n1 = 0, d1 = 0, psum = 0;
             if (c.it == 0) {                         // lim_0 against the field at the step start
 #pragma unroll
-                for (int idx = 0; idx < 16; ++idx) {
-                    if (exact0 || idx == 0) {        // (bound: one register in sixteen = one cache line in sixteen)
+                for (int idx = 0; idx < V; ++idx) {
+                    if (exact0 || (idx == 0 && (V == 16 || !(g.b & 1)))) {   // (bound: one sample in sixteen = one cache line in sixteen)
                         const cx<T> e = g.ld(Tcur, g.rowbase + g.time_off(idx));
                         const double dr = (double)v[idx].re - (double)e.re, di = (double)v[idx].im - (double)e.im;
                         n0 += dr * dr + di * di;
@@ -1220,7 +1299,7 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
             }
             if (final_) {                            // the field after this step (channels.py:438-439)
 #pragma unroll
-                for (int idx = 0; idx < 16; ++idx) g.template stp<2>(Tnew, g.rowbase + g.time_off(idx), v[idx]);
+                for (int idx = 0; idx < V; ++idx) g.template stp<2>(Tnew, g.rowbase + g.time_off(idx), v[idx]);
             } else {
                 mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
                 if (!exact0) d0 = psum;              // exact denominator of the bound: sum Pch over the tile
@@ -1249,11 +1328,11 @@ template <typename T, int LG, int MODE, bool RAGGED, class Ctx> SSF_HD void col_
     ctx.mark(3);
     if (do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
-        fft_dit<-1>(ctx, p, g.b, v, lds);
+        fft_dit<-1, V>(ctx, p, g.b, v, lds);
         global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) g.template stp<0>(a.G, g.rowbase + g.freq_off(q), v[q]);
+        for (int q = 0; q < V; ++q) g.template stp<4>(a.G, g.rowbase + g.freq_off(q), v[q]);
         ctx.mark(5);
         ctx.flush(do_inv ? 0 : 1);
     }
@@ -1296,10 +1375,11 @@ SSF_HD void pair_pow(cx<pf2> e, float &ax, float &ay) {
 // step start (channels.py:388-395): Pch = |Ex|^2 + |Ey|^2 -> Pbuf, block max of phi -> pmax.  Ends with a barrier.
 template <class Ctx, class G>
 SSF_HD void pk_step_start(Ctx &ctx, const G &g, const ColArgs<pf2> &a, const cx<pf2> *v, float *Pbuf) {
+    constexpr int V = G::kV;
     const float c8g = (float)a.k.c8g;
     double m = -INFINITY;
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) {
+    for (int idx = 0; idx < V; ++idx) {
         float ax, ay;
         pair_pow(v[idx], ax, ay);
         const float pw = ax + ay;
@@ -1314,18 +1394,18 @@ SSF_HD void pk_step_start(Ctx &ctx, const G &g, const ColArgs<pf2> &a, const cx<
     ctx.sync();
 }
 
-template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2> &a) {
+template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2> &a) {
     using T = pf2;
     ctx.mark(0);
     MkColStage st;
     mk_col_stage(ctx, a, st);
     if (st.op < 0) return;
     const int op = st.op;
-    ColGeom<T, LG, Ctx, false> g(ctx, a);
+    ColGeom<T, LG, Ctx, false, V> g(ctx, a);
     const PassPlan &p = g.p;
     cx<T> *lds = (cx<T> *)ctx.lds + (size_t)g.c * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
     double *red = (double *)ctx.lds;
-    cx<T> v[16];
+    cx<T> v[V];
     cx<T> *Tcur = st.c.cur ? a.T1 : a.T0;                    // field at the step start
     cx<T> *Tnew = st.c.cur ? a.T0 : a.T1;                    // receives the field at the step end
     const long long psz = g.N * a.ngroups;
@@ -1333,39 +1413,39 @@ template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2
 
     if (st.do_inv) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
+        for (int q = 0; q < V; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
         ctx.mark(1);
         global_twiddle<+1, false>(g, a.log2N1 + a.log2N2, v);
-        fft_dif<+1>(ctx, p, g.b, v, lds);
+        fft_dif<+1, V>(ctx, p, g.b, v, lds);
         ctx.mark(2);
     } else if (op != 3) {
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
+        for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
     }
 
     const float shz = (float)(a.k.sgn * st.c.hz), c8g = (float)a.k.c8g;
     if (op == 0) {                                           // span start: Pch into the current buffer
         pk_step_start(ctx, g, a, v, Pcur);
     } else if (op == 1 || op == 3) {                         // H (channels.py:409-417) | rebuild of iterate 0
-        float pw[16];
+        float pw[V];
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) pw[idx] = g.ld(Pcur, g.pbase + g.time_off(idx));
+        for (int idx = 0; idx < V; ++idx) pw[idx] = g.ld(Pcur, g.pbase + g.time_off(idx));
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) {
+        for (int idx = 0; idx < V; ++idx) {
             const long long t = g.time_off(idx);
             if (op == 1) g.template stp<2>(a.Ehd, g.rowbase + t, v[idx]);
             else v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + t);
         }
 #pragma unroll
-        for (int idx = 0; idx < 16; ++idx) v[idx] = tmul(v[idx], cis_t<float>(shz * (c8g * (pw[idx] + pw[idx]) / 2.0f)));
+        for (int idx = 0; idx < V; ++idx) v[idx] = tmul(v[idx], cis_t<float>(shz * (c8g * (pw[idx] + pw[idx]) / 2.0f)));
         ctx.sync();                                          // the inverse transform's LDS reads are done
     } else {                                                 // I: iterate `it` is in registers
         double n0 = 0, d0 = 0, n1 = 0, d1 = 0, psum = 0;
         const bool first = st.c.it == 0;
         if (first) {                                         // lim_0 against the field at the step start
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) {
-                if (st.exact0 || idx == 0) {                 // (bound: one register in sixteen = one cache line in sixteen)
+            for (int idx = 0; idx < V; ++idx) {
+                if (st.exact0 || (idx == 0 && (V == 16 || !(g.b & 1)))) {   // (bound: one sample in sixteen = one cache line in sixteen)
                     const cx<T> e = g.ld(Tcur, g.rowbase + g.time_off(idx));
 #pragma unroll
                     for (int l = 0; l < 2; ++l) {
@@ -1378,19 +1458,19 @@ template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2
         }
         if (st.final_) {                                     // the field after this step (channels.py:438-439)
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) g.template stp<2>(Tnew, g.rowbase + g.time_off(idx), v[idx]);
+            for (int idx = 0; idx < V; ++idx) g.template stp<2>(Tnew, g.rowbase + g.time_off(idx), v[idx]);
         } else {
             // next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
             // sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the note at the top of this file)
-            float pw[16], prev[16], pn[16];
+            float pw[V], prev[V], pn[V];
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) {
+            for (int idx = 0; idx < V; ++idx) {
                 const long long t = g.pbase + g.time_off(idx);
                 pw[idx] = g.ld(Pcur, t);
                 prev[idx] = first ? 0.0f : g.ld(a.Theta, t);
             }
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) {
+            for (int idx = 0; idx < V; ++idx) {
                 float ax, ay;
                 pair_pow(v[idx], ax, ay);
                 pn[idx] = shz * (c8g * (pw[idx] + ax + ay) / 2.0f);                    // the new phase
@@ -1399,12 +1479,12 @@ template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2
             }
             ctx.mark(6);
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
+            for (int idx = 0; idx < V; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) g.st(a.Theta, g.pbase + g.time_off(idx), pn[idx]);
+            for (int idx = 0; idx < V; ++idx) g.st(a.Theta, g.pbase + g.time_off(idx), pn[idx]);
             ctx.mark(7);
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) {
+            for (int idx = 0; idx < V; ++idx) {
                 // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2); the two phases agree to a few digits, so
                 // their single-precision difference is exact (Sterbenz) and small: the float kernel is enough
                 const float dth = pn[idx] - prev[idx];
@@ -1440,11 +1520,11 @@ template <int LG, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2
 
     ctx.mark(3);
     if (st.do_fwd) {
-        fft_dit<-1>(ctx, p, g.b, v, lds);
+        fft_dit<-1, V>(ctx, p, g.b, v, lds);
         global_twiddle<-1, false>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) g.template stp<0>(a.G, g.rowbase + g.freq_off(q), v[q]);
+        for (int q = 0; q < V; ++q) g.template stp<4>(a.G, g.rowbase + g.freq_off(q), v[q]);
         ctx.mark(5);
         ctx.flush(st.do_inv ? 0 : 1);
     }

@@ -106,6 +106,31 @@ int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int
     return SSF_OK;
 }
 
+int ssf_plan_set_units(ssf_plan *plan, int32_t n_units) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    if (n_units < 1 || plan->nrows % n_units) return fail(plan, SSF_ERR_BAD_ARG, "ssf_plan_set_units: nrows must be a multiple of n_units");
+    if (n_units == plan->units) return SSF_OK;
+    if (plan->engine_id != SSF_ENGINE_FUSED || !fused_supports(plan->N, plan->nrows, plan->precision))
+        return fail(plan, SSF_ERR_UNSUPPORTED, "independent units need the natively split fused engine");
+    if (n_units > 65535) return fail(plan, SSF_ERR_BAD_ARG, "ssf_plan_set_units: at most 65535 units");
+    SSF_HIP(plan, hipSetDevice(plan->device));
+    (void)plan->sink.sync();
+    delete plan->engine;
+    plan->engine = nullptr;
+    const int old = plan->units;
+    plan->units = n_units;
+    plan->has_field = false;
+    plan->engine = make_fused_engine(plan);
+    if (!plan->engine) {                                    // (out of memory?) back to what worked
+        const std::string why = plan->err;
+        plan->units = old;
+        plan->engine = make_fused_engine(plan);
+        return fail(plan, why.find("out of memory") != std::string::npos ? SSF_ERR_OOM : SSF_ERR_HIP,
+                    why.empty() ? "engine creation failed" : why);
+    }
+    return SSF_OK;
+}
+
 int ssf_plan_destroy(ssf_plan *plan) {
     if (!plan) return SSF_OK;
     (void)hipSetDevice(plan->device);

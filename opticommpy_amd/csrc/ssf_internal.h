@@ -58,6 +58,7 @@ struct ssf_plan {
     int device = 0;
     int64_t N = 0;
     int nrows = 0;
+    int units = 1;               // rows form `units` independent fields (ssf_plan_set_units)
     int precision = SSF_C128;
     int engine_id = 0;
     hipStream_t stream = nullptr;

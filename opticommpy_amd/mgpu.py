@@ -277,6 +277,15 @@ def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
         mine = shard_range(n, world, rank)
         local = {u: fields[u] for u in mine}
     outs = [None] * n
+    # Small units are latency-bound one at a time (a launch is one ~10 us chain of load -> transform -> store whatever its
+    # size): a rank's units of one shape go to the device as ONE batch of independent units -- every launch carries all of
+    # them, each with its own control block, step sizes and convergence decisions (ssf_plan_set_units) -- with results
+    # bit-equal to one call per unit.  SSF_MGPU_BATCH=0 turns it off; fields of 2^19 samples and more fill the GPU alone.
+    if compute is None and _batchable(local, mine, param):
+        _run_batched(local, list(mine), param, outs)
+        mine_left = []
+    else:
+        mine_left = list(mine)
     # Two lanes per GPU: the rank's units are taken by two host threads (each with its own plan and stream; ctypes
     # releases the GIL inside the library), so that one unit's transfers overlap the other's kernels and the kernels of
     # two independent fields fill each other's load / store phases (ssf_mgpu_run does the same).
@@ -294,11 +303,11 @@ def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
         out = np.asarray(compute(local[u], p))
         return u, out
 
-    if lanes > 1:
-        for u, o in _lane_pool(lanes).map(one, mine):
+    if lanes > 1 and len(mine_left) > 1:
+        for u, o in _lane_pool(lanes).map(one, mine_left):
             outs[u] = o
     else:
-        for u in mine:
+        for u in mine_left:
             outs[u] = one(u)[1]
     if not (comm is not None and gather and world > 1):
         return outs
@@ -326,6 +335,46 @@ def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
         for i, u in enumerate(shard_range(n, world, r)):
             outs[u] = parts[r][i].astype(odt, copy=False)
     return outs
+
+
+_BATCH_MAX_SAMPLES = 1 << 18        # per polarisation row: larger fields fill the GPU by themselves
+_BATCH_MAX_UNITS = 64
+
+
+def _batchable(local, mine, param):
+    """True when the rank's units can go to the device as one batch of independent units: default compute, host
+    arrays of one shape and dtype, more than one unit, small fields, final field only (or one pair per unit)."""
+    from . import device as _dev
+    if os.environ.get("SSF_MGPU_BATCH", "1") == "0" or len(mine) < 2:
+        return False
+    f0 = local[mine[0]]
+    if _dev.is_device(f0) or np.ndim(f0) != 2 or np.shape(f0)[1] % 2 or np.shape(f0)[0] > _BATCH_MAX_SAMPLES:
+        return False
+    if getattr(param, "returnParameters", False):
+        return False
+    save = getattr(param, "saveSpanN", None)
+    if np.shape(f0)[1] > 2 and (save is None or len(save) > 0):   # (K > 1 per unit needs saveSpanN = [], like the reference)
+        return False
+    return all(not _dev.is_device(local[u]) and np.shape(local[u]) == np.shape(f0) and np.asarray(local[u]).dtype == np.asarray(f0).dtype
+               for u in mine)
+
+
+def _run_batched(local, units, param, outs):
+    from .models import manakovSSF
+    N, ncols = np.shape(local[units[0]])
+    for i in range(0, len(units), _BATCH_MAX_UNITS):
+        chunk = units[i:i + _BATCH_MAX_UNITS]                    # (contiguous unit numbers: the rank's block)
+        p = copy.deepcopy(param)
+        try:
+            p._rng_row_offset = int(getattr(param, "_rng_row_offset", 0)) + chunk[0] * ncols
+        except AttributeError:
+            pass
+        E = np.concatenate([np.asarray(local[u]) for u in chunk], axis=1)
+        out = np.asarray(manakovSSF(E, p, _units=len(chunk)))
+        nblk = out.shape[1] // (ncols * len(chunk))              # saved spans per unit (1: the final field)
+        for j, u in enumerate(chunk):                            # snapshot b of the batch = columns [b * ncols_all, ...)
+            cols = [b * ncols * len(chunk) + j * ncols + c for b in range(nblk) for c in range(ncols)]
+            outs[u] = np.ascontiguousarray(out[:, cols])
 
 
 def run_coupled(Ei_block, param, comm):

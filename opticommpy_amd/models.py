@@ -55,12 +55,19 @@ def checkGPU():
 # plan cache: one handle per (device, N, nrows, precision, engine)
 # ----------------------------------------------------------------------------
 class _Plan:
-    def __init__(self, device, N, nrows, prec_code, engine):
+    def __init__(self, device, N, nrows, prec_code, engine, units=1):
         self.lib = _lib.load()
         h = C.c_void_p()
         rc = self.lib.ssf_plan_create(device, N, nrows, prec_code, engine, C.byref(h))
         _lib.raise_for(self.lib, None, rc)
-        self.h, self.N, self.nrows, self.prec_code = h, N, nrows, prec_code
+        if units > 1:                                         # rows form `units` independent fields (include/ssf.h)
+            rc = self.lib.ssf_plan_set_units(h, units)
+            if rc:
+                try:
+                    _lib.raise_for(self.lib, h, rc)
+                finally:
+                    self.lib.ssf_plan_destroy(h)
+        self.h, self.N, self.nrows, self.prec_code, self.units = h, N, nrows, prec_code, units
         self.dtype = np.complex128 if prec_code == _lib.SSF_C128 else np.complex64
 
     def check(self, rc):
@@ -89,8 +96,10 @@ def _plans():
     return d
 
 
-def _get_plan(N, nrows, prec_code):
-    key = (_state["device"], int(N), int(nrows), prec_code, _state["engine"])
+def _get_plan(N, nrows, prec_code, engine=None, units=1):
+    """engine: None = the process-wide choice (set_engine); an explicit code otherwise (never through the global: other
+    threads -- run_sharded's lanes -- create plans at the same time)."""
+    key = (_state["device"], int(N), int(nrows), prec_code, _state["engine"] if engine is None else engine, int(units))
     plans = _plans()
     pl = plans.pop(key, None)
     if pl is None:
@@ -354,7 +363,7 @@ def ssfm(Ei, param=None, _trace=False, _cpu_seed_policy=False):
 # ----------------------------------------------------------------------------
 # manakovSSF / manakovDBP
 # ----------------------------------------------------------------------------
-def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=None):
+def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=None, _units=1):
     Fs = _require_fs(param)
     defaults = [("Ltotal", 400), ("Lspan", 80), ("hz", 0.5), ("alpha", 0.2), ("D", 16), ("gamma", 1.3),
                 ("Fc", 193.1e12), ("prec", np.complex128), ("amp", "edfa")]
@@ -377,20 +386,18 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
     N, ncols = Ei.shape
     K = ncols // 2
     save_list = list(param.saveSpanN) if param.saveSpanN is not None else []
-    if save_list and K > 1:
+    if _units > 1 and (_trace or _coupling is not None or ncols % (2 * _units)):
+        raise ValueError("independent units: (N, 2 K units) columns, no trace, no cross-process coupling")
+    if save_list and K > 1 and (_units == 1 or K // _units > 1):
         # the reference's snapshot write only broadcasts for K = 1 (channels.py:454-455)
         raise ValueError(f"could not broadcast input array from shape ({N},{K}) into shape ({N},1): "
                          "with more than one polarisation pair set param.saveSpanN = []")
     Nspans = int(np.floor(param.Ltotal / param.Lspan))
     prec = _prec_code(param.prec)
     if _coupling is not None:                 # rows of ONE reference call spread over several processes (mgpu.run_coupled):
-        saved_engine, _state["engine"] = _state["engine"], _lib.ENGINE_ROCFFT      # host-driven control flow
-        try:
-            pl = _get_plan(N, ncols, prec)
-        finally:
-            _state["engine"] = saved_engine
+        pl = _get_plan(N, ncols, prec, engine=_lib.ENGINE_ROCFFT)                  # host-driven control flow
     else:
-        pl = _get_plan(N, ncols, prec)
+        pl = _get_plan(N, ncols, prec, units=_units)
     # the reference's own layout goes over the bus; the (N, 2K) -> (2K, N) conversion runs on the GPU
     in_ptr, _keep = _dev.arg(Ei, pl.dtype)
 
@@ -421,24 +428,25 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
         hint = 1 << 16
     else:
         hint = int(np.ceil(param.Lspan / param.hz)) + 1
-    sink = _open_sink(pl, on_dev, N, ncols, len(save_list), len(captured)) if save_list else None
-    reducer = None
-    if _coupling is not None:
-        def _reduce(_ctx, vals, n, op):       # called by the engine with the partial sums / maxima it is about to use
-            try:
-                a = np.ctypeslib.as_array(vals, shape=(n,))
-                a[:] = _coupling.allreduce(a.copy(), "max" if op else "sum")
-                return 0
-            except Exception:                 # (never let an exception cross the C boundary)
-                return 1
-        reducer = _lib.REDUCE_FN(_reduce)
-        pl.check(pl.lib.ssf_set_coupling(pl.h, C.cast(reducer, C.c_void_p), None))
-    try:
+    sink, reducer = None, None
+    try:                                      # (whatever fails below, the cached plan keeps no sink and no reducer)
+        if save_list:
+            sink = _open_sink(pl, on_dev, N, ncols, len(save_list), len(captured))
+        if _coupling is not None:
+            def _reduce(_ctx, vals, n, op):   # called by the engine with the partial sums / maxima it is about to use
+                try:
+                    a = np.ctypeslib.as_array(vals, shape=(n,))
+                    a[:] = _coupling.allreduce(a.copy(), "max" if op else "sum")
+                    return 0
+                except Exception:             # (never let an exception cross the C boundary)
+                    return 1
+            reducer = _lib.REDUCE_FN(_reduce)
+            pl.check(pl.lib.ssf_set_coupling(pl.h, C.cast(reducer, C.c_void_p), None))
         st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, hint)
     finally:
         if reducer is not None:
             pl.lib.ssf_set_coupling(pl.h, None, None)
-        if sink is not None:
+        if save_list:
             _close_sink(pl, len(captured))
     for _ in range(int(st.nonconverged_steps)):
         logg.warning(NONCONV_WARNING.format(param.maxIter))
@@ -455,7 +463,7 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
     return (out, param) if param.returnParameters else out
 
 
-def manakovSSF(Ei, param, _trace=False, _cpu_seed_policy=False, _noise=None, _coupling=None):
+def manakovSSF(Ei, param, _trace=False, _cpu_seed_policy=False, _noise=None, _coupling=None, _units=1):
     """Manakov split-step Fourier model (symmetric, dual-pol.) on the GPU.
 
     Reference: optic/models/modelsGPU.py:281-511 == optic/models/channels.py:252-468.
@@ -465,7 +473,7 @@ def manakovSSF(Ei, param, _trace=False, _cpu_seed_policy=False, _noise=None, _co
     [10], tol [1e-5], nlprMethod [True], maxNlinPhaseRot [2e-2], prgsBar [True],
     saveSpanN [[Ltotal // Lspan]], seed [None], returnParameters [False].
     """
-    return _manakov(Ei, param, +1, _trace, _cpu_seed_policy, _noise, _coupling)
+    return _manakov(Ei, param, +1, _trace, _cpu_seed_policy, _noise, _coupling, _units)
 
 
 def manakovDBP(Ei, param, _trace=False):

@@ -33,6 +33,7 @@ struct EmuCtx {
     void flush(int) {}
     void issue_fence() {}
     void sleep64(int) {}
+    void drain() {}
     double wave_sum(double v) { return v; }
     double wave_max(double v) { return v; }
 };
@@ -148,8 +149,15 @@ struct EmuBackend {
     std::string last_error() const { return ""; }
     void time_begin() {}
     double time_end() { return 0.0; }
-    template <typename T> void launch_row(const ssf::fused::RowArgs<T> &a, int grid, int block, size_t lds) {
+    template <typename T> void launch_row(const ssf::fused::RowArgs<T> &a0, int grid, int block, size_t lds, int units = 1) {
         ++launches;
+        for (int u = 0; u < units; ++u) {
+            const ssf::fused::RowArgs<T> a = ssf::fused::unit_view(a0, u);
+            launch_row_unit(a, grid, block, lds);
+        }
+    }
+    template <typename T> void launch_row_unit(const ssf::fused::RowArgs<T> &a, int grid, int block, size_t lds) {
+        if (getenv("SSF_EMU_DEBUG") && launches < 8) fprintf(stderr, "emu row: vpt %d block %d grid %d lds %zu\n", a.vpt, block, grid, lds);
         if constexpr (!std::is_same<T, ssf::fused::pf2>::value) {
             if (a.mixed) {
                 run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_mixed_body<T>(c, a); });
@@ -166,13 +174,32 @@ struct EmuBackend {
         ++launches;
         run_grid(std::min(grid, 8), block, 64, [&](EmuCtx &c) { ssf::fused::repack_body(c, a); });
     }
-    template <typename T> void launch_col(const ssf::fused::ColArgs<T> &a, int grid, int block, size_t lds) {
+    template <typename T> void launch_col(const ssf::fused::ColArgs<T> &a0, int grid, int block, size_t lds, int units = 1) {
         ++launches;
+        for (int u = 0; u < units; ++u) {
+            const ssf::fused::ColArgs<T> a = ssf::fused::unit_view(a0, u);
+            launch_col_unit(a, grid, block, lds);
+        }
+    }
+    template <typename T> void launch_col_unit(const ssf::fused::ColArgs<T> &a, int grid, int block, size_t lds) {
+        if (getenv("SSF_EMU_DEBUG") && launches < 8) fprintf(stderr, "emu col: vpt %d block %d grid %d lds %zu\n", a.vpt, block, grid, lds);
         using namespace ssf::fused;
         if constexpr (std::is_same<T, pf2>::value) {          // packed pair: only the Manakov stage exists
-            run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0>(c, a); });
+            if (a.vpt == 8) run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0, 8>(c, a); });
+            else run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0>(c, a); });
             return;
-        } else
+        } else {
+        if (a.vpt == 8 && !a.N2) {                          // eight values per thread (no ragged variant)
+            switch (a.mode) {
+            case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST, false, 8>(c, a); }); break;
+            case CM_NLSE_STEP: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_STEP, false, 8>(c, a); }); break;
+            case CM_NLSE_LAST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST, false, 8>(c, a); }); break;
+            case CM_MK: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false, 8>(c, a); }); break;
+            case CM_PLAIN_FWD: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD, false, 8>(c, a); }); break;
+            default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV, false, 8>(c, a); }); break;
+            }
+            return;
+        }
         switch (a.mode) {
         case CM_NLSE_FIRST:
             if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST, true>(c, a); });
@@ -198,6 +225,7 @@ struct EmuBackend {
             if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV, true>(c, a); });
             else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_INV, false>(c, a); });
             break;
+        }
         }
     }
     template <typename T> void launch_amp(const ssf::fused::AmpArgs<T> &a, int grid, int block) {
@@ -235,7 +263,8 @@ template <typename T>
 int run_t(int64_t N, int nrows, int prec, const ssf_params *p, const void *in, void *out, void *snaps,
           const void *noise, ssf_stats *st, ssf_trace *tr, long *launches) {
     EmuBackend be;
-    ssf::fused::FusedCore<T, EmuBackend> core(be, N, nrows, prec);
+    const char *eu = getenv("SSF_EMU_UNITS");                 // the rows form this many independent units
+    ssf::fused::FusedCore<T, EmuBackend> core(be, N, nrows, prec, nullptr, eu ? atoi(eu) : 1);
     int rc = core.init();
     if (rc) return rc;
     if ((rc = core.upload(in, false))) return rc;

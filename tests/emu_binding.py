@@ -59,6 +59,7 @@ def run(func, Ei, cfg, noise=None, max_steps=4096, trace=True):
     p.maxNlinPhaseRot = cfg.get("maxNlinPhaseRot", 2e-2)
     p.amp, p.NF = _amp(cfg.get("amp", "edfa")), cfg.get("NF", 4.5)
     p.rng_seed = int(cfg.get("_rng_seed", 0))
+    p.rng_row_offset = int(cfg.get("_rng_row_offset", 0))
     p.n_save = len(save_arr)
     p.save_spans = save_arr.ctypes.data_as(C.POINTER(C.c_int32)) if len(save_arr) else None
     out = np.empty_like(soa)

@@ -423,10 +423,14 @@ def test_mixed_radix_planner_covers_every_row_length_the_split_can_ask_for():
 # ---- round 3: eight values per thread (128-register kernels, four waves per SIMD) ---------------------------------
 @pytest.mark.parametrize("N,prec", [(1 << 12, "complex128"), (1 << 14, "complex128"), (1 << 16, "complex128"),
                                     (1 << 17, "complex128"), (1 << 14, "complex64")])
-def test_rows_with_eight_values_per_thread(monkeypatch, N, prec):
+@pytest.mark.parametrize("which", ["rows", "cols", "both"])
+def test_rows_with_eight_values_per_thread(monkeypatch, N, prec, which):
     """SSF_ROW_V=8: radix-8 row passes (a fourth LDS exchange per 4096-point transform), operator on the eight bins
     N/8 apart of a last-pass butterfly.  Same results as the oracle, same iteration counts; ssfm and the linear channel too."""
-    monkeypatch.setenv("SSF_ROW_V", "8")
+    if which != "cols":
+        monkeypatch.setenv("SSF_ROW_V", "8")
+    if which != "rows":
+        monkeypatch.setenv("SSF_COL_V", "8")
     dt = np.complex64 if prec == "complex64" else np.complex128
     E = synth_field(N, 2, 41, 8.4).astype(dt)
     cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5, prgsBar=False,
@@ -443,3 +447,34 @@ def test_rows_with_eight_values_per_thread(monkeypatch, N, prec):
         assert rel_l2(eb.linear_channel(E, 512e9, 193.1e12, 0.2, 16, 3.0), orc.linearFiberChannel(E, p)) < 1e-13
     else:
         assert rel_l2(out.T, ref) <= 5e-4
+
+
+# ---- round 3: independent units in one launch sequence ---------------------------------------------------------------
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("N,prec", [(1 << 12, "complex128"), (6000, "complex128"), (1 << 12, "complex64")])
+def test_independent_units_share_the_launches_not_the_decisions(monkeypatch, N, prec, adaptive):
+    """Three fields of very different power as ONE batch of independent units (grid.y = units): every unit keeps its own
+    control block, step sizes and convergence decisions, so the batch is bit-equal to three separate runs -- and not to the
+    coupled K = 3 call of the reference, which shares max(phi) and the norms."""
+    dt = np.complex64 if prec == "complex64" else np.complex128
+    fields = [synth_field(N, 2, 50 + u, p).astype(dt) for u, p in enumerate((-12.0, 6.0, 18.0))]
+    cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=64e9, maxIter=10, tol=1e-5, prgsBar=False,
+               Ltotal=20, Lspan=10, hz=1.0, nlprMethod=adaptive, maxNlinPhaseRot=5e-3, amp="edfa", NF=4.5, saveSpanN=[], prec=prec)
+    monkeypatch.delenv("SSF_EMU_UNITS", raising=False)
+    alone, steps = [], []
+    cfg["_rng_seed"] = 1234                                         # device ASE noise: unit u draws rows 2u, 2u + 1 of the stream
+    for u, E in enumerate(fields):
+        out, info = eb.run("manakovSSF", E, dict(cfg, _rng_row_offset=2 * u), trace=False)
+        alone.append(out)
+        steps.append((info["steps"], info["iterations"]))
+    assert len({s for s in steps}) > 1                              # the units really need different step / iteration counts
+    monkeypatch.setenv("SSF_EMU_UNITS", "3")
+    out, info = eb.run("manakovSSF", np.concatenate(fields, axis=1), cfg, trace=False)
+    for u in range(3):
+        assert np.array_equal(out[2 * u:2 * u + 2], alone[u]), u
+    assert info["steps"] == sum(s[0] for s in steps) and info["iterations"] == sum(s[1] for s in steps)
+    if prec == "complex128" and not adaptive:
+        ref = orc.manakovSSF(fields[1], make_param(orc.parameters, dict(cfg, amp="ideal")))
+        cfg2 = dict(cfg, amp="ideal")
+        out2, _ = eb.run("manakovSSF", np.concatenate(fields, axis=1), cfg2, trace=False)
+        assert rel_l2(out2[2:4].T, ref) <= TOL_C128

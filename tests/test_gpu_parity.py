@@ -291,8 +291,11 @@ def test_c64_long_run_does_not_drift_from_c128(engine):
         outs[prec], _, run = _run_hip(cfg, E.astype(prec))
         assert run["steps"] == 2002
     a, b = outs["complex64"].astype(np.complex128), outs["complex128"]
-    # the fused kernels hold the SURVEY 8c single-precision gate over twice its 1000 steps; the
-    # rocFFT engine inherits the library's single-precision transforms (measured 5.3e-4 here)
+    # the fused kernels (the product path) hold the SURVEY 8c single-precision gate over twice its 1000 steps.  The
+    # rocFFT engine is only the on-GPU cross-check of the transforms (never selected by AUTO inside the fused range): it
+    # inherits the library's single-precision transforms, whose rounded twiddles drift like the reference's own complex64
+    # path (measured 5.3e-4 here; the reference itself: 7.3e-4 after 10 spans, long_c64drift_*) -- its bound is that
+    # yardstick, not the product gate
     tol, ptol = (TOL_C64, 4e-4) if engine == "fused" else (1.5e-3, 2e-3)
     assert rel_l2(a, b) <= tol
     assert np.sum(np.abs(a) ** 2) / np.sum(np.abs(b) ** 2) == pytest.approx(1.0, abs=ptol)

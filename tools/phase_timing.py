@@ -53,7 +53,17 @@ def main():
             col = us[:, i]
             col = col[m[:, i] > 0]
             if len(col):
-                print(f"   {n:20s} min {col.min():7.2f}  med {np.median(col):7.2f}  max {col.max():7.2f} us")
+                bids = np.nonzero(used)[0][m[:, i] > 0]
+                late = bids[np.argsort(col)[-4:]][::-1]
+                print(f"   {n:20s} min {col.min():7.2f}  med {np.median(col):7.2f}  p90 {np.percentile(col, 90):7.2f}  p99 {np.percentile(col, 99):7.2f}"
+                      f"  max {col.max():7.2f} us   latest workgroups {list(late)}")
+        last = us[:, len(names) - 1]
+        bids_all = np.nonzero(used)[0]
+        print("   end of workgroup by XCD (bid % 8), median / max: " +
+              " ".join(f"{np.median(last[bids_all % 8 == x]):.1f}/{last[bids_all % 8 == x].max():.1f}" for x in range(8)))
+        q = max(1, len(last) // 4)
+        print("   end of workgroup by quarter of the grid, median / max: " +
+              " ".join(f"{np.median(last[i * q:(i + 1) * q]):.1f}/{last[i * q:(i + 1) * q].max():.1f}" for i in range(4)))
         G = int(os.environ.get("PHASE_GROUPS", "1"))
         if G > 1:                                         # experiment: statistics per workgroup class
             bids = np.nonzero(used)[0]

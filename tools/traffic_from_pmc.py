@@ -5,7 +5,7 @@ FETCH_SIZE counts 64 B per 128-B request for wide (16 B/lane) coalesced reads =>
 taken as is.  Both corrections are re-checked in the same run on k_amp (a plain read-modify-write of
 a known 32 MiB / 64 MiB buffer).  Units of both counters: KiB.
 
-usage: traffic_from_pmc.py fetch.db write.db TOTAL_STEPS ENGINE [out.json]"""
+usage: traffic_from_pmc.py fetch.db write.db TOTAL_UNIT_STEPS ENGINE [out.json CONFIG ALGORITHMIC_BYTES_PER_STEP ITER_PER_STEP SOURCE]"""
 import json
 import sqlite3
 import sys
@@ -17,7 +17,7 @@ def per_kernel(path, counter):
     return {n: (c, v) for n, c, v in db.execute(q, (counter,))}
 
 
-def main(fetch_db, write_db, total_steps, engine, out=None):
+def main(fetch_db, write_db, total_steps, engine, out=None, config="2", alg_bytes=536870912, it_step=3.0, source=""):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
     total = 0.0
@@ -42,10 +42,10 @@ def main(fetch_db, write_db, total_steps, engine, out=None):
             d = {}
         # bench.py scales this to its own run: traffic is linear in (1 + iterations per step); the profiled
         # run (fixed step, 8.4 dBm, first 200 steps of config 2) needs 3 iterations in every step
-        d[engine] = {"bytes_per_step": per_step, "iterations_per_step": 3.0, "steps": total_steps,
-                     "algorithmic_bytes_per_step": 536870912}
+        d["config%s" % config] = {"bytes_per_step": per_step, "iterations_per_step": float(it_step), "steps": total_steps,
+                                  "algorithmic_bytes_per_step": int(alg_bytes), "engine": engine, "source": source}
         json.dump(d, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], *sys.argv[5:])
