@@ -12,6 +12,8 @@ struct DevCtxCore {
     __device__ __forceinline__ void sync() { __syncthreads(); }
     // keeps the instruction scheduler from moving memory operations across this point
     __device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
+    // issue priority of this wave against the other waves of its SIMD (0 .. 3); the hardware default is 0
+    template <int P> __device__ __forceinline__ void setprio() { __builtin_amdgcn_s_setprio(P); }
     // wait for every outstanding vector-memory operation of this wave (the compiler does not count inline-asm stores)
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     // idle for n * 64 clocks (s_sleep takes at most 127 ticks at a time)

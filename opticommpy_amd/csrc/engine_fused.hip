@@ -12,6 +12,8 @@ Engine *make_fused_engine_f64(ssf_plan *plan);
 Engine *make_fused_engine_f32(ssf_plan *plan);
 FusedConv *make_fused_conv_f64(ssf_plan *plan, int64_t M, int nrows);
 FusedConv *make_fused_conv_f32(ssf_plan *plan, int64_t M, int nrows);
+FusedRows *make_fused_rows_f64(ssf_plan *plan, int64_t N, int nrows);
+FusedRows *make_fused_rows_f32(ssf_plan *plan, int64_t N, int nrows);
 int fused_overlap_save_f64(int64_t sigLen, int nrows, int log2nfft, int K, const void *Hfft, const void *in, void *out, std::string *err);
 int fused_overlap_save_f32(int64_t sigLen, int nrows, int log2nfft, int K, const void *Hfft, const void *in, void *out, std::string *err);
 
@@ -21,6 +23,19 @@ Engine *make_fused_engine(ssf_plan *plan) {
 
 FusedConv *make_fused_conv(ssf_plan *plan, int64_t M, int nrows) {
     return plan->precision == SSF_C128 ? make_fused_conv_f64(plan, M, nrows) : make_fused_conv_f32(plan, M, nrows);
+}
+
+bool fused_rows_supports(int64_t n) {
+    if (n < 16 || n > fused::kMixMaxRow) return false;
+    int64_t r = n;
+    for (int q : {2, 3, 5})
+        while (r % q == 0) r /= q;
+    fused::MixPlan mp;
+    return r == 1 && fused::mix_make_plan((int)n, &mp);
+}
+
+FusedRows *make_fused_rows(ssf_plan *plan, int64_t N, int nrows) {
+    return plan->precision == SSF_C128 ? make_fused_rows_f64(plan, N, nrows) : make_fused_rows_f32(plan, N, nrows);
 }
 
 int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int log2nfft, int K, const void *Hfft,

@@ -5,6 +5,7 @@
 namespace ssf {
 Engine *make_fused_engine_f32(ssf_plan *plan) { return make_fused_engine_t<float>(plan); }
 FusedConv *make_fused_conv_f32(ssf_plan *plan, int64_t M, int nrows) { return make_fused_conv_t<float>(plan, M, nrows); }
+FusedRows *make_fused_rows_f32(ssf_plan *plan, int64_t N, int nrows) { return make_fused_rows_t<float>(plan, N, nrows); }
 int fused_overlap_save_f32(int64_t sigLen, int nrows, int log2nfft, int K, const void *Hfft, const void *in, void *out, std::string *err) {
     return overlap_save_t<float>(sigLen, nrows, log2nfft, K, Hfft, in, out, err);
 }

@@ -546,6 +546,77 @@ template <typename T> class FusedConvImpl final : public FusedConv {
     }
 };
 
+template <typename T> class FusedRowsImpl final : public FusedRows {
+    ssf_plan *pl;
+    HipBackend be;
+    int64_t N;
+    int nrows, tpr = 128, rows_wg = 1;
+    MixPlan plan{};
+    cx<double> *wtab = nullptr;
+    LinOp *lin_d = nullptr;
+    double key[5] = {0, 0, 0, 0, 0};             // parameters of the operator that is on the device
+    std::string err_;
+
+  public:
+    FusedRowsImpl(ssf_plan *p, int64_t N_, int nrows_) : pl(p), be(p), N(N_), nrows(nrows_) {}
+    ~FusedRowsImpl() override {
+        if (wtab) (void)hipFree(wtab);
+        if (lin_d) (void)hipFree(lin_d);
+    }
+    static bool supports(int64_t n) {
+        if (n < 16 || n > kMixMaxRow) return false;
+        int64_t r = n;
+        for (int q : {2, 3, 5})
+            while (r % q == 0) r /= q;
+        MixPlan mp;
+        return r == 1 && mix_make_plan((int)n, &mp);
+    }
+    int init() {
+        while (16 * tpr < N) tpr *= 2;
+        rows_wg = std::max(1, 256 / tpr);
+        while (nrows % rows_wg) rows_wg >>= 1;
+        if (!mix_make_plan((int)N, &plan, tpr)) return SSF_ERR_UNSUPPORTED;
+        std::vector<cx<double>> w((size_t)N);
+        for (int64_t q = 0; q < N; ++q) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)q / (double)N;
+            w[(size_t)q].re = std::cos(a);
+            w[(size_t)q].im = std::sin(a);
+        }
+        if (hipMalloc(&wtab, sizeof(cx<double>) * (size_t)N) != hipSuccess || hipMalloc(&lin_d, sizeof(LinOp)) != hipSuccess) {
+            err_ = "out of memory (row transform tables)";
+            return SSF_ERR_OOM;
+        }
+        be.h2d(wtab, w.data(), sizeof(cx<double>) * (size_t)N);
+        return be.ok() ? SSF_OK : SSF_ERR_HIP;
+    }
+    std::string error() const override { return err_.empty() ? be.last_error() : err_; }
+    int lin(const void *in, void *out, double hzh, double lin_a, double lin_b, double w_scale, double scale) override {
+        const double k5[5] = {hzh, lin_a, lin_b, w_scale, scale};
+        if (std::memcmp(k5, key, sizeof(key)) != 0) {            // a new step size / span: the operator block changes
+            const double w2 = (w_scale / (double)N) * (w_scale / (double)N);
+            LinOp lo = make_linop(hzh, lin_a, lin_b, w2, scale, 4);
+            be.h2d(lin_d, &lo, sizeof(LinOp));
+            std::memcpy(key, k5, sizeof(key));
+        }
+        RowArgs<T> a{};
+        a.G = (cx<T> *)out;
+        a.src = in == out ? nullptr : (const cx<T> *)in;
+        a.log2N1 = 0;
+        a.log2N2 = 0;
+        a.nfft = nrows;
+        a.use_ctrl = 0;
+        a.lin = lin_d;
+        a.N2 = (int)N;
+        a.N = N;
+        a.mixed = 1;
+        a.plan = plan;
+        a.wtab = wtab;
+        a.rows_per_wg = rows_wg;
+        be.launch_row(a, nrows / rows_wg, tpr * rows_wg, 4096 + (size_t)rows_wg * (size_t)N * sizeof(cx<T>));
+        return be.ok() ? SSF_OK : SSF_ERR_HIP;
+    }
+};
+
 template <typename T>
 int overlap_save_t(int64_t sigLen, int nrows, int lg, int K, const void *Hfft, const void *in, void *out, std::string *err) {
     using Cc = cx<T>;
@@ -611,6 +682,15 @@ int overlap_save_t(int64_t sigLen, int nrows, int lg, int K, const void *Hfft, c
 // entry points of this translation unit (one per precision; engine_fused.hip dispatches)
 template <typename T> Engine *make_fused_engine_t(ssf_plan *plan) {
     auto *x = new FusedEngine<T>(plan);
+    if (x->init() != SSF_OK) {
+        delete x;
+        return nullptr;
+    }
+    return x;
+}
+template <typename T> FusedRows *make_fused_rows_t(ssf_plan *plan, int64_t N, int nrows) {
+    if (!FusedRowsImpl<T>::supports(N)) return nullptr;
+    auto *x = new FusedRowsImpl<T>(plan, N, nrows);
     if (x->init() != SSF_OK) {
         delete x;
         return nullptr;

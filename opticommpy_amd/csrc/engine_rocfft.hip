@@ -317,6 +317,7 @@ template <typename T> class RocfftEngine final : public Engine {
     const bool blue;                              // transforms by Bluestein on the fused kernels instead of rocFFT
     int64_t M = 0;
     FusedConv *conv = nullptr;                    // M > 8192: three fused launches per convolution
+    FusedRows *rows = nullptr;                    // N = 2^a 3^b 5^c <= 8192: FFT . H . IFFT of a row in ONE launch (no Bluestein)
     fused::cx<T> *Bhat[2] = {nullptr, nullptr};   // M <= 8192: spectra of the two chirp kernels for the one-launch transform
     double2 *chirp = nullptr;                     // exp(-j pi n^2 / N), n < N
     std::vector<C *> snaps;
@@ -417,6 +418,7 @@ template <typename T> class RocfftEngine final : public Engine {
         if (blue) {
             fwd = (rocfft_plan)(void *)this;             // direction tags only (never dereferenced)
             inv = (rocfft_plan)(void *)&M;
+            rows = make_fused_rows(pl, N, nrows);        // (nullptr unless the length is short and 5-smooth)
             return init_bluestein();
         }
         const size_t len = (size_t)N;
@@ -446,6 +448,7 @@ template <typename T> class RocfftEngine final : public Engine {
         if (inv && !blue) rocfft_plan_destroy(inv);
         if (info) rocfft_execution_info_destroy(info);
         delete conv;
+        delete rows;
         for (auto *q : Bhat)
             if (q) (void)hipFree(q);
         if (chirp) (void)hipFree(chirp);
@@ -522,6 +525,10 @@ template <typename T> class RocfftEngine final : public Engine {
     }
     // out = ifft(fft(in) * lin)  with 1/N folded into lin
     int lin_step(C *in, C *out) {
+        if (rows) {                                  // one launch: the row lives in LDS, the operator comes from the bin index
+            const int rc = rows->lin(in, out, lin_hz, lin_a, lin_b, lin_w, lin_scale);
+            return rc ? fail(pl, rc, "row transform: " + rows->error()) : SSF_OK;
+        }
         int rc = fft(fwd, in, F);
         if (rc) return rc;
         k_mul_lin<T><<<grid_for(N * nrows), kBlock, 0, pl->stream>>>(F, lin, N, nrows);

@@ -99,6 +99,11 @@ template <> SSF_HD pf2 fma_s<pf2>(pf2 x, float a, pf2 c) {
 // bit 4: G stores of the column stage.
 // SSF_WT bits (same numbering, stores only): write-through stores (sc0 sc1): the line leaves the L2 when it is stored
 // instead of waiting, dirty, for the end-of-kernel write-back (up to 32 MiB of L2 to flush before the next launch starts).
+// Default: bit 0 -- the row stage's G stores -- in double precision only.  Measured (MI355X, config 2, same-box A/B,
+// gpurun_out/r3b..r3d): row launch 23.2 -> 21.4 us, +4 % steps/s; the column stage's G stores: nothing (bit 4), its field
+// stores: nothing (bit 2).  Parity of the write-through rows: every complex128 GPU test, the bench's oracle gate at 2^20,
+// 2^21 and 2^22.  complex64 (packed pairs): no gain at config 3 AND wrong results through the bench path (rel-L2 0.67,
+// every size; not understood) -- so the single-precision kernels keep plain stores whatever SSF_WT says.
 #ifndef SSF_MEMPOL
 #define SSF_MEMPOL 0
 #endif
@@ -119,11 +124,11 @@ template <int BIT, typename T> SSF_HD cx<T> ld_pol(const cx<T> *p) {
     return *p;
 }
 #ifndef SSF_WT
-#define SSF_WT 0
+#define SSF_WT 1
 #endif
 template <int BIT, typename T> SSF_HD void st_pol(cx<T> *p, cx<T> x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr ((SSF_WT >> BIT) & 1) {
+    if constexpr (((SSF_WT >> BIT) & 1) && sizeof(T) == 8 && sizeof(scalar_t<T>) == 8) {
         if constexpr (sizeof(cx<T>) == 16) {
             typedef float vec4 __attribute__((ext_vector_type(4)));
             vec4 v;
@@ -416,6 +421,42 @@ template <typename T> SSF_HD void powers16(cx<T> w, cx<T> *p) {
     p[14] = p[8] * p[6];
     p[15] = p[8] * p[7];
 }
+
+// ---------------------------------------------------------------------------------------
+// Single precision (one row per polarisation and packed pairs): apply unit factors (twiddles, operator) as hi + lo float pairs.  A factor rounded to
+// one float is off by up to 3e-8 in magnitude and phase, and it is the SAME error at every step (the twiddle of a given
+// butterfly never changes), so over 10^4 steps the errors add up coherently: -1.2e-7 of power per step and a spectral
+// ripple of 1e-3 after BASELINE config 3's 10 010 steps (the reference's own complex64 path, pocketfft with float
+// twiddles, drifts by 5e-4 there).  With the low part the effective factor is exact to 1e-15 and only the random
+// rounding of the products is left, which grows with the square root of the step count.
+#ifndef SSF_C64_HILO
+#define SSF_C64_HILO 1
+#endif
+// v * h for a factor given in double precision
+template <typename T> SSF_HD cx<T> mul_by_d(cx<T> v, cx<double> h) {
+    using S = scalar_t<T>;
+    if constexpr (sizeof(S) == 8) {
+        return v * mk<T>((T)h.re, (T)h.im);
+    } else if constexpr (SSF_C64_HILO) {                                    // float and packed float pairs alike
+        const S hr = (S)h.re, hi = (S)h.im;
+        const S lr = (S)(h.re - (double)hr), li = (S)(h.im - (double)hi);
+        const T cr = fma_s<T>(v.re, lr, -(v.im * splat<T>(li)));            // v.re lr - v.im li
+        const T ci = fma_s<T>(v.re, li, v.im * splat<T>(lr));               // v.re li + v.im lr
+        return mk<T>(fma_s<T>(v.re, hr, fma_s<T>(-v.im, hi, cr)), fma_s<T>(v.re, hi, fma_s<T>(v.im, hr, ci)));
+    } else {
+        return tmul(v, mk<S>((S)h.re, (S)h.im));
+    }
+}
+// a real constant given in double precision (radix-3 / 5 butterfly constants of the mixed-radix rows): x * c
+template <typename T> SSF_HD T mul_cd(T x, double c) {
+    using S = scalar_t<T>;
+    if constexpr (sizeof(S) == 8) return x * (T)c;
+    else if constexpr (SSF_C64_HILO) {
+        const S hi = (S)c, lo = (S)(c - (double)hi);
+        return fma_s<T>(x, hi, x * splat<T>(lo));
+    } else return x * splat<T>((S)c);
+}
+
 
 // ---------------------------------------------------------------------------------------
 // Mixed-radix pass plan for one length-L transform (L = 2^m, 16 <= L <= 65536), V = 2^lgV values

@@ -111,33 +111,7 @@ SSF_HD double pick_hz(const MkConst &k, double z, double maxphi) {
 }
 
 // ------------------------------------------------------------------------ thread-level FFT
-// Single precision (one row per polarisation and packed pairs): apply unit factors (twiddles, operator) as hi + lo float pairs.  A factor rounded to
-// one float is off by up to 3e-8 in magnitude and phase, and it is the SAME error at every step (the twiddle of a given
-// butterfly never changes), so over 10^4 steps the errors add up coherently: -1.2e-7 of power per step and a spectral
-// ripple of 1e-3 after BASELINE config 3's 10 010 steps (the reference's own complex64 path, pocketfft with float
-// twiddles, drifts by 5e-4 there).  With the low part the effective factor is exact to 1e-15 and only the random
-// rounding of the products is left, which grows with the square root of the step count.
-#ifndef SSF_C64_HILO
-#define SSF_C64_HILO 1
-#endif
-// v * h for a factor given in double precision
-template <typename T> SSF_HD cx<T> mul_by_d(cx<T> v, cx<double> h) {
-    using S = scalar_t<T>;
-    if constexpr (sizeof(S) == 8) {
-        return v * mk<T>((T)h.re, (T)h.im);
-    } else if constexpr (SSF_C64_HILO) {                                    // float and packed float pairs alike
-        const S hr = (S)h.re, hi = (S)h.im;
-        const S lr = (S)(h.re - (double)hr), li = (S)(h.im - (double)hi);
-        const T cr = fma_s<T>(v.re, lr, -(v.im * splat<T>(li)));            // v.re lr - v.im li
-        const T ci = fma_s<T>(v.re, li, v.im * splat<T>(lr));               // v.re li + v.im lr
-        return mk<T>(fma_s<T>(v.re, hr, fma_s<T>(-v.im, hi, cr)), fma_s<T>(v.re, hi, fma_s<T>(v.im, hr, ci)));
-    } else {
-        return tmul(v, mk<S>((S)h.re, (S)h.im));
-    }
-}
-// (the mixed-radix rows of mixed_fft.h -- lengths 2^a 3^b 5^c -- still round their factors and butterfly constants to
-//  one float: complex64 at those lengths behaves like the reference's own complex64 path)
-
+// (mul_by_d -- factors applied as hi + lo pairs in single precision -- lives in fused_core.h: the mixed-radix rows use it too)
 // w[s] = cis(sign * 2 pi j s / 2^lgL), s = 0..R-1.  The power tree always runs in double and is
 // rounded once, where it is applied: in single precision a float tree gives every twiddle a magnitude error
 // that is the same at every step (w^s inherits s times the rounding of w), and those errors add up
@@ -294,6 +268,15 @@ template <int V = 16, typename T> SSF_HD void lds_get(const PassPlan &p, int i, 
 #ifndef SSF_ABL
 #define SSF_ABL 0
 #endif
+// SSF_PRIO: issue priority by phase (s_setprio): a wave that is further behind in its launch gets the VALU first.  The two
+// workgroups of a CU start together, but the older one wins every arbitration, runs through at full speed and leaves the
+// younger one to finish alone, one wave per SIMD (phase stamps, gpurun_out/r3c: first half of the row grid done at 13.3 us,
+// second half at 17.5 us).  With the forward transform above the inverse one (rows) and inverse > time domain > forward
+// (columns) the late workgroup catches up while the early one is in a later phase.  Measured (same-box A/B, config 2):
+// 1: +3 % steps/s (row 23.5 -> 23.0 us, column 25.8 -> 24.9 us); 2 (three levels in the row stage): the same; config 3: +-0.
+#ifndef SSF_PRIO
+#define SSF_PRIO 1
+#endif
 #define SSF_ABL_NOMEM (SSF_ABL == 2 || SSF_ABL == 5 || SSF_ABL == 6)    /* 5 = 2 + 3: arithmetic only; 6 = 2 + 4: LDS only */
 #define SSF_ABL_NOLDS (SSF_ABL == 3 || SSF_ABL == 5)
 #define SSF_ABL_NOVALU (SSF_ABL == 4 || SSF_ABL == 6)
@@ -444,6 +427,7 @@ template <typename T> struct RowArgs {
     // an array in the row kernel's own spectrum order, [k1][position after the forward passes], the same for every field row
     const cx<T> *harr;        // use_ctrl == 0 and lin == nullptr: spectrum *= harr[(rr mod N1) * N2 + position]
     int fwd_only;             // 1: stop after the forward row transform and store the spectrum in that order (makes harr)
+    const cx<T> *src;         // mixed-radix rows only: read the rows from here instead of G (out-of-place; nullptr = in place)
     int vpt;                  // values per thread of the radix-2^n row kernel: 16 (0 = 16) or 8
     // independent units (grid.y = number of units): unit u works on G + u * u_elems with control blocks cin[u] / cout[u]
     // and partial sums at + u * u_part of every array (unit_view below); 0 / unused for a single unit
@@ -630,6 +614,7 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
     const MixPlan &p = a.plan;                             // (host-made: indexed from the kernel arguments, not from scratch)
     const long long rr = (long long)ctx.bid * R_ + f;      // global row index (grid is exact)
     cx<T> *g = a.G + rr * L;
+    const cx<T> *gin = a.src ? a.src + rr * L : g;
     LinOp lo;
     double part[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if (a.use_ctrl) {
@@ -650,7 +635,7 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
 #pragma unroll
     for (int m = 0; m < kMaxPerThread; ++m) {
         const int i = t + T_ * m;
-        v[m] = i < L ? g[i] : mk<T>((T)0, (T)0);
+        v[m] = i < L ? gin[i] : mk<T>((T)0, (T)0);
     }
     if (a.use_ctrl) {
         ctx.issue_fence();
@@ -746,8 +731,15 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     const int k1 = (int)(rr & (N1 - 1));
     cx<T> *l = lds + (size_t)f * lds_slots_per_fft(p.L);
     ctx.mark(1);
+    // SSF_PRIO (experiment): a wave that is further behind gets the VALU first.  The two workgroups of a CU start together,
+    // but the older one wins every arbitration, runs through at full speed and leaves the younger one to finish alone, one
+    // wave per SIMD (phase stamps: first half of the grid done at 13.3 us, second half at 17.5 us).
+    if (SSF_PRIO == 2) ctx.template setprio<3>();
+    else if (SSF_PRIO) ctx.template setprio<2>();
     if (SSF_ABL != 1) fft_dif<-1, V>(ctx, p, b, v, l);
     ctx.mark(2);
+    if (SSF_PRIO == 2) ctx.template setprio<2>();
+    else if (SSF_PRIO) ctx.template setprio<1>();
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
     const int last = p.npass - 1;
     if (!a.use_ctrl && !a.lin) {                 // fixed-kernel convolution: multiplier array in this kernel's spectrum order
@@ -770,12 +762,14 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
         }
     }
     ctx.mark(3);
+    if (SSF_PRIO == 2) ctx.template setprio<1>();
     if (SSF_ABL != 1) fft_dit<+1, V>(ctx, p, b, v, l);
+    if (SSF_PRIO) ctx.template setprio<0>();
     ctx.mark(4);
 #pragma unroll
     for (int q = 0; q < V; ++q)
         if (!SSF_ABL_NOMEM || a.nfft < 0) st_pol<0>(g + b + p.tpf * q, v[q]);
-    if (SSF_WT & 1) ctx.drain();
+    if ((SSF_WT & 1) && sizeof(T) == 8 && sizeof(scalar_t<T>) == 8) ctx.drain();   // (inline-asm stores: not counted by the compiler)
     ctx.mark(5);
     ctx.flush(0);
 }
@@ -1245,9 +1239,11 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 #pragma unroll
         for (int q = 0; q < V; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
         ctx.mark(1);
+        if (SSF_PRIO) ctx.template setprio<3>();
         global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         fft_dif<+1, V>(ctx, p, g.b, v, lds);
         ctx.mark(2);
+        if (SSF_PRIO) ctx.template setprio<2>();
     } else if (!(kMk && op == 3)) {
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
@@ -1326,11 +1322,13 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 
     // ---- forward column transform: registers -> G -------------------------------------------
     ctx.mark(3);
+    if (SSF_PRIO) ctx.template setprio<1>();
     if (do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
         fft_dit<-1, V>(ctx, p, g.b, v, lds);
         global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
+        if (SSF_PRIO) ctx.template setprio<0>();
 #pragma unroll
         for (int q = 0; q < V; ++q) g.template stp<4>(a.G, g.rowbase + g.freq_off(q), v[q]);
         ctx.mark(5);

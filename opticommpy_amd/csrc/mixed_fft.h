@@ -110,24 +110,26 @@ SSF_HD int mix_pos(const MixPlan &p, int k) {
 }
 
 // ---- small DFTs, natural order in and out, X[k] = sum_q x[q] cis(SIGN 2 pi q k / R) ------------------
+// (the irrational constants go through mul_cd: hi + lo in single precision, see mul_by_d)
 template <int SIGN, typename T> SSF_HD void dft3(cx<T> &a, cx<T> &b, cx<T> &c) {
-    const T h = (T)-0.5, s = (T)(SIGN * 0.86602540378443864676);
+    constexpr double s = SIGN * 0.86602540378443864676;
+    const T h = (T)-0.5;
     const cx<T> t = b + c, d = b - c;
     const cx<T> m = mk<T>(a.re + h * t.re, a.im + h * t.im);
-    const cx<T> r = mk<T>(-s * d.im, s * d.re);                 // j s d
+    const cx<T> r = mk<T>(-mul_cd(d.im, s), mul_cd(d.re, s));     // j s d
     a = a + t;
     b = m + r;
     c = m - r;
 }
 template <int SIGN, typename T> SSF_HD void dft5(cx<T> *v) {
-    const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;
-    const T s1 = (T)(SIGN * 0.95105651629515357212), s2 = (T)(SIGN * 0.58778525229247312917);
+    constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    constexpr double s1 = SIGN * 0.95105651629515357212, s2 = SIGN * 0.58778525229247312917;
     const cx<T> t1 = v[1] + v[4], t2 = v[2] + v[3], d1 = v[1] - v[4], d2 = v[2] - v[3];
     const cx<T> a = v[0];
-    const cx<T> m1 = mk<T>(a.re + c1 * t1.re + c2 * t2.re, a.im + c1 * t1.im + c2 * t2.im);
-    const cx<T> m2 = mk<T>(a.re + c2 * t1.re + c1 * t2.re, a.im + c2 * t1.im + c1 * t2.im);
-    const cx<T> r1 = mk<T>(-(s1 * d1.im + s2 * d2.im), s1 * d1.re + s2 * d2.re);       // j (s1 d1 + s2 d2)
-    const cx<T> r2 = mk<T>(-(s2 * d1.im - s1 * d2.im), s2 * d1.re - s1 * d2.re);       // j (s2 d1 - s1 d2)
+    const cx<T> m1 = mk<T>(a.re + mul_cd(t1.re, c1) + mul_cd(t2.re, c2), a.im + mul_cd(t1.im, c1) + mul_cd(t2.im, c2));
+    const cx<T> m2 = mk<T>(a.re + mul_cd(t1.re, c2) + mul_cd(t2.re, c1), a.im + mul_cd(t1.im, c2) + mul_cd(t2.im, c1));
+    const cx<T> r1 = mk<T>(-(mul_cd(d1.im, s1) + mul_cd(d2.im, s2)), mul_cd(d1.re, s1) + mul_cd(d2.re, s2));       // j (s1 d1 + s2 d2)
+    const cx<T> r2 = mk<T>(-(mul_cd(d1.im, s2) - mul_cd(d2.im, s1)), mul_cd(d1.re, s2) - mul_cd(d2.re, s1));       // j (s2 d1 - s1 d2)
     v[0] = a + t1 + t2;
     v[1] = m1 + r1;
     v[4] = m1 - r1;
@@ -190,8 +192,7 @@ template <int SIGN, int A, int B, typename T> SSF_HD void dft_ab(cx<T> *v) {
             if (b * ka == 0) {
                 v[b + B * ka] = t[ka];
             } else {
-                const T c = (T)SmallW<R>::c[(b * ka) % R], s = (T)(SIGN * SmallW<R>::s[(b * ka) % R]);
-                v[b + B * ka] = t[ka] * mk<T>(c, s);
+                v[b + B * ka] = mul_by_d(t[ka], mk<double>(SmallW<R>::c[(b * ka) % R], SIGN * SmallW<R>::s[(b * ka) % R]));
             }
         }
     }
@@ -254,7 +255,7 @@ template <int R, typename T> SSF_HD void mix_apply_op(const MixPlan &p, const Mi
             vv = mk<double>(c, s);
             wrapped = neg;
         }
-        v[q] = v[q] * mk<T>((T)u.re, (T)u.im);
+        v[q] = mul_by_d(v[q], u);
         u = u * vv;
         vv = vv * op.c2;
     }
@@ -307,7 +308,7 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
         if (!DIF && s > 1) {                         // inputs are in natural order q
 #pragma unroll
             for (int q = 1; q < R; ++q) {
-                v[q] = v[q] * mk<T>((T)ch[q % NCH].re, (T)ch[q % NCH].im);
+                v[q] = mul_by_d(v[q], ch[q % NCH]);
                 if (q + NCH < R) ch[q % NCH] = ch[q % NCH] * wn;
             }
         }
@@ -316,7 +317,7 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
 #pragma unroll
             for (int kq = 1; kq < R; ++kq) {
                 const int slot = dft_bin_slot<R>(kq);          // compile-time after unrolling
-                v[slot] = v[slot] * mk<T>((T)ch[kq % NCH].re, (T)ch[kq % NCH].im);
+                v[slot] = mul_by_d(v[slot], ch[kq % NCH]);
                 if (kq + NCH < R) ch[kq % NCH] = ch[kq % NCH] * wn;
             }
         }

@@ -63,6 +63,12 @@ int ssf_device_info(int device, ssf_device_info_t *out) {
 
 const char *ssf_last_error(const ssf_plan *plan) { return plan ? plan->err.c_str() : g_err.c_str(); }
 
+static bool smooth13(int64_t n) {
+    for (int q : {2, 3, 5, 7, 11, 13})
+        while (n % q == 0) n /= q;
+    return n == 1;
+}
+
 int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int32_t engine, ssf_plan **out) {
     if (!out) return set_err(SSF_ERR_BAD_ARG, "out is NULL");
     *out = nullptr;
@@ -87,7 +93,14 @@ int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int
     // for lengths beyond the Bluestein range (2N - 1 > 2^22 complex128 / 2^23 complex64)
     const bool native = fused_supports(N, nrows, precision), general = !native && general_supports(N, nrows, precision);
     int want = engine;
-    if (want == SSF_ENGINE_AUTO) want = (native || general) ? SSF_ENGINE_FUSED : SSF_ENGINE_ROCFFT;
+    if (want == SSF_ENGINE_AUTO) {
+        want = (native || general) ? SSF_ENGINE_FUSED : SSF_ENGINE_ROCFFT;
+        // AUTO is never the slower engine: lengths the hand-written kernels only reach through a Bluestein convolution, but
+        // whose prime factors are all <= 13 (30 030 = 2 3 5 7 11 13), are one or two native kernels for rocFFT (measured,
+        // tools/bench_lengths.py: 30 030: 4 653 against 3 446 steps/s); primes and other lengths stay on the fused kernels
+        // (10 007: 3 753 against 2 950; rocFFT itself falls back to Bluestein there).  SSF_ENGINE_FUSED still forces them.
+        if (!native && general && !fused_rows_supports(N) && smooth13(N)) want = SSF_ENGINE_ROCFFT;
+    }
     if (want == SSF_ENGINE_FUSED && !native && !general) {
         (void)hipStreamDestroy(pl->stream);
         delete pl;

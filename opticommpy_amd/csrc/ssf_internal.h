@@ -92,6 +92,20 @@ class FusedConv {
     virtual std::string error() const = 0;
 };
 FusedConv *make_fused_conv(ssf_plan *plan, int64_t M, int nrows);
+
+// FFT . H . IFFT of every row of an (nrows, N) block in ONE launch, N = 2^a 3^b 5^c small enough for a row to live in LDS
+// (mixed_fft.h, at most 8192 values): the linear step of the general-length engine at the short notebook lengths
+// (1500, 3000, 6000 ...), which the column x row split does not take (fewer than four factors of two) and a Bluestein
+// convolution serves with three launches of two to four times the length.
+class FusedRows {
+  public:
+    virtual ~FusedRows() {}
+    // out = ifft(fft(in) * exp((lin_a + j lin_b w^2) hzh)) * scale * N, w = w_scale * fftfreq(N) (in may be out)
+    virtual int lin(const void *in, void *out, double hzh, double lin_a, double lin_b, double w_scale, double scale) = 0;
+    virtual std::string error() const = 0;
+};
+FusedRows *make_fused_rows(ssf_plan *plan, int64_t N, int nrows);      // nullptr: this length is not served
+bool fused_rows_supports(int64_t N);
 // general-length engine with its transforms on the fused kernels (Bluestein) instead of rocFFT; nullptr if N is out of range
 Engine *make_general_engine(ssf_plan *plan);
 bool general_supports(int64_t N, int nrows, int precision);

@@ -250,6 +250,7 @@ def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
     gather : True: every rank returns the full list (one all-gather); "root": only `root` (or rank 0) does, the
              others get None in the slots they do not own; False: own units only
     """
+    default_compute = compute is None
     if compute is None:
         from .models import manakovSSF as compute
     world = comm.world if comm is not None else 1
@@ -281,7 +282,7 @@ def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
     # size): a rank's units of one shape go to the device as ONE batch of independent units -- every launch carries all of
     # them, each with its own control block, step sizes and convergence decisions (ssf_plan_set_units) -- with results
     # bit-equal to one call per unit.  SSF_MGPU_BATCH=0 turns it off; fields of 2^19 samples and more fill the GPU alone.
-    if compute is None and _batchable(local, mine, param):
+    if default_compute and _batchable(local, mine, param):
         _run_batched(local, list(mine), param, outs)
         mine_left = []
     else:

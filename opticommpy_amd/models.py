@@ -547,6 +547,48 @@ def _edc_filter(param, Fs):
     return NfilterCoeffs, Nfft, np.exp(-1j * (b2 / 2) * (w**2) * L)
 
 
+_OLS_MAX_TAPS = 4096          # longer impulse responses are convolved segment by segment (8192-point blocks, >= half output)
+
+
+def _edc_long(sigIn, sig2, one_d, on_dev, K, Hf):
+    """Overlap-save convolution with an impulse response of more than _OLS_MAX_TAPS taps: h is cut into segments h_p of at
+    most _OLS_MAX_TAPS taps, conv(x, h)[m] = sum_p conv(x, h_p)[m - p S], every partial convolution is one launch of the
+    LDS overlap-save kernel (ssf_overlap_save) over the zero-extended signal, and the partial results are added with the
+    segment's offset.  Same linear convolution, same 'same'-mode cut (delay (K - 1) // 2) as optic/dsp/core.py:1043-1046."""
+    lib = _lib.load()
+    x = sig2.get() if on_dev else sig2
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    n, ncols = x.shape
+    h = np.fft.fftshift(np.fft.ifft(Hf))                          # core.py:1015-1016: centred impulse response, K taps
+    S, D = _OLS_MAX_TAPS, (K - 1) // 2
+    xp = np.zeros((n + 2 * K, ncols), dtype=np.complex128)        # zero-extended: every partial 'same' output we need exists
+    xp[K:K + n] = x
+    acc = np.zeros((n, ncols), dtype=np.complex128)
+    part = np.empty_like(xp)
+    nfft = 2 * S
+    for p0 in range(0, K, S):
+        hp = h[p0:p0 + S]
+        Kp, Dp = len(hp), (len(hp) - 1) // 2
+        H = np.ascontiguousarray(np.fft.fft(np.pad(hp, (0, nfft - Kp))), dtype=np.complex128)
+        rc = lib.ssf_overlap_save(_state["device"], xp.shape[0], ncols, _lib.SSF_C128, nfft, Kp, H.ctypes.data_as(C.c_void_p),
+                                  xp.ctypes.data_as(C.c_void_p), part.ctypes.data_as(C.c_void_p))
+        _lib.raise_for(lib, None, rc)
+        # part[i] = full_p[i + Dp] over the extended signal; y[j] = sum_p full_p[(j + K) + D - p0]
+        o = K + D - p0 - Dp
+        acc += part[o:o + n]
+    if on_dev:
+        out = _dev.empty(True, sig2.shape, np.complex128)
+        out.set(acc)
+        return out.reshape(-1) if one_d else out
+    res = acc if np.iscomplexobj(sigIn) else acc.real
+    if np.iscomplexobj(sigIn):
+        for m_ in range(ncols):
+            if not np.any(np.iscomplex(sig2[:, m_])):
+                res[:, m_] = res[:, m_].real
+    res = res.astype(sigIn.dtype, copy=False)
+    return res.flatten() if one_d else res
+
+
 def edc(sigIn, param):
     """Electronic chromatic dispersion compensation on the GPU (optic/dsp/equalization.py:36-122).
 
@@ -569,10 +611,11 @@ def edc(sigIn, param):
     # The block size of an overlap-save evaluation does not change the linear convolution it computes: the device
     # kernel takes powers of two in [16, 8192], so any other request of the reference (Nfft = 2 for a 1 km link,
     # a non power of two, > 8192) is served with the smallest supported block that leaves >= 3/4 of each transform as
-    # output.  Filters longer than 8192 taps do not fit one LDS transform.
+    # output.  Filters that leave less than half of an 8192-point block as output (> 4096 taps) are split into segments
+    # of the impulse response (_edc_long): the reference takes any length (core.py:973-1046).
+    if K > _OLS_MAX_TAPS:
+        return _edc_long(sigIn, sig2, one_d, on_dev, K, Hf)
     if Nfft < 16 or Nfft > 8192 or (Nfft & (Nfft - 1)):
-        if K > 8192:
-            raise ValueError(f"edc: {K} filter taps exceed the 8192-point blocks of the device kernel (reduce Fs/Rs or L)")
         Nfft = 16
         while Nfft < min(4 * K, 8192) or Nfft < K:
             Nfft *= 2

@@ -34,6 +34,7 @@ struct EmuCtx {
     void issue_fence() {}
     void sleep64(int) {}
     void drain() {}
+    template <int P> void setprio() {}
     double wave_sum(double v) { return v; }
     double wave_max(double v) { return v; }
 };
@@ -299,6 +300,40 @@ int lin_t(int64_t N, int nrows, int prec, double Fs, double Fc, double alpha, do
 
 }  // namespace
 
+// the general-length engine's one-launch linear step at short 5-smooth lengths (engine_fused_impl.h: FusedRowsImpl):
+// out = ifft(fft(in) * exp((lin_a + j lin_b w^2) hzh)) row by row, the whole row in LDS (row_mixed_body with N1 = 1)
+template <typename T>
+static int rows_lin_t(int64_t N, int nrows, const void *in, void *out, double hzh, double lin_a, double lin_b, double w_scale) {
+    using namespace ssf::fused;
+    int tpr = 128, rows_wg;
+    while (16 * tpr < N) tpr *= 2;
+    rows_wg = std::max(1, 256 / tpr);
+    while (nrows % rows_wg) rows_wg >>= 1;
+    MixPlan plan;
+    if (N > 8192 || !mix_make_plan((int)N, &plan, tpr)) return SSF_ERR_UNSUPPORTED;
+    std::vector<cx<double>> w((size_t)N);
+    for (int64_t q = 0; q < N; ++q) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)q / (double)N;
+        w[(size_t)q].re = std::cos(a);
+        w[(size_t)q].im = std::sin(a);
+    }
+    const double w2 = (w_scale / (double)N) * (w_scale / (double)N);
+    LinOp lo = make_linop(hzh, lin_a, lin_b, w2, 1.0 / (double)N, 4);
+    RowArgs<T> a{};
+    a.G = (cx<T> *)out;
+    a.src = in == out ? nullptr : (const cx<T> *)in;
+    a.nfft = nrows;
+    a.lin = &lo;
+    a.N2 = (int)N;
+    a.N = N;
+    a.mixed = 1;
+    a.plan = plan;
+    a.wtab = w.data();
+    a.rows_per_wg = rows_wg;
+    run_grid(nrows / rows_wg, tpr * rows_wg, 4096 + (size_t)rows_wg * (size_t)N * sizeof(cx<T>), [&](EmuCtx &c) { row_mixed_body<T>(c, a); });
+    return SSF_OK;
+}
+
 extern "C" {
 
 int emu_supported(int64_t N, int precision) {
@@ -439,6 +474,11 @@ int emu_decimate(int64_t N, int ncols, int SpSin, int dec, const void *in, void 
     EmuBackend be;
     ssf::rx::RxCore<EmuBackend> core(be);
     return core.decimate(N, ncols, SpSin, dec, in, out, sd);
+}
+
+int emu_rows_lin(int64_t N, int nrows, int precision, const void *in, void *out, double hzh, double lin_a, double lin_b, double w_scale) {
+    return precision == SSF_C128 ? rows_lin_t<double>(N, nrows, in, out, hzh, lin_a, lin_b, w_scale)
+                                 : rows_lin_t<float>(N, nrows, in, out, hzh, lin_a, lin_b, w_scale);
 }
 
 int emu_linear_channel(int64_t N, int nrows, int precision, double Fs, double Fc, double alpha, double D, double L,

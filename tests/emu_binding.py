@@ -25,6 +25,7 @@ def load():
         _emu.emu_overlap_save.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _emu.emu_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
         _emu.emu_gauss.argtypes = [C.c_int64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]
+        _emu.emu_rows_lin.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p] + [C.c_double] * 4
         _emu.emu_split.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return _emu
 
@@ -83,6 +84,19 @@ def run(func, Ei, cfg, noise=None, max_steps=4096, trace=True):
     info.update(hz=hz[:n], iters=it[:n], lims=[r[~np.isnan(r)] for r in lm[: n * p.maxIter].reshape(n, p.maxIter)],
                 launches=launches.value, snaps=snaps[: st.n_snapshots])
     return out, info
+
+
+def rows_lin(rows, hzh, lin_a, lin_b, w_scale, in_place=False):
+    """(nrows, N) -> ifft(fft(row) * exp((lin_a + 1j * lin_b * w**2) * hzh)), w = w_scale * fftfreq(N): the one-launch
+    linear step of the general-length engine (short 5-smooth lengths)."""
+    emu = load()
+    x = np.ascontiguousarray(rows)
+    out = x.copy() if in_place else np.empty_like(x)
+    src = out if in_place else x
+    rc = emu.emu_rows_lin(x.shape[1], x.shape[0], 0 if x.dtype == np.complex64 else 1, src.ctypes.data_as(C.c_void_p),
+                          out.ctypes.data_as(C.c_void_p), hzh, lin_a, lin_b, w_scale)
+    assert rc == 0, f"emu_rows_lin rc={rc}"
+    return out
 
 
 def linear_channel(Ei, Fs, Fc, alpha, D, L, dtype=np.complex128):

@@ -459,7 +459,7 @@ def test_independent_units_share_the_launches_not_the_decisions(monkeypatch, N, 
     dt = np.complex64 if prec == "complex64" else np.complex128
     fields = [synth_field(N, 2, 50 + u, p).astype(dt) for u, p in enumerate((-12.0, 6.0, 18.0))]
     cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=64e9, maxIter=10, tol=1e-5, prgsBar=False,
-               Ltotal=20, Lspan=10, hz=1.0, nlprMethod=adaptive, maxNlinPhaseRot=5e-3, amp="edfa", NF=4.5, saveSpanN=[], prec=prec)
+               Ltotal=8, Lspan=4, hz=1.0, nlprMethod=adaptive, maxNlinPhaseRot=2e-2, amp="edfa", NF=4.5, saveSpanN=[], prec=prec)
     monkeypatch.delenv("SSF_EMU_UNITS", raising=False)
     alone, steps = [], []
     cfg["_rng_seed"] = 1234                                         # device ASE noise: unit u draws rows 2u, 2u + 1 of the stream
@@ -478,3 +478,19 @@ def test_independent_units_share_the_launches_not_the_decisions(monkeypatch, N, 
         cfg2 = dict(cfg, amp="ideal")
         out2, _ = eb.run("manakovSSF", np.concatenate(fields, axis=1), cfg2, trace=False)
         assert rel_l2(out2[2:4].T, ref) <= TOL_C128
+
+
+@pytest.mark.parametrize("N", [1500, 3000, 6000, 375, 8100, 96])
+@pytest.mark.parametrize("in_place", [False, True])
+def test_one_launch_linear_step_at_short_smooth_lengths(N, in_place):
+    """Lengths with fewer than four factors of two (1500 = 4 x 375 ...) have no column x row split; the general-length engine
+    used to give them Bluestein transforms (three launches of a 4096- or 8192-point convolution per linear step).  5-smooth
+    rows of up to 8192 values are transformed directly in LDS instead: FFT . H . IFFT in one launch, operator from the bin index."""
+    rng = np.random.default_rng(N)
+    x = rng.normal(size=(2, N)) + 1j * rng.normal(size=(2, N))
+    hzh, lin_a, lin_b, w_scale = 0.04, -0.023, -1.02e-23, 2 * np.pi * 64e9
+    w = w_scale * np.fft.fftfreq(N)
+    ref = np.fft.ifft(np.fft.fft(x, axis=1) * np.exp((lin_a + 1j * lin_b * w ** 2) * hzh), axis=1)
+    assert rel_l2(eb.rows_lin(x, hzh, lin_a, lin_b, w_scale, in_place), ref) <= 1e-13
+    ref32 = ref.astype(np.complex64)
+    assert rel_l2(eb.rows_lin(x.astype(np.complex64), hzh, lin_a, lin_b, w_scale, in_place), ref32) <= 2e-6
