@@ -354,6 +354,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": w["scaling"],
             "vs_baseline": None, "dtype": "f64" if s == 16 else "f32", "data": "synthetic",
             "config": {"workload": w["text"], "baseline_config": cfg, "engine": _lib.ENGINE_NAMES[st0.engine],
+                       "pipeline": _lib.PIPELINE_NAMES.get(lib.ssf_plan_pipeline(plans[u0]), "?"),
                        "units_total": U, "units_per_gpu": len(mine), "lanes_per_gpu": lanes,
                        "unit_steps_total": steps_total, "iterations_per_step": it_step,
                        "transforms_per_step": sum(int(st.transforms) for st in sts.values()) / max(steps_local, 1)},

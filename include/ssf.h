@@ -241,6 +241,16 @@ const char *ssf_comm_last_error(const ssf_comm *comm);       /* never NULL; comm
 typedef int (*ssf_reduce_fn)(void *ctx, double *values, int32_t n, int32_t op);
 int  ssf_set_coupling(ssf_plan *plan, ssf_reduce_fn reduce, void *ctx);
 
+/* ---- which pipeline a plan runs on (ssf_stats.engine says SSF_ENGINE_FUSED for everything on the hand-written kernels) ----
+ *   SSF_PIPE_DEVICE     natively split length: device-resident control flow, no host synchronisation inside a span
+ *   SSF_PIPE_ROWS       short 2^a 3^b 5^c length: host-driven step loop, FFT . H . IFFT of a row in one LDS launch
+ *   SSF_PIPE_BLUESTEIN  any other length: host-driven step loop, every transform a Bluestein convolution on the fused kernels
+ *   SSF_PIPE_ROCFFT     host-driven step loop on rocFFT transforms (the cross-check engine)
+ * The host-driven ones read 16 bytes back per iteration: a bench or roofline record should not file them under the
+ * device-resident pipeline.  Returns the code (>= 0) or a negative status. */
+enum { SSF_PIPE_DEVICE = 0, SSF_PIPE_ROWS = 1, SSF_PIPE_BLUESTEIN = 2, SSF_PIPE_ROCFFT = 3 };
+int  ssf_plan_pipeline(const ssf_plan *plan);
+
 /* ---- independent units in one plan (no reference equivalent: the reference runs one field per call) ----------------
  * Small fields are latency-bound one at a time: a launch is one chain of load -> transform -> store of ~10 us whatever its
  * size.  ssf_plan_set_units(plan, n) declares the plan's rows to be n independent fields ("units") of nrows / n rows each,

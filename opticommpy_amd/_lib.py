@@ -12,6 +12,7 @@ MODEL_NLSE, MODEL_MANAKOV = 0, 1
 AMP_NONE, AMP_IDEAL, AMP_EDFA = 0, 1, 2
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_FUSED = 0, 1, 2
 ENGINE_NAMES = {ENGINE_AUTO: "auto", ENGINE_ROCFFT: "rocfft", ENGINE_FUSED: "fused"}
+PIPELINE_NAMES = {0: "fused-device", 1: "fused-rows", 2: "fused-bluestein", 3: "rocfft"}      # ssf_plan_pipeline
 
 STATUS = {0: "OK", -1: "bad argument", -2: "HIP error", -3: "out of device memory", -4: "FFT error",
           -5: "no device", -6: "unsupported", -7: "bad call order", -8: "RCCL error"}
@@ -77,6 +78,7 @@ SYMBOLS = {
     "ssf_plan_create": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "ssf_plan_destroy": (C.c_int, [C.c_void_p]),
     "ssf_plan_set_units": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ssf_plan_pipeline": (C.c_int, [C.c_void_p]),
     "ssf_last_error": (C.c_char_p, [C.c_void_p]),
     "ssf_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ssf_execute": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int32, C.c_int32, C.c_void_p,

@@ -345,6 +345,7 @@ template <typename T> class RocfftEngine final : public Engine {
     }
     // (with Bluestein every transform runs on the fused kernels: reported as the fused engine)
     int id() const override { return blue ? SSF_ENGINE_FUSED : SSF_ENGINE_ROCFFT; }
+    int pipeline() const override { return !blue ? SSF_PIPE_ROCFFT : rows ? SSF_PIPE_ROWS : SSF_PIPE_BLUESTEIN; }
 
     static int64_t bluestein_length(int64_t n) {
         int64_t m = 256;
@@ -354,6 +355,10 @@ template <typename T> class RocfftEngine final : public Engine {
     int init_bluestein() {
         M = bluestein_length(N);
         const bool one_launch = M <= 8192;
+        if (one_launch) {                            // the one-launch transform needs more than the default dynamic LDS: once per plan
+            SSF_HIP(pl, hipFuncSetAttribute((const void *)k_blue<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            SSF_HIP(pl, hipFuncSetAttribute((const void *)k_blue<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
         if (!one_launch) {
             conv = make_fused_conv(pl, M, nrows);
             if (!conv) return pl->err.find("out of memory") != std::string::npos ? SSF_ERR_OOM : SSF_ERR_UNSUPPORTED;
@@ -496,13 +501,8 @@ template <typename T> class RocfftEngine final : public Engine {
             const int tpf = (int)(M / 16), block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
             const int grid = (nrows + fpw - 1) / fpw;
             const size_t lds = (size_t)fpw * fused::lds_slots_per_fft((int)M) * sizeof(fused::cx<T>);
-            if (block <= 256) {
-                (void)hipFuncSetAttribute((const void *)k_blue<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                k_blue<T, 256><<<grid, block, lds, pl->stream>>>(a);
-            } else {
-                (void)hipFuncSetAttribute((const void *)k_blue<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                k_blue<T, 512><<<grid, block, lds, pl->stream>>>(a);
-            }
+            if (block <= 256) k_blue<T, 256><<<grid, block, lds, pl->stream>>>(a);      // (LDS cap raised once, init_bluestein)
+            else k_blue<T, 512><<<grid, block, lds, pl->stream>>>(a);
             SSF_HIP(pl, hipGetLastError());
             return SSF_OK;
         }
@@ -510,8 +510,10 @@ template <typename T> class RocfftEngine final : public Engine {
             const int inverse = p == inv ? 1 : 0;
             C *wk = (C *)conv->work();
             k_blue_pre<T><<<grid_for(M * nrows), kBlock, 0, pl->stream>>>(in, wk, chirp, N, M, nrows, inverse);
+            SSF_HIP(pl, hipGetLastError());
             if (int rc = conv->run(inverse)) return fail(pl, rc, "Bluestein convolution: " + conv->error());
             k_blue_post<T><<<grid_for(N * nrows), kBlock, 0, pl->stream>>>(wk, out, chirp, N, M, nrows, inverse);
+            SSF_HIP(pl, hipGetLastError());
             return SSF_OK;
         }
         void *ib[1] = {in}, *ob[1] = {out};

@@ -99,7 +99,11 @@ int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int
         // whose prime factors are all <= 13 (30 030 = 2 3 5 7 11 13), are one or two native kernels for rocFFT (measured,
         // tools/bench_lengths.py: 30 030: 4 653 against 3 446 steps/s); primes and other lengths stay on the fused kernels
         // (10 007: 3 753 against 2 950; rocFFT itself falls back to Bluestein there).  SSF_ENGINE_FUSED still forces them.
-        if (!native && general && !fused_rows_supports(N) && smooth13(N)) want = SSF_ENGINE_ROCFFT;
+        // The one-launch LDS rows (2^a 3^b 5^c <= 8192) win from about 4000 samples on (6000: 7 491 against 4 918 steps/s); below,
+        // a single workgroup per row is one long latency chain and rocFFT's small kernels are faster (1500: 6 040 against
+        // 7 427, 3000: 5 477 against 6 393; gpurun_out/r3e/lengths.txt).
+        const bool rows_win = fused_rows_supports(N) && N >= 4000;
+        if (!native && general && !rows_win && smooth13(N)) want = SSF_ENGINE_ROCFFT;
     }
     if (want == SSF_ENGINE_FUSED && !native && !general) {
         (void)hipStreamDestroy(pl->stream);
@@ -117,6 +121,11 @@ int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int
     pl->engine_id = pl->engine->id();
     *out = pl;
     return SSF_OK;
+}
+
+int ssf_plan_pipeline(const ssf_plan *plan) {
+    if (!plan || !plan->engine) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    return plan->engine->pipeline();
 }
 
 int ssf_plan_set_units(ssf_plan *plan, int32_t n_units) {
@@ -173,6 +182,13 @@ int ssf_execute(ssf_plan *plan, const ssf_params *params, int32_t span_first, in
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     if (!plan->has_field) return fail(plan, SSF_ERR_STATE, "ssf_execute before ssf_upload");
     int rc = check_params(plan, params, span_first, span_last);
+    if (!rc && plan->sink.active()) {          // every capture of this call must fit the caller's (N, ld) array
+        long long ncap = 0;
+        for (int i = 0; i < params->n_save; ++i)
+            if (params->save_spans[i] >= span_first && params->save_spans[i] <= span_last) ++ncap;
+        if (((long long)plan->sink.count() + ncap) * plan->nrows > plan->sink.leading())
+            return fail(plan, SSF_ERR_BAD_ARG, "snapshot sink: the captures of this call do not fit the destination's columns");
+    }
     if (rc) return rc;
     SSF_HIP(plan, hipSetDevice(plan->device));
     if (trace) trace->count = 0;

@@ -78,7 +78,7 @@ class SnapshotSink {
             }
             hipError_t e = hipEventSynchronize(ready[j.buf]);              // the conversion kernel has written the block
             const size_t row = (size_t)j.nrows * esz;                      // bytes of one sample of the field
-            const long long rows_per_chunk = (long long)(kChunk / row);
+            const long long rows_per_chunk = std::max<long long>(1, (long long)(kChunk / row));   // (set() rejects rows wider than a chunk)
             const long long nchunks = (j.N + rows_per_chunk - 1) / rows_per_chunk;
             for (long long i = 0; e == hipSuccess && i <= nchunks; ++i) {
                 if (i < nchunks) {                                          // DMA chunk i into pinned buffer i & 1
@@ -111,11 +111,12 @@ class SnapshotSink {
     }
     hipError_t start() {
         if (started) return hipSuccess;
-        hipError_t e = hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking);
+        // idempotent per resource: a start that failed half way is continued, not repeated (no second set of buffers)
+        hipError_t e = copy_st ? hipSuccess : hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking);
         for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-            e = hipHostMalloc(&pin[i], kChunk);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&pin_ev[i], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ready[i], hipEventDisableTiming);
+            if (!pin[i]) e = hipHostMalloc(&pin[i], kChunk);
+            if (e == hipSuccess && !pin_ev[i]) e = hipEventCreateWithFlags(&pin_ev[i], hipEventDisableTiming);
+            if (e == hipSuccess && !ready[i]) e = hipEventCreateWithFlags(&ready[i], hipEventDisableTiming);
         }
         if (e != hipSuccess) return e;
         worker = std::thread([this] { run(); });
@@ -146,6 +147,7 @@ class SnapshotSink {
     }
     bool active() const { return dst != nullptr; }
     int count() const { return index; }
+    long long leading() const { return ld; }
     // dst = nullptr detaches.  Waits for copies into the previous destination first.
     hipError_t set(int dev, void *d, long long ld_, int first_index, size_t elem_size) {
         hipError_t e = sync();
@@ -160,6 +162,9 @@ class SnapshotSink {
     // Called by the engine at a captured span, on the thread that owns the plan; `soa` is the (nrows, N) field and
     // every earlier launch on `st` has produced it.
     template <typename C> hipError_t capture(const C *soa, long long N, int nrows, hipStream_t st) {
+        // capture i goes to columns [i * nrows, (i + 1) * nrows) of the caller's (N, ld) array: never beyond it (a save_spans
+        // list longer than the array, or a first_index that is too large, is the caller's error, not a stray write)
+        if (((long long)index + 1) * nrows > ld || (size_t)nrows * esz > kChunk) return hipErrorInvalidValue;
         const long long col0 = (long long)index * nrows;
         ++index;
         if (dst_dev) {

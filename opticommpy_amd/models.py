@@ -240,6 +240,7 @@ def _execute(pl, cp, Nspans, save, prgs, noise_fn, want_trace, max_steps_hint):
         info["iters"] = np.concatenate([t[1] for t in traces]) if traces else np.zeros(0, np.int32)
         info["lims"] = [row[~np.isnan(row)] for t in traces for row in t[2]]
         info["trace_truncated"] = any(t[3] > len(t[0]) for t in traces)
+    info["pipeline"] = _lib.PIPELINE_NAMES.get(lib.ssf_plan_pipeline(pl.h), "?")
     last_run.clear()
     last_run.update(info)
     return st
