@@ -496,6 +496,7 @@ template <typename T> class FusedEngine final : public Engine {
         return SSF_OK;
     }
     void reset_times() { be.kt = ssf_kernel_times{}; }
+    int unit_stats(int u, ssf_stats *out) override { return core.unit_stats(u, out) ? SSF_OK : SSF_ERR_BAD_ARG; }
 };
 
 template <typename T> class FusedConvImpl final : public FusedConv {

@@ -141,6 +141,7 @@ template <typename T, class Backend> class FusedCore {
     size_t row_lds, col_lds_mk, col_lds_1;
     std::string err;
 
+    std::vector<ssf_stats> ustats;   // per unit, accumulated since the last upload (ssf_get_unit_stats)
     int units = 1;               // the rows form `units` independent fields: own control block, partial sums, step sizes and
                                  // convergence decisions per unit, every launch carries all of them (grid.y = units)
     int npairs() const { return kPacked ? nrows : std::max(nrows / 2, 1); }
@@ -281,7 +282,16 @@ template <typename T, class Backend> class FusedCore {
         for (C *s : snaps) be.free(s);
         snaps.clear();
         n_sunk = 0;
+        ustats.assign((size_t)units, ssf_stats{});
+        if (pk) pk->ustats.assign((size_t)units, ssf_stats{});
         return be.ok() ? SSF_OK : hiperr();
+    }
+    // counters of one unit (the packed-pair core keeps them for complex64 Manakov runs)
+    bool unit_stats(int u, ssf_stats *out) const {
+        const std::vector<ssf_stats> &v = (pk && !pk->ustats.empty()) ? pk->ustats : ustats;
+        if (u < 0 || u >= (int)v.size()) return false;
+        *out = v[(size_t)u];
+        return true;
     }
     int download(void *field, int which, bool aos) {
         if constexpr (kPacked) return SSF_ERR_UNSUPPORTED;
@@ -636,6 +646,17 @@ template <typename T, class Backend> class FusedCore {
                     be.d2d((char *)(cur ? T1 : T0) + (size_t)u * ub, (char *)(cur ? T0 : T1) + (size_t)u * ub, ub);
         }
         sr.trace_n = cs[0].trace_n;
+        if ((int)ustats.size() != units) ustats.assign((size_t)units, ssf_stats{});
+        for (int u = 0; u < units; ++u) {
+            const Ctrl &c = cs[(size_t)u];
+            ssf_stats &us = ustats[(size_t)u];
+            us.steps += c.steps;
+            us.iterations += c.iterations;
+            us.nonconverged_steps += c.nonconv;
+            us.decided_ahead += c.n_ahead;
+            us.rebuilt_iterates += c.n_rebuilt;
+            us.transforms += (int64_t)(kPacked ? 2 * rows_u() : rows_u()) * (2 * c.steps + 2 * c.iterations);
+        }
         for (const Ctrl &c : cs) {
             st->steps += c.steps;
             st->iterations += c.iterations;

@@ -153,6 +153,22 @@ int ssf_plan_set_units(ssf_plan *plan, int32_t n_units) {
     return SSF_OK;
 }
 
+int ssf_get_unit_stats(ssf_plan *plan, int32_t unit, ssf_stats *out) {
+    if (!plan || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_get_unit_stats: NULL argument");
+    ssf_stats u{};
+    int rc = plan->engine->unit_stats(unit, &u);
+    if (rc) return fail(plan, rc, "ssf_get_unit_stats: no such unit (or not a plan of independent units)");
+    *out = plan->stats;
+    out->steps = u.steps;
+    out->iterations = u.iterations;
+    out->transforms = u.transforms;
+    out->nonconverged_steps = u.nonconverged_steps;
+    out->decided_ahead = u.decided_ahead;
+    out->rebuilt_iterates = u.rebuilt_iterates;
+    out->bytes_algorithmic = (double)u.transforms * 2.0 * (plan->precision == SSF_C128 ? 16.0 : 8.0) * (double)plan->N;
+    return SSF_OK;
+}
+
 int ssf_plan_destroy(ssf_plan *plan) {
     if (!plan) return SSF_OK;
     (void)hipSetDevice(plan->device);
@@ -353,6 +369,47 @@ int ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_t
     // (measured +12-15 % field-steps/s).  Units are independent: the results do not depend on it.
     int lanes = 2;
     if (const char *e = std::getenv("SSF_MGPU_LANES")) lanes = std::max(1, std::min(4, std::atoi(e)));
+    // Small units (a launch is one ~10 us latency chain whatever its size): all the units of a device go through ONE plan as
+    // independent units -- every launch carries all of them, own control block and decisions per unit, results bit-equal to
+    // one plan per unit (ssf_plan_set_units).  SSF_MGPU_BATCH=0 turns it off.
+    bool batch = N <= (1ll << 18) && n_units > n_dev && params->model == SSF_MODEL_MANAKOV && (rows_per_unit % 2) == 0 &&
+                 engine != SSF_ENGINE_ROCFFT && fused_supports(N, rows_per_unit, precision);
+    if (const char *e = std::getenv("SSF_MGPU_BATCH")) batch = batch && std::atoi(e) != 0;
+    if (batch) {
+        std::vector<int> brc((size_t)n_dev, SSF_OK);
+        std::vector<std::string> berr((size_t)n_dev);
+        std::vector<std::thread> bt;
+        for (int d = 0; d < n_dev; ++d) {
+            const int u0 = (int)((int64_t)n_units * d / n_dev), u1 = (int)((int64_t)n_units * (d + 1) / n_dev);
+            bt.emplace_back([=, &brc, &berr] {
+                constexpr int kMaxBatch = 64;
+                for (int b0 = u0; b0 < u1 && brc[(size_t)d] == SSF_OK; b0 += kMaxBatch) {
+                    const int nb = std::min(kMaxBatch, u1 - b0);
+                    ssf_plan *pl = nullptr;
+                    int rc = ssf_plan_create(dev_ids[d], N, rows_per_unit * nb, precision, engine, &pl);
+                    if (!rc && nb > 1) rc = ssf_plan_set_units(pl, nb);
+                    ssf_params p = *params;
+                    p.rng_row_offset = params->rng_row_offset + b0 * rows_per_unit;     // unit u draws rows u * rows_per_unit ...
+                    ssf_stats st{};
+                    if (!rc) rc = ssf_run(pl, &p, (const char *)fields_in + (size_t)b0 * unit_bytes,
+                                          (char *)fields_out + (size_t)b0 * unit_bytes, nullptr, nullptr, &st, nullptr);
+                    for (int u = 0; u < nb && !rc && stats; ++u) {
+                        if (nb > 1) rc = ssf_get_unit_stats(pl, u, &stats[b0 + u]);
+                        else stats[b0 + u] = st;
+                    }
+                    if (rc) {
+                        brc[(size_t)d] = rc;
+                        berr[(size_t)d] = ssf_last_error(pl);
+                    }
+                    if (pl) ssf_plan_destroy(pl);
+                }
+            });
+        }
+        for (auto &t : bt) t.join();
+        for (int d = 0; d < n_dev; ++d)
+            if (brc[(size_t)d]) return set_err(brc[(size_t)d], "device " + std::to_string(dev_ids[d]) + ": " + berr[(size_t)d]);
+        return SSF_OK;
+    }
     const int nslots = n_dev * lanes;
     std::vector<int> rcs((size_t)nslots, SSF_OK);
     std::vector<std::string> errs((size_t)nslots);
@@ -373,7 +430,9 @@ int ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_t
                 }
                 for (int u = u0 + l; u < u1 && rc == SSF_OK; u += lanes) {
                     ssf_stats st{};
-                    rc = ssf_run(pl, params, (const char *)fields_in + (size_t)u * unit_bytes,
+                    ssf_params pu = *params;                   // a shared seed keys ONE noise stream: unit u draws its own rows of it
+                    pu.rng_row_offset = params->rng_row_offset + u * rows_per_unit;
+                    rc = ssf_run(pl, &pu, (const char *)fields_in + (size_t)u * unit_bytes,
                                  (char *)fields_out + (size_t)u * unit_bytes, nullptr, nullptr, &st, nullptr);
                     if (stats) stats[u] = st;
                 }

@@ -48,6 +48,7 @@ class Engine {
     virtual int linear_channel(double Fs, double Fc, double alpha, double D, double L) = 0;
     virtual int id() const = 0;
     virtual int pipeline() const { return SSF_PIPE_DEVICE; }
+    virtual int unit_stats(int, ssf_stats *) { return SSF_ERR_UNSUPPORTED; }
     virtual int set_coupling(ssf_reduce_fn, void *) { return SSF_ERR_UNSUPPORTED; }
     virtual int set_profiling(int) { return SSF_ERR_UNSUPPORTED; }
     virtual int kernel_times(ssf_kernel_times *) { return SSF_ERR_UNSUPPORTED; }
