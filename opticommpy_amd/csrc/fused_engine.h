@@ -50,7 +50,11 @@ inline bool choose_split(int log2N, int precision, Split *s, bool packed = false
         l1 = std::min(log2N - l2soft, l1pref + 1);
         l2 = log2N - l1;
     }
-    if (l2 > l2max || l1 < 4 || l2 < 4) return false;
+    if (l2 > l2max) {                      // the longest fields (2^23 complex128, 2^24 complex64): rows as long as the LDS takes,
+        l2 = l2max;                        // columns of up to 1024 (64-B row segments: slower per sample, but the hand-written
+        l1 = log2N - l2;                   // kernels then cover every Bluestein length up to N = 2^22 / 2^23 as well)
+    }
+    if (l1 > 10 || l1 < 4 || l2 < 4) return false;
     s->l1 = l1;
     s->l2 = l2;
     return true;

@@ -269,3 +269,23 @@ def test_c64_drift_at_a_notebook_length_over_config3_step_count():
     a, b = outs["complex64"].astype(np.complex128), outs["complex128"]
     assert rel_l2(a, b) <= 5e-4
     assert abs(np.sum(np.abs(a) ** 2) / np.sum(np.abs(b) ** 2) - 1) <= 2e-4
+
+
+# ------------------------------------------------------------------------------------------ the longest fields
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1 << 23, (1 << 21) + 1])
+def test_longest_fields_stay_on_the_hand_written_kernels(N):
+    """2^23 complex128 samples (1024 x 8192 split) and a length whose Bluestein convolution needs 2^23 points (2^21 + 1 =
+    3 * 43 * 16 257): round 2 sent both to rocFFT under AUTO.  One step against the oracle."""
+    import opticommpy_amd as oa
+    from helpers import make_param, rel_l2, synth_field
+    from opticommpy_amd import models
+    from oracle import ssf_oracle as orc
+    E = synth_field(N, 2, 97, 8.4)
+    cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=0.08, Lspan=0.08,
+               hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+    out = oa.manakovSSF(E, make_param(oa.parameters, cfg))
+    assert models.last_run["engine"] == "fused" and models.last_run["iterations"] == tr["iterations"]
+    assert rel_l2(out, ref) <= 1e-10
