@@ -272,6 +272,9 @@ def main():
         _lib.raise_for(lib, None, lib.ssf_plan_create(local_rank, N, ncols, prec, engine, C.byref(h)))
         plans[u] = h
     lanes = max(1, min(args.lanes, len(mine)))
+    if lanes > 1:                                               # the plans of a rank share its GPU: no phase priorities (ssf.h)
+        for h in plans.values():
+            lib.ssf_plan_set_lanes(h, lanes)
     lane_units = [mine[i::lanes] for i in range(lanes)]
 
     def run_unit(u, steps, stats):

@@ -22,6 +22,7 @@
  *   ssf_mgpu_run                         (no reference equivalent) independent fields
  *                                        sharded over the GPUs of one node, SURVEY.md 8e
  *   ssf_plan_set_units                   (no reference equivalent) several independent fields per launch
+ *   ssf_plan_set_lanes                   (no reference equivalent) this plan shares the GPU with others
  *   ssf_set_coupling                     np.max(phiRot) / scipy.linalg.norm over ALL rows of a K > 1 batch
  *                                        (channels.py:394, 517-519) when the rows live in several plans
  *   ssf_comm_*                           (no reference equivalent) one process per GPU: RCCL
@@ -266,6 +267,13 @@ int  ssf_plan_set_units(ssf_plan *plan, int32_t n_units);
 /* steps / iterations / transforms / nonconverged_steps / decided_ahead / rebuilt_iterates of ONE unit since the last upload
  * (the Manakov models; the other fields of *out are those of the plan). */
 int  ssf_get_unit_stats(ssf_plan *plan, int32_t unit, ssf_stats *out);
+
+/* ---- lanes: several plans sharing one GPU concurrently (no reference equivalent) ------------------------------------
+ * ssf_mgpu_run / mgpu.run_sharded / bench.py --config 4 | 5 keep two plans (own stream, own host thread) busy per GPU so that one
+ * unit's launches fill the other's load / store phases.  A hint that this plan is one of n_lanes such plans: the kernels
+ * then leave the issue priorities alone (with one field on the GPU, priority by phase is worth +3 %; with two fields
+ * interleaving it costs 4 %: profiles/r3_lanes_prio_wt.txt).  Default 1; may be called at any time between executes. */
+int  ssf_plan_set_lanes(ssf_plan *plan, int32_t n_lanes);
 
 /* ---- per-kernel timing (measurement aid; fused engine only) ------------------------------ */
 /* With profiling enabled every kernel launch of ssf_execute is bracketed by HIP events on the

@@ -79,6 +79,7 @@ SYMBOLS = {
     "ssf_plan_destroy": (C.c_int, [C.c_void_p]),
     "ssf_plan_set_units": (C.c_int, [C.c_void_p, C.c_int32]),
     "ssf_plan_pipeline": (C.c_int, [C.c_void_p]),
+    "ssf_plan_set_lanes": (C.c_int, [C.c_void_p, C.c_int32]),
     "ssf_get_unit_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     "ssf_last_error": (C.c_char_p, [C.c_void_p]),
     "ssf_upload": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -496,6 +496,11 @@ template <typename T> class FusedEngine final : public Engine {
         return SSF_OK;
     }
     void reset_times() { be.kt = ssf_kernel_times{}; }
+    int set_lanes(int n) override {
+        core.lanes_hint = n;
+        if (core.pk) core.pk->lanes_hint = n;
+        return SSF_OK;
+    }
     int unit_stats(int u, ssf_stats *out) override { return core.unit_stats(u, out) ? SSF_OK : SSF_ERR_BAD_ARG; }
 };
 

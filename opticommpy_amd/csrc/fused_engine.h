@@ -138,6 +138,7 @@ template <typename T, class Backend> class FusedCore {
     int row_v = 16;              // values per thread of the radix-2^n row kernel (SSF_ROW_V=8: 128-register kernels)
     int row_stagger = 0;         // 64-clock ticks the second half of the row grid starts late (SSF_ROW_STAGGER)
     int col_v = 16;              // values per thread of the column kernels (SSF_COL_V=8)
+    int lanes_hint = 1;          // plans that share the GPU concurrently (ssf_plan_set_lanes): > 1 turns the phase priorities off
     int cur = 0;                 // which of T0/T1 holds the current field
     unsigned seq = 0;
     // launch geometry
@@ -328,6 +329,7 @@ template <typename T, class Backend> class FusedCore {
         a.wtab = wtab;
         a.rows_per_wg = mix_rows;
         a.vpt = row_v;
+        a.prio = lanes_hint <= 1 ? 1 : 0;
         a.stagger = row_stagger;
         return a;
     }
@@ -347,6 +349,7 @@ template <typename T, class Backend> class FusedCore {
         a.mode = mode;
         a.ngroups = pairs_u();
         a.vpt = col_v;
+        a.prio = lanes_hint <= 1 ? 1 : 0;
         a.u_elems = (long long)rows_u() * N;
         a.u_part = npart_max;
         const size_t ps = (size_t)units * (size_t)npart_max;       // one array of partial sums: [unit][npart_max]
@@ -724,6 +727,7 @@ template <typename T, class Backend> class FusedCore {
             int rc;
             if (!pk) {
                 pk.reset(new FusedCore<pf2, Backend>(be, N, nrows / 2, SSF_C128, (void *)G, units));
+                pk->lanes_hint = lanes_hint;
                 if ((rc = pk->init())) {
                     err = pk->err;
                     pk.reset();

@@ -433,6 +433,7 @@ template <typename T> struct RowArgs {
     // and partial sums at + u * u_part of every array (unit_view below); 0 / unused for a single unit
     long long u_elems;
     int u_part;
+    int prio;                 // 1: issue priority by phase (s_setprio, SSF_PRIO); 0 when several plans share the GPU (lanes)
     int stagger;              // > 0: the second half of the grid starts this many 64-clock ticks late (co-resident workgroups
                               // out of phase: one loads / stores while the other transforms)
 };
@@ -734,12 +735,12 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     // SSF_PRIO (experiment): a wave that is further behind gets the VALU first.  The two workgroups of a CU start together,
     // but the older one wins every arbitration, runs through at full speed and leaves the younger one to finish alone, one
     // wave per SIMD (phase stamps: first half of the grid done at 13.3 us, second half at 17.5 us).
-    if (SSF_PRIO == 2) ctx.template setprio<3>();
-    else if (SSF_PRIO) ctx.template setprio<2>();
+    if (SSF_PRIO == 2 && a.prio) ctx.template setprio<3>();
+    else if (SSF_PRIO && a.prio) ctx.template setprio<2>();
     if (SSF_ABL != 1) fft_dif<-1, V>(ctx, p, b, v, l);
     ctx.mark(2);
-    if (SSF_PRIO == 2) ctx.template setprio<2>();
-    else if (SSF_PRIO) ctx.template setprio<1>();
+    if (SSF_PRIO == 2 && a.prio) ctx.template setprio<2>();
+    else if (SSF_PRIO && a.prio) ctx.template setprio<1>();
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
     const int last = p.npass - 1;
     if (!a.use_ctrl && !a.lin) {                 // fixed-kernel convolution: multiplier array in this kernel's spectrum order
@@ -762,9 +763,9 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
         }
     }
     ctx.mark(3);
-    if (SSF_PRIO == 2) ctx.template setprio<1>();
+    if (SSF_PRIO == 2 && a.prio) ctx.template setprio<1>();
     if (SSF_ABL != 1) fft_dit<+1, V>(ctx, p, b, v, l);
-    if (SSF_PRIO) ctx.template setprio<0>();
+    if (SSF_PRIO && a.prio) ctx.template setprio<0>();
     ctx.mark(4);
 #pragma unroll
     for (int q = 0; q < V; ++q)
@@ -803,6 +804,7 @@ template <typename T> struct ColArgs {
     int vpt;                  // values per thread: 16 (0 = 16) or 8 (128-register kernels, four waves per SIMD)
     long long u_elems;        // independent units (see RowArgs): field elements per unit; P / Theta advance by 2 / 1 x ngroups x N
     int u_part;
+    int prio;                 // see RowArgs
 };
 
 // Arguments of unit u of a batch of independent units: every pointer moved to the unit's block.  The kernel bodies never
@@ -1239,11 +1241,11 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 #pragma unroll
         for (int q = 0; q < V; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
         ctx.mark(1);
-        if (SSF_PRIO) ctx.template setprio<3>();
+        if (SSF_PRIO && a.prio) ctx.template setprio<3>();
         global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         fft_dif<+1, V>(ctx, p, g.b, v, lds);
         ctx.mark(2);
-        if (SSF_PRIO) ctx.template setprio<2>();
+        if (SSF_PRIO && a.prio) ctx.template setprio<2>();
     } else if (!(kMk && op == 3)) {
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
@@ -1322,13 +1324,13 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 
     // ---- forward column transform: registers -> G -------------------------------------------
     ctx.mark(3);
-    if (SSF_PRIO) ctx.template setprio<1>();
+    if (SSF_PRIO && a.prio) ctx.template setprio<1>();
     if (do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
         fft_dit<-1, V>(ctx, p, g.b, v, lds);
         global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
-        if (SSF_PRIO) ctx.template setprio<0>();
+        if (SSF_PRIO && a.prio) ctx.template setprio<0>();
 #pragma unroll
         for (int q = 0; q < V; ++q) g.template stp<4>(a.G, g.rowbase + g.freq_off(q), v[q]);
         ctx.mark(5);

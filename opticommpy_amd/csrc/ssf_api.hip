@@ -123,6 +123,13 @@ int ssf_plan_create(int device, int64_t N, int32_t nrows, int32_t precision, int
     return SSF_OK;
 }
 
+int ssf_plan_set_lanes(ssf_plan *plan, int32_t n_lanes) {
+    if (!plan || !plan->engine) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    if (n_lanes < 1) return fail(plan, SSF_ERR_BAD_ARG, "ssf_plan_set_lanes: n_lanes must be >= 1");
+    plan->lanes = n_lanes;
+    return plan->engine->set_lanes(n_lanes);
+}
+
 int ssf_plan_pipeline(const ssf_plan *plan) {
     if (!plan || !plan->engine) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     return plan->engine->pipeline();
@@ -143,6 +150,7 @@ int ssf_plan_set_units(ssf_plan *plan, int32_t n_units) {
     plan->units = n_units;
     plan->has_field = false;
     plan->engine = make_fused_engine(plan);
+    if (plan->engine) (void)plan->engine->set_lanes(plan->lanes);
     if (!plan->engine) {                                    // (out of memory?) back to what worked
         const std::string why = plan->err;
         plan->units = old;
@@ -428,6 +436,7 @@ int ssf_mgpu_run(int32_t n_dev, const int32_t *dev_ids, int32_t n_units, int64_t
                     errs[(size_t)slot] = ssf_last_error(nullptr);
                     return;
                 }
+                if (std::min(lanes, u1 - u0) > 1) (void)ssf_plan_set_lanes(pl, std::min(lanes, u1 - u0));
                 for (int u = u0 + l; u < u1 && rc == SSF_OK; u += lanes) {
                     ssf_stats st{};
                     ssf_params pu = *params;                   // a shared seed keys ONE noise stream: unit u draws its own rows of it

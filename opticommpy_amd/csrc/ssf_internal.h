@@ -49,6 +49,7 @@ class Engine {
     virtual int id() const = 0;
     virtual int pipeline() const { return SSF_PIPE_DEVICE; }
     virtual int unit_stats(int, ssf_stats *) { return SSF_ERR_UNSUPPORTED; }
+    virtual int set_lanes(int) { return SSF_OK; }
     virtual int set_coupling(ssf_reduce_fn, void *) { return SSF_ERR_UNSUPPORTED; }
     virtual int set_profiling(int) { return SSF_ERR_UNSUPPORTED; }
     virtual int kernel_times(ssf_kernel_times *) { return SSF_ERR_UNSUPPORTED; }
@@ -61,6 +62,7 @@ struct ssf_plan {
     int64_t N = 0;
     int nrows = 0;
     int units = 1;               // rows form `units` independent fields (ssf_plan_set_units)
+    int lanes = 1;               // plans sharing this GPU concurrently (ssf_plan_set_lanes)
     int precision = SSF_C128;
     int engine_id = 0;
     hipStream_t stream = nullptr;

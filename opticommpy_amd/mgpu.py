@@ -293,6 +293,8 @@ def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
     lanes = max(1, min(int(os.environ.get("SSF_MGPU_LANES", "2")), len(mine)))
 
     def one(u):
+        from . import models as _models
+        _models._set_lane_hint(lanes if len(mine_left) > 1 else 1)
         p = copy.deepcopy(param)
         # a fixed param.seed keys ONE noise stream: unit u draws its own rows of it (ssf_params::rng_row_offset), so the
         # Monte-Carlo units of a seeded run get independent ASE noise, the same whatever the number of ranks

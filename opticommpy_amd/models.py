@@ -107,7 +107,13 @@ def _get_plan(N, nrows, prec_code, engine=None, units=1):
             plans.popitem(last=False)[1].close()
         pl = _Plan(*key)
     plans[key] = pl
+    pl.lib.ssf_plan_set_lanes(pl.h, int(getattr(_tls, "lanes", 1)))       # (mgpu.run_sharded: this thread is one of several lanes)
     return pl
+
+
+def _set_lane_hint(n):
+    """Called by the lanes of mgpu.run_sharded: the plans this thread uses share the GPU with n - 1 other lanes."""
+    _tls.lanes = max(1, int(n))
 
 
 def engine_supported(name, N, nrows=2, prec=np.complex128):
