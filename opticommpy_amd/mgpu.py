@@ -363,10 +363,18 @@ def _batchable(local, mine, param):
 
 
 def _run_batched(local, units, param, outs):
+    from . import models as _models
     from .models import manakovSSF
     N, ncols = np.shape(local[units[0]])
-    for i in range(0, len(units), _BATCH_MAX_UNITS):
-        chunk = units[i:i + _BATCH_MAX_UNITS]                    # (contiguous unit numbers: the rank's block)
+    # From 2^16 samples on a batch alone no longer hides every load / store phase: two lanes, each with half of the units in
+    # one plan, are faster still (16 units of 2^18, unit-steps/s: one at a time 7 905, two lanes 15 382, one batch of 8
+    # 19 036, two lanes x batches of 4 23 808; tools/bench_units_large.py, profiles/r3_units_large.txt)
+    lanes = max(1, min(int(os.environ.get("SSF_MGPU_LANES", "2")), len(units) // 2)) if N >= (1 << 16) else 1
+    per = min(_BATCH_MAX_UNITS, (len(units) + lanes - 1) // lanes)
+    chunks = [units[i:i + per] for i in range(0, len(units), per)]   # (contiguous unit numbers: the rank's block)
+
+    def one(chunk):
+        _models._set_lane_hint(lanes)
         p = copy.deepcopy(param)
         try:
             p._rng_row_offset = int(getattr(param, "_rng_row_offset", 0)) + chunk[0] * ncols
@@ -378,6 +386,12 @@ def _run_batched(local, units, param, outs):
         for j, u in enumerate(chunk):                            # snapshot b of the batch = columns [b * ncols_all, ...)
             cols = [b * ncols * len(chunk) + j * ncols + c for b in range(nblk) for c in range(ncols)]
             outs[u] = np.ascontiguousarray(out[:, cols])
+
+    if lanes > 1 and len(chunks) > 1:
+        list(_lane_pool(lanes).map(one, chunks))
+    else:
+        for chunk in chunks:
+            one(chunk)
 
 
 def run_coupled(Ei_block, param, comm):
