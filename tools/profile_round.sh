@@ -18,6 +18,7 @@ cd "$REPO"
 KT=$(find "$OUT/kt" -name '*.db' | head -1); PF=$(find "$OUT/pf" -name '*.db' | head -1); PW=$(find "$OUT/pw" -name '*.db' | head -1)
 python tools/rocpd_stats.py "$KT" > "$OUT/kernel_stats.txt" 2>&1
 UNITS=$(python -c "print({4: 16, 5: 8}.get($CFG, 1))")
-python tools/traffic_from_pmc.py "$PF" "$PW" $((STEPS * UNITS)) fused "$OUT/traffic.json" > "$OUT/traffic.txt" 2>&1
-find "$OUT" -name '*.db' -size +40M -delete          # (gpurun_out merges back at most 64 MiB)
+ALG=$(python -c "print({2: 536870912, 3: 1073741824, 4: 536870912, 5: 1073741824}.get($CFG, 536870912))")
+python tools/traffic_from_pmc.py "$PF" "$PW" $((STEPS * UNITS)) fused "$OUT/traffic.json" $CFG $ALG 3.0 "$TAG" > "$OUT/traffic.txt" 2>&1
+find "$OUT" -name '*.db' -exec gzip -f {} \;          # keep the raw databases (gpurun_out merges back at most 64 MiB: they are a few MiB)
 tail -1 "$OUT/bench.json" | cut -c1-300; head -6 "$OUT/kernel_stats.txt" | cut -c1-160; tail -3 "$OUT/traffic.txt"
