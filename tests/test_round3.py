@@ -289,3 +289,19 @@ def test_longest_fields_stay_on_the_hand_written_kernels(N):
     out = oa.manakovSSF(E, make_param(oa.parameters, cfg))
     assert models.last_run["engine"] == "fused" and models.last_run["iterations"] == tr["iterations"]
     assert rel_l2(out, ref) <= 1e-10
+
+
+# ------------------------------------------------------------------------------------------ configs 4 and 5 at workload size
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,units", [("4", 16), ("5", 8)])
+def test_configs_4_and_5_at_workload_size_on_one_gpu(cfg, units):
+    """BASELINE configs 4 (16 WDM units of 2^20) and 5 (8 units, forward + manakovDBP chained in HBM) at their full unit size,
+    all units on this GPU's two lanes (more GPUs only change who owns which block): every unit present and distinguishable,
+    rank 0's unit against the oracle at 2^20 in the same run."""
+    r, rec = _bench(["--config", cfg, "--steps", "8", "--warmup", "2", "--no-kernel-times", "--cpu-steps", "3"], timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    assert rec["config"]["units_total"] == units and rec["config"]["units_per_gpu"] == units and rec["config"]["lanes_per_gpu"] == 2
+    cs = rec["unit_checksums"]
+    assert len(cs) == units and len({round(c[1], 9) for c in cs}) == units
+    assert rec["parity"]["ok"] and rec["parity"]["rel_l2_vs_oracle"] <= 1e-10
+    assert rec["metric"].endswith("2^20 samples)") and rec["config"]["unit_steps_total"] >= units * 8
