@@ -181,6 +181,87 @@ template <typename T, int LGR, int LGC> __global__ void __launch_bounds__(256) k
     col_stage(CM_NLSE_LAST);                                      // channels.py:232
 }
 
+// ---- persistent span kernel (Manakov): Col, [Row, Col]* of a span in ONE launch ------------------------------------------------------
+// north_star's "persistent HIP pipeline" for the Manakov path.  Same stage bodies, virtual workgroup numbers, the control block of
+// section 3.3 read through an LDS copy (fetched with L1-bypassing loads after every barrier: the scalar cache is not covered
+// by an acquire).  Two barriers: the agent-scope one of the ssfm span kernel (grid_sync: L2 write-back + invalidate), and an
+// XCD-confined one -- only the workgroups that happen to run on one XCD take part (ticket counter; the others exit at once), their
+// stores meet in that XCD's L2, so a barrier is: drain the stores, arrive / spin, invalidate the L1.  OFF by default
+// (SSF_PERSIST_MK=<workers>, SSF_PERSIST_XCD=1): measured against the launch sequence in profiles/r3_persistent_manakov.txt.
+__device__ __forceinline__ bool grid_sync_xcd(unsigned *bar, unsigned nwg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's stores are in the XCD's L2 (the L1 writes through)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned g = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned spins = 0;
+            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22) || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // no stale L1 lines of what the other CUs of this XCD wrote
+    return __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+template <typename T, int LGR, int LGC> __global__ void __launch_bounds__(256) k_mk_span(const SpanMkArgs<T> a) {
+    SSF_DEV_CTX(0);
+    __shared__ int s_me;
+    int me = (int)blockIdx.x, nwg = (int)gridDim.x;
+    if (a.xcd >= 0) {
+        if (threadIdx.x == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 0xf;
+            s_me = (int)xcc == a.xcd ? (int)__hip_atomic_fetch_add(a.bar + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        }
+        __syncthreads();
+        me = s_me;
+        nwg = a.nworkers;
+        if (me < 0 || me >= nwg) return;
+    }
+    Ctrl *lc = (Ctrl *)(ssf_smem + a.ctrl_lds);
+    unsigned seq = a.seq0;
+    for (int stage = 0; stage < a.max_stages; ++stage) {
+        const Ctrl *gin = a.ctrl + (seq & 1);
+        Ctrl *gout = a.ctrl + ((seq + 1) & 1);
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(Ctrl) / 8); i += (int)blockDim.x)
+            ((unsigned long long *)lc)[i] = __hip_atomic_load((const unsigned long long *)gin + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (lc->state == ST_SPAN_DONE && !lc->pend0) {
+            if (me == 0 && threadIdx.x == 0) a.bar[4] = seq & 1u;           // which block holds the final state
+            break;
+        }
+        if ((stage & 1) == 0) {
+            ColArgs<T> ca = a.col;
+            ca.cin = lc;
+            ca.cout = gout;
+            for (int vb = me; vb < a.col_grid; vb += nwg) {
+                ctx.bid = vb;
+                col_body<T, LGC, CM_MK, false>(ctx, ca);
+                __syncthreads();
+            }
+        } else {
+            RowArgs<T> ra = a.row;
+            ra.cin = lc;
+            ra.cout = gout;
+            for (int vb = me; vb < a.row_grid; vb += nwg) {
+                ctx.bid = vb;
+                row_body<T, LGR>(ctx, ra);
+                __syncthreads();
+            }
+        }
+        ++seq;
+        const bool ok = a.xcd >= 0 ? grid_sync_xcd(a.bar, (unsigned)nwg) : grid_sync(a.bar, (unsigned)nwg);
+        if (!ok) return;
+    }
+}
+
 template <typename T> using RowFn = void (*)(const RowArgs<T>);
 template <typename T> using ColFn = void (*)(const ColArgs<T>);
 
@@ -448,6 +529,28 @@ struct HipBackend {
             return ok() ? SSF_OK : SSF_ERR_HIP;
         }
     }
+    // persistent Manakov span kernel (experiment, off by default): workers = SSF_PERSIST_MK, SSF_PERSIST_XCD=1: one XCD only
+    int persist_mk_workers() {
+        if (const char *e = getenv("SSF_PERSIST_MK")) return atoi(e);
+        return 0;
+    }
+    bool persist_mk_xcd() {
+        const char *e = getenv("SSF_PERSIST_XCD");
+        return e && atoi(e) != 0;
+    }
+    template <typename T> int launch_mk_span(const SpanMkArgs<T> &a, int grid, size_t lds) {
+        if constexpr (!std::is_same<T, double>::value) return SSF_ERR_UNSUPPORTED;     // (an experiment: double precision only)
+        else {
+            void (*f)(const SpanMkArgs<T>) = k_mk_span<T, 0, 0>;       // (length-specialised bodies spill 1.8 KiB per lane here)
+            arm((const void *)f);
+            chk(hipMemsetAsync(a.bar, 0, 8 * sizeof(unsigned), pl->stream), "hipMemsetAsync(barrier)");
+            stamp_begin(3);
+            f<<<grid, 256, lds, pl->stream>>>(a);
+            stamp_end();
+            chk(hipGetLastError(), "launch k_mk_span");
+            return ok() ? SSF_OK : SSF_ERR_HIP;
+        }
+    }
     bool sink_active() const { return pl->sink.active(); }
     template <typename C> void sink_capture(const C *soa, long long N, int nrows) {
         chk(pl->sink.capture(soa, N, nrows, pl->stream), "snapshot sink");
@@ -577,10 +680,18 @@ template <typename T> class FusedRowsImpl final : public FusedRows {
         MixPlan mp;
         return r == 1 && mix_make_plan((int)n, &mp);
     }
+    bool use_wtab = false;
     int init() {
+        // These launches are latency chains of one workgroup per row on an otherwise idle GPU (a field has 2 K rows): as many
+        // threads per row as a pass has butterflies (one round per pass), one row per workgroup, and the pass twiddles from
+        // sincospi instead of a table in global memory (a dependent L2 round trip per pass costs more than 60 instructions
+        // here; the big mixed-radix rows are throughput-bound and keep the table).  SSF_ROWS_TPR / SSF_ROWS_WTAB: A/B knobs.
+        tpr = N <= 2048 ? 256 : 512;
+        if (const char *e = getenv("SSF_ROWS_TPR")) tpr = std::max(64, std::min(1024, atoi(e)));
         while (16 * tpr < N) tpr *= 2;
-        rows_wg = std::max(1, 256 / tpr);
+        rows_wg = nrows > 512 ? std::max(1, 256 / tpr) : 1;
         while (nrows % rows_wg) rows_wg >>= 1;
+        if (const char *e = getenv("SSF_ROWS_WTAB")) use_wtab = atoi(e) != 0;
         if (!mix_make_plan((int)N, &plan, tpr)) return SSF_ERR_UNSUPPORTED;
         std::vector<cx<double>> w((size_t)N);
         for (int64_t q = 0; q < N; ++q) {
@@ -616,7 +727,7 @@ template <typename T> class FusedRowsImpl final : public FusedRows {
         a.N = N;
         a.mixed = 1;
         a.plan = plan;
-        a.wtab = wtab;
+        a.wtab = use_wtab ? wtab : nullptr;
         a.rows_per_wg = rows_wg;
         be.launch_row(a, nrows / rows_wg, tpr * rows_wg, 4096 + (size_t)rows_wg * (size_t)N * sizeof(cx<T>));
         return be.ok() ? SSF_OK : SSF_ERR_HIP;

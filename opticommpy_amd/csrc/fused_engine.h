@@ -242,7 +242,7 @@ template <typename T, class Backend> class FusedCore {
         if (kPacked && mk_buffers()) return SSF_ERR_OOM;      // (the other cores allocate them when a Manakov run needs them)
         if (!(ctrl = (Ctrl *)be.alloc(2 * (size_t)units * sizeof(Ctrl)))) return oom();      // [launch parity][unit]
         if (!(linops = (LinOp *)be.alloc(2 * sizeof(LinOp)))) return oom();
-        if (!(gbar = (unsigned *)be.alloc(4 * sizeof(unsigned)))) return oom();
+        if (!(gbar = (unsigned *)be.alloc(8 * sizeof(unsigned)))) return oom();
         if (!(part = (double *)be.alloc(sizeof(double) * 5 * (size_t)units * (size_t)npart_max))) return oom();   // [array][unit][npart_max]
         if (N2mix) {
             if (!(wtab = (cx<double> *)be.alloc(sizeof(cx<double>) * (size_t)N2mix))) return oom();
@@ -600,6 +600,55 @@ template <typename T, class Backend> class FusedCore {
         }
         const size_t cbytes = sizeof(Ctrl) * (size_t)units;
         be.h2d(ctrl + (size_t)(seq & 1) * units, cs.data(), cbytes);
+        bool persisted = false;
+        if constexpr (Backend::kCanPersist && !kPacked) {
+            // experiment (off by default): the whole span as ONE persistent launch (engine_fused_impl.h: k_mk_span)
+            const int workers = be.persist_mk_workers();
+            if (workers > 0 && units == 1 && !N2mix && row_block == 256 && col_block_mk == 256 && row_v == 16 && col_v == 16 &&
+                std::is_same<T, double>::value) {
+                SpanMkArgs<T> a{};
+                a.row = row_args();
+                a.row.use_ctrl = 1;
+                a.row.k = k;
+                a.row.pmax = part;
+                a.row.pnum = part + npart_max;
+                a.row.pden = part + 2 * (size_t)npart_max;
+                a.row.pnum0 = part + 3 * (size_t)npart_max;
+                a.row.pden0 = part + 4 * (size_t)npart_max;
+                a.row.npart = col_grid_mk;
+                a.row.stagger = 0;
+                a.col = col_args(2, CM_MK);
+                a.col.k = k;
+                a.col.npart = col_grid_mk;
+                a.ctrl = ctrl;
+                a.seq0 = seq;
+                a.row_grid = row_grid;
+                a.col_grid = col_grid_mk;
+                a.max_stages = 1 << 20;
+                a.nworkers = std::min(workers, std::max(row_grid, col_grid_mk));
+                a.xcd = be.persist_mk_xcd() ? 0 : -1;
+                a.ctrl_lds = (std::max(row_lds, col_lds_mk) + 15) / 16 * 16;
+                a.bar = gbar;
+                const int grid = a.xcd >= 0 ? 8 * a.nworkers : a.nworkers;
+                if (be.launch_mk_span(a, grid, a.ctrl_lds + sizeof(Ctrl) + 64)) return hiperr();
+                unsigned flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                be.d2h(flags, gbar, sizeof(flags));
+                if (!be.ok()) return hiperr();
+                if (flags[2]) {
+                    err = "persistent Manakov kernel: grid barrier timed out (workgroups not co-resident / not on one XCD?)";
+                    return SSF_ERR_STATE;
+                }
+                seq = (seq & ~1u) | (flags[4] & 1u);                                       // parity of the block the span ended in
+                be.d2h(cs.data(), ctrl + (seq & 1), sizeof(Ctrl));
+                if (!be.ok()) return hiperr();
+                if (cs[0].state != ST_SPAN_DONE || cs[0].pend0) {
+                    err = "persistent Manakov kernel: span not finished";
+                    return SSF_ERR_STATE;
+                }
+                persisted = true;
+            }
+        }
+        if (!persisted) {
         launch_mk_col(k, CM_MK);                                                       // first step start
         int guard = 0;
         long long prev_steps = 0, prev_iters = 0;
@@ -644,6 +693,7 @@ template <typename T, class Backend> class FusedCore {
                 return SSF_ERR_STATE;
             }
         }
+        }   // (!persisted)
         if (units == 1) {
             cur = cs[0].cur;
         } else {                                   // units may have taken different numbers of steps (adaptive step): bring

@@ -1539,6 +1539,21 @@ template <typename T> struct SpanNlseArgs {
     unsigned *bar;            // [0] arrivals, [1] generation, [2] abort
 };
 
+// arguments of the persistent Manakov span kernel (engine_fused_impl.h: k_mk_span): the launch sequence Col, [Row, Col]* of a
+// span inside ONE launch, the device-resident control block deciding what every stage does exactly as between launches
+template <typename T> struct SpanMkArgs {
+    RowArgs<T> row;           // use_ctrl = 1; cin / cout are set per stage by the kernel
+    ColArgs<T> col;           // mode CM_MK
+    Ctrl *ctrl;               // [2], double-buffered by stage parity
+    unsigned seq0;            // parity of the block the first stage reads
+    int row_grid, col_grid;   // (virtual) workgroups of the two stages
+    int max_stages;
+    int nworkers;             // workgroups that take part
+    int xcd;                  // >= 0: only workgroups that run on this XCD take part (one coherent L2: no write-back per barrier)
+    size_t ctrl_lds;          // byte offset of the control block's LDS copy (behind the stages' own LDS)
+    unsigned *bar;            // [0] arrivals, [1] generation, [2] abort, [3] tickets
+};
+
 // --------------------------------------------------------------------- elementwise helpers
 template <typename T> struct AmpArgs {
     cx<T> *E;
