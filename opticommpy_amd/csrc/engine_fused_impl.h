@@ -213,15 +213,15 @@ __device__ __forceinline__ bool grid_sync_xcd(unsigned *bar, unsigned nwg) {
 }
 template <typename T, int LGR, int LGC> __global__ void __launch_bounds__(256) k_mk_span(const SpanMkArgs<T> a) {
     SSF_DEV_CTX(0);
-    __shared__ int s_me;
+    int *s_me = (int *)(ssf_smem + a.ctrl_lds + sizeof(Ctrl));          // (no static LDS: the dynamic part may take all 160 KiB)
     int me = (int)blockIdx.x, nwg = (int)gridDim.x;
     if (a.xcd >= 0) {
         if (threadIdx.x == 0) {
             const unsigned xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 0xf;
-            s_me = (int)xcc == a.xcd ? (int)__hip_atomic_fetch_add(a.bar + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+            *s_me = (int)xcc == a.xcd ? (int)__hip_atomic_fetch_add(a.bar + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
         }
         __syncthreads();
-        me = s_me;
+        me = *s_me;
         nwg = a.nworkers;
         if (me < 0 || me >= nwg) return;
     }

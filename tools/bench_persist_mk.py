@@ -29,7 +29,7 @@ def main():
                   f"checksum {np.sum(np.abs(out) ** 2):.12e} proj {abs(np.vdot(np.arange(out.size).reshape(out.shape) % 7 - 3.0, out)):.12e}", flush=True)
         except Exception as e:
             print(f"N=2^{lg}: FAILED {e}", flush=True)
-        oa.release_plans()
+        models.release_plans()
 
 
 if __name__ == "__main__":
