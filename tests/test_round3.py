@@ -305,3 +305,39 @@ def test_configs_4_and_5_at_workload_size_on_one_gpu(cfg, units):
     assert len(cs) == units and len({round(c[1], 9) for c in cs}) == units
     assert rec["parity"]["ok"] and rec["parity"]["rel_l2_vs_oracle"] <= 1e-10
     assert rec["metric"].endswith("2^20 samples)") and rec["config"]["unit_steps_total"] >= units * 8
+
+
+# ------------------------------------------------------------------------------------------ persistent Manakov span kernel
+@pytest.mark.gpu
+@pytest.mark.parametrize("xcd", ["0", "1"])
+def test_persistent_manakov_span_kernel_reproduces_the_launch_sequence(monkeypatch, xcd):
+    """A whole Manakov span as ONE persistent launch (k_mk_span; off by default because it measured slower at every size,
+    profiles/r3_persistent_manakov.txt): the stage bodies and the device-resident control flow are the launch sequence's, so
+    the iteration counts are identical and the field agrees to rounding -- with the agent-scope barrier and with the one that
+    only admits the workgroups of one XCD.  Adaptive step and an amplifier between the spans included."""
+    import opticommpy_amd as oa
+    from helpers import make_param, rel_l2, synth_field
+    from opticommpy_amd import models
+    from oracle import ssf_oracle as orc
+    E = synth_field(1 << 14, 2, 31, 8.4)
+    monkeypatch.setenv("SSF_COL_HALF", "128")                       # 256-thread column workgroups, as the merged kernel needs
+    for adaptive in (False, True):
+        cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=8.0, Lspan=4.0,
+                   hz=0.08, nlprMethod=adaptive, maxNlinPhaseRot=2e-2, amp="edfa", NF=4.5, saveSpanN=[])
+        runs = {}
+        for workers in ("0", "32"):
+            monkeypatch.setenv("SSF_PERSIST_MK", workers)
+            monkeypatch.setenv("SSF_PERSIST_XCD", xcd)
+            models.release_plans()
+            out = oa.manakovSSF(E, make_param(oa.parameters, dict(cfg, seed=3)))
+            runs[workers] = (out, models.last_run["steps"], models.last_run["iterations"])
+        assert runs["32"][1:] == runs["0"][1:]
+        assert rel_l2(runs["32"][0], runs["0"][0]) <= 1e-12
+        tr = {}
+        ref = orc.manakovSSF(E, make_param(orc.parameters, dict(cfg, amp="ideal")), trace=tr)
+        monkeypatch.setenv("SSF_PERSIST_MK", "32")
+        out = oa.manakovSSF(E, make_param(oa.parameters, dict(cfg, amp="ideal")))
+        assert models.last_run["iterations"] == tr["iterations"] and rel_l2(out, ref) <= 1e-10
+    for k in ("SSF_PERSIST_MK", "SSF_PERSIST_XCD", "SSF_COL_HALF"):
+        monkeypatch.delenv(k)
+    models.release_plans()
