@@ -138,6 +138,7 @@ template <typename T, class Backend> class FusedCore {
     int row_v = 16;              // values per thread of the radix-2^n row kernel (SSF_ROW_V=8: 128-register kernels)
     int row_stagger = 0;         // 64-clock ticks the second half of the row grid starts late (SSF_ROW_STAGGER)
     int col_v = 16;              // values per thread of the column kernels (SSF_COL_V=8)
+    bool underfilled = false;    // the field does not fill the chip: 8-value kernels, one row per workgroup (init)
     int lanes_hint = 1;          // plans that share the GPU concurrently (ssf_plan_set_lanes): > 1 turns the phase priorities off
     int cur = 0;                 // which of T0/T1 holds the current field
     unsigned seq = 0;
@@ -182,8 +183,12 @@ template <typename T, class Backend> class FusedCore {
         while (half / tpf > N2 && half > tpf) half >>= 1;    // (a power of two also when N2 is not)
         // a grid that only just covers the 256 CUs leaves every CU with one lock-stepped workgroup:
         // prefer two smaller independent ones (measured +3 % at N = 2^20) while rows stay >= 128 B wide
-        while (!std::getenv("SSF_COL_HALF") && (long long)groups * (N2 / (half / tpf)) < 512 &&
-               (half / tpf) * sizeof(C) > 128 && half > 64)
+        // ... and below 256 workgroups (2^16 ... 2^18 samples, one field) even 64-B segments pay: the launch is a latency chain,
+        // more and smaller workgroups shorten it (measured, gpurun_out/r3k: 2^16 9 222 -> 9 720 steps/s, 2^18 8 188 -> 8 531)
+        // (per unit, not per launch: a batch of independent units keeps the geometry -- and so the partial sums -- of the single plan)
+        auto wgs = [&](int h) { return (long long)groups * (N2 / (h / tpf)); };
+        while (!std::getenv("SSF_COL_HALF") && half > 64 &&
+               ((wgs(half) < 512 && (half / tpf) * sizeof(C) > 128) || (wgs(half) < 256 && (half / tpf) * sizeof(C) > 64)))
             half >>= 1;
         const int Cc = half / tpf;
         *block = half * npol;
@@ -193,6 +198,15 @@ template <typename T, class Backend> class FusedCore {
 
     int init() {
         if (const char *e = std::getenv("SSF_LIM0_BOUND")) lim0_bound = std::atoi(e) != 0;
+        // Fields that do not fill the chip -- fewer than two 16-value waves per SIMD: rows x N <= 2^20 values per unit, i.e. up to
+        // 2^19 samples for a complex128 pair, 2^20 for a packed complex64 pair -- run on the 8-value kernels (twice the waves
+        // and workgroups, shorter dependent chains per thread) with one row per workgroup: measured +7 ... +75 % there
+        // (profiles/r3_underfilled_sweep.txt: 2^12 7 138 -> 12 489 steps/s, 2^16 9 739 -> 11 940, 2^18 8 557 -> 10 219, 2^19 7 462 ->
+        // 7 992; complex64 2^20 6 080 -> 6 949; config 1 51 422 -> 60 329), while a field that fills the chip is faster on the
+        // 16-value kernels (section 3.16).  Columns of 128 keep 16 values (8 values: three passes instead of two, -13 % at 2^14 /
+        // 2^15).  Decided per unit, so a batch of independent units has the geometry -- and the arithmetic -- of the single plan.
+        underfilled = (double)rows_u() * (double)N <= 1048576.0;
+        col_v = underfilled && sp.l1 != 7 ? 8 : 16;
         if (const char *e = std::getenv("SSF_COL_V")) col_v = std::atoi(e) == 8 ? 8 : 16;
         if (N2mix || sp.l1 < 6 || sp.l1 > 10) col_v = 16;      // (ragged tiles / very short or very long columns: 16-value kernels only)
         const int64_t nfft = (int64_t)rows_u() << sp.l1;       // row transforms of one unit
@@ -222,11 +236,13 @@ template <typename T, class Backend> class FusedCore {
                 if (mix_plan_from_radices(N2mix, r, n, &mp) && mp.r[mp.npass - 1] <= kMixMaxOpRadix) mix_plan = mp;
             }
         } else {
+            row_v = underfilled ? 8 : 16;
             if (const char *e = std::getenv("SSF_ROW_V")) row_v = std::atoi(e) == 8 ? 8 : 16;
             if (const char *e = std::getenv("SSF_ROW_STAGGER")) row_stagger = std::max(0, std::atoi(e));
             if (sp.l2 < 6) row_v = 16;
             const int tpf2 = (1 << sp.l2) / row_v, wg = row_v == 8 ? 512 : 256;
             int fpw = tpf2 >= wg ? 1 : wg / tpf2;             // row transforms per workgroup
+            if (underfilled && row_v == 8) fpw = 1;           // (under-filled chip: a workgroup per row)
             if (const char *e = std::getenv("SSF_ROW_FPW")) fpw = std::max(1, std::min(fpw, std::atoi(e)));   // tuning knob
             while (nfft % fpw) fpw >>= 1;                      // (nrows need not be a power of two)
             row_block = fpw * tpf2;
@@ -449,7 +465,7 @@ template <typename T, class Backend> class FusedCore {
         size_t plds = 0;
         if constexpr (Backend::kCanPersist && !kPacked) {
             const int tpf1 = (1 << sp.l1) / 16, tpf2 = (1 << sp.l2) / 16, lim = be.persist_limit();
-            if (!N2mix && tpf1 <= 256 && tpf2 <= 256 && nsteps >= 1 && lim > 0 && units == 1) {
+            if (!N2mix && tpf1 <= 256 && tpf2 <= 256 && nsteps >= 1 && lim > 0 && units == 1 && row_v == 16 && col_v == 16) {
                 const int fpw = 256 / tpf2, Cc = 256 / tpf1;
                 const int64_t nfft = (int64_t)nrows << sp.l1;
                 if (nfft % fpw == 0 && (1 << sp.l2) % Cc == 0) {

@@ -423,14 +423,13 @@ def test_mixed_radix_planner_covers_every_row_length_the_split_can_ask_for():
 # ---- round 3: eight values per thread (128-register kernels, four waves per SIMD) ---------------------------------
 @pytest.mark.parametrize("N,prec", [(1 << 12, "complex128"), (1 << 14, "complex128"), (1 << 16, "complex128"),
                                     (1 << 17, "complex128"), (1 << 14, "complex64")])
-@pytest.mark.parametrize("which", ["rows", "cols", "both"])
+@pytest.mark.parametrize("which", ["rows", "cols", "both", "sixteen"])
 def test_rows_with_eight_values_per_thread(monkeypatch, N, prec, which):
     """SSF_ROW_V=8: radix-8 row passes (a fourth LDS exchange per 4096-point transform), operator on the eight bins
     N/8 apart of a last-pass butterfly.  Same results as the oracle, same iteration counts; ssfm and the linear channel too."""
-    if which != "cols":
-        monkeypatch.setenv("SSF_ROW_V", "8")
-    if which != "rows":
-        monkeypatch.setenv("SSF_COL_V", "8")
+    # (fields that do not fill the chip get the 8-value kernels by default: force each combination, the 16-value pair included)
+    monkeypatch.setenv("SSF_ROW_V", "8" if which in ("rows", "both") else "16")
+    monkeypatch.setenv("SSF_COL_V", "8" if which in ("cols", "both") else "16")
     dt = np.complex64 if prec == "complex64" else np.complex128
     E = synth_field(N, 2, 41, 8.4).astype(dt)
     cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5, prgsBar=False,
