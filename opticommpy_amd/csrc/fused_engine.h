@@ -242,7 +242,9 @@ template <typename T, class Backend> class FusedCore {
             if (sp.l2 < 6) row_v = 16;
             const int tpf2 = (1 << sp.l2) / row_v, wg = row_v == 8 ? 512 : 256;
             int fpw = tpf2 >= wg ? 1 : wg / tpf2;             // row transforms per workgroup
-            if (underfilled && row_v == 8) fpw = 1;           // (under-filled chip: a workgroup per row)
+            // under-filled chip: a workgroup per row.  A batch of independent units fills the chip by itself: 256-thread workgroups
+            // there (rows per workgroup do not enter a row's arithmetic, so the units' fields stay those of the single plan)
+            if (underfilled && row_v == 8) fpw = units > 1 ? std::max(1, std::min(fpw, 256 / std::max(tpf2, 1))) : 1;
             if (const char *e = std::getenv("SSF_ROW_FPW")) fpw = std::max(1, std::min(fpw, std::atoi(e)));   // tuning knob
             while (nfft % fpw) fpw >>= 1;                      // (nrows need not be a power of two)
             row_block = fpw * tpf2;
