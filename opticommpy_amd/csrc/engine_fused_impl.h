@@ -270,6 +270,10 @@ template <typename T> RowFn<T> pick_row(int lg2, int block, int occ, int vpt = 1
     if (vpt == 8) {
         if (block <= 512) {
             switch (lg2) {
+            case 6: return k_row8<T, 512, 6>;          // (the short rows of fields that do not fill the chip: 2^12 ... 2^17 samples;
+            case 7: return k_row8<T, 512, 7>;          //  compile-time lengths are worth 25 - 30 % of a launch there)
+            case 8: return k_row8<T, 512, 8>;
+            case 9: return k_row8<T, 512, 9>;
             case 10: return k_row8<T, 512, 10>;
             case 11: return k_row8<T, 512, 11>;
             case 12: return k_row8<T, 512, 12>;
@@ -336,6 +340,7 @@ template <typename T, int LG> ColFn<T> pick_col8_mode(int mode) {
 }
 template <typename T> ColFn<T> pick_col8(int lg1, int mode) {
     switch (lg1) {
+    case 6: return pick_col8_mode<T, 6>(mode);
     case 8: return pick_col8_mode<T, 8>(mode);
     default: return pick_col8_mode<T, 0>(mode);
     }
@@ -473,6 +478,7 @@ struct HipBackend {
         if constexpr (std::is_same<T, pf2>::value) {
             if (a.vpt == 8) {
                 switch (a.log2N1) {
+                case 6: f = k_col_pk8<6>; break;
                 case 8: f = k_col_pk8<8>; break;
                 case 10: f = k_col_pk8<10>; break;
                 default: f = k_col_pk8<0>; break;
