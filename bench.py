@@ -265,6 +265,20 @@ def main():
         for u in mine:
             fields[u] = np.ascontiguousarray(synth_field(N, ncols, *w["units"][u], dtype).T)
 
+    # ---- the inputs are device-resident before anything is timed: one HBM copy per unit, from which every run (warm-up,
+    # timed, profiling, parity) re-initialises its plan by a device copy -- no PCIe transfer (and no idle GPU) between the
+    # warm-up steps and the timed ones
+    dev_in = {}
+    host_in = bool(os.environ.get("SSF_BENCH_HOST_INPUT"))     # (A/B switch: re-upload from host memory before every run, as rounds 1-2 did)
+    for u in mine:
+        if host_in:
+            dev_in[u] = fields[u].ctypes.data_as(C.c_void_p)
+            continue
+        q = C.c_void_p()
+        _lib.raise_for(lib, None, lib.ssf_device_malloc(local_rank, fields[u].nbytes, C.byref(q)))
+        _lib.raise_for(lib, None, lib.ssf_device_memcpy(local_rank, q, fields[u].ctypes.data_as(C.c_void_p), fields[u].nbytes))
+        dev_in[u] = q
+
     # ---- one plan per unit (its field stays resident in HBM), units dealt to the lanes alternately
     plans = {}
     for u in mine:
@@ -289,7 +303,7 @@ def main():
 
     def run_all(steps, sync=True):
         for u in mine:
-            _lib.raise_for(lib, plans[u], lib.ssf_upload(plans[u], fields[u].ctypes.data_as(C.c_void_p)))
+            _lib.raise_for(lib, plans[u], lib.ssf_upload(plans[u], dev_in[u]))
         stats = {}
         if comm is not None and sync:
             comm.barrier()
@@ -378,7 +392,7 @@ def main():
         # themselves cost a few microseconds per launch)
         if not args.no_kernel_times and w["model"] == "manakov" and lib.ssf_set_profiling(plans[u0], 1) == 0:
             nprof = min(args.steps, 200)
-            _lib.raise_for(lib, plans[u0], lib.ssf_upload(plans[u0], fields[u0].ctypes.data_as(C.c_void_p)))
+            _lib.raise_for(lib, plans[u0], lib.ssf_upload(plans[u0], dev_in[u0]))
             stp = {}
             run_unit(u0, nprof, stp)
             kt = _lib.KernelTimes()
@@ -429,7 +443,7 @@ def main():
             E0 = np.ascontiguousarray(fields[u0].T)
             ref, tc, tr = oracle_run(w, E0, n, dtype)
             was_dbp, w["dbp"] = w["dbp"], False
-            _lib.raise_for(lib, plans[u0], lib.ssf_upload(plans[u0], fields[u0].ctypes.data_as(C.c_void_p)))
+            _lib.raise_for(lib, plans[u0], lib.ssf_upload(plans[u0], dev_in[u0]))
             stp = {}
             run_unit(u0, n, stp)
             w["dbp"] = was_dbp
@@ -459,6 +473,8 @@ def main():
                 rec["value"] = None                              # a wrong result is not a benchmark result
     for h in plans.values():
         lib.ssf_plan_destroy(h)
+    for q in ([] if host_in else dev_in.values()):
+        lib.ssf_device_free(local_rank, q)
     if comm is not None:
         flag = comm.allreduce(np.array([0.0 if ok else 1.0]), "max")     # rank 0 arrives after its extra passes
         ok = flag[0] == 0.0

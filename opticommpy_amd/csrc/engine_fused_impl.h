@@ -55,47 +55,95 @@ struct DevCtx : DevCtxCore {
     extern __shared__ __attribute__((aligned(16))) char ssf_smem[];           \
     DevCtx ctx{{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, ssf_smem} SSF_CTX_KIND(k)}
 
+// ---- chained launches (fused_kernels.h: Chain) -------------------------------------------------------------------------------
+// Entry: count this workgroup as started, wait until every workgroup of the earlier chained launches has finished, acquire at
+// agent scope (no stale L1 / L2 / scalar-cache lines of what those launches wrote on other XCDs).  Exit: drain this
+// workgroup's stores, release at agent scope (L2 write-back), count it as finished.  Bounded spin: a wait that cannot complete
+// sets the abort word, every later workgroup skips its body (still counting, so nothing else waits for it) and the host reports
+// the failure instead of hanging.  Deadlock freedom is the host's job: a launch only enters its queue behind a gate that has
+// seen the previous launch fully dispatched (k_gate), so waiting workgroups never hold a slot the launch they wait for needs.
+__device__ __forceinline__ bool chain_enter(const Chain &c) {
+    if (!c.cnt) return true;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(c.cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(c.cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.need_done) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22) || __hip_atomic_load(c.cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(c.cnt + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // the scalar cache is not covered by the fence
+    }
+    __syncthreads();
+    return __hip_atomic_load(c.cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+__device__ __forceinline__ void chain_exit(const Chain &c) {
+    if (!c.cnt) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // (inline-asm stores included)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(c.cnt + 1, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one thread: returns once every workgroup of the earlier chained launches has been dispatched
+__global__ void k_gate(unsigned long long *cnt, unsigned long long need_started) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_started) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22) || __hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(cnt + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+#define SSF_CHAINED(args, call)              \
+    do {                                     \
+        if (chain_enter((args).chain)) call; \
+        chain_exit((args).chain);            \
+    } while (0)
+
 // OCC = minimum waves per SIMD the register allocator must leave room for: 1 = up to 512
 // registers per lane and no spills (one 256-thread workgroup per CU), 2 = 256 registers
 // (two workgroups per CU).  LG = compile-time log2 of the transform length (0 = runtime).
 template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds__(MAXT, OCC) k_row(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    row_body<T, LG>(ctx, unit_view(a, (int)blockIdx.y));
+    SSF_CHAINED(a, (row_body<T, LG>(ctx, unit_view(a, (int)blockIdx.y))));
 }
 // eight values per thread: at most 128 registers, four waves per SIMD (two 512-thread workgroups, or one of 1024, per CU)
 template <typename T, int MAXT, int LG> __global__ void __launch_bounds__(MAXT, 4) k_row8(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    row_body<T, LG, 8>(ctx, unit_view(a, (int)blockIdx.y));
+    SSF_CHAINED(a, (row_body<T, LG, 8>(ctx, unit_view(a, (int)blockIdx.y))));
 }
 // Manakov column kernels run 512 threads (x half | y half); the single-row modes run 256
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    col_body<T, LG, MODE, false>(ctx, unit_view(a, (int)blockIdx.y));
+    SSF_CHAINED(a, (col_body<T, LG, MODE, false>(ctx, unit_view(a, (int)blockIdx.y))));
 }
 // row lengths with factors 3 / 5 (mixed_fft.h): mixed-radix row stage, column stage with ragged last tiles
 template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT, MAXT <= 256 ? 2 : 1) k_row_mixed(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    row_mixed_body<T>(ctx, unit_view(a, (int)blockIdx.y));
+    SSF_CHAINED(a, (row_mixed_body<T>(ctx, unit_view(a, (int)blockIdx.y))));
 }
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    col_body<T, LG, MODE, true>(ctx, unit_view(a, (int)blockIdx.y));
+    SSF_CHAINED(a, (col_body<T, LG, MODE, true>(ctx, unit_view(a, (int)blockIdx.y))));
 }
 // eight values per thread (at most 128 registers, four waves per SIMD): 512-thread workgroups, two per CU
 template <typename T, int LG, int MODE> __global__ void __launch_bounds__(512, 4) k_col8(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    col_body<T, LG, MODE, false, 8>(ctx, unit_view(a, (int)blockIdx.y));
+    SSF_CHAINED(a, (col_body<T, LG, MODE, false, 8>(ctx, unit_view(a, (int)blockIdx.y))));
 }
 template <int LG> __global__ void __launch_bounds__(512, 4) k_col_pk8(const ColArgs<pf2> a) {
     SSF_DEV_CTX(1);
-    col_pk_body<LG, 8>(ctx, unit_view(a, (int)blockIdx.y));
+    SSF_CHAINED(a, (col_pk_body<LG, 8>(ctx, unit_view(a, (int)blockIdx.y))));
 }
 // complex64 Manakov: packed polarisation pairs (fused_kernels.h: col_pk_body); up to 512 threads (8 columns of 1024)
 template <int LG> __global__ void __launch_bounds__(512) k_col_pk(const ColArgs<pf2> a) {
     SSF_DEV_CTX(1);
-    col_pk_body<LG>(ctx, unit_view(a, (int)blockIdx.y));
+    SSF_CHAINED(a, (col_pk_body<LG>(ctx, unit_view(a, (int)blockIdx.y))));
 }
 __global__ void __launch_bounds__(256) k_repack(const RepackArgs a) {
     SSF_DEV_CTX(1);
@@ -361,6 +409,51 @@ struct HipBackend {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     int row_occ = 2;
+    // chained launches (fused_kernels.h: Chain; chain_enter / chain_exit above): SSF_CHAIN=1.  Between chain_begin() and
+    // chain_end() the row / column launches alternate between the plan's stream and a second one, each behind a gate.
+    bool chain_want = false, chain_open = false;
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned long long *chain_cnt = nullptr;                 // device: started, finished, abort
+    unsigned long long chain_started = 0, chain_done = 0;    // host: workgroups of every chained launch enqueued so far
+    unsigned long long *chain_abort_host = nullptr;          // pinned copy of the abort word (read after the next synchronise)
+    unsigned chain_n = 0;
+    void chain_begin() {
+        if (!chain_want || profiling || !ok()) return;
+        if (!st2) {
+            chk(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking), "hipStreamCreate(chain)");
+            chk(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "hipEventCreate");
+            chk(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming), "hipEventCreate");
+            chk(hipMalloc((void **)&chain_cnt, 4 * sizeof(unsigned long long)), "hipMalloc(chain)");
+            chk(hipHostMalloc((void **)&chain_abort_host, sizeof(unsigned long long)), "hipHostMalloc(chain)");
+            if (!ok()) return;
+            *chain_abort_host = 0;
+            chk(hipMemsetAsync(chain_cnt, 0, 4 * sizeof(unsigned long long), pl->stream), "hipMemsetAsync(chain)");
+        }
+        chk(hipEventRecord(ev_fork, pl->stream), "hipEventRecord");
+        chk(hipStreamWaitEvent(st2, ev_fork, 0), "hipStreamWaitEvent");
+        chain_open = ok();
+        chain_n = 0;
+    }
+    void chain_end() {
+        if (!chain_open) return;
+        chain_open = false;
+        chk(hipEventRecord(ev_join, st2), "hipEventRecord");
+        chk(hipStreamWaitEvent(pl->stream, ev_join, 0), "hipStreamWaitEvent");
+        chk(hipMemcpyAsync(chain_abort_host, chain_cnt + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, pl->stream), "chain abort word");
+    }
+    bool chain_aborted() const { return chain_abort_host && *chain_abort_host != 0; }    // (valid after a synchronise)
+    // the stream of the next row / column launch and its Chain block; enqueues the gate in front of it
+    hipStream_t chain_next(Chain &c, long long wgs) {
+        if (!chain_open) return pl->stream;
+        hipStream_t s = (chain_n++ & 1) ? st2 : pl->stream;
+        k_gate<<<1, 1, 0, s>>>(chain_cnt, chain_started);
+        c.cnt = chain_cnt;
+        c.need_done = chain_done;
+        chain_started += (unsigned long long)wgs;
+        chain_done += (unsigned long long)wgs;
+        return s;
+    }
     // optional per-launch event timing (ssf_set_profiling)
     bool profiling = false;
     struct Stamp { hipEvent_t a, b; int cat; };
@@ -399,12 +492,18 @@ struct HipBackend {
     }
     explicit HipBackend(ssf_plan *p) : pl(p) {
         if (const char *s = getenv("SSF_FUSED_ROW_OCC")) row_occ = atoi(s) == 1 ? 1 : 2;
+        if (const char *s = getenv("SSF_CHAIN")) chain_want = atoi(s) != 0;
         chk(hipEventCreate(&ev0), "hipEventCreate");
         chk(hipEventCreate(&ev1), "hipEventCreate");
     }
     ~HipBackend() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (st2) (void)hipStreamDestroy(st2);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (chain_cnt) (void)hipFree(chain_cnt);
+        if (chain_abort_host) (void)hipHostFree(chain_abort_host);
         for (auto &s : stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         for (auto e : pool) (void)hipEventDestroy(e);
     }
@@ -469,7 +568,9 @@ struct HipBackend {
                 : block <= 256 ? (RowFn<T>)k_row_mixed<T, 256> : block <= 512 ? (RowFn<T>)k_row_mixed<T, 512> : (RowFn<T>)k_row_mixed<T, 1024>;
         arm((const void *)f);
         stamp_begin(0);
-        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, pl->stream>>>(a);
+        RowArgs<T> b = a;
+        hipStream_t s = chain_next(b.chain, (long long)grid * units);
+        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, s>>>(b);
         stamp_end();
         chk(hipGetLastError(), "launch k_row");
     }
@@ -495,7 +596,9 @@ struct HipBackend {
             f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : a.vpt == 8 ? pick_col8<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
         arm((const void *)f);
         stamp_begin(a.mode == CM_MK ? 1 : 3);
-        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, pl->stream>>>(a);
+        ColArgs<T> b = a;
+        hipStream_t s = chain_next(b.chain, (long long)grid * units);
+        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, s>>>(b);
         stamp_end();
         chk(hipGetLastError(), "launch k_col");
     }

@@ -136,7 +136,9 @@ template <typename T, class Backend> class FusedCore {
     int tr_maxIter = 0;
     std::vector<C *> snaps;
     int row_v = 16;              // values per thread of the radix-2^n row kernel (SSF_ROW_V=8: 128-register kernels)
-    int row_stagger = 0;         // 64-clock ticks the second half of the row grid starts late (SSF_ROW_STAGGER)
+    int row_stagger = 0;         // 64-clock ticks the second resident workgroup of every CU starts late (SSF_ROW_STAGGER; experiment)
+    int col_stagger = 0;         // the same for the column stage (SSF_COL_STAGGER)
+    int stagger_resident = 512;  // workgroups resident at once (two per CU): bids [resident / 2, resident) are the late ones
     int col_v = 16;              // values per thread of the column kernels (SSF_COL_V=8)
     bool underfilled = false;    // the field does not fill the chip: 8-value kernels, one row per workgroup (init)
     int lanes_hint = 1;          // plans that share the GPU concurrently (ssf_plan_set_lanes): > 1 turns the phase priorities off
@@ -239,6 +241,8 @@ template <typename T, class Backend> class FusedCore {
             row_v = underfilled ? 8 : 16;
             if (const char *e = std::getenv("SSF_ROW_V")) row_v = std::atoi(e) == 8 ? 8 : 16;
             if (const char *e = std::getenv("SSF_ROW_STAGGER")) row_stagger = std::max(0, std::atoi(e));
+            if (const char *e = std::getenv("SSF_COL_STAGGER")) col_stagger = std::max(0, std::atoi(e));
+            if (const char *e = std::getenv("SSF_STAGGER_RESIDENT")) stagger_resident = std::max(2, std::atoi(e));
             if (sp.l2 < 6) row_v = 16;
             const int tpf2 = (1 << sp.l2) / row_v, wg = row_v == 8 ? 512 : 256;
             int fpw = tpf2 >= wg ? 1 : wg / tpf2;             // row transforms per workgroup
@@ -349,6 +353,8 @@ template <typename T, class Backend> class FusedCore {
         a.vpt = row_v;
         a.prio = lanes_hint <= 1 ? 1 : 0;
         a.stagger = row_stagger;
+        a.stagger_hi = std::min(row_grid, stagger_resident);
+        a.stagger_lo = a.stagger_hi / 2;
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {
@@ -376,6 +382,9 @@ template <typename T, class Backend> class FusedCore {
         a.pden = part + 2 * ps;
         a.pnum0 = part + 3 * ps;
         a.pden0 = part + 4 * ps;
+        a.stagger = mode == CM_MK ? col_stagger : 0;
+        a.stagger_hi = std::min(col_grid_mk, stagger_resident);
+        a.stagger_lo = a.stagger_hi / 2;
         return a;
     }
     void launch_row_lin(const LinOp *lin) {
@@ -686,12 +695,18 @@ template <typename T, class Backend> class FusedCore {
             }
             double est = p.nlprMethod ? steps_rem * (1.0 + sr.avg_it) * 0.6 : steps_rem * (1.0 + sr.avg_it) + 3.0;
             int chunk = (int)std::min(512.0, std::max(2.0, std::ceil(est)));
-            for (int i = 0; i < chunk; ++i) {
+            if (units == 1 && lanes_hint <= 1) be.chain_begin();                     // (experiment, SSF_CHAIN=1: launches chained
+            for (int i = 0; i < chunk; ++i) {                                          //  across two streams, waits inside the kernels)
                 launch_mk_row(k);
                 launch_mk_col(k, CM_MK);
             }
+            be.chain_end();
             be.d2h(cs.data(), ctrl + (size_t)(seq & 1) * units, cbytes);              // synchronising read
             if (!be.ok()) return hiperr();
+            if (be.chain_aborted()) {
+                err = "fused engine: a chained launch waited for its predecessor in vain (SSF_CHAIN)";
+                return SSF_ERR_STATE;
+            }
             long long steps = 0, iters = 0;
             bool done = true;
             double worst = 0.0;

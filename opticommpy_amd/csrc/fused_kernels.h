@@ -405,6 +405,16 @@ template <class Ctx> SSF_HD double global_max(Ctx &ctx, const double *a, int n, 
 }
 
 // ------------------------------------------------------------------------------ row kernel
+// Chained launches (engine_fused_impl.h: chain_enter / chain_exit; all zero = off).  The launches of a span alternate between
+// two streams, so the workgroups of launch j + 1 are dispatched while launch j still runs (they take the slots its early
+// workgroups leave) and wait INSIDE the kernel for launch j's workgroups to have finished, instead of waiting at a kernel
+// boundary (end-of-kernel write-back, completion signal, the command processor's next packet, dispatch: ~2.5 us per launch).
+// cnt[0] = workgroups started, cnt[1] = workgroups finished -- both over the engine's whole life --, cnt[2] = abort word.
+struct Chain {
+    unsigned long long *cnt;
+    unsigned long long need_done;     // this launch's workgroups proceed once cnt[1] >= need_done (every earlier chained launch done)
+};
+
 template <typename T> struct RowArgs {
     cx<T> *G;                 // (nrows, N1, N2)
     int log2N1, log2N2, nfft; // nfft = nrows * N1 row transforms
@@ -434,8 +444,10 @@ template <typename T> struct RowArgs {
     long long u_elems;
     int u_part;
     int prio;                 // 1: issue priority by phase (s_setprio, SSF_PRIO); 0 when several plans share the GPU (lanes)
-    int stagger;              // > 0: the second half of the grid starts this many 64-clock ticks late (co-resident workgroups
-                              // out of phase: one loads / stores while the other transforms)
+    int stagger;              // > 0: workgroups stagger_lo <= bid < stagger_hi start this many 64-clock ticks late (the second
+    int stagger_lo, stagger_hi;   // workgroup of every CU in the first round of residency: co-resident workgroups out of phase,
+                              // one loads / stores while the other transforms)
+    Chain chain;
 };
 
 // linear operator for the V registers of a last-radix-V butterfly (V = 16 | 8): bins k0 + (N/V) q, signed q' = q or q - V;
@@ -692,7 +704,7 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     const long long rr = (long long)ctx.bid * fpw + f;     // global row-transform index (grid is exact)
     cx<T> *g = a.G + (rr << a.log2N2);
     cx<T> v[V];
-    if (a.stagger > 0 && ctx.bid >= (ctx.nblocks >> 1)) ctx.sleep64(a.stagger);
+    if (a.stagger > 0 && ctx.bid >= a.stagger_lo && ctx.bid < a.stagger_hi) ctx.sleep64(a.stagger);
     ctx.mark(0);
     // Issue order matters (vmcnt retires in order): first the convergence sums the last column
     // stage may have left (fetched unconditionally, they are only used if the control block says
@@ -805,6 +817,8 @@ template <typename T> struct ColArgs {
     long long u_elems;        // independent units (see RowArgs): field elements per unit; P / Theta advance by 2 / 1 x ngroups x N
     int u_part;
     int prio;                 // see RowArgs
+    int stagger, stagger_lo, stagger_hi;   // see RowArgs (experiment: SSF_COL_STAGGER)
+    Chain chain;
 };
 
 // Arguments of unit u of a batch of independent units: every pointer moved to the unit's block.  The kernel bodies never
@@ -1198,6 +1212,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     bool final_ = false, more = false, exact0 = true;
     struct { int state, it, cur, pcur; double z, hz; } c{};
     double *red = (double *)ctx.lds;
+    if (a.stagger > 0 && ctx.bid >= a.stagger_lo && ctx.bid < a.stagger_hi) ctx.sleep64(a.stagger);
     ctx.mark(0);
     if (kMk) {
         MkColStage st;
@@ -1396,6 +1411,7 @@ SSF_HD void pk_step_start(Ctx &ctx, const G &g, const ColArgs<pf2> &a, const cx<
 
 template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2> &a) {
     using T = pf2;
+    if (a.stagger > 0 && ctx.bid >= a.stagger_lo && ctx.bid < a.stagger_hi) ctx.sleep64(a.stagger);
     ctx.mark(0);
     MkColStage st;
     mk_col_stage(ctx, a, st);

@@ -145,6 +145,9 @@ struct EmuBackend {
     }
     void memset(void *d, int v, size_t n) { ::memset(d, v, n); }
     void prepare(size_t, size_t) {}
+    void chain_begin() {}                              // (chained launches: a GPU scheduling matter, nothing to emulate)
+    void chain_end() {}
+    bool chain_aborted() const { return false; }
     void sync() {}
     bool ok() const { return true; }
     std::string last_error() const { return ""; }
