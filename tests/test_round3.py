@@ -356,13 +356,14 @@ def test_chained_launches_reproduce_the_launch_sequence(monkeypatch, prec):
     E = synth_field(1 << 16, 2, 33, 8.4)
     cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=16.0, Lspan=8.0,
                hz=0.08, nlprMethod=True, maxNlinPhaseRot=2e-2, amp="edfa", NF=4.5, saveSpanN=[], seed=5, prec=prec)
-    runs = {}
-    for chain in ("0", "1"):
-        monkeypatch.setenv("SSF_CHAIN", chain)
-        models.release_plans()
-        out = oa.manakovSSF(E, make_param(oa.parameters, cfg))
-        runs[chain] = (out, models.last_run["steps"], models.last_run["iterations"])
+    for adaptive in (True, False):
+        runs = {}
+        for chain in ("0", "1"):
+            monkeypatch.setenv("SSF_CHAIN", chain)
+            models.release_plans()
+            out = oa.manakovSSF(E, make_param(oa.parameters, dict(cfg, nlprMethod=adaptive)))
+            runs[chain] = (out, models.last_run["steps"], models.last_run["iterations"])
+        assert runs["1"][1:] == runs["0"][1:] and runs["0"][1] >= (10 if adaptive else 200), runs["0"][1:]
+        assert np.array_equal(runs["1"][0], runs["0"][0])
     monkeypatch.delenv("SSF_CHAIN")
     models.release_plans()
-    assert runs["1"][1:] == runs["0"][1:] and runs["0"][1] > 100
-    assert np.array_equal(runs["1"][0], runs["0"][0])
