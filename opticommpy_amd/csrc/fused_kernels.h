@@ -280,26 +280,37 @@ template <int V = 16, typename T> SSF_HD void lds_get(const PassPlan &p, int i, 
 #define SSF_ABL_NOMEM (SSF_ABL == 2 || SSF_ABL == 5 || SSF_ABL == 6)    /* 5 = 2 + 3: arithmetic only; 6 = 2 + 4: LDS only */
 #define SSF_ABL_NOLDS (SSF_ABL == 3 || SSF_ABL == 5)
 #define SSF_ABL_NOVALU (SSF_ABL == 4 || SSF_ABL == 6)
-template <int SIGN, int V = 16, typename T, class Ctx>
+// SSF_XPRIO (experiment builds): the LDS exchanges of a transform run at issue priority 3 and its butterflies at PB (1: the
+// phase's own level, 2: level 0) -- an exchange's 16 wide stores need the SIMD for 13 cycles each and are otherwise served
+// behind the other workgroup's butterflies.  PB < 0: priorities untouched.  Measured (profiles/r3_chained_launches_and_stagger.txt):
+// config 2 +- 0.5 %, config 3 rows 52 -> 61 - 64 us: off.
+#ifndef SSF_XPRIO
+#define SSF_XPRIO 0
+#endif
+template <int SIGN, int V = 16, int PB = -1, typename T, class Ctx>
 SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
     if (!SSF_ABL_NOVALU) dif_pass<SIGN, V>(p, 0, b, v);
 #pragma unroll
     for (int i = 1; i < p.npass; ++i) {
+        if constexpr (SSF_XPRIO && PB >= 0) ctx.template setprio<3>();
         if (!SSF_ABL_NOLDS) lds_put<V>(p, i - 1, b, v, lds);
         ctx.sync();
         if (!SSF_ABL_NOLDS) lds_get<V>(p, i, b, v, lds);
+        if constexpr (SSF_XPRIO && PB >= 0) ctx.template setprio<(SSF_XPRIO == 2 ? 0 : PB)>();
         if (!SSF_ABL_NOVALU) dif_pass<SIGN, V>(p, i, b, v);
     }
 }
 // DIT transform: v holds pass-(p-1) positions on entry, pass-0 positions (natural) on exit
-template <int SIGN, int V = 16, typename T, class Ctx>
+template <int SIGN, int V = 16, int PB = -1, typename T, class Ctx>
 SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
 #pragma unroll
     for (int i = p.npass - 1; i >= 1; --i) {
         if (!SSF_ABL_NOVALU) dit_pass<SIGN, V>(p, i, b, v);
+        if constexpr (SSF_XPRIO && PB >= 0) ctx.template setprio<3>();
         if (!SSF_ABL_NOLDS) lds_put<V>(p, i, b, v, lds);
         ctx.sync();
         if (!SSF_ABL_NOLDS) lds_get<V>(p, i - 1, b, v, lds);
+        if constexpr (SSF_XPRIO && PB >= 0) ctx.template setprio<(SSF_XPRIO == 2 ? 0 : PB)>();
     }
     if (!SSF_ABL_NOVALU) dit_pass<SIGN, V>(p, 0, b, v);
 }
@@ -749,7 +760,7 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     // wave per SIMD (phase stamps: first half of the grid done at 13.3 us, second half at 17.5 us).
     if (SSF_PRIO == 2 && a.prio) ctx.template setprio<3>();
     else if (SSF_PRIO && a.prio) ctx.template setprio<2>();
-    if (SSF_ABL != 1) fft_dif<-1, V>(ctx, p, b, v, l);
+    if (SSF_ABL != 1) fft_dif<-1, V, 2>(ctx, p, b, v, l);
     ctx.mark(2);
     if (SSF_PRIO == 2 && a.prio) ctx.template setprio<2>();
     else if (SSF_PRIO && a.prio) ctx.template setprio<1>();
@@ -776,7 +787,7 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     }
     ctx.mark(3);
     if (SSF_PRIO == 2 && a.prio) ctx.template setprio<1>();
-    if (SSF_ABL != 1) fft_dit<+1, V>(ctx, p, b, v, l);
+    if (SSF_ABL != 1) fft_dit<+1, V, 1>(ctx, p, b, v, l);
     if (SSF_PRIO && a.prio) ctx.template setprio<0>();
     ctx.mark(4);
 #pragma unroll
@@ -1258,7 +1269,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
         ctx.mark(1);
         if (SSF_PRIO && a.prio) ctx.template setprio<3>();
         global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v);
-        fft_dif<+1, V>(ctx, p, g.b, v, lds);
+        fft_dif<+1, V, 2>(ctx, p, g.b, v, lds);
         ctx.mark(2);
         if (SSF_PRIO && a.prio) ctx.template setprio<2>();
     } else if (!(kMk && op == 3)) {
@@ -1342,7 +1353,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     if (SSF_PRIO && a.prio) ctx.template setprio<1>();
     if (do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
-        fft_dit<-1, V>(ctx, p, g.b, v, lds);
+        fft_dit<-1, V, 1>(ctx, p, g.b, v, lds);
         global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
         if (SSF_PRIO && a.prio) ctx.template setprio<0>();
@@ -1432,7 +1443,7 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
         for (int q = 0; q < V; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
         ctx.mark(1);
         global_twiddle<+1, false>(g, a.log2N1 + a.log2N2, v);
-        fft_dif<+1, V>(ctx, p, g.b, v, lds);
+        fft_dif<+1, V, 2>(ctx, p, g.b, v, lds);
         ctx.mark(2);
     } else if (op != 3) {
 #pragma unroll
@@ -1536,7 +1547,7 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
 
     ctx.mark(3);
     if (st.do_fwd) {
-        fft_dit<-1, V>(ctx, p, g.b, v, lds);
+        fft_dit<-1, V, 1>(ctx, p, g.b, v, lds);
         global_twiddle<-1, false>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
 #pragma unroll
