@@ -62,6 +62,7 @@ struct DevCtx : DevCtxCore {
 // sets the abort word, every later workgroup skips its body (still counting, so nothing else waits for it) and the host reports
 // the failure instead of hanging.  Deadlock freedom is the host's job: a launch only enters its queue behind a gate that has
 // seen the previous launch fully dispatched (k_gate), so waiting workgroups never hold a slot the launch they wait for needs.
+#if SSF_CHAIN
 __device__ __forceinline__ bool chain_enter(const Chain &c) {
     if (!c.cnt) return true;
     if (threadIdx.x == 0) {
@@ -102,6 +103,9 @@ __global__ void k_gate(unsigned long long *cnt, unsigned long long need_started)
         if (chain_enter((args).chain)) call; \
         chain_exit((args).chain);            \
     } while (0)
+#else
+#define SSF_CHAINED(args, call) call
+#endif
 
 // OCC = minimum waves per SIMD the register allocator must leave room for: 1 = up to 512
 // registers per lane and no spills (one 256-thread workgroup per CU), 2 = 256 registers
@@ -409,6 +413,7 @@ struct HipBackend {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     int row_occ = 2;
+#if SSF_CHAIN
     // chained launches (fused_kernels.h: Chain; chain_enter / chain_exit above): SSF_CHAIN=1.  Between chain_begin() and
     // chain_end() the row / column launches alternate between the plan's stream and a second one, each behind a gate.
     bool chain_want = false, chain_open = false;
@@ -443,6 +448,7 @@ struct HipBackend {
         chk(hipMemcpyAsync(chain_abort_host, chain_cnt + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, pl->stream), "chain abort word");
     }
     bool chain_aborted() const { return chain_abort_host && *chain_abort_host != 0; }    // (valid after a synchronise)
+    template <class A> hipStream_t chain_next_of(A &b, long long wgs) { return chain_next(b.chain, wgs); }
     // the stream of the next row / column launch and its Chain block; enqueues the gate in front of it
     hipStream_t chain_next(Chain &c, long long wgs) {
         if (!chain_open) return pl->stream;
@@ -454,6 +460,9 @@ struct HipBackend {
         chain_done += (unsigned long long)wgs;
         return s;
     }
+#else
+    template <class A> hipStream_t chain_next_of(A &, long long) { return pl->stream; }
+#endif
     // optional per-launch event timing (ssf_set_profiling)
     bool profiling = false;
     struct Stamp { hipEvent_t a, b; int cat; };
@@ -492,18 +501,22 @@ struct HipBackend {
     }
     explicit HipBackend(ssf_plan *p) : pl(p) {
         if (const char *s = getenv("SSF_FUSED_ROW_OCC")) row_occ = atoi(s) == 1 ? 1 : 2;
+#if SSF_CHAIN
         if (const char *s = getenv("SSF_CHAIN")) chain_want = atoi(s) != 0;
+#endif
         chk(hipEventCreate(&ev0), "hipEventCreate");
         chk(hipEventCreate(&ev1), "hipEventCreate");
     }
     ~HipBackend() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+#if SSF_CHAIN
         if (st2) (void)hipStreamDestroy(st2);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (chain_cnt) (void)hipFree(chain_cnt);
         if (chain_abort_host) (void)hipHostFree(chain_abort_host);
+#endif
         for (auto &s : stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         for (auto e : pool) (void)hipEventDestroy(e);
     }
@@ -569,7 +582,7 @@ struct HipBackend {
         arm((const void *)f);
         stamp_begin(0);
         RowArgs<T> b = a;
-        hipStream_t s = chain_next(b.chain, (long long)grid * units);
+        hipStream_t s = chain_next_of(b, (long long)grid * units);
         f<<<dim3((unsigned)grid, (unsigned)units), block, lds, s>>>(b);
         stamp_end();
         chk(hipGetLastError(), "launch k_row");
@@ -597,7 +610,7 @@ struct HipBackend {
         arm((const void *)f);
         stamp_begin(a.mode == CM_MK ? 1 : 3);
         ColArgs<T> b = a;
-        hipStream_t s = chain_next(b.chain, (long long)grid * units);
+        hipStream_t s = chain_next_of(b, (long long)grid * units);
         f<<<dim3((unsigned)grid, (unsigned)units), block, lds, s>>>(b);
         stamp_end();
         chk(hipGetLastError(), "launch k_col");

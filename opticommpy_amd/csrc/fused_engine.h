@@ -241,7 +241,7 @@ template <typename T, class Backend> class FusedCore {
             row_v = underfilled ? 8 : 16;
             if (const char *e = std::getenv("SSF_ROW_V")) row_v = std::atoi(e) == 8 ? 8 : 16;
             if (const char *e = std::getenv("SSF_ROW_STAGGER")) row_stagger = std::max(0, std::atoi(e));
-            if (const char *e = std::getenv("SSF_COL_STAGGER")) col_stagger = std::max(0, std::atoi(e));
+            if (const char *e = std::getenv("SSF_COL_STAGGER")) col_stagger = std::max(0, std::atoi(e));      // (SSF_CHAIN builds only)
             if (const char *e = std::getenv("SSF_STAGGER_RESIDENT")) stagger_resident = std::max(2, std::atoi(e));
             if (sp.l2 < 6) row_v = 16;
             const int tpf2 = (1 << sp.l2) / row_v, wg = row_v == 8 ? 512 : 256;
@@ -382,9 +382,11 @@ template <typename T, class Backend> class FusedCore {
         a.pden = part + 2 * ps;
         a.pnum0 = part + 3 * ps;
         a.pden0 = part + 4 * ps;
+#if SSF_CHAIN
         a.stagger = mode == CM_MK ? col_stagger : 0;
         a.stagger_hi = std::min(col_grid_mk, stagger_resident);
         a.stagger_lo = a.stagger_hi / 2;
+#endif
         return a;
     }
     void launch_row_lin(const LinOp *lin) {
@@ -695,18 +697,24 @@ template <typename T, class Backend> class FusedCore {
             }
             double est = p.nlprMethod ? steps_rem * (1.0 + sr.avg_it) * 0.6 : steps_rem * (1.0 + sr.avg_it) + 3.0;
             int chunk = (int)std::min(512.0, std::max(2.0, std::ceil(est)));
-            if (units == 1 && lanes_hint <= 1) be.chain_begin();                     // (experiment, SSF_CHAIN=1: launches chained
-            for (int i = 0; i < chunk; ++i) {                                          //  across two streams, waits inside the kernels)
+#if SSF_CHAIN
+            if (units == 1 && lanes_hint <= 1) be.chain_begin();                     // (experiment builds: launches chained across
+#endif                                                                                //  two streams, waits inside the kernels)
+            for (int i = 0; i < chunk; ++i) {
                 launch_mk_row(k);
                 launch_mk_col(k, CM_MK);
             }
+#if SSF_CHAIN
             be.chain_end();
+#endif
             be.d2h(cs.data(), ctrl + (size_t)(seq & 1) * units, cbytes);              // synchronising read
             if (!be.ok()) return hiperr();
+#if SSF_CHAIN
             if (be.chain_aborted()) {
                 err = "fused engine: a chained launch waited for its predecessor in vain (SSF_CHAIN)";
                 return SSF_ERR_STATE;
             }
+#endif
             long long steps = 0, iters = 0;
             bool done = true;
             double worst = 0.0;

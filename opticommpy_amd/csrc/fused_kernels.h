@@ -416,15 +416,22 @@ template <class Ctx> SSF_HD double global_max(Ctx &ctx, const double *a, int n, 
 }
 
 // ------------------------------------------------------------------------------ row kernel
-// Chained launches (engine_fused_impl.h: chain_enter / chain_exit; all zero = off).  The launches of a span alternate between
-// two streams, so the workgroups of launch j + 1 are dispatched while launch j still runs (they take the slots its early
-// workgroups leave) and wait INSIDE the kernel for launch j's workgroups to have finished, instead of waiting at a kernel
-// boundary (end-of-kernel write-back, completion signal, the command processor's next packet, dispatch: ~2.5 us per launch).
+// SSF_CHAIN (experiment builds, make variant TAG=chain VFLAGS=-DSSF_CHAIN=1; then SSF_CHAIN=1 in the environment): chained
+// launches.  The launches of a span alternate between two streams, so the workgroups of launch j + 1 are dispatched while launch
+// j still runs (they take the slots its early workgroups leave) and wait INSIDE the kernel for launch j's workgroups to have
+// finished, instead of waiting at a kernel boundary (engine_fused_impl.h: chain_enter / chain_exit / k_gate).  Bit-equal
+// results, 1.6 - 4 x slower -- and the mere presence of the wrappers cost the default path 2 % (same-box A/B,
+// profiles/r3_chained_launches_and_stagger.txt), so the product build compiles none of it.
 // cnt[0] = workgroups started, cnt[1] = workgroups finished -- both over the engine's whole life --, cnt[2] = abort word.
+#ifndef SSF_CHAIN
+#define SSF_CHAIN 0
+#endif
+#if SSF_CHAIN
 struct Chain {
     unsigned long long *cnt;
     unsigned long long need_done;     // this launch's workgroups proceed once cnt[1] >= need_done (every earlier chained launch done)
 };
+#endif
 
 template <typename T> struct RowArgs {
     cx<T> *G;                 // (nrows, N1, N2)
@@ -458,7 +465,9 @@ template <typename T> struct RowArgs {
     int stagger;              // > 0: workgroups stagger_lo <= bid < stagger_hi start this many 64-clock ticks late (the second
     int stagger_lo, stagger_hi;   // workgroup of every CU in the first round of residency: co-resident workgroups out of phase,
                               // one loads / stores while the other transforms)
+#if SSF_CHAIN
     Chain chain;
+#endif
 };
 
 // linear operator for the V registers of a last-radix-V butterfly (V = 16 | 8): bins k0 + (N/V) q, signed q' = q or q - V;
@@ -828,8 +837,10 @@ template <typename T> struct ColArgs {
     long long u_elems;        // independent units (see RowArgs): field elements per unit; P / Theta advance by 2 / 1 x ngroups x N
     int u_part;
     int prio;                 // see RowArgs
-    int stagger, stagger_lo, stagger_hi;   // see RowArgs (experiment: SSF_COL_STAGGER)
+#if SSF_CHAIN
+    int stagger, stagger_lo, stagger_hi;   // see RowArgs (experiment builds only: SSF_COL_STAGGER)
     Chain chain;
+#endif
 };
 
 // Arguments of unit u of a batch of independent units: every pointer moved to the unit's block.  The kernel bodies never
@@ -1223,7 +1234,9 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     bool final_ = false, more = false, exact0 = true;
     struct { int state, it, cur, pcur; double z, hz; } c{};
     double *red = (double *)ctx.lds;
+#if SSF_CHAIN
     if (a.stagger > 0 && ctx.bid >= a.stagger_lo && ctx.bid < a.stagger_hi) ctx.sleep64(a.stagger);
+#endif
     ctx.mark(0);
     if (kMk) {
         MkColStage st;
@@ -1422,7 +1435,9 @@ SSF_HD void pk_step_start(Ctx &ctx, const G &g, const ColArgs<pf2> &a, const cx<
 
 template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2> &a) {
     using T = pf2;
+#if SSF_CHAIN
     if (a.stagger > 0 && ctx.bid >= a.stagger_lo && ctx.bid < a.stagger_hi) ctx.sleep64(a.stagger);
+#endif
     ctx.mark(0);
     MkColStage st;
     mk_col_stage(ctx, a, st);
