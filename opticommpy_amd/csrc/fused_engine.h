@@ -352,9 +352,11 @@ template <typename T, class Backend> class FusedCore {
         a.rows_per_wg = mix_rows;
         a.vpt = row_v;
         a.prio = lanes_hint <= 1 ? 1 : 0;
+#if SSF_CHAIN
         a.stagger = row_stagger;
         a.stagger_hi = std::min(row_grid, stagger_resident);
         a.stagger_lo = a.stagger_hi / 2;
+#endif
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {
@@ -500,7 +502,11 @@ template <typename T, class Backend> class FusedCore {
                     a.row = row_args();
                     a.row.use_ctrl = 0;
                     a.row.vpt = 16;
-                    a.row.stagger = 0;
+#if SSF_CHAIN
+    #if SSF_CHAIN
+                a.row.stagger = 0;
+#endif
+#endif
                     a.col = col_args(1, CM_NLSE_STEP);
                     a.col.vpt = 16;
                     a.col.T0 = E;
@@ -645,7 +651,9 @@ template <typename T, class Backend> class FusedCore {
                 a.row.pnum0 = part + 3 * (size_t)npart_max;
                 a.row.pden0 = part + 4 * (size_t)npart_max;
                 a.row.npart = col_grid_mk;
+#if SSF_CHAIN
                 a.row.stagger = 0;
+#endif
                 a.col = col_args(2, CM_MK);
                 a.col.k = k;
                 a.col.npart = col_grid_mk;

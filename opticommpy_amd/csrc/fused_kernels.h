@@ -462,10 +462,10 @@ template <typename T> struct RowArgs {
     long long u_elems;
     int u_part;
     int prio;                 // 1: issue priority by phase (s_setprio, SSF_PRIO); 0 when several plans share the GPU (lanes)
+#if SSF_CHAIN                 // (experiment builds only: every extra word the prologue waits for costs the launch sequence)
     int stagger;              // > 0: workgroups stagger_lo <= bid < stagger_hi start this many 64-clock ticks late (the second
     int stagger_lo, stagger_hi;   // workgroup of every CU in the first round of residency: co-resident workgroups out of phase,
-                              // one loads / stores while the other transforms)
-#if SSF_CHAIN
+                              // one loads / stores while the other transforms); SSF_ROW_STAGGER
     Chain chain;
 #endif
 };
@@ -724,7 +724,9 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     const long long rr = (long long)ctx.bid * fpw + f;     // global row-transform index (grid is exact)
     cx<T> *g = a.G + (rr << a.log2N2);
     cx<T> v[V];
+#if SSF_CHAIN
     if (a.stagger > 0 && ctx.bid >= a.stagger_lo && ctx.bid < a.stagger_hi) ctx.sleep64(a.stagger);
+#endif
     ctx.mark(0);
     // Issue order matters (vmcnt retires in order): first the convergence sums the last column
     // stage may have left (fetched unconditionally, they are only used if the control block says
@@ -846,21 +848,26 @@ template <typename T> struct ColArgs {
 // Arguments of unit u of a batch of independent units: every pointer moved to the unit's block.  The kernel bodies never
 // know: a unit has its own rows, control blocks, partial sums, step sizes and convergence decisions.
 template <typename T> SSF_HD RowArgs<T> unit_view(const RowArgs<T> &a, int u) {
+    // No `if (u > 0)` around this: a branch here cuts the kernel's argument loads into two dependent round trips in front of
+    // the first row load, and the launch's start-up is latency, chip-wide (every workgroup starts at once, scalar cache cold):
+    // with the branch and the (experiment-only) stagger test gone the row stage's prologue is 51 instructions and ONE wait
+    // instead of 119 and three: + 1 - 2 % steps/s for fields of 2^12 ... 2^18 samples, within the noise at 2^20
+    // (profiles/r3_chained_launches_and_stagger.txt).
     RowArgs<T> b = a;
-    if (u > 0) {
-        b.G += (long long)u * a.u_elems;
-        if (a.cin) b.cin += u;
-        if (a.cout) b.cout += u;
-        const long long po = (long long)u * a.u_part;
-        if (a.pmax) b.pmax += po;
-        if (a.pnum) b.pnum += po;
-        if (a.pden) b.pden += po;
-        if (a.pnum0) b.pnum0 += po;
-        if (a.pden0) b.pden0 += po;
-    }
+    b.G += (long long)u * a.u_elems;
+    if (a.cin) b.cin += u;
+    if (a.cout) b.cout += u;
+    const long long po = (long long)u * a.u_part;
+    if (a.pmax) b.pmax += po;
+    if (a.pnum) b.pnum += po;
+    if (a.pden) b.pden += po;
+    if (a.pnum0) b.pnum0 += po;
+    if (a.pden0) b.pden0 += po;
     return b;
 }
 template <typename T> SSF_HD ColArgs<T> unit_view(const ColArgs<T> &a, int u) {
+    // (Kept with its branch, unlike the row stage's: branch-free, the 128-register column kernels spill 12 registers instead
+    // of 4 and the small fields lose 1 - 2 %; nothing measurable at 2^20.)
     ColArgs<T> b = a;
     if (u > 0) {
         const long long fo = (long long)u * a.u_elems;
