@@ -55,6 +55,16 @@ def synth_field(N, ncols, seed, p_dbm, dtype=np.complex128):
     return E.astype(dtype)
 
 
+def synth_unit(N, ncols, seed, p_dbm, dtype, nfields=1, via_c64=False):
+    """(ncols, N) SoA block of one unit; nfields > 1 (ssfm): row f is the field of seed + f; via_c64: complex64 samples cast up
+    (the input of the reference's complex128 run in tests/golden/wl_cfg3_n22.npz)"""
+    if via_c64:
+        return np.ascontiguousarray(synth_field(N, ncols, seed, p_dbm, np.complex64).T).astype(dtype)
+    if nfields > 1:
+        return np.ascontiguousarray(np.concatenate([synth_field(N, 1, seed + f, p_dbm, dtype).T for f in range(nfields)], axis=0))
+    return np.ascontiguousarray(synth_field(N, ncols, seed, p_dbm, dtype).T)
+
+
 def workload(cfg, log2n, prec, world):
     """-> dict(model, log2n, prec, hz, units=[(seed, dBm)], dbp, scaling, text)"""
     w = dict(model="manakov", log2n=20, prec="c128", hz=0.08, dbp=False, scaling="weak")
@@ -192,59 +202,24 @@ def self_launch(n):
     sys.exit(0)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", default=os.environ.get("SSF_BENCH_CONFIG", "2"), help="1 | 2 (default) | 3 | 4 | 5")
-    ap.add_argument("--log2n", type=int, default=0, help="experiments: override the configuration's length")
-    ap.add_argument("--prec", default="", choices=["", "c128", "c64"], help="experiments: override the precision")
-    ap.add_argument("--dbp-hz", type=float, default=0.08)
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("SSF_MGPU_LANES", "2")))
-    ap.add_argument("--engine", default=os.environ.get("SSF_ENGINE", "auto"))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU oracle leg (0: sized for ~10-20 s)")
-    ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel HIP-event pass")
-    args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher: be one (a launcher's environment wins)
-        self_launch(args.gpus)
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if "SSF_BENCH_DEVICE" in os.environ:                       # (test knob: several ranks against one GPU)
-        local_rank = int(os.environ["SSF_BENCH_DEVICE"])
-
-    if rank > 0:                                               # only rank 0 reports: nothing of the other ranks (RCCL's
-        devnull = os.open(os.devnull, os.O_WRONLY)             # version banner comes through C stdio at exit) may follow
-        os.dup2(devnull, 1)                                    # rank 0's JSON line on the launcher's merged stdout
-    from opticommpy_amd import _lib, mgpu
-    lib = _lib.load()
-    if lib.ssf_device_count() <= 0:
-        raise SystemExit("bench.py needs a GPU: no HIP device visible (there is no CPU fallback)")
-
-    comm, comm_name = None, "none (single process)"
-    if world > 1 or os.environ.get("SSF_BENCH_FORCE_COMM"):    # (the env var exercises the RCCL path on one GPU)
-        if os.environ.get("SSF_BENCH_COMM") == "gloo":          # (explicit opt-in, tests: N ranks against one GPU,
-            sys.path.insert(0, os.path.join(ROOT, "tests"))     #  which RCCL refuses)
-            from comm_gloo import GlooComm
-            comm = GlooComm()
-            comm_name = "torch.distributed gloo stand-in (SSF_BENCH_COMM=gloo)"
-        else:                                                   # RCCL or nothing: a failure here fails the run
-            comm = mgpu.RcclComm.from_env(device=local_rank)
-            comm_name = "RCCL via libssf_hip.so (ssf_comm_*)"
-
-    cfg = int(args.config)
-    w = workload(cfg, args.log2n, args.prec, world)
+def measure(env, cfg, m):
+    """One configuration: synthesise / scatter the inputs, warm up, time EXACTLY m.steps steps per unit, gather the per-unit
+    checksums, and (rank 0) build the record with the roofline, the per-kernel pass and the parity leg m.parity asks for.
+    -> (rec or None, ok)"""
+    lib, _lib, mgpu, comm, comm_name = env.lib, env._lib, env.mgpu, env.comm, env.comm_name
+    rank, world, local_rank = env.rank, env.world, env.local_rank
+    w = workload(cfg, m.log2n, m.prec, world)
+    if m.nfields > 1:
+        assert w["model"] == "nlse" and world == 1
+        w["text"] += " [%d independent fields as the rows of ONE plan: every launch carries all of them]" % m.nfields
     w = mgpu.bcast_object(comm, w, 0)                           # "broadcast of the parameter block"
     N = 1 << w["log2n"]
     dtype = np.complex128 if w["prec"] == "c128" else np.complex64
     prec = _lib.SSF_C128 if w["prec"] == "c128" else _lib.SSF_C64
     s = 16 if w["prec"] == "c128" else 8
-    ncols = 1 if w["model"] == "nlse" else 2
-    engine = {"auto": 0, "rocfft": 1, "fused": 2}[args.engine]
+    ncols = m.nfields if w["model"] == "nlse" else 2
+    engine = {"auto": 0, "rocfft": 1, "fused": 2}[m.engine]
     U = len(w["units"])
     mine = list(mgpu.shard_range(U, world, rank))
 
@@ -254,7 +229,7 @@ def main():
         for r in range(world):
             for u in mgpu.shard_range(U, world, r):
                 if rank == 0:
-                    E = np.ascontiguousarray(synth_field(N, ncols, *w["units"][u], dtype).T)
+                    E = synth_unit(N, ncols, *w["units"][u], dtype)
                     if r == 0:
                         fields[u] = E
                     else:
@@ -263,7 +238,7 @@ def main():
                     fields[u] = comm.recv(np.empty((ncols, N), dtype=dtype), 0)
     else:
         for u in mine:
-            fields[u] = np.ascontiguousarray(synth_field(N, ncols, *w["units"][u], dtype).T)
+            fields[u] = synth_unit(N, ncols, *w["units"][u], dtype, m.nfields, getattr(m, "samples_c64", False))
 
     # ---- the inputs are device-resident before anything is timed: one HBM copy per unit, from which every run (warm-up,
     # timed, profiling, parity) re-initialises its plan by a device copy -- no PCIe transfer (and no idle GPU) between the
@@ -285,7 +260,7 @@ def main():
         h = C.c_void_p()
         _lib.raise_for(lib, None, lib.ssf_plan_create(local_rank, N, ncols, prec, engine, C.byref(h)))
         plans[u] = h
-    lanes = max(1, min(args.lanes, len(mine)))
+    lanes = max(1, min(m.lanes, len(mine)))
     if lanes > 1:                                               # the plans of a rank share its GPU: no phase priorities (ssf.h)
         for h in plans.values():
             lib.ssf_plan_set_lanes(h, lanes)
@@ -297,7 +272,7 @@ def main():
         cp = make_params(_lib, w, steps)
         rc = lib.ssf_execute(h, C.byref(cp), 1, 1, None, C.byref(st), None)              # synchronous at return
         if rc == 0 and w["dbp"]:
-            cpb = make_params(_lib, w, steps, direction=-1, hz=args.dbp_hz)
+            cpb = make_params(_lib, w, steps, direction=-1, hz=m.dbp_hz)
             rc = lib.ssf_execute(h, C.byref(cpb), 1, 1, None, C.byref(st), None)         # chained: the field never leaves HBM
         stats[u] = (rc, st)
 
@@ -322,11 +297,11 @@ def main():
             _lib.raise_for(lib, plans[u], stats[u][0])
         return t1 - t0, {u: stats[u][1] for u in mine}
 
-    if args.warmup > 0:
-        run_all(args.warmup)
-    dt_local, sts = run_all(args.steps)
+    if m.warmup > 0:
+        run_all(m.warmup)
+    dt_local, sts = run_all(m.steps)
     steps_local = sum(int(st.steps) for st in sts.values())
-    fwd_steps = args.steps * len(mine)
+    fwd_steps = m.steps * len(mine)
     assert steps_local >= fwd_steps and (w["dbp"] or steps_local == fwd_steps), (steps_local, fwd_steps)
     dt = dt_local
     steps_total = steps_local
@@ -342,9 +317,9 @@ def main():
         _lib.raise_for(lib, plans[u], lib.ssf_download(plans[u], o.ctypes.data_as(C.c_void_p)))
         outs[u] = o
     per = max(len(mgpu.shard_range(U, world, r)) for r in range(world))
-    cs = np.zeros((per, 2))
+    cs = np.zeros((per, 3))
     for i, u in enumerate(mine):
-        cs[i] = unit_checksum(outs[u])
+        cs[i] = unit_checksum(outs[u]) + (float(sts[u].iterations),)
     if comm is not None:
         allcs = comm.allgather(cs)
         checksums = [[float(x) for x in allcs[r][i]] for r in range(world) for i in range(len(mgpu.shard_range(U, world, r)))]
@@ -366,9 +341,10 @@ def main():
         achieved = bytes_local / dev_s / 1e9
         it_step = sum(int(st.iterations) for st in sts.values()) / max(steps_local, 1)
         rec = {
-            "metric": "SSFM steps/sec (%d-pol, 2^%d samples)" % (ncols, w["log2n"]), "value": steps_total / dt, "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": w["scaling"],
+            "metric": "SSFM steps/sec (%d-pol, 2^%d samples)" % (1 if w["model"] == "nlse" else 2, w["log2n"]),
+            "value": steps_total * m.nfields / dt, "unit": "steps/s" if m.nfields == 1 else "field-steps/s",
+            "n_gpus": world, "steps": m.steps, "warmup": m.warmup,
+            "ms_per_step": dt / m.steps * 1e3, "higher_is_better": True, "scaling": w["scaling"],
             "vs_baseline": None, "dtype": "f64" if s == 16 else "f32", "data": "synthetic",
             "config": {"workload": w["text"], "baseline_config": cfg, "engine": _lib.ENGINE_NAMES[st0.engine],
                        "pipeline": _lib.PIPELINE_NAMES.get(lib.ssf_plan_pipeline(plans[u0]), "?"),
@@ -385,13 +361,13 @@ def main():
                                  "(complex128) / 2^22 run out of it (out-of-cache fraction of the same complex128 kernels: "
                                  "python bench.py --log2n 22, profiles/r3_c2_out_of_cache.json)"},
             "comm": comm_name, "rccl_ranks": world if comm is not None and comm_name.startswith("RCCL") else 0,
-            "unit_checksums": checksums,          # per unit: [sum |E|^2, |<q, E>|] with a seeded random vector q
+            "unit_checksums": checksums,          # per unit: [sum |E|^2, |<q, E>|, iterations] with a seeded random vector q
         }
 
         # per-kernel timing pass (HIP events around every launch; separate from the headline run because the events
         # themselves cost a few microseconds per launch)
-        if not args.no_kernel_times and w["model"] == "manakov" and lib.ssf_set_profiling(plans[u0], 1) == 0:
-            nprof = min(args.steps, 200)
+        if not m.no_kernel_times and w["model"] == "manakov" and lib.ssf_set_profiling(plans[u0], 1) == 0:
+            nprof = min(m.steps, 200)
             _lib.raise_for(lib, plans[u0], lib.ssf_upload(plans[u0], dev_in[u0]))
             stp = {}
             run_unit(u0, nprof, stp)
@@ -419,7 +395,7 @@ def main():
             rec["roofline"]["measured_copy_note"] = ("burst copy kernel, %d MiB read + %d MiB written per launch, no arithmetic"
                                                      % (probe_bytes >> 20, probe_bytes >> 20))
         traffic_file = os.path.join(ROOT, "profiles", "traffic_bytes_per_step.json")
-        if os.path.exists(traffic_file) and not args.log2n and not args.prec:
+        if os.path.exists(traffic_file) and not m.log2n and not m.prec:
             try:
                 t = json.load(open(traffic_file)).get("config%d" % cfg)
                 if t and t.get("engine") == _lib.ENGINE_NAMES[st0.engine]:
@@ -434,14 +410,14 @@ def main():
             except Exception:
                 pass
 
-        # ---- CPU oracle leg: in-run parity gate (always) and cpu_baseline (one GPU only)
-        if not args.no_cpu_baseline:
-            n = args.cpu_steps or {16: 100, 20: 16, 22: 6}.get(w["log2n"], 8)
+        # ---- parity gate of the run: the CPU oracle (+ cpu_baseline on one GPU), or a reference-generated fixture
+        if m.parity == "oracle":
+            n = m.cpu_steps or {16: 100, 20: 16, 22: 6}.get(w["log2n"], 8)
             if world > 1:
                 n = min(n, 4)
             n = max(2, n)
             E0 = np.ascontiguousarray(fields[u0].T)
-            ref, tc, tr = oracle_run(w, E0, n, dtype)
+            ref, tc, tr = oracle_run(w, E0[:, :1] if w["model"] == "nlse" else E0, n, dtype)
             was_dbp, w["dbp"] = w["dbp"], False
             _lib.raise_for(lib, plans[u0], lib.ssf_upload(plans[u0], dev_in[u0]))
             stp = {}
@@ -449,13 +425,14 @@ def main():
             w["dbp"] = was_dbp
             got = np.empty_like(fields[u0])
             _lib.raise_for(lib, plans[u0], lib.ssf_download(plans[u0], got.ctypes.data_as(C.c_void_p)))
+            got = got[:1] if w["model"] == "nlse" else got
             err = float(np.linalg.norm(got.T.astype(np.complex128) - ref) / np.linalg.norm(ref))
             gate = 1e-10 if s == 16 else 5e-4
             it_gpu, it_cpu = int(stp[u0][1].iterations), int(tr.get("iterations", 0))
             ok = bool(err <= gate) and (s != 16 or it_gpu == it_cpu)
             rec["parity"] = {"rel_l2_vs_oracle": err, "steps": n, "iterations_gpu": it_gpu, "iterations_oracle": it_cpu,
                              "gate": gate, "ok": ok}
-            if world == 1:
+            if world == 1 and m.nfields == 1:
                 cpu_model = "unknown"
                 try:
                     for line in open("/proc/cpuinfo"):
@@ -469,12 +446,144 @@ def main():
                                                  % (n, os.cpu_count(), cpu_model, np.__version__),
                                        "iterations_per_step": it_cpu / n}
                 rec["speedup_vs_cpu"] = rec["value"] / (n / tc)
-            if not ok:
-                rec["value"] = None                              # a wrong result is not a benchmark result
+        elif m.parity == "fixture_cfg3":
+            # tests/golden/wl_cfg3_n22.npz: the REFERENCE on config 3's own field (2^22, seed 3) for six steps, complex128 and
+            # complex64 (tools/gen_golden.py cfg3): decimated output + a seeded projection of the whole output
+            z = np.load(os.path.join(ROOT, "tests", "golden", "wl_cfg3_n22.npz"))
+            fc = json.loads(str(z["cfg"]))
+            n, dec, tag = int(fc["steps"]), int(fc["dec"]), "128" if s == 16 else "64"
+            _lib.raise_for(lib, plans[u0], lib.ssf_upload(plans[u0], dev_in[u0]))
+            stp = {}
+            run_unit(u0, n, stp)
+            got = np.empty_like(fields[u0])
+            _lib.raise_for(lib, plans[u0], lib.ssf_download(plans[u0], got.ctypes.data_as(C.c_void_p)))
+            o = got.T.astype(np.complex128)
+            ref_dec = z["out128_dec"].astype(np.complex128)
+            err = float(np.linalg.norm(o[::dec] - ref_dec) / np.linalg.norm(ref_dec))
+            rng = np.random.default_rng(4242)
+            r = (rng.normal(size=o.shape[0]) + 1j * rng.normal(size=o.shape[0])) / np.sqrt(2)
+            perr = float(np.max(np.abs(o.T @ r - z["out128_proj"])) / np.sqrt(np.sum(z["out128_power"])))
+            gate = 1e-10 if s == 16 else 5e-4
+            it_gpu, it_ref = int(stp[u0][1].iterations), int(np.sum(z["iters" + tag]))
+            ok = bool(err <= gate and perr <= 10 * gate) and it_gpu == it_ref
+            rec["parity"] = {"rel_l2_vs_reference_c128": err, "projection_err": perr, "steps": n, "iterations_gpu": it_gpu,
+                             "iterations_reference": it_ref, "gate": gate, "ok": ok,
+                             "what": "reference-generated fixture tests/golden/wl_cfg3_n22.npz (decimated output + seeded projection)"}
+        elif m.parity == "fixture_units":
+            # tests/golden/wl_units45_n20.npz: every unit of configs 4 / 5 through the REFERENCE for eight steps
+            z = np.load(os.path.join(ROOT, "tests", "golden", "wl_units45_n%d.npz" % w["log2n"]))
+            fc = json.loads(str(z["cfg"]))
+            n = int(fc["steps"])
+            _dt, sts8 = run_all(n, sync=False)
+            worst = 0.0
+            its_ok = True
+            refc, refit = (z["c5"], z["c5_iterations"].sum(axis=1)) if w["dbp"] else (z["c4"], z["c4_iterations"])
+            for u in mine:
+                o = np.empty_like(fields[u])
+                _lib.raise_for(lib, plans[u], lib.ssf_download(plans[u], o.ctypes.data_as(C.c_void_p)))
+                pw, pr = unit_checksum(o)
+                worst = max(worst, abs(pw / refc[u][0] - 1.0), abs(pr - abs(complex(refc[u][1], refc[u][2]))) / np.sqrt(refc[u][0]))
+                its_ok = its_ok and int(sts8[u].iterations) == int(refit[u])
+            ok = bool(worst <= 1e-9) and its_ok
+            rec["parity"] = {"worst_unit_checksum_err": worst, "units": len(mine), "steps": n, "iterations_match": its_ok,
+                             "gate": 1e-9, "ok": ok,
+                             "what": "every unit's (sum |E|^2, |<q,E>|, iterations) against the reference-generated fixture wl_units45"}
+        if not ok:
+            rec["value"] = None                              # a wrong result is not a benchmark result
     for h in plans.values():
         lib.ssf_plan_destroy(h)
     for q in ([] if host_in else dev_in.values()):
         lib.ssf_device_free(local_rank, q)
+    return rec, ok
+
+
+def also_configs(env, args):
+    """The other single-GPU configurations BASELINE.json names, measured in the same run after the headline (VERDICT round 3,
+    item 3): each with its own short parity gate, reported under one extra key.  Budget: about a minute."""
+    out = {}
+
+    def leg(key, cfg, **kw):
+        m = argparse.Namespace(**vars(args))
+        m.nfields, m.parity, m.log2n, m.prec, m.cpu_steps, m.no_kernel_times = 1, "oracle", 0, "", 0, False
+        for k, v in kw.items():
+            setattr(m, k, v)
+        t0 = time.perf_counter()
+        try:
+            rec, ok = measure(env, cfg, m)
+            rl = rec["roofline"]
+            out[key] = {"workload": rec["config"]["workload"], "value": rec["value"], "unit": rec["unit"], "steps": m.steps,
+                        "warmup": m.warmup, "ms_per_step": rec["ms_per_step"], "dtype": rec["dtype"],
+                        "iterations_per_step": rec["config"]["iterations_per_step"],
+                        "roofline_frac": rl["frac"], "achieved_GBs": rl["achieved"],
+                        "kernels": {k: {"avg_us": v["avg_us"], "frac": v["frac"]} for k, v in rl.get("kernels", {}).items()
+                                    if isinstance(v, dict) and "avg_us" in v},
+                        "parity": rec.get("parity"), "wall_s": time.perf_counter() - t0}
+        except Exception as e:                                   # an extra leg never takes the headline line down
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    leg("config3", 3, steps=100, warmup=20, parity="fixture_cfg3")
+    leg("config2_out_of_cache_2^22", 3, steps=50, warmup=10, prec="c128", parity="fixture_cfg3", samples_c64=True)
+    leg("config4_one_gpu_two_lanes", 4, steps=20, warmup=5, parity="fixture_units", no_kernel_times=True)
+    leg("config5_one_gpu_two_lanes", 5, steps=20, warmup=5, parity="fixture_units", no_kernel_times=True)
+    leg("config1_16_fields_per_launch", 1, steps=100, warmup=20, nfields=16, no_kernel_times=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", default=os.environ.get("SSF_BENCH_CONFIG", "2"), help="1 | 2 (default) | 3 | 4 | 5")
+    ap.add_argument("--log2n", type=int, default=0, help="experiments: override the configuration's length")
+    ap.add_argument("--prec", default="", choices=["", "c128", "c64"], help="experiments: override the precision")
+    ap.add_argument("--dbp-hz", type=float, default=0.08)
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("SSF_MGPU_LANES", "2")))
+    ap.add_argument("--engine", default=os.environ.get("SSF_ENGINE", "auto"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="steps of the CPU oracle leg (0: sized for ~10-20 s)")
+    ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-also", action="store_true", help="headline configuration only (no 'also' legs)")
+    ap.add_argument("--parity", default="", help="parity leg: oracle (default) | fixture_cfg3 | fixture_units | none")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher: be one (a launcher's environment wins)
+        self_launch(args.gpus)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("SSF_BENCH_DEVICE") == "mod":            # (test knob: more ranks than GPUs -- rank r on device r % count)
+        from opticommpy_amd import _lib as _l0
+        local_rank = local_rank % max(1, _l0.load().ssf_device_count())
+    elif "SSF_BENCH_DEVICE" in os.environ:                     # (test knob: several ranks against one GPU)
+        local_rank = int(os.environ["SSF_BENCH_DEVICE"])
+
+    if rank > 0:                                               # only rank 0 reports: nothing of the other ranks (RCCL's
+        devnull = os.open(os.devnull, os.O_WRONLY)             # version banner comes through C stdio at exit) may follow
+        os.dup2(devnull, 1)                                    # rank 0's JSON line on the launcher's merged stdout
+    from opticommpy_amd import _lib, mgpu
+    lib = _lib.load()
+    if lib.ssf_device_count() <= 0:
+        raise SystemExit("bench.py needs a GPU: no HIP device visible (there is no CPU fallback)")
+
+    comm, comm_name = None, "none (single process)"
+    if world > 1 or os.environ.get("SSF_BENCH_FORCE_COMM"):    # (the env var exercises the RCCL path on one GPU)
+        if os.environ.get("SSF_BENCH_COMM") == "gloo":          # (explicit opt-in, tests: N ranks against one GPU,
+            sys.path.insert(0, os.path.join(ROOT, "tests"))     #  which RCCL refuses)
+            from comm_gloo import GlooComm
+            comm = GlooComm()
+            comm_name = "torch.distributed gloo stand-in (SSF_BENCH_COMM=gloo)"
+        else:                                                   # RCCL or nothing: a failure here fails the run
+            comm = mgpu.RcclComm.from_env(device=local_rank)
+            comm_name = "RCCL via libssf_hip.so (ssf_comm_*)"
+
+    env = argparse.Namespace(lib=lib, _lib=_lib, mgpu=mgpu, comm=comm, comm_name=comm_name, rank=rank, world=world, local_rank=local_rank)
+    m = argparse.Namespace(**vars(args))
+    m.nfields, m.parity = 1, (args.parity or ("none" if args.no_cpu_baseline else "oracle"))
+    rec, ok = measure(env, int(args.config), m)
+    if rec is not None and world == 1 and int(args.config) == 2 and not (args.log2n or args.prec or args.no_also):
+        rec["also"] = also_configs(env, args)
     if comm is not None:
         flag = comm.allreduce(np.array([0.0 if ok else 1.0]), "max")     # rank 0 arrives after its extra passes
         ok = flag[0] == 0.0

@@ -14,14 +14,6 @@ struct DevCtxCore {
     __device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
     // issue priority of this wave against the other waves of its SIMD (0 .. 3); the hardware default is 0
     template <int P> __device__ __forceinline__ void setprio() { __builtin_amdgcn_s_setprio(P); }
-    // wait for every outstanding vector-memory operation of this wave (the compiler does not count inline-asm stores)
-    __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    // idle for n * 64 clocks (s_sleep takes at most 127 ticks at a time)
-    __device__ __forceinline__ void sleep64(int n) {
-        for (; n >= 64; n -= 64) __builtin_amdgcn_s_sleep(64);
-        for (; n >= 8; n -= 8) __builtin_amdgcn_s_sleep(8);
-        for (; n >= 1; n -= 1) __builtin_amdgcn_s_sleep(1);
-    }
     // all-lanes butterfly over the 64-lane wave (every lane returns the same value)
     __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

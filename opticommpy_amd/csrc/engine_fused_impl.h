@@ -55,99 +55,47 @@ struct DevCtx : DevCtxCore {
     extern __shared__ __attribute__((aligned(16))) char ssf_smem[];           \
     DevCtx ctx{{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, ssf_smem} SSF_CTX_KIND(k)}
 
-// ---- chained launches (fused_kernels.h: Chain) -------------------------------------------------------------------------------
-// Entry: count this workgroup as started, wait until every workgroup of the earlier chained launches has finished, acquire at
-// agent scope (no stale L1 / L2 / scalar-cache lines of what those launches wrote on other XCDs).  Exit: drain this
-// workgroup's stores, release at agent scope (L2 write-back), count it as finished.  Bounded spin: a wait that cannot complete
-// sets the abort word, every later workgroup skips its body (still counting, so nothing else waits for it) and the host reports
-// the failure instead of hanging.  Deadlock freedom is the host's job: a launch only enters its queue behind a gate that has
-// seen the previous launch fully dispatched (k_gate), so waiting workgroups never hold a slot the launch they wait for needs.
-#if SSF_CHAIN
-__device__ __forceinline__ bool chain_enter(const Chain &c) {
-    if (!c.cnt) return true;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(c.cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(c.cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.need_done) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22) || __hip_atomic_load(c.cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(c.cnt + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // the scalar cache is not covered by the fence
-    }
-    __syncthreads();
-    return __hip_atomic_load(c.cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-}
-__device__ __forceinline__ void chain_exit(const Chain &c) {
-    if (!c.cnt) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // (inline-asm stores included)
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(c.cnt + 1, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one thread: returns once every workgroup of the earlier chained launches has been dispatched
-__global__ void k_gate(unsigned long long *cnt, unsigned long long need_started) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_started) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 22) || __hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            __hip_atomic_store(cnt + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
-}
-#define SSF_CHAINED(args, call)              \
-    do {                                     \
-        if (chain_enter((args).chain)) call; \
-        chain_exit((args).chain);            \
-    } while (0)
-#else
-#define SSF_CHAINED(args, call) call
-#endif
-
 // OCC = minimum waves per SIMD the register allocator must leave room for: 1 = up to 512
 // registers per lane and no spills (one 256-thread workgroup per CU), 2 = 256 registers
 // (two workgroups per CU).  LG = compile-time log2 of the transform length (0 = runtime).
 template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds__(MAXT, OCC) k_row(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    SSF_CHAINED(a, (row_body<T, LG>(ctx, unit_view(a, (int)blockIdx.y))));
+    row_body<T, LG>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // eight values per thread: at most 128 registers, four waves per SIMD (two 512-thread workgroups, or one of 1024, per CU)
 template <typename T, int MAXT, int LG> __global__ void __launch_bounds__(MAXT, 4) k_row8(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    SSF_CHAINED(a, (row_body<T, LG, 8>(ctx, unit_view(a, (int)blockIdx.y))));
+    row_body<T, LG, 8>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // Manakov column kernels run 512 threads (x half | y half); the single-row modes run 256
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    SSF_CHAINED(a, (col_body<T, LG, MODE, false>(ctx, unit_view(a, (int)blockIdx.y))));
+    col_body<T, LG, MODE, false>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // row lengths with factors 3 / 5 (mixed_fft.h): mixed-radix row stage, column stage with ragged last tiles
 template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT, MAXT <= 256 ? 2 : 1) k_row_mixed(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    SSF_CHAINED(a, (row_mixed_body<T>(ctx, unit_view(a, (int)blockIdx.y))));
+    row_mixed_body<T>(ctx, unit_view(a, (int)blockIdx.y));
 }
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    SSF_CHAINED(a, (col_body<T, LG, MODE, true>(ctx, unit_view(a, (int)blockIdx.y))));
+    col_body<T, LG, MODE, true>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // eight values per thread (at most 128 registers, four waves per SIMD): 512-thread workgroups, two per CU
 template <typename T, int LG, int MODE> __global__ void __launch_bounds__(512, 4) k_col8(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    SSF_CHAINED(a, (col_body<T, LG, MODE, false, 8>(ctx, unit_view(a, (int)blockIdx.y))));
+    col_body<T, LG, MODE, false, 8>(ctx, unit_view(a, (int)blockIdx.y));
 }
 template <int LG> __global__ void __launch_bounds__(512, 4) k_col_pk8(const ColArgs<pf2> a) {
     SSF_DEV_CTX(1);
-    SSF_CHAINED(a, (col_pk_body<LG, 8>(ctx, unit_view(a, (int)blockIdx.y))));
+    col_pk_body<LG, 8>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // complex64 Manakov: packed polarisation pairs (fused_kernels.h: col_pk_body); up to 512 threads (8 columns of 1024)
 template <int LG> __global__ void __launch_bounds__(512) k_col_pk(const ColArgs<pf2> a) {
     SSF_DEV_CTX(1);
-    SSF_CHAINED(a, (col_pk_body<LG>(ctx, unit_view(a, (int)blockIdx.y))));
+    col_pk_body<LG>(ctx, unit_view(a, (int)blockIdx.y));
 }
 __global__ void __launch_bounds__(256) k_repack(const RepackArgs a) {
     SSF_DEV_CTX(1);
@@ -163,156 +111,9 @@ template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT) k_ols(co
     ols_body<T>(ctx, a);
 }
 
-// ---- persistent span kernel (scalar NLSE): every stage of a span in ONE launch ----------------------------------------
-// For small N a launch is one latency chain (dispatch -> loads -> transform -> stores -> end-of-kernel write-back),
-// ~10 us whatever the size, and a span is 2 * nsteps + 1 of them.  Here the stages run inside one launch of <= 256
-// co-resident workgroups (one per CU at most) with a grid barrier in between: arrival counter + generation word,
-// agent-scope release before / acquire after (the L2s of the eight XCDs are not coherent with each other, so the stage's
-// output is written back and the readers' lines invalidated), bounded spin (a barrier that cannot complete sets the abort
-// word and the host reports it instead of hanging).  The stage bodies are the ones of the per-stage kernels, called with
-// virtual workgroup numbers.  Reference loop: optic/models/channels.py:215-232.
-__device__ __forceinline__ bool grid_sync(unsigned *bar, unsigned nwg) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();                                          // release: this workgroup's stores, device-wide
-        const unsigned g = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
-            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            unsigned spins = 0;
-            while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == g) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24) || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __threadfence();
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // every wave: no stale L1 / L2 lines of the previous stage
-    return __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-}
-template <typename T, int LGR, int LGC> __global__ void __launch_bounds__(256) k_nlse_span(const SpanNlseArgs<T> a) {
-    SSF_DEV_CTX(0);
-    const int me = (int)blockIdx.x, nwg = (int)gridDim.x;
-    auto col_stage = [&](int mode) {
-        for (int vb = me; vb < a.col_grid; vb += nwg) {
-            ctx.bid = vb;
-            if (mode == CM_NLSE_FIRST) col_body<T, LGC, CM_NLSE_FIRST, false>(ctx, a.col);
-            else if (mode == CM_NLSE_STEP) col_body<T, LGC, CM_NLSE_STEP, false>(ctx, a.col);
-            else col_body<T, LGC, CM_NLSE_LAST, false>(ctx, a.col);
-            __syncthreads();
-        }
-    };
-    auto row_stage = [&](const LinOp *lin) {
-        RowArgs<T> ra = a.row;
-        ra.lin = lin;
-        for (int vb = me; vb < a.row_grid; vb += nwg) {
-            ctx.bid = vb;
-            row_body<T, LGR>(ctx, ra);
-            __syncthreads();
-        }
-    };
-    col_stage(CM_NLSE_FIRST);                                     // channels.py:216
-    if (!grid_sync(a.bar, nwg)) return;
-    row_stage(a.lin_half);
-    if (!grid_sync(a.bar, nwg)) return;
-    for (int s = 1; s < a.nsteps; ++s) {
-        col_stage(CM_NLSE_STEP);
-        if (!grid_sync(a.bar, nwg)) return;
-        row_stage(a.lin_full);                                    // lin * lin: second half of one step, first half of the next
-        if (!grid_sync(a.bar, nwg)) return;
-    }
-    col_stage(CM_NLSE_STEP);
-    if (!grid_sync(a.bar, nwg)) return;
-    row_stage(a.lin_half);
-    if (!grid_sync(a.bar, nwg)) return;
-    col_stage(CM_NLSE_LAST);                                      // channels.py:232
-}
-
-// ---- persistent span kernel (Manakov): Col, [Row, Col]* of a span in ONE launch ------------------------------------------------------
-// north_star's "persistent HIP pipeline" for the Manakov path.  Same stage bodies, virtual workgroup numbers, the control block of
-// section 3.3 read through an LDS copy (fetched with L1-bypassing loads after every barrier: the scalar cache is not covered
-// by an acquire).  Two barriers: the agent-scope one of the ssfm span kernel (grid_sync: L2 write-back + invalidate), and an
-// XCD-confined one -- only the workgroups that happen to run on one XCD take part (ticket counter; the others exit at once), their
-// stores meet in that XCD's L2, so a barrier is: drain the stores, arrive / spin, invalidate the L1.  OFF by default
-// (SSF_PERSIST_MK=<workers>, SSF_PERSIST_XCD=1): measured against the launch sequence in profiles/r3_persistent_manakov.txt.
-__device__ __forceinline__ bool grid_sync_xcd(unsigned *bar, unsigned nwg) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's stores are in the XCD's L2 (the L1 writes through)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned g = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
-            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            unsigned spins = 0;
-            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22) || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // no stale L1 lines of what the other CUs of this XCD wrote
-    return __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-}
-template <typename T, int LGR, int LGC> __global__ void __launch_bounds__(256) k_mk_span(const SpanMkArgs<T> a) {
-    SSF_DEV_CTX(0);
-    int *s_me = (int *)(ssf_smem + a.ctrl_lds + sizeof(Ctrl));          // (no static LDS: the dynamic part may take all 160 KiB)
-    int me = (int)blockIdx.x, nwg = (int)gridDim.x;
-    if (a.xcd >= 0) {
-        if (threadIdx.x == 0) {
-            const unsigned xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 0xf;
-            *s_me = (int)xcc == a.xcd ? (int)__hip_atomic_fetch_add(a.bar + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-        }
-        __syncthreads();
-        me = *s_me;
-        nwg = a.nworkers;
-        if (me < 0 || me >= nwg) return;
-    }
-    Ctrl *lc = (Ctrl *)(ssf_smem + a.ctrl_lds);
-    unsigned seq = a.seq0;
-    for (int stage = 0; stage < a.max_stages; ++stage) {
-        const Ctrl *gin = a.ctrl + (seq & 1);
-        Ctrl *gout = a.ctrl + ((seq + 1) & 1);
-        for (int i = (int)threadIdx.x; i < (int)(sizeof(Ctrl) / 8); i += (int)blockDim.x)
-            ((unsigned long long *)lc)[i] = __hip_atomic_load((const unsigned long long *)gin + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (lc->state == ST_SPAN_DONE && !lc->pend0) {
-            if (me == 0 && threadIdx.x == 0) a.bar[4] = seq & 1u;           // which block holds the final state
-            break;
-        }
-        if ((stage & 1) == 0) {
-            ColArgs<T> ca = a.col;
-            ca.cin = lc;
-            ca.cout = gout;
-            for (int vb = me; vb < a.col_grid; vb += nwg) {
-                ctx.bid = vb;
-                col_body<T, LGC, CM_MK, false>(ctx, ca);
-                __syncthreads();
-            }
-        } else {
-            RowArgs<T> ra = a.row;
-            ra.cin = lc;
-            ra.cout = gout;
-            for (int vb = me; vb < a.row_grid; vb += nwg) {
-                ctx.bid = vb;
-                row_body<T, LGR>(ctx, ra);
-                __syncthreads();
-            }
-        }
-        ++seq;
-        const bool ok = a.xcd >= 0 ? grid_sync_xcd(a.bar, (unsigned)nwg) : grid_sync(a.bar, (unsigned)nwg);
-        if (!ok) return;
-    }
-}
+#if SSF_EXPERIMENTS
+#include "fused_experiments.h"      // persistent span kernels (measured slower at every size: DESIGN.md appendix)
+#endif
 
 template <typename T> using RowFn = void (*)(const RowArgs<T>);
 template <typename T> using ColFn = void (*)(const ColArgs<T>);
@@ -413,56 +214,6 @@ struct HipBackend {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     int row_occ = 2;
-#if SSF_CHAIN
-    // chained launches (fused_kernels.h: Chain; chain_enter / chain_exit above): SSF_CHAIN=1.  Between chain_begin() and
-    // chain_end() the row / column launches alternate between the plan's stream and a second one, each behind a gate.
-    bool chain_want = false, chain_open = false;
-    hipStream_t st2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    unsigned long long *chain_cnt = nullptr;                 // device: started, finished, abort
-    unsigned long long chain_started = 0, chain_done = 0;    // host: workgroups of every chained launch enqueued so far
-    unsigned long long *chain_abort_host = nullptr;          // pinned copy of the abort word (read after the next synchronise)
-    unsigned chain_n = 0;
-    void chain_begin() {
-        if (!chain_want || profiling || !ok()) return;
-        if (!st2) {
-            chk(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking), "hipStreamCreate(chain)");
-            chk(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "hipEventCreate");
-            chk(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming), "hipEventCreate");
-            chk(hipMalloc((void **)&chain_cnt, 4 * sizeof(unsigned long long)), "hipMalloc(chain)");
-            chk(hipHostMalloc((void **)&chain_abort_host, sizeof(unsigned long long)), "hipHostMalloc(chain)");
-            if (!ok()) return;
-            *chain_abort_host = 0;
-            chk(hipMemsetAsync(chain_cnt, 0, 4 * sizeof(unsigned long long), pl->stream), "hipMemsetAsync(chain)");
-        }
-        chk(hipEventRecord(ev_fork, pl->stream), "hipEventRecord");
-        chk(hipStreamWaitEvent(st2, ev_fork, 0), "hipStreamWaitEvent");
-        chain_open = ok();
-        chain_n = 0;
-    }
-    void chain_end() {
-        if (!chain_open) return;
-        chain_open = false;
-        chk(hipEventRecord(ev_join, st2), "hipEventRecord");
-        chk(hipStreamWaitEvent(pl->stream, ev_join, 0), "hipStreamWaitEvent");
-        chk(hipMemcpyAsync(chain_abort_host, chain_cnt + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, pl->stream), "chain abort word");
-    }
-    bool chain_aborted() const { return chain_abort_host && *chain_abort_host != 0; }    // (valid after a synchronise)
-    template <class A> hipStream_t chain_next_of(A &b, long long wgs) { return chain_next(b.chain, wgs); }
-    // the stream of the next row / column launch and its Chain block; enqueues the gate in front of it
-    hipStream_t chain_next(Chain &c, long long wgs) {
-        if (!chain_open) return pl->stream;
-        hipStream_t s = (chain_n++ & 1) ? st2 : pl->stream;
-        k_gate<<<1, 1, 0, s>>>(chain_cnt, chain_started);
-        c.cnt = chain_cnt;
-        c.need_done = chain_done;
-        chain_started += (unsigned long long)wgs;
-        chain_done += (unsigned long long)wgs;
-        return s;
-    }
-#else
-    template <class A> hipStream_t chain_next_of(A &, long long) { return pl->stream; }
-#endif
     // optional per-launch event timing (ssf_set_profiling)
     bool profiling = false;
     struct Stamp { hipEvent_t a, b; int cat; };
@@ -500,23 +251,13 @@ struct HipBackend {
         stamps.clear();
     }
     explicit HipBackend(ssf_plan *p) : pl(p) {
-        if (const char *s = getenv("SSF_FUSED_ROW_OCC")) row_occ = atoi(s) == 1 ? 1 : 2;
-#if SSF_CHAIN
-        if (const char *s = getenv("SSF_CHAIN")) chain_want = atoi(s) != 0;
-#endif
+        if (const char *s = tune_env("SSF_FUSED_ROW_OCC")) row_occ = atoi(s) == 1 ? 1 : 2;
         chk(hipEventCreate(&ev0), "hipEventCreate");
         chk(hipEventCreate(&ev1), "hipEventCreate");
     }
     ~HipBackend() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-#if SSF_CHAIN
-        if (st2) (void)hipStreamDestroy(st2);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (chain_cnt) (void)hipFree(chain_cnt);
-        if (chain_abort_host) (void)hipHostFree(chain_abort_host);
-#endif
         for (auto &s : stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         for (auto e : pool) (void)hipEventDestroy(e);
     }
@@ -581,9 +322,7 @@ struct HipBackend {
                 : block <= 256 ? (RowFn<T>)k_row_mixed<T, 256> : block <= 512 ? (RowFn<T>)k_row_mixed<T, 512> : (RowFn<T>)k_row_mixed<T, 1024>;
         arm((const void *)f);
         stamp_begin(0);
-        RowArgs<T> b = a;
-        hipStream_t s = chain_next_of(b, (long long)grid * units);
-        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, s>>>(b);
+        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, pl->stream>>>(a);
         stamp_end();
         chk(hipGetLastError(), "launch k_row");
     }
@@ -609,9 +348,7 @@ struct HipBackend {
             f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : a.vpt == 8 ? pick_col8<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
         arm((const void *)f);
         stamp_begin(a.mode == CM_MK ? 1 : 3);
-        ColArgs<T> b = a;
-        hipStream_t s = chain_next_of(b, (long long)grid * units);
-        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, s>>>(b);
+        f<<<dim3((unsigned)grid, (unsigned)units), block, lds, pl->stream>>>(a);
         stamp_end();
         chk(hipGetLastError(), "launch k_col");
     }
@@ -625,6 +362,7 @@ struct HipBackend {
             "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         armed.push_back(f);
     }
+#if SSF_EXPERIMENTS
     // persistent span kernel: grid <= CUs (every workgroup resident), 256 threads, any supported power-of-two split.
     // OFF by default: measured slower than one launch per stage at every size (MI355X, ssfm, steps/s, launches vs
     // persistent: 2^12 41.1k / 31.6k, 2^14 43.6k / 28.7k, 2^16 51.2k / 49.0k, 2^18 49.6k / 25.6k, 2^20 33.1k / 7.6k;
@@ -633,7 +371,7 @@ struct HipBackend {
     // wave's ~2000 dependent FP64 instructions, not launch overhead.  SSF_PERSIST=<largest grid> turns it on.
     static constexpr bool kCanPersist = true;
     int persist_limit() {
-        if (const char *e = getenv("SSF_PERSIST")) return atoi(e);
+        if (const char *e = tune_env("SSF_PERSIST")) return atoi(e);
         return 0;
     }
     template <typename T> int launch_nlse_span(const SpanNlseArgs<T> &a, int grid, size_t lds) {
@@ -653,11 +391,11 @@ struct HipBackend {
     }
     // persistent Manakov span kernel (experiment, off by default): workers = SSF_PERSIST_MK, SSF_PERSIST_XCD=1: one XCD only
     int persist_mk_workers() {
-        if (const char *e = getenv("SSF_PERSIST_MK")) return atoi(e);
+        if (const char *e = tune_env("SSF_PERSIST_MK")) return atoi(e);
         return 0;
     }
     bool persist_mk_xcd() {
-        const char *e = getenv("SSF_PERSIST_XCD");
+        const char *e = tune_env("SSF_PERSIST_XCD");
         return e && atoi(e) != 0;
     }
     template <typename T> int launch_mk_span(const SpanMkArgs<T> &a, int grid, size_t lds) {
@@ -673,6 +411,9 @@ struct HipBackend {
             return ok() ? SSF_OK : SSF_ERR_HIP;
         }
     }
+#else
+    static constexpr bool kCanPersist = false;
+#endif
     bool sink_active() const { return pl->sink.active(); }
     template <typename C> void sink_capture(const C *soa, long long N, int nrows) {
         chk(pl->sink.capture(soa, N, nrows, pl->stream), "snapshot sink");
@@ -809,11 +550,11 @@ template <typename T> class FusedRowsImpl final : public FusedRows {
         // sincospi instead of a table in global memory (a dependent L2 round trip per pass costs more than 60 instructions
         // here; the big mixed-radix rows are throughput-bound and keep the table).  SSF_ROWS_TPR / SSF_ROWS_WTAB: A/B knobs.
         tpr = N <= 2048 ? 256 : 512;
-        if (const char *e = getenv("SSF_ROWS_TPR")) tpr = std::max(64, std::min(1024, atoi(e)));
+        if (const char *e = tune_env("SSF_ROWS_TPR")) tpr = std::max(64, std::min(1024, atoi(e)));
         while (16 * tpr < N) tpr *= 2;
         rows_wg = nrows > 512 ? std::max(1, 256 / tpr) : 1;
         while (nrows % rows_wg) rows_wg >>= 1;
-        if (const char *e = getenv("SSF_ROWS_WTAB")) use_wtab = atoi(e) != 0;
+        if (const char *e = tune_env("SSF_ROWS_WTAB")) use_wtab = atoi(e) != 0;
         if (!mix_make_plan((int)N, &plan, tpr)) return SSF_ERR_UNSUPPORTED;
         std::vector<cx<double>> w((size_t)N);
         for (int64_t q = 0; q < N; ++q) {

@@ -6,6 +6,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -92,91 +93,9 @@ template <> SSF_HD pf2 fma_s<pf2>(pf2 x, float a, pf2 c) {
 #endif
 }
 
-// Streaming-memory policy (compile-time, SSF_MEMPOL bits): the exchange buffer G and the time-domain fields are
-// written by one launch and read by the next one, normally from another XCD: keeping them in the writer's L2 buys
-// nothing and leaves the whole output dirty until the end-of-kernel write-back.  A non-temporal access streams
-// through instead.  bit 0: G stores of the row stage, bit 1: G loads, bit 2: field / E_hd stores, bit 3: field / E_hd loads,
-// bit 4: G stores of the column stage.
-// SSF_WT bits (same numbering, stores only): write-through stores (sc0 sc1): the line leaves the L2 when it is stored
-// instead of waiting, dirty, for the end-of-kernel write-back (up to 32 MiB of L2 to flush before the next launch starts).
-// Default: bit 0 -- the row stage's G stores -- in double precision only.  Measured (MI355X, config 2, same-box A/B,
-// gpurun_out/r3b..r3d): row launch 23.2 -> 21.4 us, +4 % steps/s; the column stage's G stores: nothing (bit 4), its field
-// stores: nothing (bit 2).  Parity of the write-through rows: every complex128 GPU test, the bench's oracle gate at 2^20,
-// 2^21 and 2^22.  complex64 (packed pairs): no gain at config 3 AND wrong results through the bench path (rel-L2 0.67,
-// every size; not understood) -- so the single-precision kernels keep plain stores whatever SSF_WT says.
-#ifndef SSF_MEMPOL
-#define SSF_MEMPOL 0
-#endif
-template <int BIT, typename T> SSF_HD cx<T> ld_pol(const cx<T> *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr ((SSF_MEMPOL >> BIT) & 1) {
-        if constexpr (sizeof(T) == sizeof(scalar_t<T>)) {
-            typedef T vec2 __attribute__((ext_vector_type(2)));
-            const vec2 v = __builtin_nontemporal_load((const vec2 *)p);
-            return mk<T>(v.x, v.y);
-        } else {                                             // packed pair: one 16-byte access
-            typedef float vec4 __attribute__((ext_vector_type(4)));
-            const vec4 v = __builtin_nontemporal_load((const vec4 *)p);
-            return mk<T>(mk2(v.x, v.y), mk2(v.z, v.w));
-        }
-    }
-#endif
-    return *p;
-}
-#ifndef SSF_WT
-#define SSF_WT 1
-#endif
-template <int BIT, typename T> SSF_HD void st_pol(cx<T> *p, cx<T> x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (((SSF_WT >> BIT) & 1) && sizeof(T) == 8 && sizeof(scalar_t<T>) == 8) {
-        if constexpr (sizeof(cx<T>) == 16) {
-            typedef float vec4 __attribute__((ext_vector_type(4)));
-            vec4 v;
-            __builtin_memcpy(&v, &x, 16);
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        } else {
-            typedef float vec2 __attribute__((ext_vector_type(2)));
-            vec2 v;
-            __builtin_memcpy(&v, &x, 8);
-            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        }
-        return;
-    }
-    if constexpr ((SSF_MEMPOL >> BIT) & 1) {
-        if constexpr (sizeof(T) == sizeof(scalar_t<T>)) {
-            typedef T vec2 __attribute__((ext_vector_type(2)));
-            vec2 v;
-            v.x = x.re;
-            v.y = x.im;
-            __builtin_nontemporal_store(v, (vec2 *)p);
-        } else {
-            typedef float vec4 __attribute__((ext_vector_type(4)));
-            vec4 v;
-            v.x = x.re[0];
-            v.y = x.re[1];
-            v.z = x.im[0];
-            v.w = x.im[1];
-            __builtin_nontemporal_store(v, (vec4 *)p);
-        }
-        return;
-    }
-#endif
-    *p = x;
-}
-
 // cis(2*pi*frac) evaluated in double (frac is exact: integer / power of two)
-// SSF_FAKE_TRIG (diagnostic builds only, wrong results): every sine / cosine costs two instructions -- what the launches would
-// take if the twiddle bases came for free
-#ifndef SSF_FAKE_TRIG
-#define SSF_FAKE_TRIG 0
-#endif
 SSF_HD void cis2pi_d(double frac, double &c, double &s) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (SSF_FAKE_TRIG) {
-        c = 1.0 - frac;
-        s = frac;
-        return;
-    }
     sincospi(2.0 * frac, &s, &c);
 #else
     const double a = kTwoPi * frac;
@@ -234,11 +153,6 @@ constexpr double kQuarterPi = 0.78539816339744830962;
 // sincos (whose Payne-Hanek path bloats the kernel); the reduction error |a| * 2^-53 is the
 // rounding a itself already carries
 SSF_HD void cis_rad_d(double a, double &c, double &s) {
-    if (SSF_FAKE_TRIG == 2) {
-        c = 1.0 - a;
-        s = a;
-        return;
-    }
     if (fabs(a) <= kQuarterPi) {
         s = ksin_d(a);
         c = kcos_d(a);
@@ -445,6 +359,44 @@ template <typename T> SSF_HD cx<T> mul_by_d(cx<T> v, cx<double> h) {
         return mk<T>(fma_s<T>(v.re, hr, fma_s<T>(-v.im, hi, cr)), fma_s<T>(v.re, hi, fma_s<T>(v.im, hr, ci)));
     } else {
         return tmul(v, mk<S>((S)h.re, (S)h.im));
+    }
+}
+// ---------------------------------------------------------------------------------------
+// Twiddle tables.  The twiddles of a pass never change: generating them in every launch -- sincospi, a double-precision power
+// tree and, in single precision, the hi + lo split of every factor -- is half of the complex64 row kernel's vector instructions
+// (1 905 double-precision-rate instructions next to 1 896 packed ones, tools/kernel_mix.py) and a fifth of the complex128
+// one's.  An entry holds cis(-2 pi j s / L_i) in the form the kernels apply it: the factor itself in double precision, the
+// (hi.re, hi.im, lo.re, lo.im) float quadruple of mul_by_d in single precision (16 bytes either way); the inverse transforms
+// use the conjugate (sign flips, free).
+struct TwEntryF {
+    float hr, hi, lr, li;
+};
+template <typename T> using tw_entry_t = typename std::conditional<sizeof(scalar_t<T>) == 8, cx<double>, TwEntryF>::type;
+template <typename T> SSF_HD tw_entry_t<T> tw_make(cx<double> h) {
+    if constexpr (sizeof(scalar_t<T>) == 8) return h;
+    else {
+        TwEntryF e;
+        e.hr = (float)h.re;
+        e.hi = (float)h.im;
+        e.lr = SSF_C64_HILO ? (float)(h.re - (double)e.hr) : 0.0f;
+        e.li = SSF_C64_HILO ? (float)(h.im - (double)e.hi) : 0.0f;
+        return e;
+    }
+}
+// v * e (CONJ: v * conj(e))
+template <bool CONJ, typename T> SSF_HD cx<T> tw_mul(cx<T> v, const tw_entry_t<T> &e) {
+    using S = scalar_t<T>;
+    if constexpr (sizeof(S) == 8) {
+        return v * mk<T>((T)e.re, CONJ ? (T)-e.im : (T)e.im);
+    } else {
+        const S hr = e.hr, hi = CONJ ? -e.hi : e.hi, lr = e.lr, li = CONJ ? -e.li : e.li;
+        if constexpr (SSF_C64_HILO) {
+            const T cr = fma_s<T>(v.re, lr, -(v.im * splat<T>(li)));
+            const T ci = fma_s<T>(v.re, li, v.im * splat<T>(lr));
+            return mk<T>(fma_s<T>(v.re, hr, fma_s<T>(-v.im, hi, cr)), fma_s<T>(v.re, hi, fma_s<T>(v.im, hr, ci)));
+        } else {
+            return tmul(v, mk<S>(hr, hi));
+        }
     }
 }
 // a real constant given in double precision (radix-3 / 5 butterfly constants of the mixed-radix rows): x * c

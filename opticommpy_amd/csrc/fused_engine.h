@@ -20,6 +20,21 @@
 namespace ssf {
 namespace fused {
 
+// Tuning knobs of the A/B experiments (forced splits, values per thread, persistent kernels, ...) are read from the environment
+// only by experiment builds (-DSSF_EXPERIMENTS=1: `make exp`, the CPU emulator of tests/emu); the product library reads
+// SSF_C64_PACKED, SSF_MGPU_LANES and SSF_MGPU_BATCH and nothing else.
+#ifndef SSF_EXPERIMENTS
+#define SSF_EXPERIMENTS 0
+#endif
+inline const char *tune_env(const char *name) {
+#if SSF_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 struct Split {
     int l1, l2;   // log2 N1 (column length), log2 N2 (row length)
 };
@@ -28,7 +43,7 @@ struct Split {
 // (C = 4096/N1 columns x sizeof(complex)); rows are bounded by the 160 KiB LDS.
 inline bool choose_split(int log2N, int precision, Split *s, bool packed = false) {
     if (log2N < 8) return false;
-    if (const char *e = std::getenv("SSF_SPLIT_L1")) {        // tuning knob: force log2 N1
+    if (const char *e = tune_env("SSF_SPLIT_L1")) {        // tuning knob: force log2 N1
         const int l1 = std::atoi(e);
         if (l1 >= 4 && log2N - l1 >= 4 && log2N - l1 <= 14) {
             s->l1 = l1;
@@ -78,7 +93,7 @@ inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
     for (int q : {3, 5})
         while (rest % q == 0) rest /= q;
     if (rest != 1 || a < 4) return false;
-    if (const char *e = std::getenv("SSF_MIX_L1")) {               // tuning knob: force log2 N1
+    if (const char *e = tune_env("SSF_MIX_L1")) {               // tuning knob: force log2 N1
         const int l = std::atoi(e);
         const int64_t n2 = N >> l;
         MixPlan mp;
@@ -119,6 +134,8 @@ template <typename T, class Backend> class FusedCore {
     int mix_rows = 1;            // rows per workgroup there
     MixPlan mix_plan{};          // radices of the row passes, chosen for the threads a row gets
     cx<double> *wtab = nullptr;  // cis(-2 pi k / N2mix)
+    void *tw0_row = nullptr, *tw0_col = nullptr;   // pass-0 twiddle tables of three-pass row / column transforms (fused_kernels.h: TwSrc)
+    int row_tw_off = 0, col_tw_off_mk = 0, col_tw_off_1 = 0;   // LDS offsets of the workgroups' twiddle tables
     size_t field_bytes;
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
     S *P = nullptr, *Theta = nullptr;
@@ -136,9 +153,6 @@ template <typename T, class Backend> class FusedCore {
     int tr_maxIter = 0;
     std::vector<C *> snaps;
     int row_v = 16;              // values per thread of the radix-2^n row kernel (SSF_ROW_V=8: 128-register kernels)
-    int row_stagger = 0;         // 64-clock ticks the second resident workgroup of every CU starts late (SSF_ROW_STAGGER; experiment)
-    int col_stagger = 0;         // the same for the column stage (SSF_COL_STAGGER)
-    int stagger_resident = 512;  // workgroups resident at once (two per CU): bids [resident / 2, resident) are the late ones
     int col_v = 16;              // values per thread of the column kernels (SSF_COL_V=8)
     bool underfilled = false;    // the field does not fill the chip: 8-value kernels, one row per workgroup (init)
     int lanes_hint = 1;          // plans that share the GPU concurrently (ssf_plan_set_lanes): > 1 turns the phase priorities off
@@ -176,7 +190,7 @@ template <typename T, class Backend> class FusedCore {
     void col_geometry(int groups, int npol, int *block, int *grid, size_t *lds) const {
         const int tpf = (1 << sp.l1) / col_v, N2 = N2mix ? N2mix : 1 << sp.l2;
         int half = col_v == 8 ? 512 / npol : 256;              // (eight values per thread: 512-thread workgroups, two per CU)
-        if (const char *e = std::getenv("SSF_COL_HALF")) {        // tuning knob: threads per polarisation row
+        if (const char *e = tune_env("SSF_COL_HALF")) {        // tuning knob: threads per polarisation row
             const int h = std::atoi(e);
             if (h >= tpf && h <= 512 && (h & (h - 1)) == 0) half = h;
         }
@@ -189,7 +203,7 @@ template <typename T, class Backend> class FusedCore {
         // more and smaller workgroups shorten it (measured, gpurun_out/r3k: 2^16 9 222 -> 9 720 steps/s, 2^18 8 188 -> 8 531)
         // (per unit, not per launch: a batch of independent units keeps the geometry -- and so the partial sums -- of the single plan)
         auto wgs = [&](int h) { return (long long)groups * (N2 / (h / tpf)); };
-        while (!std::getenv("SSF_COL_HALF") && half > 64 &&
+        while (!tune_env("SSF_COL_HALF") && half > 64 &&
                ((wgs(half) < 512 && (half / tpf) * sizeof(C) > 128) || (wgs(half) < 256 && (half / tpf) * sizeof(C) > 64)))
             half >>= 1;
         const int Cc = half / tpf;
@@ -199,7 +213,7 @@ template <typename T, class Backend> class FusedCore {
     }
 
     int init() {
-        if (const char *e = std::getenv("SSF_LIM0_BOUND")) lim0_bound = std::atoi(e) != 0;
+        if (const char *e = tune_env("SSF_LIM0_BOUND")) lim0_bound = std::atoi(e) != 0;
         // Fields that do not fill the chip -- fewer than two 16-value waves per SIMD: rows x N <= 2^20 values per unit, i.e. up to
         // 2^19 samples for a complex128 pair, 2^20 for a packed complex64 pair -- run on the 8-value kernels (twice the waves
         // and workgroups, shorter dependent chains per thread) with one row per workgroup: measured +7 ... +75 % there
@@ -209,12 +223,12 @@ template <typename T, class Backend> class FusedCore {
         // 2^15).  Decided per unit, so a batch of independent units has the geometry -- and the arithmetic -- of the single plan.
         underfilled = (double)rows_u() * (double)N <= 1048576.0;
         col_v = underfilled && sp.l1 != 7 ? 8 : 16;
-        if (const char *e = std::getenv("SSF_COL_V")) col_v = std::atoi(e) == 8 ? 8 : 16;
+        if (const char *e = tune_env("SSF_COL_V")) col_v = std::atoi(e) == 8 ? 8 : 16;
         if (N2mix || sp.l1 < 6 || sp.l1 > 10) col_v = 16;      // (ragged tiles / very short or very long columns: 16-value kernels only)
         const int64_t nfft = (int64_t)rows_u() << sp.l1;       // row transforms of one unit
         if (N2mix) {               // rows in LDS after 4 KiB of scratch; 128 threads per row while 16 values per thread suffice
             int tpr = 128;
-            if (const char *e = std::getenv("SSF_MIX_TPR")) tpr = std::max(64, std::min(1024, std::atoi(e)));
+            if (const char *e = tune_env("SSF_MIX_TPR")) tpr = std::max(64, std::min(1024, std::atoi(e)));
             while (16 * tpr < N2mix) tpr *= 2;
             mix_rows = std::max(1, 256 / tpr);
             while (nfft % mix_rows) mix_rows >>= 1;
@@ -227,7 +241,7 @@ template <typename T, class Backend> class FusedCore {
             row_grid = (int)(nfft / mix_rows);
             row_lds = 4096 + (size_t)mix_rows * N2mix * sizeof(C);
             mix_make_plan(N2mix, &mix_plan, tpr);
-            if (const char *e = std::getenv("SSF_MIX_PLAN")) {       // experiments: "15,5,5,5"
+            if (const char *e = tune_env("SSF_MIX_PLAN")) {       // experiments: "15,5,5,5"
                 int r[kMixMaxPass], n = 0;
                 for (const char *q = e; *q && n < kMixMaxPass;) {
                     r[n++] = std::atoi(q);
@@ -239,25 +253,32 @@ template <typename T, class Backend> class FusedCore {
             }
         } else {
             row_v = underfilled ? 8 : 16;
-            if (const char *e = std::getenv("SSF_ROW_V")) row_v = std::atoi(e) == 8 ? 8 : 16;
-            if (const char *e = std::getenv("SSF_ROW_STAGGER")) row_stagger = std::max(0, std::atoi(e));
-            if (const char *e = std::getenv("SSF_COL_STAGGER")) col_stagger = std::max(0, std::atoi(e));      // (SSF_CHAIN builds only)
-            if (const char *e = std::getenv("SSF_STAGGER_RESIDENT")) stagger_resident = std::max(2, std::atoi(e));
+            if (const char *e = tune_env("SSF_ROW_V")) row_v = std::atoi(e) == 8 ? 8 : 16;
             if (sp.l2 < 6) row_v = 16;
             const int tpf2 = (1 << sp.l2) / row_v, wg = row_v == 8 ? 512 : 256;
             int fpw = tpf2 >= wg ? 1 : wg / tpf2;             // row transforms per workgroup
             // under-filled chip: a workgroup per row.  A batch of independent units fills the chip by itself: 256-thread workgroups
             // there (rows per workgroup do not enter a row's arithmetic, so the units' fields stay those of the single plan)
             if (underfilled && row_v == 8) fpw = units > 1 ? std::max(1, std::min(fpw, 256 / std::max(tpf2, 1))) : 1;
-            if (const char *e = std::getenv("SSF_ROW_FPW")) fpw = std::max(1, std::min(fpw, std::atoi(e)));   // tuning knob
+            if (const char *e = tune_env("SSF_ROW_FPW")) fpw = std::max(1, std::min(fpw, std::atoi(e)));   // tuning knob
             while (nfft % fpw) fpw >>= 1;                      // (nrows need not be a power of two)
             row_block = fpw * tpf2;
             row_grid = (int)(nfft / fpw);
             row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 16 + 2048);
+            if (SSF_TW_TAB) {                                  // the workgroup's twiddle table behind the transform area
+                row_tw_off = (int)((row_lds + 15) / 16 * 16);
+                row_lds = (size_t)row_tw_off + kTwLdsBytes;
+            }
         }
         if (const char *e = std::getenv("SSF_C64_PACKED")) use_packed = std::atoi(e) != 0;
         col_geometry(pairs_u(), kPacked ? 1 : 2, &col_block_mk, &col_grid_mk, &col_lds_mk);
         col_geometry(rows_u(), 1, &col_block_1, &col_grid_1, &col_lds_1);
+        if (SSF_TW_TAB) {
+            col_tw_off_mk = (int)((col_lds_mk + 15) / 16 * 16);
+            col_lds_mk = (size_t)col_tw_off_mk + kTwLdsBytes;
+            col_tw_off_1 = (int)((col_lds_1 + 15) / 16 * 16);
+            col_lds_1 = (size_t)col_tw_off_1 + kTwLdsBytes;
+        }
         npart_max = std::max(col_grid_mk, col_grid_1);
         if (own_G && !(G = (C *)be.alloc(field_bytes))) return oom();
         if (!(T0 = (C *)be.alloc(field_bytes))) return oom();
@@ -276,8 +297,28 @@ template <typename T, class Backend> class FusedCore {
             }
             be.h2d(wtab, w.data(), sizeof(cx<double>) * (size_t)N2mix);
         }
+        if ((SSF_TW_TAB & 2) && !N2mix && !(tw0_row = make_tw0(sp.l2, row_v))) return oom();
+        if ((SSF_TW_TAB & 2) && !(tw0_col = make_tw0(sp.l1, col_v))) return oom();
         be.prepare(row_lds, std::max(col_lds_mk, col_lds_1));
         return SSF_OK;
+    }
+    // pass-0 twiddles of a three-pass transform of length 2^lg with V values per thread: entry [s * L_1 + j] =
+    // cis(-2 pi j s / L), j < L_1 = L / V, s < V; (void *)1 when the plan has fewer passes (nothing to tabulate)
+    void *make_tw0(int lg, int V) {
+        const PassPlan p = make_plan(lg, V == 16 ? 4 : 3);
+        if (p.npass < 3) return (void *)1;
+        const int L = 1 << lg, L1 = 1 << p.lgLn(0);
+        std::vector<tw_entry_t<T>> h((size_t)L);
+        for (int s = 0; s < (1 << p.lg(0)); ++s)
+            for (int j = 0; j < L1; ++j) {
+                const long long m = ((long long)j * s) & (L - 1);
+                double c, sn;
+                cis2pi_d(-(double)m / (double)L, c, sn);
+                h[(size_t)s * L1 + j] = tw_make<T>(mk<double>(c, sn));
+            }
+        void *d = be.alloc(sizeof(tw_entry_t<T>) * (size_t)L);
+        if (d) be.h2d(d, h.data(), sizeof(tw_entry_t<T>) * (size_t)L);
+        return d;
     }
     // second time-domain field, E_hd, Pch (two buffers) and the phase array: only the Manakov pipeline uses them
     int mk_buffers() {
@@ -296,6 +337,8 @@ template <typename T, class Backend> class FusedCore {
         for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)Theta, (void *)ctrl, (void *)linops, (void *)gbar,
                         (void *)part, (void *)wtab, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
             if (p) be.free(p);
+        for (void *p : {tw0_row, tw0_col})
+            if (p && p != (void *)1) be.free(p);
         for (C *s : snaps) be.free(s);
     }
 
@@ -352,11 +395,8 @@ template <typename T, class Backend> class FusedCore {
         a.rows_per_wg = mix_rows;
         a.vpt = row_v;
         a.prio = lanes_hint <= 1 ? 1 : 0;
-#if SSF_CHAIN
-        a.stagger = row_stagger;
-        a.stagger_hi = std::min(row_grid, stagger_resident);
-        a.stagger_lo = a.stagger_hi / 2;
-#endif
+        a.tw_off = N2mix ? 0 : row_tw_off;
+        a.tw0 = tw0_row == (void *)1 ? nullptr : tw0_row;
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {
@@ -376,6 +416,8 @@ template <typename T, class Backend> class FusedCore {
         a.ngroups = pairs_u();
         a.vpt = col_v;
         a.prio = lanes_hint <= 1 ? 1 : 0;
+        a.tw_off = npol == 1 && !kPacked ? col_tw_off_1 : col_tw_off_mk;
+        a.tw0 = tw0_col == (void *)1 ? nullptr : tw0_col;
         a.u_elems = (long long)rows_u() * N;
         a.u_part = npart_max;
         const size_t ps = (size_t)units * (size_t)npart_max;       // one array of partial sums: [unit][npart_max]
@@ -384,11 +426,6 @@ template <typename T, class Backend> class FusedCore {
         a.pden = part + 2 * ps;
         a.pnum0 = part + 3 * ps;
         a.pden0 = part + 4 * ps;
-#if SSF_CHAIN
-        a.stagger = mode == CM_MK ? col_stagger : 0;
-        a.stagger_hi = std::min(col_grid_mk, stagger_resident);
-        a.stagger_lo = a.stagger_hi / 2;
-#endif
         return a;
     }
     void launch_row_lin(const LinOp *lin) {
@@ -502,13 +539,10 @@ template <typename T, class Backend> class FusedCore {
                     a.row = row_args();
                     a.row.use_ctrl = 0;
                     a.row.vpt = 16;
-#if SSF_CHAIN
-    #if SSF_CHAIN
-                a.row.stagger = 0;
-#endif
-#endif
+                    a.row.tw_off = 0;                               // (the merged kernel's LDS has no room for the tables)
                     a.col = col_args(1, CM_NLSE_STEP);
                     a.col.vpt = 16;
+                    a.col.tw_off = 0;
                     a.col.T0 = E;
                     a.col.g_hz = (S)(p.gamma * p.hz);
                     a.col.npart = pcol;
@@ -651,10 +685,8 @@ template <typename T, class Backend> class FusedCore {
                 a.row.pnum0 = part + 3 * (size_t)npart_max;
                 a.row.pden0 = part + 4 * (size_t)npart_max;
                 a.row.npart = col_grid_mk;
-#if SSF_CHAIN
-                a.row.stagger = 0;
-#endif
                 a.col = col_args(2, CM_MK);
+                a.col.tw_off = a.row.tw_off = 0;
                 a.col.k = k;
                 a.col.npart = col_grid_mk;
                 a.ctrl = ctrl;
@@ -705,24 +737,12 @@ template <typename T, class Backend> class FusedCore {
             }
             double est = p.nlprMethod ? steps_rem * (1.0 + sr.avg_it) * 0.6 : steps_rem * (1.0 + sr.avg_it) + 3.0;
             int chunk = (int)std::min(512.0, std::max(2.0, std::ceil(est)));
-#if SSF_CHAIN
-            if (units == 1 && lanes_hint <= 1) be.chain_begin();                     // (experiment builds: launches chained across
-#endif                                                                                //  two streams, waits inside the kernels)
             for (int i = 0; i < chunk; ++i) {
                 launch_mk_row(k);
                 launch_mk_col(k, CM_MK);
             }
-#if SSF_CHAIN
-            be.chain_end();
-#endif
             be.d2h(cs.data(), ctrl + (size_t)(seq & 1) * units, cbytes);              // synchronising read
             if (!be.ok()) return hiperr();
-#if SSF_CHAIN
-            if (be.chain_aborted()) {
-                err = "fused engine: a chained launch waited for its predecessor in vain (SSF_CHAIN)";
-                return SSF_ERR_STATE;
-            }
-#endif
             long long steps = 0, iters = 0;
             bool done = true;
             double worst = 0.0;

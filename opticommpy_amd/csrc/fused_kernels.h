@@ -139,109 +139,122 @@ template <int R> SSF_HD void tw_powers(int sign, int j, int lgL, cx<double> *p) 
     }
 }
 
+// Where the twiddles of a transform come from (fused_core.h: tw_entry_t).  SSF_TW_TAB: bit 0 = the next-to-last pass reads them
+// from a table in LDS that the workgroup builds when it starts (j < r_last, s < r: at most 256 entries = 4 KiB; that pass is
+// pass 0 of a two-pass transform -- columns of 256 -- and pass 1 of a three-pass one -- rows of 4096, columns of 1024); bit 1 =
+// pass 0 of a three-pass transform reads them from a table in global memory ([s][j], L entries = 64 KiB for rows of 4096:
+// the same lines for every workgroup, L2-resident); everything else (and everything when a table is absent) is generated in
+// registers: one sincospi per butterfly + a double-precision power tree of depth <= 4, rounded once.
+#ifndef SSF_TW_TAB
+#define SSF_TW_TAB 3
+#endif
+template <typename T> struct TwSrc {
+    const tw_entry_t<T> *lds = nullptr;      // table of pass npass - 2: entry [s * r_last + j]
+    const tw_entry_t<T> *g0 = nullptr;       // table of pass 0: entry [s * L_1 + j]
+};
+constexpr int kTwLdsBytes = 4096;
+
+// the workgroup's LDS table (no barrier inside: the caller's next barrier -- the first exchange of a three-pass transform, an
+// explicit one for two passes -- publishes it)
+template <typename T, class Ctx> SSF_HD void tw_lds_build(Ctx &ctx, const PassPlan &p, tw_entry_t<T> *tab) {
+    if (!(SSF_TW_TAB & 1) || p.npass < 2) return;
+    const int it = p.npass - 2, lgr = p.lg(it), lgl = p.lg(p.npass - 1);
+    for (int t = ctx.tid; t < (1 << (lgr + lgl)); t += ctx.nthreads) {
+        const int s = t >> lgl, j = t & ((1 << lgl) - 1);
+        double c, sn;
+        cis2pi_d(scale_pow2((double)(-(j * s)), lgr + lgl), c, sn);
+        tab[t] = tw_make<T>(mk<double>(c, sn));
+    }
+}
+
+// twiddles of the R values of one butterfly (bb) of pass i: v[s] *= cis(SIGN 2 pi j s / L_i), s = 1 .. R-1
+template <int SIGN, int R, typename T>
+SSF_HD void apply_tw(const PassPlan &p, int i, int bb, cx<T> *v, const TwSrc<T> &src) {
+    if ((SSF_TW_TAB & 1) && src.lds && i == p.npass - 2) {
+        const int lgl = p.lg(p.npass - 1);
+        const tw_entry_t<T> *e = src.lds + (bb & ((1 << lgl) - 1));
+#pragma unroll
+        for (int s = 1; s < R; ++s) v[s] = tw_mul<(SIGN > 0)>(v[s], e[s << lgl]);
+        return;
+    }
+    if ((SSF_TW_TAB & 2) && src.g0 && i == 0 && p.npass >= 3) {
+        const int lgS = p.lgLn(0);
+        const tw_entry_t<T> *e = src.g0 + (bb & ((1 << lgS) - 1));
+#pragma unroll
+        for (int s = 1; s < R; ++s) v[s] = tw_mul<(SIGN > 0)>(v[s], e[s << lgS]);
+        return;
+    }
+    cx<double> w[R];
+    tw_powers<R>(SIGN, pass_j(p, i, bb), pass_lgLi(p, i), w);
+#pragma unroll
+    for (int s = 1; s < R; ++s) v[s] = mul_by_d(v[s], w[s]);
+}
+
 // butterflies of pass i for thread b (values v[u*r + q]); DIF: DFT then twiddle w^s.  V = values per thread (16, or 8 for
 // the 128-register kernels): a thread carries V / r butterflies of a radix-r pass.
-template <int SIGN, int V = 16, typename T> SSF_HD void dif_pass(const PassPlan &p, int i, int b, cx<T> *v) {
-    const int lgLi = pass_lgLi(p, i);
+template <int SIGN, int V = 16, typename T>
+SSF_HD void dif_pass(const PassPlan &p, int i, int b, cx<T> *v, const TwSrc<T> &src = TwSrc<T>()) {
     const bool tw = p.lgLn(i) > 0;
     switch (p.lg(i)) {
     case 4:
         if constexpr (V >= 16) {
             dft16<SIGN>(v);
-            if (tw) {
-                cx<double> w[16];
-                tw_powers<16>(SIGN, pass_j(p, i, b), lgLi, w);
-#pragma unroll
-                for (int s = 1; s < 16; ++s) v[s] = mul_by_d(v[s], w[s]);
-            }
+            if (tw) apply_tw<SIGN, 16>(p, i, b, v, src);
         }
         break;
     case 3:
 #pragma unroll
         for (int u = 0; u < V / 8; ++u) {
             dft8<SIGN>(v + 8 * u);
-            if (tw) {
-                cx<double> w[8];
-                tw_powers<8>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
-#pragma unroll
-                for (int s = 1; s < 8; ++s) v[8 * u + s] = mul_by_d(v[8 * u + s], w[s]);
-            }
+            if (tw) apply_tw<SIGN, 8>(p, i, b + p.tpf * u, v + 8 * u, src);
         }
         break;
     case 2:
 #pragma unroll
         for (int u = 0; u < V / 4; ++u) {
             dft4<SIGN>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
-            if (tw) {
-                cx<double> w[4];
-                tw_powers<4>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
-#pragma unroll
-                for (int s = 1; s < 4; ++s) v[4 * u + s] = mul_by_d(v[4 * u + s], w[s]);
-            }
+            if (tw) apply_tw<SIGN, 4>(p, i, b + p.tpf * u, v + 4 * u, src);
         }
         break;
     default:
 #pragma unroll
         for (int u = 0; u < V / 2; ++u) {
             dft2<SIGN>(v[2 * u], v[2 * u + 1]);
-            if (tw) {
-                cx<double> w[2];
-                tw_powers<2>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
-                v[2 * u + 1] = mul_by_d(v[2 * u + 1], w[1]);
-            }
+            if (tw) apply_tw<SIGN, 2>(p, i, b + p.tpf * u, v + 2 * u, src);
         }
         break;
     }
 }
 
 // DIT: twiddle w^s then DFT (exact mirror of dif_pass with the opposite SIGN)
-template <int SIGN, int V = 16, typename T> SSF_HD void dit_pass(const PassPlan &p, int i, int b, cx<T> *v) {
-    const int lgLi = pass_lgLi(p, i);
+template <int SIGN, int V = 16, typename T>
+SSF_HD void dit_pass(const PassPlan &p, int i, int b, cx<T> *v, const TwSrc<T> &src = TwSrc<T>()) {
     const bool tw = p.lgLn(i) > 0;
     switch (p.lg(i)) {
     case 4:
         if constexpr (V >= 16) {
-            if (tw) {
-                cx<double> w[16];
-                tw_powers<16>(SIGN, pass_j(p, i, b), lgLi, w);
-#pragma unroll
-                for (int s = 1; s < 16; ++s) v[s] = mul_by_d(v[s], w[s]);
-            }
+            if (tw) apply_tw<SIGN, 16>(p, i, b, v, src);
             dft16<SIGN>(v);
         }
         break;
     case 3:
 #pragma unroll
         for (int u = 0; u < V / 8; ++u) {
-            if (tw) {
-                cx<double> w[8];
-                tw_powers<8>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
-#pragma unroll
-                for (int s = 1; s < 8; ++s) v[8 * u + s] = mul_by_d(v[8 * u + s], w[s]);
-            }
+            if (tw) apply_tw<SIGN, 8>(p, i, b + p.tpf * u, v + 8 * u, src);
             dft8<SIGN>(v + 8 * u);
         }
         break;
     case 2:
 #pragma unroll
         for (int u = 0; u < V / 4; ++u) {
-            if (tw) {
-                cx<double> w[4];
-                tw_powers<4>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
-#pragma unroll
-                for (int s = 1; s < 4; ++s) v[4 * u + s] = mul_by_d(v[4 * u + s], w[s]);
-            }
+            if (tw) apply_tw<SIGN, 4>(p, i, b + p.tpf * u, v + 4 * u, src);
             dft4<SIGN>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
         }
         break;
     default:
 #pragma unroll
         for (int u = 0; u < V / 2; ++u) {
-            if (tw) {
-                cx<double> w[2];
-                tw_powers<2>(SIGN, pass_j(p, i, b + p.tpf * u), lgLi, w);
-                v[2 * u + 1] = mul_by_d(v[2 * u + 1], w[1]);
-            }
+            if (tw) apply_tw<SIGN, 2>(p, i, b + p.tpf * u, v + 2 * u, src);
             dft2<SIGN>(v[2 * u], v[2 * u + 1]);
         }
         break;
@@ -264,55 +277,28 @@ template <int V = 16, typename T> SSF_HD void lds_get(const PassPlan &p, int i, 
 }
 
 // DIF transform: v holds pass-0 positions on entry, pass-(p-1) positions (digit-reversed) on exit
-// (SSF_ABL 3 / 4, diagnostic builds, wrong results: no LDS exchanges / no butterflies -- which pipe the transform phase waits for)
-#ifndef SSF_ABL
-#define SSF_ABL 0
-#endif
-// SSF_PRIO: issue priority by phase (s_setprio): a wave that is further behind in its launch gets the VALU first.  The two
-// workgroups of a CU start together, but the older one wins every arbitration, runs through at full speed and leaves the
-// younger one to finish alone, one wave per SIMD (phase stamps, gpurun_out/r3c: first half of the row grid done at 13.3 us,
-// second half at 17.5 us).  With the forward transform above the inverse one (rows) and inverse > time domain > forward
-// (columns) the late workgroup catches up while the early one is in a later phase.  Measured (same-box A/B, config 2):
-// 1: +3 % steps/s (row 23.5 -> 23.0 us, column 25.8 -> 24.9 us); 2 (three levels in the row stage): the same; config 3: +-0.
-#ifndef SSF_PRIO
-#define SSF_PRIO 1
-#endif
-#define SSF_ABL_NOMEM (SSF_ABL == 2 || SSF_ABL == 5 || SSF_ABL == 6)    /* 5 = 2 + 3: arithmetic only; 6 = 2 + 4: LDS only */
-#define SSF_ABL_NOLDS (SSF_ABL == 3 || SSF_ABL == 5)
-#define SSF_ABL_NOVALU (SSF_ABL == 4 || SSF_ABL == 6)
-// SSF_XPRIO (experiment builds): the LDS exchanges of a transform run at issue priority 3 and its butterflies at PB (1: the
-// phase's own level, 2: level 0) -- an exchange's 16 wide stores need the SIMD for 13 cycles each and are otherwise served
-// behind the other workgroup's butterflies.  PB < 0: priorities untouched.  Measured (profiles/r3_chained_launches_and_stagger.txt):
-// config 2 +- 0.5 %, config 3 rows 52 -> 61 - 64 us: off.
-#ifndef SSF_XPRIO
-#define SSF_XPRIO 0
-#endif
-template <int SIGN, int V = 16, int PB = -1, typename T, class Ctx>
-SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
-    if (!SSF_ABL_NOVALU) dif_pass<SIGN, V>(p, 0, b, v);
+template <int SIGN, int V = 16, typename T, class Ctx>
+SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds, const TwSrc<T> &src = TwSrc<T>()) {
+    dif_pass<SIGN, V>(p, 0, b, v, src);
 #pragma unroll
     for (int i = 1; i < p.npass; ++i) {
-        if constexpr (SSF_XPRIO && PB >= 0) ctx.template setprio<3>();
-        if (!SSF_ABL_NOLDS) lds_put<V>(p, i - 1, b, v, lds);
+        lds_put<V>(p, i - 1, b, v, lds);
         ctx.sync();
-        if (!SSF_ABL_NOLDS) lds_get<V>(p, i, b, v, lds);
-        if constexpr (SSF_XPRIO && PB >= 0) ctx.template setprio<(SSF_XPRIO == 2 ? 0 : PB)>();
-        if (!SSF_ABL_NOVALU) dif_pass<SIGN, V>(p, i, b, v);
+        lds_get<V>(p, i, b, v, lds);
+        dif_pass<SIGN, V>(p, i, b, v, src);
     }
 }
 // DIT transform: v holds pass-(p-1) positions on entry, pass-0 positions (natural) on exit
-template <int SIGN, int V = 16, int PB = -1, typename T, class Ctx>
-SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
+template <int SIGN, int V = 16, typename T, class Ctx>
+SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds, const TwSrc<T> &src = TwSrc<T>()) {
 #pragma unroll
     for (int i = p.npass - 1; i >= 1; --i) {
-        if (!SSF_ABL_NOVALU) dit_pass<SIGN, V>(p, i, b, v);
-        if constexpr (SSF_XPRIO && PB >= 0) ctx.template setprio<3>();
-        if (!SSF_ABL_NOLDS) lds_put<V>(p, i, b, v, lds);
+        dit_pass<SIGN, V>(p, i, b, v, src);
+        lds_put<V>(p, i, b, v, lds);
         ctx.sync();
-        if (!SSF_ABL_NOLDS) lds_get<V>(p, i - 1, b, v, lds);
-        if constexpr (SSF_XPRIO && PB >= 0) ctx.template setprio<(SSF_XPRIO == 2 ? 0 : PB)>();
+        lds_get<V>(p, i - 1, b, v, lds);
     }
-    if (!SSF_ABL_NOVALU) dit_pass<SIGN, V>(p, 0, b, v);
+    dit_pass<SIGN, V>(p, 0, b, v, src);
 }
 
 // ------------------------------------------------------------------------ block reductions
@@ -416,23 +402,6 @@ template <class Ctx> SSF_HD double global_max(Ctx &ctx, const double *a, int n, 
 }
 
 // ------------------------------------------------------------------------------ row kernel
-// SSF_CHAIN (experiment builds, make variant TAG=chain VFLAGS=-DSSF_CHAIN=1; then SSF_CHAIN=1 in the environment): chained
-// launches.  The launches of a span alternate between two streams, so the workgroups of launch j + 1 are dispatched while launch
-// j still runs (they take the slots its early workgroups leave) and wait INSIDE the kernel for launch j's workgroups to have
-// finished, instead of waiting at a kernel boundary (engine_fused_impl.h: chain_enter / chain_exit / k_gate).  Bit-equal
-// results, 1.6 - 4 x slower -- and the mere presence of the wrappers cost the default path 2 % (same-box A/B,
-// profiles/r3_chained_launches_and_stagger.txt), so the product build compiles none of it.
-// cnt[0] = workgroups started, cnt[1] = workgroups finished -- both over the engine's whole life --, cnt[2] = abort word.
-#ifndef SSF_CHAIN
-#define SSF_CHAIN 0
-#endif
-#if SSF_CHAIN
-struct Chain {
-    unsigned long long *cnt;
-    unsigned long long need_done;     // this launch's workgroups proceed once cnt[1] >= need_done (every earlier chained launch done)
-};
-#endif
-
 template <typename T> struct RowArgs {
     cx<T> *G;                 // (nrows, N1, N2)
     int log2N1, log2N2, nfft; // nfft = nrows * N1 row transforms
@@ -461,13 +430,9 @@ template <typename T> struct RowArgs {
     // and partial sums at + u * u_part of every array (unit_view below); 0 / unused for a single unit
     long long u_elems;
     int u_part;
-    int prio;                 // 1: issue priority by phase (s_setprio, SSF_PRIO); 0 when several plans share the GPU (lanes)
-#if SSF_CHAIN                 // (experiment builds only: every extra word the prologue waits for costs the launch sequence)
-    int stagger;              // > 0: workgroups stagger_lo <= bid < stagger_hi start this many 64-clock ticks late (the second
-    int stagger_lo, stagger_hi;   // workgroup of every CU in the first round of residency: co-resident workgroups out of phase,
-                              // one loads / stores while the other transforms); SSF_ROW_STAGGER
-    Chain chain;
-#endif
+    int prio;                 // 1: issue priority by phase (s_setprio); 0 when several plans share the GPU (lanes)
+    int tw_off;               // > 0: byte offset of the workgroup's twiddle table in LDS (kTwLdsBytes behind the transform area)
+    const void *tw0;          // global twiddle table of pass 0 (three-pass rows: tw_entry_t<T>[N2], [s][j]) or nullptr
 };
 
 // linear operator for the V registers of a last-radix-V butterfly (V = 16 | 8): bins k0 + (N/V) q, signed q' = q or q - V;
@@ -711,6 +676,54 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
     ctx.flush(0);
 }
 
+// The row stage's G stores.  A launch ends with up to 32 MiB of dirty lines in the eight L2s, which the end-of-kernel release
+// writes back before the next launch can start; stored write-through (sc0 sc1) the lines leave the L2 while the other workgroups
+// still compute: row launch 23.2 -> 21.4 us at config 2, +4 % steps/s (profiles/r3_ab_runs.txt; the column stage's G and field
+// stores gain nothing that way).  The stores are buffer stores with the cache policy in the instruction's aux bits
+// (__builtin_amdgcn_raw_buffer_store_*), so the compiler sees them: it counts them in vmcnt and keeps the store-data hazard
+// of a 128-bit store (two wait states before a VALU instruction may overwrite the data registers on gfx940+).  Round 3 issued
+// them by inline assembly, which the hazard recogniser does not look into: where the data sat in a temporary register tuple
+// that the next value's moves overwrote at once -- the packed complex64 kernel -- the store sent the NEXT element's data
+// (rel-L2 0.67 at every size); the double-precision kernel's values happened to live in aligned tuples of their own and
+// passed every test.  SSF_WT_ROWS: bit 0 double, bit 1 packed pairs, bit 2 float.
+#ifndef SSF_WT_ROWS
+#define SSF_WT_ROWS 1
+#endif
+template <typename T> constexpr bool wt_rows() {
+    return sizeof(scalar_t<T>) == 8 ? (SSF_WT_ROWS & 1) != 0 : sizeof(T) == 8 ? (SSF_WT_ROWS & 2) != 0 : (SSF_WT_ROWS & 4) != 0;
+}
+template <int V, typename T, class Ctx>
+SSF_HD void row_store(Ctx &ctx, const RowArgs<T> &a, const PassPlan &p, int f, int b, const cx<T> *v) {
+    const int fpw = ctx.nthreads / p.tpf;
+    cx<T> *base = a.G + (((long long)ctx.bid * fpw) << a.log2N2);       // first row of this workgroup (wave-uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (wt_rows<T>()) {
+        const unsigned bytes = (unsigned)(((size_t)fpw << a.log2N2) * sizeof(cx<T>));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, bytes, 0x00020000);
+        constexpr int kWT = 0x11;                                         // aux: sc0 | sc1 (system-scope write-through)
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const unsigned off = (unsigned)(((f << a.log2N2) + b + p.tpf * q) * (int)sizeof(cx<T>));
+            if constexpr (sizeof(cx<T>) == 16) {
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                u4 w;
+                __builtin_memcpy(&w, &v[q], 16);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, kWT);
+            } else {
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                u2 w;
+                __builtin_memcpy(&w, &v[q], 8);
+                __builtin_amdgcn_raw_buffer_store_b64(w, rs, off, 0, kWT);
+            }
+        }
+        return;
+    }
+#endif
+    cx<T> *g = base + ((long long)f << a.log2N2);
+#pragma unroll
+    for (int q = 0; q < V; ++q) g[b + p.tpf * q] = v[q];
+}
+
 // LG > 0: row length fixed at compile time (index math folds to immediates); 0: runtime
 // V = values per thread: 16 (256 registers, two waves per SIMD) or 8 (128 registers, four waves per SIMD: while the waves
 // of one workgroup wait for their row or for their stores to drain, the other workgroup of the CU has the SIMDs)
@@ -724,9 +737,6 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     const long long rr = (long long)ctx.bid * fpw + f;     // global row-transform index (grid is exact)
     cx<T> *g = a.G + (rr << a.log2N2);
     cx<T> v[V];
-#if SSF_CHAIN
-    if (a.stagger > 0 && ctx.bid >= a.stagger_lo && ctx.bid < a.stagger_hi) ctx.sleep64(a.stagger);
-#endif
     ctx.mark(0);
     // Issue order matters (vmcnt retires in order): first the convergence sums the last column
     // stage may have left (fetched unconditionally, they are only used if the control block says
@@ -749,12 +759,14 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
         }
         ctx.issue_fence();
     }
-    // SSF_ABL (diagnostic builds): 1 = no transforms (the launch's memory phase alone), 2 = no row loads / stores (its
-    // arithmetic and LDS phase alone); results are garbage either way
 #pragma unroll
-    for (int q = 0; q < V; ++q) {
-        if (SSF_ABL_NOMEM) v[q] = mk<T>(splat<T>((scalar_t<T>)(ctx.tid + q)), splat<T>((scalar_t<T>)(ctx.bid - q)));
-        else v[q] = ld_pol<1>(g + b + p.tpf * q);
+    for (int q = 0; q < V; ++q) v[q] = g[b + p.tpf * q];
+    TwSrc<T> tws;                                           // (the table is built while the row is in flight)
+    if (SSF_TW_TAB && a.tw_off > 0) {
+        tw_entry_t<T> *tab = (tw_entry_t<T> *)(ctx.lds + a.tw_off);
+        tw_lds_build<T>(ctx, p, tab);
+        tws.lds = tab;
+        tws.g0 = (const tw_entry_t<T> *)a.tw0;
     }
     if (a.use_ctrl) {
         ctx.issue_fence();
@@ -762,19 +774,21 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     } else if (a.lin) {
         lo = *a.lin;
     }
+    if (tws.lds && p.npass == 2) ctx.sync();                // (three passes: the first exchange's barrier publishes the table)
     const int N1 = 1 << a.log2N1, log2N = a.log2N1 + a.log2N2;
     const int k1 = (int)(rr & (N1 - 1));
     cx<T> *l = lds + (size_t)f * lds_slots_per_fft(p.L);
     ctx.mark(1);
-    // SSF_PRIO (experiment): a wave that is further behind gets the VALU first.  The two workgroups of a CU start together,
-    // but the older one wins every arbitration, runs through at full speed and leaves the younger one to finish alone, one
-    // wave per SIMD (phase stamps: first half of the grid done at 13.3 us, second half at 17.5 us).
-    if (SSF_PRIO == 2 && a.prio) ctx.template setprio<3>();
-    else if (SSF_PRIO && a.prio) ctx.template setprio<2>();
-    if (SSF_ABL != 1) fft_dif<-1, V, 2>(ctx, p, b, v, l);
+    // Issue priority by phase (s_setprio): a wave that is further behind in its launch gets the VALU first.  The two workgroups
+    // of a CU start together, but the older one wins every arbitration, runs through at full speed and leaves the younger one
+    // to finish alone, one wave per SIMD (phase stamps: first half of the row grid done at 13.3 us, second half at 17.5 us).
+    // With the forward transform above the inverse one (rows) and inverse > time domain > forward (columns) the late
+    // workgroup catches up while the early one is in a later phase: +3 % steps/s at config 2 (profiles/r3_ab_runs.txt);
+    // off (a.prio = 0) when several plans share the GPU, where it costs 4 % (profiles/r3_lanes_prio_wt.txt).
+    if (a.prio) ctx.template setprio<2>();
+    fft_dif<-1, V>(ctx, p, b, v, l, tws);
     ctx.mark(2);
-    if (SSF_PRIO == 2 && a.prio) ctx.template setprio<2>();
-    else if (SSF_PRIO && a.prio) ctx.template setprio<1>();
+    if (a.prio) ctx.template setprio<1>();
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
     const int last = p.npass - 1;
     if (!a.use_ctrl && !a.lin) {                 // fixed-kernel convolution: multiplier array in this kernel's spectrum order
@@ -797,14 +811,10 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
         }
     }
     ctx.mark(3);
-    if (SSF_PRIO == 2 && a.prio) ctx.template setprio<1>();
-    if (SSF_ABL != 1) fft_dit<+1, V, 1>(ctx, p, b, v, l);
-    if (SSF_PRIO && a.prio) ctx.template setprio<0>();
+    fft_dit<+1, V>(ctx, p, b, v, l, tws);
+    if (a.prio) ctx.template setprio<0>();
     ctx.mark(4);
-#pragma unroll
-    for (int q = 0; q < V; ++q)
-        if (!SSF_ABL_NOMEM || a.nfft < 0) st_pol<0>(g + b + p.tpf * q, v[q]);
-    if ((SSF_WT & 1) && sizeof(T) == 8 && sizeof(scalar_t<T>) == 8) ctx.drain();   // (inline-asm stores: not counted by the compiler)
+    row_store<V>(ctx, a, p, f, b, v);
     ctx.mark(5);
     ctx.flush(0);
 }
@@ -839,10 +849,8 @@ template <typename T> struct ColArgs {
     long long u_elems;        // independent units (see RowArgs): field elements per unit; P / Theta advance by 2 / 1 x ngroups x N
     int u_part;
     int prio;                 // see RowArgs
-#if SSF_CHAIN
-    int stagger, stagger_lo, stagger_hi;   // see RowArgs (experiment builds only: SSF_COL_STAGGER)
-    Chain chain;
-#endif
+    int tw_off;               // see RowArgs
+    const void *tw0;          // global twiddle table of pass 0 (three-pass columns: tw_entry_t<T>[N1]) or nullptr
 };
 
 // Arguments of unit u of a batch of independent units: every pointer moved to the unit's block.  The kernel bodies never
@@ -941,14 +949,6 @@ template <typename T, int LG, class Ctx, bool RAGGED = false, int V = 16> struct
     template <typename W> SSF_HD void st(W *ptr, long long i, W x) const {
         if (!RAGGED || valid) ptr[i] = x;
     }
-    // the same with a streaming policy bit (fused_core.h: SSF_MEMPOL)
-    template <int BIT, typename U> SSF_HD cx<U> ldp(const cx<U> *ptr, long long i) const {
-        if (RAGGED && !valid) return cx<U>{};
-        return ld_pol<BIT>(ptr + i);
-    }
-    template <int BIT, typename U> SSF_HD void stp(cx<U> *ptr, long long i, cx<U> x) const {
-        if (!RAGGED || valid) st_pol<BIT>(ptr + i, x);
-    }
 };
 
 // inter-pass twiddle of the N = N1*N2 decomposition, applied on the frequency side of the
@@ -964,23 +964,24 @@ template <int SIGN, bool RAGGED, typename T, class G> SSF_HD void global_twiddle
         w0 = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.b) & (N - 1)), log2N));
         ws = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.p.tpf) & (N - 1)), log2N));
     }
+    // t[q] = w0 * ws^q by doubling: ws^2, ws^4, ws^8, then t[q + 2^k] = t[q] * ws^(2^k) -- 18 complex products of depth <= 7
+    // (a power tree of ws followed by w0 * ws^q costs 30); rounded once, where it is applied (see tw_powers)
     constexpr int V = G::kV;
-    cx<double> w[16];                        // (double tree, rounded once: see tw_powers)
-    if constexpr (V == 16) powers16(ws, w);
-    else {
-        w[0] = mk<double>(1.0, 0.0);
-        w[1] = ws;
-        w[2] = ws * ws;
-        w[3] = w[2] * ws;
-        w[4] = w[2] * w[2];
-        w[5] = w[4] * ws;
-        w[6] = w[3] * w[3];
-        w[7] = w[4] * w[3];
+    cx<double> t[V];
+    const cx<double> s2 = ws * ws, s4 = s2 * s2;
+    t[0] = w0;
+    t[1] = w0 * ws;
+    t[2] = t[0] * s2;
+    t[3] = t[1] * s2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[4 + q] = t[q] * s4;
+    if constexpr (V == 16) {
+        const cx<double> s8 = s4 * s4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[8 + q] = t[q] * s8;
     }
 #pragma unroll
-    for (int q = 0; q < V; ++q) {
-        v[q] = mul_by_d(v[q], w0 * w[q]);
-    }
+    for (int q = 0; q < V; ++q) v[q] = mul_by_d(v[q], t[q]);
 }
 
 // exchange V per-thread values with the partner thread (same column/butterfly, other
@@ -1102,11 +1103,8 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     // the sines and cosines are evaluated.  To make room the loop keeps nothing but the two phases per sample:
     // rotation and |d rot|^2 go to LDS and all sixteen come back from there (own and partner's alike) once the
     // partners have met.
-#ifndef SSF_EHD_EARLY
-#define SSF_EHD_EARLY (V / 2)
-#endif
 #pragma unroll
-    for (int idx = 0; idx < SSF_EHD_EARLY; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
+    for (int idx = 0; idx < H; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
 #pragma unroll
     for (int j = 0; j < H; ++j) {
         const long long t = own_time_off(g, j);
@@ -1119,7 +1117,7 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     }
     ctx.mark(7);
 #pragma unroll
-    for (int idx = SSF_EHD_EARLY; idx < V; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
+    for (int idx = H; idx < V; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
     ctx.sync();
 #pragma unroll
     for (int idx = 0; idx < V; ++idx) {
@@ -1241,9 +1239,6 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     bool final_ = false, more = false, exact0 = true;
     struct { int state, it, cur, pcur; double z, hz; } c{};
     double *red = (double *)ctx.lds;
-#if SSF_CHAIN
-    if (a.stagger > 0 && ctx.bid >= a.stagger_lo && ctx.bid < a.stagger_hi) ctx.sleep64(a.stagger);
-#endif
     ctx.mark(0);
     if (kMk) {
         MkColStage st;
@@ -1283,15 +1278,25 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     }
 
     // ---- inverse column transform: G -> time samples in registers -------------------------
+    TwSrc<T> tws;
     if (do_inv) {
 #pragma unroll
-        for (int q = 0; q < V; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
+        for (int q = 0; q < V; ++q) v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+    }
+    if (SSF_TW_TAB && a.tw_off > 0) {                       // (built while the loads are in flight)
+        tw_entry_t<T> *tab = (tw_entry_t<T> *)(ctx.lds + a.tw_off);
+        tw_lds_build<T>(ctx, p, tab);
+        tws.lds = tab;
+        tws.g0 = (const tw_entry_t<T> *)a.tw0;
+        if (do_inv && p.npass == 2) ctx.sync();             // (otherwise an exchange barrier comes before the table's first use)
+    }
+    if (do_inv) {
         ctx.mark(1);
-        if (SSF_PRIO && a.prio) ctx.template setprio<3>();
+        if (a.prio) ctx.template setprio<3>();
         global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v);
-        fft_dif<+1, V, 2>(ctx, p, g.b, v, lds);
+        fft_dif<+1, V>(ctx, p, g.b, v, lds, tws);
         ctx.mark(2);
-        if (SSF_PRIO && a.prio) ctx.template setprio<2>();
+        if (a.prio) ctx.template setprio<2>();
     } else if (!(kMk && op == 3)) {
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
@@ -1319,8 +1324,8 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) {
                 const long long t = g.time_off(idx);
-                if (op == 1) g.template stp<2>(a.Ehd, g.rowbase + t, v[idx]);
-                else v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + t);
+                if (op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
+                else v[idx] = g.ld(a.Ehd, g.rowbase + t);
             }
             cx<T> rot[V];
             ctx.sync();                              // inverse transform's LDS reads are done
@@ -1343,7 +1348,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
             }
             if (final_) {                            // the field after this step (channels.py:438-439)
 #pragma unroll
-                for (int idx = 0; idx < V; ++idx) g.template stp<2>(Tnew, g.rowbase + g.time_off(idx), v[idx]);
+                for (int idx = 0; idx < V; ++idx) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
             } else {
                 mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
                 if (!exact0) d0 = psum;              // exact denominator of the bound: sum Pch over the tile
@@ -1370,15 +1375,15 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 
     // ---- forward column transform: registers -> G -------------------------------------------
     ctx.mark(3);
-    if (SSF_PRIO && a.prio) ctx.template setprio<1>();
+    if (a.prio) ctx.template setprio<1>();
     if (do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
-        fft_dit<-1, V, 1>(ctx, p, g.b, v, lds);
+        fft_dit<-1, V>(ctx, p, g.b, v, lds, tws);
         global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
-        if (SSF_PRIO && a.prio) ctx.template setprio<0>();
+        if (a.prio) ctx.template setprio<0>();
 #pragma unroll
-        for (int q = 0; q < V; ++q) g.template stp<4>(a.G, g.rowbase + g.freq_off(q), v[q]);
+        for (int q = 0; q < V; ++q) g.st(a.G, g.rowbase + g.freq_off(q), v[q]);
         ctx.mark(5);
         ctx.flush(do_inv ? 0 : 1);
     }
@@ -1442,9 +1447,6 @@ SSF_HD void pk_step_start(Ctx &ctx, const G &g, const ColArgs<pf2> &a, const cx<
 
 template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2> &a) {
     using T = pf2;
-#if SSF_CHAIN
-    if (a.stagger > 0 && ctx.bid >= a.stagger_lo && ctx.bid < a.stagger_hi) ctx.sleep64(a.stagger);
-#endif
     ctx.mark(0);
     MkColStage st;
     mk_col_stage(ctx, a, st);
@@ -1460,12 +1462,22 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
     const long long psz = g.N * a.ngroups;
     float *Pcur = a.P + (st.c.pcur ? psz : 0), *Palt = a.P + (st.c.pcur ? 0 : psz);
 
+    TwSrc<T> tws;
     if (st.do_inv) {
 #pragma unroll
-        for (int q = 0; q < V; ++q) v[q] = g.template ldp<1>(a.G, g.rowbase + g.freq_off(q));
+        for (int q = 0; q < V; ++q) v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+    }
+    if (SSF_TW_TAB && a.tw_off > 0) {                       // (built while the loads are in flight)
+        tw_entry_t<T> *tab = (tw_entry_t<T> *)(ctx.lds + a.tw_off);
+        tw_lds_build<T>(ctx, p, tab);
+        tws.lds = tab;
+        tws.g0 = (const tw_entry_t<T> *)a.tw0;
+        if (st.do_inv && p.npass == 2) ctx.sync();
+    }
+    if (st.do_inv) {
         ctx.mark(1);
         global_twiddle<+1, false>(g, a.log2N1 + a.log2N2, v);
-        fft_dif<+1, V, 2>(ctx, p, g.b, v, lds);
+        fft_dif<+1, V>(ctx, p, g.b, v, lds, tws);
         ctx.mark(2);
     } else if (op != 3) {
 #pragma unroll
@@ -1482,8 +1494,8 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) {
             const long long t = g.time_off(idx);
-            if (op == 1) g.template stp<2>(a.Ehd, g.rowbase + t, v[idx]);
-            else v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + t);
+            if (op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
+            else v[idx] = g.ld(a.Ehd, g.rowbase + t);
         }
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) v[idx] = tmul(v[idx], cis_t<float>(shz * (c8g * (pw[idx] + pw[idx]) / 2.0f)));
@@ -1507,7 +1519,7 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
         }
         if (st.final_) {                                     // the field after this step (channels.py:438-439)
 #pragma unroll
-            for (int idx = 0; idx < V; ++idx) g.template stp<2>(Tnew, g.rowbase + g.time_off(idx), v[idx]);
+            for (int idx = 0; idx < V; ++idx) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
         } else {
             // next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
             // sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the note at the top of this file)
@@ -1528,7 +1540,7 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
             }
             ctx.mark(6);
 #pragma unroll
-            for (int idx = 0; idx < V; ++idx) v[idx] = g.template ldp<3>(a.Ehd, g.rowbase + g.time_off(idx));
+            for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) g.st(a.Theta, g.pbase + g.time_off(idx), pn[idx]);
             ctx.mark(7);
@@ -1569,11 +1581,11 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
 
     ctx.mark(3);
     if (st.do_fwd) {
-        fft_dit<-1, V, 1>(ctx, p, g.b, v, lds);
+        fft_dit<-1, V>(ctx, p, g.b, v, lds, tws);
         global_twiddle<-1, false>(g, a.log2N1 + a.log2N2, v);
         ctx.mark(4);
 #pragma unroll
-        for (int q = 0; q < V; ++q) g.template stp<4>(a.G, g.rowbase + g.freq_off(q), v[q]);
+        for (int q = 0; q < V; ++q) g.st(a.G, g.rowbase + g.freq_off(q), v[q]);
         ctx.mark(5);
         ctx.flush(st.do_inv ? 0 : 1);
     }

@@ -135,6 +135,13 @@ int ssf_plan_pipeline(const ssf_plan *plan) {
     return plan->engine->pipeline();
 }
 
+// ssf_plan_set_units rebuilds the engine; if that fails AND the rebuild with the old unit count fails too (out of memory twice) the
+// plan is left without one: every entry point that needs it says so instead of dereferencing a null pointer
+#define SSF_NEED_ENGINE(plan)                                                                                        \
+    do {                                                                                                             \
+        if (!(plan)->engine) return fail((plan), SSF_ERR_STATE, "the plan has no engine (ssf_plan_set_units failed)"); \
+    } while (0)
+
 int ssf_plan_set_units(ssf_plan *plan, int32_t n_units) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     if (n_units < 1 || plan->nrows % n_units) return fail(plan, SSF_ERR_BAD_ARG, "ssf_plan_set_units: nrows must be a multiple of n_units");
@@ -164,6 +171,7 @@ int ssf_plan_set_units(ssf_plan *plan, int32_t n_units) {
 int ssf_get_unit_stats(ssf_plan *plan, int32_t unit, ssf_stats *out) {
     if (!plan || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_get_unit_stats: NULL argument");
     ssf_stats u{};
+    SSF_NEED_ENGINE(plan);
     int rc = plan->engine->unit_stats(unit, &u);
     if (rc) return fail(plan, rc, "ssf_get_unit_stats: no such unit (or not a plan of independent units)");
     *out = plan->stats;
@@ -191,6 +199,7 @@ static int upload_common(ssf_plan *plan, const void *field, bool aos) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     if (!field) return fail(plan, SSF_ERR_BAD_ARG, "field is NULL");
     SSF_HIP(plan, hipSetDevice(plan->device));
+    SSF_NEED_ENGINE(plan);
     int rc = plan->engine->upload(field, aos);
     if (rc) return rc;
     plan->stats = ssf_stats{};
@@ -217,6 +226,7 @@ int ssf_execute(ssf_plan *plan, const ssf_params *params, int32_t span_first, in
     SSF_HIP(plan, hipSetDevice(plan->device));
     if (trace) trace->count = 0;
     if (span_first <= span_last) {
+        SSF_NEED_ENGINE(plan);
         rc = plan->engine->execute(*params, span_first, span_last, noise, &plan->stats, trace);
         if (rc) return rc;
     }
@@ -230,6 +240,7 @@ static int download_common(ssf_plan *plan, void *dst, int which, bool aos) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     if (!dst) return fail(plan, SSF_ERR_BAD_ARG, "destination is NULL");
     if (!plan->has_field) return fail(plan, SSF_ERR_STATE, "download before ssf_upload");
+    SSF_NEED_ENGINE(plan);
     if (which < -1 || which >= plan->engine->n_snapshots()) return fail(plan, SSF_ERR_BAD_ARG, "no such snapshot");
     SSF_HIP(plan, hipSetDevice(plan->device));
     return plan->engine->download(dst, which, aos);
@@ -241,6 +252,7 @@ int ssf_download_snapshots(ssf_plan *plan, void *snap_soa) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     if (!snap_soa) return fail(plan, SSF_ERR_BAD_ARG, "snapshot buffer is NULL");
     const size_t fb = (size_t)plan->N * plan->nrows * (plan->precision == SSF_C128 ? 16 : 8);
+    SSF_NEED_ENGINE(plan);
     for (int i = 0; i < plan->engine->n_snapshots(); ++i) {
         int rc = download_common(plan, (char *)snap_soa + (size_t)i * fb, i, false);
         if (rc) return rc;
@@ -277,12 +289,14 @@ int ssf_run(ssf_plan *plan, const ssf_params *params, const void *in, void *out,
 
 int ssf_set_coupling(ssf_plan *plan, ssf_reduce_fn reduce, void *ctx) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    SSF_NEED_ENGINE(plan);
     int rc = plan->engine->set_coupling(reduce, ctx);
     return rc ? fail(plan, rc, "coupled batches need the general-length engine (create the plan with SSF_ENGINE_ROCFFT)") : SSF_OK;
 }
 
 int ssf_set_profiling(ssf_plan *plan, int32_t enable) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    SSF_NEED_ENGINE(plan);
     int rc = plan->engine->set_profiling(enable);
     return rc ? fail(plan, rc, "per-kernel profiling is only available on the fused engine") : SSF_OK;
 }
@@ -290,6 +304,7 @@ int ssf_set_profiling(ssf_plan *plan, int32_t enable) {
 int ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     if (!out) return fail(plan, SSF_ERR_BAD_ARG, "out is NULL");
+    SSF_NEED_ENGINE(plan);
     int rc = plan->engine->kernel_times(out);
     return rc ? fail(plan, rc, "per-kernel profiling is only available on the fused engine") : SSF_OK;
 }
@@ -340,6 +355,7 @@ int ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, doubl
                        void *out) {
     int rc = ssf_upload(plan, in);
     if (rc) return rc;
+    SSF_NEED_ENGINE(plan);
     if ((rc = plan->engine->linear_channel(Fs, Fc, alpha, D, L))) return rc;
     return ssf_download(plan, out);
 }

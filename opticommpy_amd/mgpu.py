@@ -282,11 +282,14 @@ def run_sharded(fields, param, compute=None, gather=True, comm=None, root=None):
     # size): a rank's units of one shape go to the device as ONE batch of independent units -- every launch carries all of
     # them, each with its own control block, step sizes and convergence decisions (ssf_plan_set_units) -- with results
     # bit-equal to one call per unit.  SSF_MGPU_BATCH=0 turns it off; fields of 2^19 samples and more fill the GPU alone.
+    mine_left = list(mine)
     if default_compute and _batchable(local, mine, param):
-        _run_batched(local, list(mine), param, outs)
-        mine_left = []
-    else:
-        mine_left = list(mine)
+        from .models import UnitsUnsupported
+        try:
+            _run_batched(local, list(mine), param, outs)
+            mine_left = []
+        except UnitsUnsupported:           # rocFFT / Bluestein / one-launch-row plans (set_engine('rocfft'), N = 1500, 3000, 30030 ...)
+            pass                           # carry no independent units: one call per unit on the lanes, as include/ssf.h says
     # Two lanes per GPU: the rank's units are taken by two host threads (each with its own plan and stream; ctypes
     # releases the GIL inside the library), so that one unit's transfers overlap the other's kernels and the kernels of
     # two independent fields fill each other's load / store phases (ssf_mgpu_run does the same).
@@ -410,11 +413,23 @@ def run_coupled(Ei_block, param, comm):
     # rows of the coupled batch held by the ranks before this one: with amp='edfa' and a fixed seed every rank keys the
     # same Philox stream, and its pairs must draw THEIR rows of it (independent noise per column, like the single call)
     counts = comm.allgather(np.array([float(np.shape(Ei_block)[1])]))
-    param._rng_row_offset = int(round(float(np.sum(counts[:comm.rank]))))
+    # (on top of an offset the caller may carry already -- run_sharded gives unit u the rows u * ncols -- and on a copy: the
+    #  caller's object keeps what it had)
+    p = copy.copy(param)
+    base = int(getattr(param, "_rng_row_offset", 0))
     try:
-        return manakovSSF(Ei_block, param, _coupling=comm)
-    finally:
-        del param._rng_row_offset
+        p._rng_row_offset = base + int(round(float(np.sum(counts[:comm.rank]))))
+    except AttributeError:
+        p = param
+    out = manakovSSF(Ei_block, p, _coupling=comm)
+    if p is not param:                     # the reference writes defaults back onto the caller's object (channels.py:305-322)
+        for k, v in vars(p).items():
+            if k != "_rng_row_offset" and not hasattr(param, k):
+                try:
+                    setattr(param, k, v)
+                except AttributeError:
+                    pass
+    return out
 
 
 def run_threads(fields, cparams, devices, precision=np.complex128, engine="auto"):

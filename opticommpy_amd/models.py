@@ -54,6 +54,11 @@ def checkGPU():
 # ----------------------------------------------------------------------------
 # plan cache: one handle per (device, N, nrows, precision, engine)
 # ----------------------------------------------------------------------------
+class UnitsUnsupported(RuntimeError):
+    """ssf_plan_set_units refused: this plan's pipeline (rocFFT / Bluestein / one-launch rows) cannot carry independent units;
+    the caller falls back to one call per unit (include/ssf.h)."""
+
+
 class _Plan:
     def __init__(self, device, N, nrows, prec_code, engine, units=1):
         self.lib = _lib.load()
@@ -64,6 +69,8 @@ class _Plan:
             rc = self.lib.ssf_plan_set_units(h, units)
             if rc:
                 try:
+                    if rc == -6:
+                        raise UnitsUnsupported(_lib.error_message(self.lib, h, rc))
                     _lib.raise_for(self.lib, h, rc)
                 finally:
                     self.lib.ssf_plan_destroy(h)

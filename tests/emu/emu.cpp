@@ -32,8 +32,6 @@ struct EmuCtx {
     void mark(int) {}
     void flush(int) {}
     void issue_fence() {}
-    void sleep64(int) {}
-    void drain() {}
     template <int P> void setprio() {}
     double wave_sum(double v) { return v; }
     double wave_max(double v) { return v; }
@@ -145,9 +143,6 @@ struct EmuBackend {
     }
     void memset(void *d, int v, size_t n) { ::memset(d, v, n); }
     void prepare(size_t, size_t) {}
-    void chain_begin() {}                              // (chained launches: a GPU scheduling matter, nothing to emulate)
-    void chain_end() {}
-    bool chain_aborted() const { return false; }
     void sync() {}
     bool ok() const { return true; }
     std::string last_error() const { return ""; }

@@ -1,8 +1,8 @@
 """A K > 1 batch of ONE reference call spread over two processes (mgpu.run_coupled / ssf_set_coupling): every process
 holds one polarisation pair, the engine's max(phi) and norm sums are all-reduced before they are used, and each process
-returns its columns of the single coupled call (reference optic/models/channels.py:394, 517-519).  Both processes share
-GPU 0 here (the product's communicator, RCCL, refuses two ranks on one device, so the gloo stand-in carries the 8- and
-16-byte all-reduces)."""
+returns its columns of the single coupled call (reference optic/models/channels.py:394, 517-519).  Rank r runs on
+GPU r % count: on a one-GPU box both share GPU 0 (the product's communicator, RCCL, refuses two ranks on one device, so the
+gloo stand-in carries the 8- and 16-byte all-reduces; tests/test_multi_gpu_rccl.py runs the same over RCCL where two GPUs exist)."""
 import os
 import socket
 import subprocess
@@ -23,7 +23,8 @@ from opticommpy_amd import mgpu, models
 from helpers import synth_field, make_param
 from comm_gloo import GlooComm
 comm = GlooComm()
-oa.set_device(0)
+from opticommpy_amd import _lib
+oa.set_device(comm.rank % max(1, _lib.load().ssf_device_count()))       # (rank r on device r % count)
 E = np.concatenate([synth_field(4096, 2, 11, 3.0), synth_field(4096, 2, 12, 12.0)], axis=1)      # two pairs, 9 dB apart
 cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=8, Lspan=4, hz=0.5,
            nlprMethod=True, maxNlinPhaseRot=1e-2, amp="ideal", saveSpanN=[])

@@ -51,7 +51,7 @@ def test_linear_channel_c64_and_large():
     assert rel_l2(eb.linear_channel(E, 512e9, 193.1e12, 0.2, 16, 2.0), ref) < 1e-13
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith(("rx_", "tx_", "long_"))])
+@pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith(("rx_", "tx_", "long_", "wl_"))])
 def test_golden_vectors_on_emulated_kernels(name):
     d, cfg = load_golden(name)
     N = d["Ei"].shape[0]
@@ -493,3 +493,32 @@ def test_one_launch_linear_step_at_short_smooth_lengths(N, in_place):
     assert rel_l2(eb.rows_lin(x, hzh, lin_a, lin_b, w_scale, in_place), ref) <= 1e-13
     ref32 = ref.astype(np.complex64)
     assert rel_l2(eb.rows_lin(x.astype(np.complex64), hzh, lin_a, lin_b, w_scale, in_place), ref32) <= 2e-6
+
+
+# ---- round 4: twiddle tables (fused_kernels.h: TwSrc) ----------------------------------------------------------------------
+@pytest.mark.parametrize("l1,prec", [(4, "complex128"), (10, "complex128"), (4, "complex64"), (10, "complex64"), (5, "complex128")])
+def test_three_pass_transforms_read_pass0_twiddles_from_the_global_table(monkeypatch, l1, prec):
+    """Rows of 1024 (2^14 = 16 x 1024: passes 16 . 4 . 16) and columns of 1024 (1024 x 16) are three-pass transforms: pass 0
+    takes its twiddles from the plan's global table, pass 1 from the workgroup's LDS table, in double precision and as
+    hi + lo float quadruples (packed complex64 pairs); 2^5 x 512 rows: passes 16 . 2 . 16.  Same results as the oracle, same
+    iteration counts; the linear channel (one-row kernels, their own table offsets) too."""
+    monkeypatch.setenv("SSF_SPLIT_L1", str(l1))
+    monkeypatch.setenv("SSF_ROW_V", "16")
+    monkeypatch.setenv("SSF_COL_V", "16")
+    N = 1 << 14
+    dt = np.complex64 if prec == "complex64" else np.complex128
+    E = synth_field(N, 2, 43, 8.4).astype(dt)
+    cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5, prgsBar=False,
+               Ltotal=0.48, Lspan=0.24, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[], prec=prec)
+    tr = {}
+    q = make_param(orc.parameters, cfg)
+    q.prec = dt
+    ref = orc.manakovSSF(E, q, trace=tr)
+    out, info = eb.run("manakovSSF", E, cfg)
+    if prec == "complex128":
+        assert rel_l2(out.T, ref) <= TOL_C128 and list(info["iters"]) == tr["iters"]
+        p = orc.parameters()
+        p.Fs, p.L, p.alpha, p.D, p.Fc = 512e9, 3.0, 0.2, 16, 193.1e12
+        assert rel_l2(eb.linear_channel(E, 512e9, 193.1e12, 0.2, 16, 3.0), orc.linearFiberChannel(E, p)) < 1e-13
+    else:
+        assert rel_l2(out.T, ref) <= 5e-5

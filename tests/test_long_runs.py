@@ -32,7 +32,7 @@ def _input(cfg, dtype=np.complex128):
 
 
 def _run_cfg(cfg):
-    return {k: v for k, v in cfg.items() if k not in ("synth", "dec")}
+    return {k: v for k, v in cfg.items() if k not in ("synth", "dec", "steps")}
 
 
 def _check(d, cfg, out, iters, lims, tol=1e-10):
@@ -110,6 +110,53 @@ def test_c64_stays_closer_to_the_reference_c128_result_than_the_reference_c64_pa
         assert dev <= 5e-4, (span, dev)
         assert dev <= max(float(d["ref_c64_rel_l2"][i]), 5e-5), (span, dev, float(d["ref_c64_rel_l2"][i]))
         assert abs(pr - 1) <= 2e-4, (span, pr)
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 3's own field
+# tests/golden/wl_cfg3_n22.npz (tools/gen_golden.py cfg3): the REFERENCE on config 3's field -- 2^22 samples, seed 3, 8.4 dBm,
+# complex64 samples -- for six passes of the step loop, in complex128 (samples cast up) and in its complex64 mode.  The 2^22
+# split (1024 x 4096) is a template instantiation of its own: this is what pins it, in both precisions, and what the
+# full-length single-precision tests below (HIP complex64 against HIP complex128) stand on.
+def test_oracle_reproduces_the_reference_on_config3s_own_field():
+    d, cfg = load_golden("wl_cfg3_n22")
+    E64 = _input(cfg, np.complex64)
+    tr = {}
+    out = orc.manakovSSF(E64.astype(np.complex128), make_param(orc.parameters, dict(_run_cfg(cfg), prec="complex128")), trace=tr)
+    assert tr["iters"] == list(d["iters128"])
+    np.testing.assert_allclose(np.concatenate([np.asarray(r, dtype=float) for r in tr["lims"]]), d["lims128"], rtol=1e-12)
+    assert np.array_equal(out[:: int(cfg["dec"])], d["out128_dec"])
+
+
+@pytest.mark.gpu
+def test_config3_first_steps_against_the_reference_at_full_size():
+    """HIP complex128 at 2^22: the reference's iteration list, lims to 1e-6, field to 1e-10 (decimated output, per-column power,
+    a seeded projection of all 2^23 output samples).  HIP complex64 (packed pairs): inside the 5e-4 gate of SURVEY 8c against
+    the reference's complex128 result AND against the reference's own complex64 result."""
+    import opticommpy_amd as oa
+    from opticommpy_amd import models
+    d, cfg = load_golden("wl_cfg3_n22")
+    dec, run = int(cfg["dec"]), _run_cfg(cfg)
+    E64 = _input(cfg, np.complex64)
+    out = oa.manakovSSF(E64.astype(np.complex128), make_param(oa.parameters, dict(run, prec="complex128")), _trace=True)
+    r128 = dict(models.last_run)
+    assert r128["engine"] == "fused" and r128["steps"] == int(cfg["steps"])
+    assert list(r128["iters"]) == list(d["iters128"])
+    flat = np.concatenate([np.asarray(r, dtype=float) for r in r128["lims"]])
+    np.testing.assert_allclose(flat, d["lims128"], rtol=1e-6, atol=1e-15)
+    assert rel_l2(out[::dec], d["out128_dec"]) <= 1e-10
+    np.testing.assert_allclose(np.sum(np.abs(out) ** 2, axis=0), d["out128_power"], rtol=1e-9)
+    scale = np.sqrt(np.sum(d["out128_power"]))
+    assert np.max(np.abs(projection(out) - d["out128_proj"])) <= 1e-9 * scale
+    o64 = oa.manakovSSF(E64, make_param(oa.parameters, dict(run, prec="complex64")), _trace=True)
+    r64 = dict(models.last_run)
+    assert o64.dtype == np.complex64 and r64["steps"] == int(cfg["steps"])
+    assert list(r64["iters"]) == list(d["iters64"])                     # (no lim near tol in these six steps)
+    assert rel_l2(o64[::dec], d["out128_dec"]) <= 5e-4
+    assert rel_l2(o64[::dec], d["out64_dec"]) <= 5e-4
+    assert np.max(np.abs(projection(o64) - d["out128_proj"])) <= 5e-4 * scale
+    np.testing.assert_allclose(np.sum(np.abs(o64.astype(np.complex128)) ** 2, axis=0), d["out128_power"], rtol=2e-4)
+    # and the HIP complex64 result is at least as close to the complex128 truth as the reference's complex64 path (9.3e-7 here)
+    assert rel_l2(o64[::dec], d["out128_dec"]) <= max(3.0 * float(d["ref_c64_rel_l2"]), 5e-6)
 
 
 @pytest.mark.gpu

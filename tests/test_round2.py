@@ -140,25 +140,6 @@ def test_any_length_runs_on_the_fused_kernels(N, prec):
 
 
 @pytest.mark.gpu
-def test_persistent_span_kernel_matches_the_launch_sequence(monkeypatch):
-    """ssfm with every stage of a span in one persistent launch (grid barrier between stages; off by default because it
-    measured slower, SSF_PERSIST=<grid> turns it on): same kernel bodies (other tile widths, so rounding-level
-    differences only)."""
-    from opticommpy_amd import models
-    E = synth_field(1 << 16, 1, 1, 0.0).reshape(-1) * np.sqrt(2)
-    cfg = dict(Fs=512e9, Ltotal=100, Lspan=50, hz=0.5, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, amp="ideal", prgsBar=False, saveSpanN=[])
-    out = {}
-    for mode in ("0", "256"):
-        monkeypatch.setenv("SSF_PERSIST", mode)
-        models.release_plans()
-        out[mode] = oa.ssfm(E, make_param(oa.parameters, cfg))
-    monkeypatch.delenv("SSF_PERSIST")
-    models.release_plans()
-    assert rel_l2(out["256"], out["0"]) <= 1e-12
-    assert rel_l2(out["256"], orc.ssfm(E, make_param(orc.parameters, cfg))) <= 1e-10
-
-
-@pytest.mark.gpu
 def test_largest_complex64_length_runs_on_packed_pairs():
     """N = 2^23 complex64 (the largest fused length): packed pairs with a 1024 x 8192 split; two steps against the oracle."""
     from opticommpy_amd import models

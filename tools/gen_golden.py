@@ -20,7 +20,7 @@ Output: tests/golden/<case>.npz, each holding
               output decimated by cfg["dec"], its per-column power and a seeded random projection of the full
               output (so an error anywhere in the array shows), see long_vectors()
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|tx|long|long20]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|tx|long|long20|cfg3|units45 [log2n]]
 """
 import json
 import os
@@ -470,9 +470,98 @@ def long20_vector():
     run_long("long_c2_n20", "manakovSSF", (1 << 20, 2, 2, 8.4), dict(c2), dec=512)
 
 
+def cfg3_vector(steps=6):
+    """BASELINE config 3's own field (2^22 samples, seed 3, 8.4 dBm, complex64 samples) through the reference for `steps`
+    passes of the step loop, in complex128 (the samples cast up) and in the reference's complex64 mode (complex64 input +
+    prec=complex64): the base the full-length single-precision tests stand on.  About 1 minute."""
+    import time
+    os.makedirs(OUT, exist_ok=True)
+    N, dec = 1 << 22, 2048
+    synth = (N, 2, 3, 8.4)
+    kw = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False,
+              Ltotal=(steps - 0.5) * 0.08, Lspan=(steps - 0.5) * 0.08, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
+    E64 = synth_field(*synth, np.complex64)
+    arrs = {}
+    for tag, Ei, prec in (("128", E64.astype(np.complex128), np.complex128), ("64", E64, np.complex64)):
+        t0 = time.time()
+        p = mk_param(**dict(kw, prec=prec))
+        with Tracer(ref_ch) as tr:
+            out = ref_ch.manakovSSF(Ei, p)
+        assert out.dtype == np.dtype(prec) and out.shape == (N, 2)
+        iters = np.array(split_iters(tr.lims, p.tol, p.maxIter), dtype=np.int8)
+        assert len(iters) == steps
+        o = out.astype(np.complex128)
+        arrs.update({"iters" + tag: iters, "lims" + tag: np.array(tr.lims), "out%s_dec" % tag: out[::dec].copy(),
+                     "out%s_power" % tag: np.sum(np.abs(o) ** 2, axis=0), "out%s_proj" % tag: projection(out)})
+        print(f"cfg3 complex{tag}: iters {iters.tolist()}  {time.time()-t0:.0f} s", flush=True)
+        if tag == "128":
+            o128 = o
+        else:
+            arrs["ref_c64_rel_l2"] = float(np.linalg.norm(o - o128) / np.linalg.norm(o128))
+    cfg = json.loads(cfg_json("manakovSSF", kw))
+    cfg["synth"], cfg["dec"], cfg["steps"] = list(synth), dec, steps
+    sz = save("wl_cfg3_n22", cfg=json.dumps(cfg), **arrs)
+    print(f"wl_cfg3_n22: reference complex64 vs complex128 after {steps} steps: {arrs['ref_c64_rel_l2']:.2e}  {sz/1024:.0f} KiB", flush=True)
+
+
+def unit_checksum(out_cols, seed=4242):
+    """bench.py's per-unit checksum of an (N, ncols) reference output: sum |E|^2 and <q, E> over the (ncols, N) SoA block
+    with the seeded unit-variance complex vector q (bench.py: unit_checksum)."""
+    o = np.ascontiguousarray(out_cols.T).astype(np.complex128)
+    rng = np.random.default_rng(seed)
+    q = (rng.normal(size=o.shape) + 1j * rng.normal(size=o.shape)) / np.sqrt(2)
+    return float(np.sum(np.abs(o) ** 2)), complex(np.vdot(q, o))
+
+
+def units45_vector(steps=8, log2n=20):
+    """Every unit of BASELINE configs 4 and 5 through the reference for `steps` passes at the workload's own size
+    (bench.py: config 4 = seeds 100..115, launch powers 0.4..7.9 dBm; config 5 = seeds 200..207 at 8.4 dBm, forward leg then
+    manakovDBP over the same span with hz 0.08): the per-unit (sum |E|^2, <q, E>) that bench.py reports as unit_checksums
+    (VERDICT round 3, item 1b).  About 4 minutes at 2^20."""
+    import time
+    os.makedirs(OUT, exist_ok=True)
+    N = 1 << log2n
+    L = (steps - 0.5) * 0.08
+    kw = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False,
+              Ltotal=L, Lspan=L, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
+    import optic.dsp.equalization as ref_eq
+    t0 = time.time()
+    c4, it4 = [], []
+    for u in range(16):
+        E = synth_field(N, 2, 100 + u, 8.4 - 8.0 + 0.5 * u)
+        with Tracer(ref_ch) as tr:
+            out = ref_ch.manakovSSF(E, mk_param(**kw))
+        pw, pr = unit_checksum(out)
+        c4.append([pw, pr.real, pr.imag])
+        it4.append(len(tr.lims))
+        print(f"config 4 unit {u:2d}: power {pw:.9e} iterations {len(tr.lims)}  {time.time()-t0:.0f} s", flush=True)
+    c5, c5f, it5 = [], [], []
+    for u in range(8):
+        E = synth_field(N, 2, 200 + u, 8.4)
+        with Tracer(ref_ch) as tr:
+            fwd = ref_ch.manakovSSF(E, mk_param(**kw))
+        with Tracer(ref_eq) as trb:
+            back = ref_dbp(fwd, mk_param(**kw))
+        pw, pr = unit_checksum(back)
+        pwf, prf = unit_checksum(fwd)
+        c5.append([pw, pr.real, pr.imag])
+        c5f.append([pwf, prf.real, prf.imag])
+        it5.append([len(tr.lims), len(trb.lims)])
+        print(f"config 5 unit {u:2d}: power {pw:.9e} iterations {it5[-1]}  {time.time()-t0:.0f} s", flush=True)
+    cfg = json.loads(cfg_json("manakovSSF+manakovDBP", kw))
+    cfg.update(steps=steps, log2n=log2n, checksum_seed=4242)
+    sz = save("wl_units45_n%d" % log2n, cfg=json.dumps(cfg), c4=np.array(c4), c4_iterations=np.array(it4), c5=np.array(c5),
+              c5_forward=np.array(c5f), c5_iterations=np.array(it5))
+    print(f"wl_units45_n{log2n}: {sz} B  {time.time()-t0:.0f} s", flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "long20":  # only the full-size config-2 vector
         long20_vector()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cfg3":    # config 3's own field, a few steps, complex128 and complex64
+        cfg3_vector()
+    elif len(sys.argv) > 1 and sys.argv[1] == "units45":  # every unit of configs 4 / 5 at workload size
+        units45_vector(log2n=int(sys.argv[2]) if len(sys.argv) > 2 else 20)
     elif len(sys.argv) > 1 and sys.argv[1] == "long":    # only the long-run vectors
         long_vectors()
     elif len(sys.argv) > 1 and sys.argv[1] == "tx":      # only the transmitter vectors

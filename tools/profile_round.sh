@@ -8,9 +8,9 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/${TAG}_c$CFG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout 600 python bench.py --config $CFG --steps $STEPS --warmup 20 > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 600 python bench.py --config $CFG --no-also --steps $STEPS --warmup 20 > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp
-BENCH="python $REPO/bench.py --config $CFG --no-cpu-baseline --no-kernel-times"
+BENCH="python $REPO/bench.py --config $CFG --no-cpu-baseline --no-kernel-times --no-also"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- $BENCH --steps $STEPS --warmup 10 > "$OUT/kt.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pf" -o pf -- $BENCH --steps $STEPS --warmup 0 > "$OUT/pf.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pw" -o pw -- $BENCH --steps $STEPS --warmup 0 > "$OUT/pw.log" 2>&1
