@@ -56,7 +56,7 @@ class RxParams(C.Structure):
                 ("R", C.c_double), ("Tc", C.c_double), ("Id", C.c_double), ("RL", C.c_double), ("B", C.c_double),
                 ("IpdSat", C.c_double), ("N", C.c_int32), ("fType", C.c_int32), ("ideal", C.c_int32),
                 ("shotNoise", C.c_int32), ("thermalNoise", C.c_int32), ("currentSaturation", C.c_int32),
-                ("bandwidthLimitation", C.c_int32), ("pad_", C.c_int32), ("rng_seed", C.c_int64)]
+                ("bandwidthLimitation", C.c_int32), ("pad_", C.c_int32), ("rng_seed", C.c_int64), ("Fs_pd", C.c_double)]
 
 
 class TxParams(C.Structure):

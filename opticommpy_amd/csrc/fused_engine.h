@@ -134,8 +134,7 @@ template <typename T, class Backend> class FusedCore {
     int mix_rows = 1;            // rows per workgroup there
     MixPlan mix_plan{};          // radices of the row passes, chosen for the threads a row gets
     cx<double> *wtab = nullptr;  // cis(-2 pi k / N2mix)
-    void *tw0_row = nullptr, *tw0_col = nullptr;   // pass-0 twiddle tables of three-pass row / column transforms (fused_kernels.h: TwSrc)
-    int row_tw_off = 0, col_tw_off_mk = 0, col_tw_off_1 = 0;   // LDS offsets of the workgroups' twiddle tables
+    int row_tw_off = 0;          // LDS offset of the row workgroups' twiddle table (single precision; 0 = none)
     size_t field_bytes;
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
     S *P = nullptr, *Theta = nullptr;
@@ -265,20 +264,14 @@ template <typename T, class Backend> class FusedCore {
             row_block = fpw * tpf2;
             row_grid = (int)(nfft / fpw);
             row_lds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2) * sizeof(C), (size_t)row_block * 16 + 2048);
-            if (SSF_TW_TAB) {                                  // the workgroup's twiddle table behind the transform area
-                row_tw_off = (int)((row_lds + 15) / 16 * 16);
-                row_lds = (size_t)row_tw_off + kTwLdsBytes;
+            if ((SSF_TW_TAB & 1) && sizeof(S) == 4) {          // single precision: the workgroup's twiddle table behind the transform
+                row_tw_off = (int)((row_lds + 15) / 16 * 16);  // area (fused_kernels.h: TwSrc; double precision and the column
+                row_lds = (size_t)row_tw_off + kTwLdsBytes;    // stages are faster without: profiles/r4_ab_twiddle_tables.txt)
             }
         }
         if (const char *e = std::getenv("SSF_C64_PACKED")) use_packed = std::atoi(e) != 0;
         col_geometry(pairs_u(), kPacked ? 1 : 2, &col_block_mk, &col_grid_mk, &col_lds_mk);
         col_geometry(rows_u(), 1, &col_block_1, &col_grid_1, &col_lds_1);
-        if (SSF_TW_TAB) {
-            col_tw_off_mk = (int)((col_lds_mk + 15) / 16 * 16);
-            col_lds_mk = (size_t)col_tw_off_mk + kTwLdsBytes;
-            col_tw_off_1 = (int)((col_lds_1 + 15) / 16 * 16);
-            col_lds_1 = (size_t)col_tw_off_1 + kTwLdsBytes;
-        }
         npart_max = std::max(col_grid_mk, col_grid_1);
         if (own_G && !(G = (C *)be.alloc(field_bytes))) return oom();
         if (!(T0 = (C *)be.alloc(field_bytes))) return oom();
@@ -297,28 +290,8 @@ template <typename T, class Backend> class FusedCore {
             }
             be.h2d(wtab, w.data(), sizeof(cx<double>) * (size_t)N2mix);
         }
-        if ((SSF_TW_TAB & 2) && !N2mix && !(tw0_row = make_tw0(sp.l2, row_v))) return oom();
-        if ((SSF_TW_TAB & 2) && !(tw0_col = make_tw0(sp.l1, col_v))) return oom();
         be.prepare(row_lds, std::max(col_lds_mk, col_lds_1));
         return SSF_OK;
-    }
-    // pass-0 twiddles of a three-pass transform of length 2^lg with V values per thread: entry [s * L_1 + j] =
-    // cis(-2 pi j s / L), j < L_1 = L / V, s < V; (void *)1 when the plan has fewer passes (nothing to tabulate)
-    void *make_tw0(int lg, int V) {
-        const PassPlan p = make_plan(lg, V == 16 ? 4 : 3);
-        if (p.npass < 3) return (void *)1;
-        const int L = 1 << lg, L1 = 1 << p.lgLn(0);
-        std::vector<tw_entry_t<T>> h((size_t)L);
-        for (int s = 0; s < (1 << p.lg(0)); ++s)
-            for (int j = 0; j < L1; ++j) {
-                const long long m = ((long long)j * s) & (L - 1);
-                double c, sn;
-                cis2pi_d(-(double)m / (double)L, c, sn);
-                h[(size_t)s * L1 + j] = tw_make<T>(mk<double>(c, sn));
-            }
-        void *d = be.alloc(sizeof(tw_entry_t<T>) * (size_t)L);
-        if (d) be.h2d(d, h.data(), sizeof(tw_entry_t<T>) * (size_t)L);
-        return d;
     }
     // second time-domain field, E_hd, Pch (two buffers) and the phase array: only the Manakov pipeline uses them
     int mk_buffers() {
@@ -337,8 +310,6 @@ template <typename T, class Backend> class FusedCore {
         for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)Theta, (void *)ctrl, (void *)linops, (void *)gbar,
                         (void *)part, (void *)wtab, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
             if (p) be.free(p);
-        for (void *p : {tw0_row, tw0_col})
-            if (p && p != (void *)1) be.free(p);
         for (C *s : snaps) be.free(s);
     }
 
@@ -396,7 +367,6 @@ template <typename T, class Backend> class FusedCore {
         a.vpt = row_v;
         a.prio = lanes_hint <= 1 ? 1 : 0;
         a.tw_off = N2mix ? 0 : row_tw_off;
-        a.tw0 = tw0_row == (void *)1 ? nullptr : tw0_row;
         return a;
     }
     ColArgs<T> col_args(int npol, int mode) const {
@@ -416,8 +386,6 @@ template <typename T, class Backend> class FusedCore {
         a.ngroups = pairs_u();
         a.vpt = col_v;
         a.prio = lanes_hint <= 1 ? 1 : 0;
-        a.tw_off = npol == 1 && !kPacked ? col_tw_off_1 : col_tw_off_mk;
-        a.tw0 = tw0_col == (void *)1 ? nullptr : tw0_col;
         a.u_elems = (long long)rows_u() * N;
         a.u_part = npart_max;
         const size_t ps = (size_t)units * (size_t)npart_max;       // one array of partial sums: [unit][npart_max]
@@ -513,7 +481,7 @@ template <typename T, class Backend> class FusedCore {
         be.h2d(linops, lo, sizeof(lo));
         // small N: the whole span in one persistent launch (engine_fused_impl.h: k_nlse_span) when both stage grids fit the
         // CUs with 256-thread workgroups
-        int pgrid = 0, prow = 0, pcol = 0;
+        int pgrid = 0, prow = 0, pcol = 0, ptw = 0;
         size_t plds = 0;
         if constexpr (Backend::kCanPersist && !kPacked) {
             const int tpf1 = (1 << sp.l1) / 16, tpf2 = (1 << sp.l2) / 16, lim = be.persist_limit();
@@ -527,6 +495,10 @@ template <typename T, class Backend> class FusedCore {
                         pgrid = std::max(prow, pcol);
                         plds = std::max((size_t)fpw * lds_slots_per_fft(1 << sp.l2), (size_t)Cc * lds_col_stride(1 << sp.l1, Cc, (int)sizeof(C))) * sizeof(C);
                         plds = std::max(plds, (size_t)256 * 16 + 2048);
+                        if ((SSF_TW_TAB & 1) && sizeof(S) == 4) {       // the row stage's twiddle table (single precision)
+                            ptw = (int)((plds + 15) / 16 * 16);
+                            plds = (size_t)ptw + kTwLdsBytes;
+                        }
                     }
                 }
             }
@@ -539,10 +511,9 @@ template <typename T, class Backend> class FusedCore {
                     a.row = row_args();
                     a.row.use_ctrl = 0;
                     a.row.vpt = 16;
-                    a.row.tw_off = 0;                               // (the merged kernel's LDS has no room for the tables)
+                    a.row.tw_off = ptw;
                     a.col = col_args(1, CM_NLSE_STEP);
                     a.col.vpt = 16;
-                    a.col.tw_off = 0;
                     a.col.T0 = E;
                     a.col.g_hz = (S)(p.gamma * p.hz);
                     a.col.npart = pcol;
@@ -686,7 +657,7 @@ template <typename T, class Backend> class FusedCore {
                 a.row.pden0 = part + 4 * (size_t)npart_max;
                 a.row.npart = col_grid_mk;
                 a.col = col_args(2, CM_MK);
-                a.col.tw_off = a.row.tw_off = 0;
+                a.row.tw_off = 0;
                 a.col.k = k;
                 a.col.npart = col_grid_mk;
                 a.ctrl = ctrl;

@@ -116,10 +116,12 @@ SSF_HD double pick_hz(const MkConst &k, double z, double maxphi) {
 // rounded once, where it is applied: in single precision a float tree gives every twiddle a magnitude error
 // that is the same at every step (w^s inherits s times the rounding of w), and those errors add up
 // coherently over thousands of steps (measured -0.26 % power after 2000 steps with a float tree).
-template <int R> SSF_HD void tw_powers(int sign, int j, int lgL, cx<double> *p) {
+SSF_HD cx<double> tw_base(int sign, int j, int lgL) {
     double c, s;
     cis2pi_d(scale_pow2((double)(sign * j), lgL), c, s);
-    const cx<double> w1 = mk<double>(c, s);
+    return mk<double>(c, s);
+}
+template <int R> SSF_HD void tw_powers(cx<double> w1, cx<double> *p) {
     p[0] = mk<double>(1.0, 0.0);
     p[1] = w1;
     if (R > 2) {
@@ -139,18 +141,32 @@ template <int R> SSF_HD void tw_powers(int sign, int j, int lgL, cx<double> *p) 
     }
 }
 
-// Where the twiddles of a transform come from (fused_core.h: tw_entry_t).  SSF_TW_TAB: bit 0 = the next-to-last pass reads them
-// from a table in LDS that the workgroup builds when it starts (j < r_last, s < r: at most 256 entries = 4 KiB; that pass is
-// pass 0 of a two-pass transform -- columns of 256 -- and pass 1 of a three-pass one -- rows of 4096, columns of 1024); bit 1 =
-// pass 0 of a three-pass transform reads them from a table in global memory ([s][j], L entries = 64 KiB for rows of 4096:
-// the same lines for every workgroup, L2-resident); everything else (and everything when a table is absent) is generated in
-// registers: one sincospi per butterfly + a double-precision power tree of depth <= 4, rounded once.
+// Where the twiddles of a transform come from.
+//  * Generated in registers (the default): one sincospi per pass for the base w = cis(2 pi j / L_i) + a double-precision
+//    power tree of depth <= 4, rounded once.  The library sincospi is ~100 issue slots (a Horner scheme whose 24
+//    coefficients are moved into registers one by one), as much as the tree and the fifteen products it feeds, and a
+//    kernel's forward and inverse transforms use conjugate bases: SSF_TW_REUSE keeps the bases of the first transform (4
+//    registers per pass; j is the same for every butterfly a thread carries in a pass >= 1, and in pass 0 there is one)
+//    and the second one conjugates them -- half the sincospi calls of a launch.
+//  * SSF_TW_TAB bit 0: the next-to-last pass (pass 0 of a two-pass transform, pass 1 of a three-pass one) reads its factors
+//    from a table in LDS that the workgroup builds when it starts (fused_core.h: tw_entry_t; j < r_last, s < r: at most 256
+//    entries = 4 KiB).  Measured (profiles/r4_ab_twiddle_tables.txt, same box): it pays only where a factor is expensive to
+//    make -- the hi + lo float quadruples of the single-precision rows (row launch 49.2 -> 47.2 us at config 3) -- and costs
+//    where the LDS is the busy unit already: double precision rows 20.8 -> 21.4 us, columns 25.5 -> 26.3 us, packed columns
+//    60.8 -> 62.1 us.  The host therefore offers the table (tw_off > 0) to the single-precision row stage only.  A second
+//    table for pass 0 of three-pass transforms in global memory (L2-resident, 64 KiB) gained nothing on top (rows 47.6 us)
+//    and cost double precision another 1.3 us per row launch: removed again.
 #ifndef SSF_TW_TAB
-#define SSF_TW_TAB 3
+#define SSF_TW_TAB 1
 #endif
+#ifndef SSF_TW_REUSE
+#define SSF_TW_REUSE 1
+#endif
+constexpr int kTwMaxPass = 5;
 template <typename T> struct TwSrc {
     const tw_entry_t<T> *lds = nullptr;      // table of pass npass - 2: entry [s * r_last + j]
-    const tw_entry_t<T> *g0 = nullptr;       // table of pass 0: entry [s * L_1 + j]
+    cx<double> base[kTwMaxPass];             // SSF_TW_REUSE: cis(+2 pi j / L_i) of the passes generated so far
+    bool have[kTwMaxPass] = {false, false, false, false, false};
 };
 constexpr int kTwLdsBytes = 4096;
 
@@ -168,93 +184,98 @@ template <typename T, class Ctx> SSF_HD void tw_lds_build(Ctx &ctx, const PassPl
 }
 
 // twiddles of the R values of one butterfly (bb) of pass i: v[s] *= cis(SIGN 2 pi j s / L_i), s = 1 .. R-1
-template <int SIGN, int R, typename T>
-SSF_HD void apply_tw(const PassPlan &p, int i, int bb, cx<T> *v, const TwSrc<T> &src) {
-    if ((SSF_TW_TAB & 1) && src.lds && i == p.npass - 2) {
+// (first: this is the first butterfly of the pass this thread carries -- the only one that may set / use the kept base)
+template <int SIGN, int R, bool TAB, typename T>
+SSF_HD void apply_tw(const PassPlan &p, int i, int bb, cx<T> *v, TwSrc<T> &src, bool first) {
+    if (TAB && i == p.npass - 2) {
         const int lgl = p.lg(p.npass - 1);
         const tw_entry_t<T> *e = src.lds + (bb & ((1 << lgl) - 1));
 #pragma unroll
         for (int s = 1; s < R; ++s) v[s] = tw_mul<(SIGN > 0)>(v[s], e[s << lgl]);
         return;
     }
-    if ((SSF_TW_TAB & 2) && src.g0 && i == 0 && p.npass >= 3) {
-        const int lgS = p.lgLn(0);
-        const tw_entry_t<T> *e = src.g0 + (bb & ((1 << lgS) - 1));
-#pragma unroll
-        for (int s = 1; s < R; ++s) v[s] = tw_mul<(SIGN > 0)>(v[s], e[s << lgS]);
-        return;
+    cx<double> w1;
+    const bool keep = SSF_TW_REUSE && i < kTwMaxPass && (first || i > 0);      // (pass >= 1: every butterfly of the thread has this j)
+    if (keep && src.have[i]) {
+        w1 = SIGN > 0 ? src.base[i] : conj(src.base[i]);
+    } else {
+        w1 = tw_base(SIGN, pass_j(p, i, bb), pass_lgLi(p, i));
+        if (keep) {
+            src.base[i] = SIGN > 0 ? w1 : conj(w1);
+            src.have[i] = true;
+        }
     }
     cx<double> w[R];
-    tw_powers<R>(SIGN, pass_j(p, i, bb), pass_lgLi(p, i), w);
+    tw_powers<R>(w1, w);
 #pragma unroll
     for (int s = 1; s < R; ++s) v[s] = mul_by_d(v[s], w[s]);
 }
 
 // butterflies of pass i for thread b (values v[u*r + q]); DIF: DFT then twiddle w^s.  V = values per thread (16, or 8 for
 // the 128-register kernels): a thread carries V / r butterflies of a radix-r pass.
-template <int SIGN, int V = 16, typename T>
-SSF_HD void dif_pass(const PassPlan &p, int i, int b, cx<T> *v, const TwSrc<T> &src = TwSrc<T>()) {
+template <int SIGN, int V = 16, bool TAB = false, typename T>
+SSF_HD void dif_pass(const PassPlan &p, int i, int b, cx<T> *v, TwSrc<T> &src) {
     const bool tw = p.lgLn(i) > 0;
     switch (p.lg(i)) {
     case 4:
         if constexpr (V >= 16) {
             dft16<SIGN>(v);
-            if (tw) apply_tw<SIGN, 16>(p, i, b, v, src);
+            if (tw) apply_tw<SIGN, 16, TAB>(p, i, b, v, src, true);
         }
         break;
     case 3:
 #pragma unroll
         for (int u = 0; u < V / 8; ++u) {
             dft8<SIGN>(v + 8 * u);
-            if (tw) apply_tw<SIGN, 8>(p, i, b + p.tpf * u, v + 8 * u, src);
+            if (tw) apply_tw<SIGN, 8, TAB>(p, i, b + p.tpf * u, v + 8 * u, src, u == 0);
         }
         break;
     case 2:
 #pragma unroll
         for (int u = 0; u < V / 4; ++u) {
             dft4<SIGN>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
-            if (tw) apply_tw<SIGN, 4>(p, i, b + p.tpf * u, v + 4 * u, src);
+            if (tw) apply_tw<SIGN, 4, TAB>(p, i, b + p.tpf * u, v + 4 * u, src, u == 0);
         }
         break;
     default:
 #pragma unroll
         for (int u = 0; u < V / 2; ++u) {
             dft2<SIGN>(v[2 * u], v[2 * u + 1]);
-            if (tw) apply_tw<SIGN, 2>(p, i, b + p.tpf * u, v + 2 * u, src);
+            if (tw) apply_tw<SIGN, 2, TAB>(p, i, b + p.tpf * u, v + 2 * u, src, u == 0);
         }
         break;
     }
 }
 
 // DIT: twiddle w^s then DFT (exact mirror of dif_pass with the opposite SIGN)
-template <int SIGN, int V = 16, typename T>
-SSF_HD void dit_pass(const PassPlan &p, int i, int b, cx<T> *v, const TwSrc<T> &src = TwSrc<T>()) {
+template <int SIGN, int V = 16, bool TAB = false, typename T>
+SSF_HD void dit_pass(const PassPlan &p, int i, int b, cx<T> *v, TwSrc<T> &src) {
     const bool tw = p.lgLn(i) > 0;
     switch (p.lg(i)) {
     case 4:
         if constexpr (V >= 16) {
-            if (tw) apply_tw<SIGN, 16>(p, i, b, v, src);
+            if (tw) apply_tw<SIGN, 16, TAB>(p, i, b, v, src, true);
             dft16<SIGN>(v);
         }
         break;
     case 3:
 #pragma unroll
         for (int u = 0; u < V / 8; ++u) {
-            if (tw) apply_tw<SIGN, 8>(p, i, b + p.tpf * u, v + 8 * u, src);
+            if (tw) apply_tw<SIGN, 8, TAB>(p, i, b + p.tpf * u, v + 8 * u, src, u == 0);
             dft8<SIGN>(v + 8 * u);
         }
         break;
     case 2:
 #pragma unroll
         for (int u = 0; u < V / 4; ++u) {
-            if (tw) apply_tw<SIGN, 4>(p, i, b + p.tpf * u, v + 4 * u, src);
+            if (tw) apply_tw<SIGN, 4, TAB>(p, i, b + p.tpf * u, v + 4 * u, src, u == 0);
             dft4<SIGN>(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
         }
         break;
     default:
 #pragma unroll
         for (int u = 0; u < V / 2; ++u) {
-            if (tw) apply_tw<SIGN, 2>(p, i, b + p.tpf * u, v + 2 * u, src);
+            if (tw) apply_tw<SIGN, 2, TAB>(p, i, b + p.tpf * u, v + 2 * u, src, u == 0);
             dft2<SIGN>(v[2 * u], v[2 * u + 1]);
         }
         break;
@@ -277,28 +298,37 @@ template <int V = 16, typename T> SSF_HD void lds_get(const PassPlan &p, int i, 
 }
 
 // DIF transform: v holds pass-0 positions on entry, pass-(p-1) positions (digit-reversed) on exit
-template <int SIGN, int V = 16, typename T, class Ctx>
-SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds, const TwSrc<T> &src = TwSrc<T>()) {
-    dif_pass<SIGN, V>(p, 0, b, v, src);
+template <int SIGN, int V = 16, bool TAB = false, typename T, class Ctx>
+SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds, TwSrc<T> &src) {
+    dif_pass<SIGN, V, TAB>(p, 0, b, v, src);
 #pragma unroll
     for (int i = 1; i < p.npass; ++i) {
         lds_put<V>(p, i - 1, b, v, lds);
         ctx.sync();
         lds_get<V>(p, i, b, v, lds);
-        dif_pass<SIGN, V>(p, i, b, v, src);
+        dif_pass<SIGN, V, TAB>(p, i, b, v, src);
     }
 }
 // DIT transform: v holds pass-(p-1) positions on entry, pass-0 positions (natural) on exit
-template <int SIGN, int V = 16, typename T, class Ctx>
-SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds, const TwSrc<T> &src = TwSrc<T>()) {
+template <int SIGN, int V = 16, bool TAB = false, typename T, class Ctx>
+SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds, TwSrc<T> &src) {
 #pragma unroll
     for (int i = p.npass - 1; i >= 1; --i) {
-        dit_pass<SIGN, V>(p, i, b, v, src);
+        dit_pass<SIGN, V, TAB>(p, i, b, v, src);
         lds_put<V>(p, i, b, v, lds);
         ctx.sync();
         lds_get<V>(p, i - 1, b, v, lds);
     }
-    dit_pass<SIGN, V>(p, 0, b, v, src);
+    dit_pass<SIGN, V, TAB>(p, 0, b, v, src);
+}
+
+template <int SIGN, int V = 16, typename T, class Ctx> SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
+    TwSrc<T> none;
+    fft_dif<SIGN, V, false>(ctx, p, b, v, lds, none);
+}
+template <int SIGN, int V = 16, typename T, class Ctx> SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds) {
+    TwSrc<T> none;
+    fft_dit<SIGN, V, false>(ctx, p, b, v, lds, none);
 }
 
 // ------------------------------------------------------------------------ block reductions
@@ -431,8 +461,7 @@ template <typename T> struct RowArgs {
     long long u_elems;
     int u_part;
     int prio;                 // 1: issue priority by phase (s_setprio); 0 when several plans share the GPU (lanes)
-    int tw_off;               // > 0: byte offset of the workgroup's twiddle table in LDS (kTwLdsBytes behind the transform area)
-    const void *tw0;          // global twiddle table of pass 0 (three-pass rows: tw_entry_t<T>[N2], [s][j]) or nullptr
+    int tw_off;               // single precision: byte offset of the workgroup's twiddle table in LDS (kTwLdsBytes behind the transform area)
 };
 
 // linear operator for the V registers of a last-radix-V butterfly (V = 16 | 8): bins k0 + (N/V) q, signed q' = q or q - V;
@@ -685,9 +714,10 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
 // them by inline assembly, which the hazard recogniser does not look into: where the data sat in a temporary register tuple
 // that the next value's moves overwrote at once -- the packed complex64 kernel -- the store sent the NEXT element's data
 // (rel-L2 0.67 at every size); the double-precision kernel's values happened to live in aligned tuples of their own and
-// passed every test.  SSF_WT_ROWS: bit 0 double, bit 1 packed pairs, bit 2 float.
+// passed every test.  SSF_WT_ROWS: bit 0 double, bit 1 packed pairs, bit 2 float.  Round 4, compiler-visible stores, same box
+// (profiles/r4_ab_twiddle_tables.txt): double 24.1 -> 22.5 us per row launch, packed pairs 47.7 -> 45.5 us with correct results.
 #ifndef SSF_WT_ROWS
-#define SSF_WT_ROWS 1
+#define SSF_WT_ROWS 3
 #endif
 template <typename T> constexpr bool wt_rows() {
     return sizeof(scalar_t<T>) == 8 ? (SSF_WT_ROWS & 1) != 0 : sizeof(T) == 8 ? (SSF_WT_ROWS & 2) != 0 : (SSF_WT_ROWS & 4) != 0;
@@ -761,12 +791,13 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     }
 #pragma unroll
     for (int q = 0; q < V; ++q) v[q] = g[b + p.tpf * q];
-    TwSrc<T> tws;                                           // (the table is built while the row is in flight)
-    if (SSF_TW_TAB && a.tw_off > 0) {
+    // single precision: the next-to-last pass takes its hi + lo factors from a table in LDS, built while the row is in flight (TwSrc)
+    constexpr bool kTab = (SSF_TW_TAB & 1) && sizeof(scalar_t<T>) == 4;
+    TwSrc<T> tws;
+    if (kTab) {
         tw_entry_t<T> *tab = (tw_entry_t<T> *)(ctx.lds + a.tw_off);
         tw_lds_build<T>(ctx, p, tab);
         tws.lds = tab;
-        tws.g0 = (const tw_entry_t<T> *)a.tw0;
     }
     if (a.use_ctrl) {
         ctx.issue_fence();
@@ -774,7 +805,7 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     } else if (a.lin) {
         lo = *a.lin;
     }
-    if (tws.lds && p.npass == 2) ctx.sync();                // (three passes: the first exchange's barrier publishes the table)
+    if (kTab && p.npass == 2) ctx.sync();                   // (three passes: the first exchange's barrier publishes the table)
     const int N1 = 1 << a.log2N1, log2N = a.log2N1 + a.log2N2;
     const int k1 = (int)(rr & (N1 - 1));
     cx<T> *l = lds + (size_t)f * lds_slots_per_fft(p.L);
@@ -786,7 +817,7 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     // workgroup catches up while the early one is in a later phase: +3 % steps/s at config 2 (profiles/r3_ab_runs.txt);
     // off (a.prio = 0) when several plans share the GPU, where it costs 4 % (profiles/r3_lanes_prio_wt.txt).
     if (a.prio) ctx.template setprio<2>();
-    fft_dif<-1, V>(ctx, p, b, v, l, tws);
+    fft_dif<-1, V, kTab>(ctx, p, b, v, l, tws);
     ctx.mark(2);
     if (a.prio) ctx.template setprio<1>();
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
@@ -811,7 +842,7 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
         }
     }
     ctx.mark(3);
-    fft_dit<+1, V>(ctx, p, b, v, l, tws);
+    fft_dit<+1, V, kTab>(ctx, p, b, v, l, tws);
     if (a.prio) ctx.template setprio<0>();
     ctx.mark(4);
     row_store<V>(ctx, a, p, f, b, v);
@@ -849,8 +880,6 @@ template <typename T> struct ColArgs {
     long long u_elems;        // independent units (see RowArgs): field elements per unit; P / Theta advance by 2 / 1 x ngroups x N
     int u_part;
     int prio;                 // see RowArgs
-    int tw_off;               // see RowArgs
-    const void *tw0;          // global twiddle table of pass 0 (three-pass columns: tw_entry_t<T>[N1]) or nullptr
 };
 
 // Arguments of unit u of a batch of independent units: every pointer moved to the unit's block.  The kernel bodies never
@@ -954,15 +983,29 @@ template <typename T, int LG, class Ctx, bool RAGGED = false, int V = 16> struct
 // inter-pass twiddle of the N = N1*N2 decomposition, applied on the frequency side of the
 // column kernel (which is HBM-bound and has VALU head-room; the row kernel is VALU-bound):
 // register q holds k1 = b + tpf*q of column n2  ->  v[q] *= cis(SIGN * 2 pi n2 k1 / N)
-template <int SIGN, bool RAGGED, typename T, class G> SSF_HD void global_twiddle(const G &g, int log2N, cx<T> *v) {
+struct GTw {                      // the two bases of a thread's inter-pass twiddles, cis(+2 pi n2 b / N) and cis(+2 pi n2 tpf / N)
     cx<double> w0, ws;
-    if (RAGGED) {                            // N = N1 * N2 with N2 not a power of two: the fraction is rounded once
-        w0 = cis2pi<double>((double)SIGN * ((double)(((long long)g.n2 * g.b) % g.N) / (double)g.N));
-        ws = cis2pi<double>((double)SIGN * ((double)(((long long)g.n2 * g.p.tpf) % g.N) / (double)g.N));
+    bool have = false;            // SSF_TW_REUSE: the inverse transform's bases are kept, the forward one conjugates them
+};
+template <int SIGN, bool RAGGED, typename T, class G> SSF_HD void global_twiddle(const G &g, int log2N, cx<T> *v, GTw &gt) {
+    cx<double> w0, ws;
+    if (SSF_TW_REUSE && gt.have) {
+        w0 = SIGN > 0 ? gt.w0 : conj(gt.w0);
+        ws = SIGN > 0 ? gt.ws : conj(gt.ws);
     } else {
-        const long long N = 1ll << log2N;
-        w0 = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.b) & (N - 1)), log2N));
-        ws = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.p.tpf) & (N - 1)), log2N));
+        if (RAGGED) {                        // N = N1 * N2 with N2 not a power of two: the fraction is rounded once
+            w0 = cis2pi<double>((double)SIGN * ((double)(((long long)g.n2 * g.b) % g.N) / (double)g.N));
+            ws = cis2pi<double>((double)SIGN * ((double)(((long long)g.n2 * g.p.tpf) % g.N) / (double)g.N));
+        } else {
+            const long long N = 1ll << log2N;
+            w0 = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.b) & (N - 1)), log2N));
+            ws = cis2pi<double>((double)SIGN * scale_pow2((double)(((long long)g.n2 * g.p.tpf) & (N - 1)), log2N));
+        }
+        if (SSF_TW_REUSE) {
+            gt.w0 = SIGN > 0 ? w0 : conj(w0);
+            gt.ws = SIGN > 0 ? ws : conj(ws);
+            gt.have = true;
+        }
     }
     // t[q] = w0 * ws^q by doubling: ws^2, ws^4, ws^8, then t[q + 2^k] = t[q] * ws^(2^k) -- 18 complex products of depth <= 7
     // (a power tree of ws followed by w0 * ws^q costs 30); rounded once, where it is applied (see tw_powers)
@@ -1279,21 +1322,13 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 
     // ---- inverse column transform: G -> time samples in registers -------------------------
     TwSrc<T> tws;
+    GTw gtw;
     if (do_inv) {
 #pragma unroll
         for (int q = 0; q < V; ++q) v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
-    }
-    if (SSF_TW_TAB && a.tw_off > 0) {                       // (built while the loads are in flight)
-        tw_entry_t<T> *tab = (tw_entry_t<T> *)(ctx.lds + a.tw_off);
-        tw_lds_build<T>(ctx, p, tab);
-        tws.lds = tab;
-        tws.g0 = (const tw_entry_t<T> *)a.tw0;
-        if (do_inv && p.npass == 2) ctx.sync();             // (otherwise an exchange barrier comes before the table's first use)
-    }
-    if (do_inv) {
         ctx.mark(1);
         if (a.prio) ctx.template setprio<3>();
-        global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v);
+        global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v, gtw);
         fft_dif<+1, V>(ctx, p, g.b, v, lds, tws);
         ctx.mark(2);
         if (a.prio) ctx.template setprio<2>();
@@ -1379,7 +1414,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     if (do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
         fft_dit<-1, V>(ctx, p, g.b, v, lds, tws);
-        global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v);
+        global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v, gtw);
         ctx.mark(4);
         if (a.prio) ctx.template setprio<0>();
 #pragma unroll
@@ -1463,20 +1498,12 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
     float *Pcur = a.P + (st.c.pcur ? psz : 0), *Palt = a.P + (st.c.pcur ? 0 : psz);
 
     TwSrc<T> tws;
+    GTw gtw;
     if (st.do_inv) {
 #pragma unroll
         for (int q = 0; q < V; ++q) v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
-    }
-    if (SSF_TW_TAB && a.tw_off > 0) {                       // (built while the loads are in flight)
-        tw_entry_t<T> *tab = (tw_entry_t<T> *)(ctx.lds + a.tw_off);
-        tw_lds_build<T>(ctx, p, tab);
-        tws.lds = tab;
-        tws.g0 = (const tw_entry_t<T> *)a.tw0;
-        if (st.do_inv && p.npass == 2) ctx.sync();
-    }
-    if (st.do_inv) {
         ctx.mark(1);
-        global_twiddle<+1, false>(g, a.log2N1 + a.log2N2, v);
+        global_twiddle<+1, false>(g, a.log2N1 + a.log2N2, v, gtw);
         fft_dif<+1, V>(ctx, p, g.b, v, lds, tws);
         ctx.mark(2);
     } else if (op != 3) {
@@ -1582,7 +1609,7 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
     ctx.mark(3);
     if (st.do_fwd) {
         fft_dit<-1, V>(ctx, p, g.b, v, lds, tws);
-        global_twiddle<-1, false>(g, a.log2N1 + a.log2N2, v);
+        global_twiddle<-1, false>(g, a.log2N1 + a.log2N2, v, gtw);
         ctx.mark(4);
 #pragma unroll
         for (int q = 0; q < V; ++q) g.st(a.G, g.rowbase + g.freq_off(q), v[q]);

@@ -210,7 +210,8 @@ template <class Backend> struct RxCore {
         const bool quiet = p.ideal != 0;
         const bool noisy = !iq_only && !quiet && (p.shotNoise || p.thermalNoise);
         const bool lowpass = !iq_only && !quiet && p.bandwidthLimitation;
-        if (!iq_only && !quiet && !(p.Fs >= 2 * p.B)) return fail(SSF_ERR_BAD_ARG, "Sampling frequency Fs needs to be at least twice of B.");
+        const double fs_pd = p.Fs_pd > 0 ? p.Fs_pd : p.Fs;           // paramPD.Fs (noise, low-pass) vs paramFE.Fs (delays): ssf.h
+        if (!iq_only && !quiet && !(fs_pd >= 2 * p.B)) return fail(SSF_ERR_BAD_ARG, "Sampling frequency Fs needs to be at least twice of B.");
         int ntaps = p.N;
         if (ntaps % 2 == 0) ++ntaps;                                 // devices.py:361-365
         if (lowpass && (ntaps < 1 || ntaps > kMaxNfft / 2)) return fail(SSF_ERR_UNSUPPORTED, "photodiode filter: 1 <= N <= 4096 taps");
@@ -266,15 +267,15 @@ template <class Backend> struct RxCore {
             fa.pd.saturate = !quiet && p.currentSaturation;
             fa.pd.shot = !quiet && p.shotNoise;
             fa.pd.thermal = !quiet && p.thermalNoise;
-            fa.pd.shot_k = p.Fs * q;
+            fa.pd.shot_k = fs_pd * q;
             fa.pd.Id = p.Id;
-            fa.pd.thermal_sigma = std::sqrt(p.Fs * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
+            fa.pd.thermal_sigma = std::sqrt(fs_pd * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
             fa.pd.seed = (unsigned long long)p.rng_seed;
             fa.pd.un = dun;
             be.launch_front(fa);
             s = det;
             if (lowpass) {
-                const std::vector<double> h = low_pass_fir(p.B, p.Fs, ntaps, p.fType);
+                const std::vector<double> h = low_pass_fir(p.B, fs_pd, ntaps, p.fType);
                 std::vector<zc> hz(h.begin(), h.end());
                 const int nfft = fir_nfft(ntaps);
                 Cd *dH = upload_filter(ols_filter_from_taps(hz.data(), ntaps, nfft));

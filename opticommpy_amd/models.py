@@ -564,16 +564,28 @@ def _edc_filter(param, Fs):
 _OLS_MAX_TAPS = 4096          # longer impulse responses are convolved segment by segment (8192-point blocks, >= half output)
 
 
-def _edc_long(sigIn, sig2, one_d, on_dev, K, Hf):
-    """Overlap-save convolution with an impulse response of more than _OLS_MAX_TAPS taps: h is cut into segments h_p of at
-    most _OLS_MAX_TAPS taps, conv(x, h)[m] = sum_p conv(x, h_p)[m - p S], every partial convolution is one launch of the
-    LDS overlap-save kernel (ssf_overlap_save) over the zero-extended signal, and the partial results are added with the
-    segment's offset.  Same linear convolution, same 'same'-mode cut (delay (K - 1) // 2) as optic/dsp/core.py:1043-1046."""
+def _ols_same_host(x, Hf):
+    """blockwiseFFTConv(x, Hf, freqDomainFilter=True) of the reference (optic/dsp/core.py:973-1046) for a host (n, ncols)
+    complex128 array and a K-sample frequency response centred at DC, any K: 'same'-mode linear convolution with the centred
+    impulse response (delay (K - 1) // 2), every block one LDS transform pair of ssf_overlap_save.  The block size of an
+    overlap-save evaluation does not change the convolution it computes, so the device kernel's own block sizes are used.
+    Impulse responses of more than _OLS_MAX_TAPS taps are cut into segments h_p: conv(x, h)[m] = sum_p conv(x, h_p)[m - p S],
+    every partial convolution one launch over the zero-extended signal, the partial results added with the segment's offset."""
     lib = _lib.load()
-    x = sig2.get() if on_dev else sig2
     x = np.ascontiguousarray(x, dtype=np.complex128)
     n, ncols = x.shape
+    K = len(Hf)
     h = np.fft.fftshift(np.fft.ifft(Hf))                          # core.py:1015-1016: centred impulse response, K taps
+    if K <= _OLS_MAX_TAPS:
+        nfft = 16
+        while nfft < min(4 * K, 8192) or nfft < K:
+            nfft *= 2
+        H = np.ascontiguousarray(np.fft.fft(np.pad(h, (0, nfft - K))), dtype=np.complex128)
+        out = np.empty_like(x)
+        rc = lib.ssf_overlap_save(_state["device"], n, ncols, _lib.SSF_C128, nfft, K, H.ctypes.data_as(C.c_void_p),
+                                  x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        _lib.raise_for(lib, None, rc)
+        return out
     S, D = _OLS_MAX_TAPS, (K - 1) // 2
     xp = np.zeros((n + 2 * K, ncols), dtype=np.complex128)        # zero-extended: every partial 'same' output we need exists
     xp[K:K + n] = x
@@ -590,6 +602,13 @@ def _edc_long(sigIn, sig2, one_d, on_dev, K, Hf):
         # part[i] = full_p[i + Dp] over the extended signal; y[j] = sum_p full_p[(j + K) + D - p0]
         o = K + D - p0 - Dp
         acc += part[o:o + n]
+    return acc
+
+
+def _edc_long(sigIn, sig2, one_d, on_dev, K, Hf):
+    """edc with an impulse response of more than _OLS_MAX_TAPS taps (_ols_same_host: segment by segment)."""
+    acc = _ols_same_host(sig2.get() if on_dev else sig2, Hf)
+    ncols = acc.shape[1]
     if on_dev:
         out = _dev.empty(True, sig2.shape, np.complex128)
         out.set(acc)

@@ -19,6 +19,7 @@ device draws from counter-based Philox streams instead (one per photodiode, keye
 ``param.seed``), so noisy runs agree with the reference statistically, not sample by sample
 (same policy as the EDFA).  ``_unit_normals`` feeds host-supplied standard
 normals through the same arithmetic for exact checks."""
+import copy
 import ctypes as C
 import logging as logg
 
@@ -116,12 +117,53 @@ def firFilter(h, x, prec=None):
     return y.flatten() if input1D else y
 
 
+_FIR_MAX_TAPS = 4096           # ssf_fir_filter: one LDS block pair per 8192-point block, at least half of it output
+
+
+def _conv_same_host(x, h):
+    """full[(K - 1) // 2 : (K - 1) // 2 + n] of the linear convolution of a host (n,) complex128 signal with K complex taps,
+    any K: what blockwiseFFTConv returns (optic/dsp/core.py:1043-1046).  The impulse response is cut into segments h_p of at
+    most _FIR_MAX_TAPS taps, conv(x, h)[m] = sum_p conv(x, h_p)[m - p S]; every partial convolution is one launch of the
+    overlap-save FIR kernel (ssf_fir_filter) over the zero-extended signal."""
+    n, K = len(x), len(h)
+    S, D = _FIR_MAX_TAPS, (K - 1) // 2
+    xp = np.zeros((n + 2 * K, 1), dtype=np.complex128)
+    xp[K:K + n, 0] = x
+    acc = np.zeros(n, dtype=np.complex128)
+    part = np.empty_like(xp)
+    for p0 in range(0, K, S):
+        hp = np.ascontiguousarray(h[p0:p0 + S], dtype=np.complex128)
+        Dp = (len(hp) - 1) // 2
+        _backend.fir(xp.shape[0], 1, len(hp), hp.ctypes.data_as(C.c_void_p), xp.ctypes.data_as(C.c_void_p), part.ctypes.data_as(C.c_void_p))
+        o = K + D - p0 - Dp                       # part[i] = full_p[i + Dp] over the extended signal
+        acc += part[o:o + n, 0]
+    return acc
+
+
 def delaySignal(sig, delay, Fs=1, NFFT=1024):
-    """Fractional delay by FFT overlap-save filtering (optic/dsp/core.py:880-922) with the reference's
-    default NFFT = 1024, i.e. a 512-tap delay filter."""
-    if NFFT != 1024:
-        raise ValueError("delaySignal on the GPU uses NFFT = 1024 (the reference's default)")
+    """Fractional delay by FFT overlap-save filtering (optic/dsp/core.py:880-922).  NFFT = 1024 (the reference's default,
+    a 512-tap delay filter) is one device call; any other NFFT -- an NFFT // 2-sample frequency response, or None = the next
+    power of two above the padded length -- builds the reference's filter on the host (a few thousand values) and runs the
+    same overlap-save kernel (_conv_same_host)."""
     on_dev = _dev.is_device(sig)
+    if NFFT != 1024:
+        s0 = np.asarray(sig.get() if on_dev else sig).reshape(-1)
+        N = len(s0)
+        padLen = int(np.ceil(np.abs(delay * Fs)))                                  # core.py:905-909
+        if NFFT is None:
+            NFFT = 2 ** int(np.ceil(np.log2(N + padLen)))
+        if int(NFFT) < 2:
+            raise ValueError("delaySignal: NFFT must be at least 2")
+        freq = np.fft.fftfreq(int(NFFT) // 2, d=1 / Fs)
+        H = np.exp(-1j * 2 * np.pi * freq * delay)                                 # core.py:916
+        h = np.fft.fftshift(np.fft.ifft(H))                                        # core.py:1015-1016: centred impulse response
+        y = _conv_same_host(np.pad(s0, (0, padLen)).astype(np.complex128), h)
+        y = np.roll(y, -1)[:N]                                                     # core.py:920-922
+        if on_dev:
+            out = _dev.empty(True, (N,), np.complex128)
+            out.set(y)
+            return out
+        return y if np.any(np.iscomplex(s0)) else y.real
     if not on_dev:
         sig = np.asarray(sig)
     s1 = sig.reshape(-1)
@@ -239,8 +281,21 @@ def photodiode(E, param=None, _unit_normals=None):
 def balancedPD(E1, E2, param=None, _unit_normals=None):
     """Balanced photodiode pair (optic/models/devices.py:402-459): i(E1) - i(E2)."""
     assert E1.shape == E2.shape, "E1 and E2 need to have the same shape"
-    if np.asarray(E1).ndim != 1:
-        raise ValueError("balancedPD on the GPU takes (N,) host fields")
+    if len(E1.shape) != 1:
+        # (N, M) fields: each photodiode sums |E|^2 over its modes (devices.py:355-357), the second one with seed + 1
+        # (devices.py:447-456): two launches of the photodiode pipeline, the difference on the host / device
+        param2 = param
+        if param is not None and getattr(param, "seed", None) is not None:
+            param2 = copy.copy(param)
+            param2.seed = param.seed + 1
+        un = _unit_normals
+        i1 = photodiode(E1, param, None if un is None else un[0:1])
+        i2 = photodiode(E2, param2, None if un is None else un[1:2])
+        if _dev.is_device(i1):
+            d = _dev.empty(True, i1.shape, np.float64)
+            d.set(i1.get() - i2.get())
+            return d
+        return i1 - i2
     p = _pd_fields(_lib.RxParams(), param)
     return _rx(_MODE["balancedPD"], len(E1), 2, p, np.stack([E1, E2], axis=1), None, _unit_normals, (len(E1),), np.float64, 2)
 
@@ -265,11 +320,11 @@ def iqMixing(sig, param):
     return _rx(_MODE["iqMixing"], len(sig), 1, p, sig.reshape(-1), None, None, (len(sig),), np.complex128, 0)
 
 
-def _same_fs(pd_fs, fe_fs):
-    """ssf_rx_params carries one sampling rate: the reference takes paramPD.Fs for the photodiode noise / low-pass and
-    paramFE.Fs for IQ mixing and skew (devices.py:562-571), which only coincide when both objects agree."""
-    if pd_fs and abs(pd_fs - fe_fs) > 1e-9 * abs(fe_fs):
-        raise ValueError(f"paramPD.Fs ({pd_fs}) differs from paramFE.Fs ({fe_fs}): the device front-end runs at one sampling rate")
+def _two_rates(p, fe_fs):
+    """The reference takes paramPD.Fs for the photodiode model (noise scale, low-pass design: devices.py:331-353) and
+    paramFE.Fs for the polarisation delay, IQ mixing and skew (devices.py:562-571, 648-651): ssf_rx_params carries both."""
+    p.Fs_pd = p.Fs if p.Fs and abs(p.Fs - fe_fs) > 1e-12 * abs(fe_fs) else 0.0
+    p.Fs = fe_fs
 
 
 def coherentReceiver(Es, Elo, paramFE=None, paramPD=None, _unit_normals=None):
@@ -283,8 +338,7 @@ def coherentReceiver(Es, Elo, paramFE=None, paramPD=None, _unit_normals=None):
         paramPD = parameters()
         paramPD.Fs = Fs
     p = _pd_fields(_lib.RxParams(), paramPD)
-    _same_fs(p.Fs, Fs)
-    p.Fs = Fs
+    _two_rates(p, Fs)
     _iq_fields(p, 0, paramFE)
     return _rx(_MODE["coherentReceiver"], len(Es), 1, p, Es, Elo, _unit_normals, (len(Es),), np.complex128, 4)
 
@@ -303,8 +357,7 @@ def pdmCoherentReceiver(Es, Elo, paramFE, paramPD=None, _unit_normals=None):
         paramPD = parameters()
         paramPD.Fs = Fs
     p = _pd_fields(_lib.RxParams(), paramPD)
-    _same_fs(p.Fs, Fs)
-    p.Fs = Fs
+    _two_rates(p, Fs)
     p.polRotation = getattr(paramFE, "polRotation", 0)
     p.pdl = getattr(paramFE, "pdl", 0)
     p.polDelay = getattr(paramFE, "polDelay", 0)

@@ -104,13 +104,16 @@ def rx_call(mod, params_cls, d, cfg):
     if f == "decimate":
         return mod.decimate(Ei, _bag(params_cls, kw))
     if f == "delaySignal":
-        return mod.delaySignal(Ei, kw["delay"], kw["Fs"])
+        return mod.delaySignal(Ei, kw["delay"], kw["Fs"], kw["NFFT"]) if "NFFT" in kw else mod.delaySignal(Ei, kw["delay"], kw["Fs"])
     if f == "iqMixing":
         return mod.iqMixing(Ei, _bag(params_cls, kw))
     if f == "photodiode":
         return mod.photodiode(Ei, _bag(params_cls, kw))
     if f == "balancedPD":
         return mod.balancedPD(Ei[:, 0].copy(), Ei[:, 1].copy(), _bag(params_cls, kw))
+    if f == "balancedPD2d":                                       # two (N, M) fields, side by side in Ei
+        M = Ei.shape[1] // 2
+        return mod.balancedPD(Ei[:, :M].copy(), Ei[:, M:].copy(), _bag(params_cls, kw))
     if f == "opticalHybrid2x4":
         return mod.opticalHybrid2x4(Ei, d["Elo"])
     if f == "coherentReceiver":

@@ -497,11 +497,11 @@ def test_one_launch_linear_step_at_short_smooth_lengths(N, in_place):
 
 # ---- round 4: twiddle tables (fused_kernels.h: TwSrc) ----------------------------------------------------------------------
 @pytest.mark.parametrize("l1,prec", [(4, "complex128"), (10, "complex128"), (4, "complex64"), (10, "complex64"), (5, "complex128")])
-def test_three_pass_transforms_read_pass0_twiddles_from_the_global_table(monkeypatch, l1, prec):
-    """Rows of 1024 (2^14 = 16 x 1024: passes 16 . 4 . 16) and columns of 1024 (1024 x 16) are three-pass transforms: pass 0
-    takes its twiddles from the plan's global table, pass 1 from the workgroup's LDS table, in double precision and as
-    hi + lo float quadruples (packed complex64 pairs); 2^5 x 512 rows: passes 16 . 2 . 16.  Same results as the oracle, same
-    iteration counts; the linear channel (one-row kernels, their own table offsets) too."""
+def test_three_pass_transforms_with_the_lds_twiddle_table_and_kept_bases(monkeypatch, l1, prec):
+    """Rows of 1024 (2^14 = 16 x 1024: passes 16 . 4 . 16) and columns of 1024 (1024 x 16) are three-pass transforms: in single
+    precision the rows' pass 1 takes its hi + lo factors from the workgroup's LDS table (fused_kernels.h: TwSrc); every other
+    pass generates them from a base that the inverse transform keeps for the forward one (conjugate); 2^5 x 512 rows: passes
+    16 . 2 . 16.  Same results as the oracle, same iteration counts; the linear channel (one-row kernels) too."""
     monkeypatch.setenv("SSF_SPLIT_L1", str(l1))
     monkeypatch.setenv("SSF_ROW_V", "16")
     monkeypatch.setenv("SSF_COL_V", "16")

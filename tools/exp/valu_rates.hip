@@ -10,7 +10,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-template <int OP> __global__ void __launch_bounds__(512) k(unsigned long long *out, int iters) {
+template <int OP> __global__ void __launch_bounds__(1024) k(unsigned long long *out, int iters) {
     double d[8];
     float f[8];
     f2 p[8];
@@ -50,26 +50,35 @@ template <int OP> __global__ void __launch_bounds__(512) k(unsigned long long *o
 }
 
 template <int OP> void run(const char *name, unsigned long long *dout) {
-    for (int threads : {256, 512}) {
+    for (int threads : {256, 512, 1024, 2048}) {
         const int iters = 256;
-        k<OP><<<256, threads>>>(dout, iters);
+        const int blocks = threads > 1024 ? 512 : 256, tpb = threads > 1024 ? 1024 : threads;       // 2048: two 1024-thread blocks per CU
+        k<OP><<<blocks, tpb>>>(dout, iters);
         hipDeviceSynchronize();
-        k<OP><<<256, threads>>>(dout, iters);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0);
+        k<OP><<<blocks, tpb>>>(dout, iters);
+        hipEventRecord(e1);
         hipDeviceSynchronize();
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
         std::vector<unsigned long long> h(256);
         hipMemcpy(h.data(), dout, 256 * 8, hipMemcpyDeviceToHost);
         double avg = 0;
         for (auto x : h) avg += (double)x;
         avg /= 256.0;
         // s_memtime counts at 100 MHz on gfx950?  report raw ticks per instruction as well as the ratio to v_fma_f32
-        printf("%-16s %d waves/SIMD: %8.1f ticks for %d wave-instructions = %.4f ticks per instruction per wave\n", name, threads / 256, avg,
-               iters * 64, avg / (iters * 64.0));
+        // per SIMD: (threads / 256) waves, each issuing iters * 64 instructions, in `ms` of wall time (launch overhead ~ 5 us included)
+        printf("%-16s %d waves/SIMD: %.3f ticks per instruction per wave;  wall %.1f us -> %.2f ns per wave-instruction per SIMD\n", name,
+               threads / 256, avg / (iters * 64.0), ms * 1e3, ms * 1e6 / ((double)(threads / 256) * iters * 64.0));
     }
 }
 
 int main() {
     unsigned long long *dout;
-    hipMalloc(&dout, 256 * 8);
+    hipMalloc(&dout, 512 * 8);
     run<8>("v_fma_f32", dout);
     run<0>("v_pk_fma_f32", dout);
     run<1>("v_pk_add_f32", dout);

@@ -20,7 +20,7 @@ Output: tests/golden/<case>.npz, each holding
               output decimated by cfg["dec"], its per-column power and a seeded random projection of the full
               output (so an error anywhere in the array shows), see long_vectors()
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|tx|long|long20|cfg3|units45 [log2n]]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|rx_edges|tx|long|long20|cfg3|units45 [log2n]]
 """
 import json
 import os
@@ -358,6 +358,42 @@ def rx_vectors():
     save("rx_pd_noise_seed11", Ei=Es[:, 0], out=out, extra_shot=u_shot, extra_thermal=u_th, cfg=cfg_json("photodiode", pdn))
 
 
+
+def rx_edge_vectors():
+    """Receiver-side argument edges: delaySignal with NFFT != 1024 (even, not a power of two, None),
+    balancedPD on (N, M) fields, pdmCoherentReceiver with paramPD.Fs != paramFE.Fs."""
+    import optic.dsp.core as ref_core
+    import optic.models.devices as ref_dev
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(62)
+    xs = (rng.normal(size=10000) + 1j * rng.normal(size=10000)) / np.sqrt(2)
+    for name, x, kw in (("rx_delay_nfft256", xs[:2500].copy(), dict(delay=0.37 / 128e9, Fs=128e9, NFFT=256)),
+                        ("rx_delay_nfft2048_neg", xs[:2500].copy(), dict(delay=-5.3 / 128e9, Fs=128e9, NFFT=2048)),
+                        ("rx_delay_nfft1000", xs[:3000].copy(), dict(delay=2.25 / 128e9, Fs=128e9, NFFT=1000)),
+                        ("rx_delay_nfft_none", xs, dict(delay=1.6 / 128e9, Fs=128e9, NFFT=None)),
+                        ("rx_delay_nfft_none_real", xs.real.copy(), dict(delay=-0.4 / 128e9, Fs=128e9, NFFT=None))):
+        out = ref_core.delaySignal(x, kw["delay"], kw["Fs"], kw["NFFT"])
+        save(name, Ei=x, out=out, cfg=cfg_json("delaySignal", kw))
+        print(f"{name:32s} in {x.dtype}{x.shape} out {out.dtype}{out.shape}")
+    Es4 = np.concatenate([synth_field(4096, 2, 63, 0.0), synth_field(4096, 2, 64, -3.0)], axis=1)
+    Fs = 128e9
+    pd_quiet = dict(Fs=Fs, B=30e9, shotNoise=False, thermalNoise=False)
+    out = ref_dev.balancedPD(Es4[:, :2].copy(), Es4[:, 2:].copy(), mk_param(**pd_quiet))
+    save("rx_bpd_two_modes_each", Ei=Es4, out=out, cfg=cfg_json("balancedPD2d", pd_quiet))
+    print(f"rx_bpd_two_modes_each            out {out.dtype}{out.shape}")
+    Es = synth_field(4096, 2, 61, 0.0)
+    tt = np.arange(4096) / Fs
+    Elo = np.sqrt(10e-3) * np.exp(1j * (2 * np.pi * 150e6 * tt + 0.3))
+    fe = dict(Fs=Fs, polRotation=0.3, polDelay=2e-12, timeSkewX=1.5e-12, timeSkewY=-1e-12)
+    pd = dict(pd_quiet, Fs=1.5 * Fs, N=129)                     # the photodiode model designed at another rate (devices.py:331-353)
+    out = ref_dev.pdmCoherentReceiver(Es.copy(), Elo, mk_param(**fe), mk_param(**pd))
+    save("rx_pdm_two_sampling_rates", Ei=Es, Elo=Elo, out=out, cfg=cfg_json("pdmCoherentReceiver", dict(fe=fe, pd=pd)))
+    print(f"rx_pdm_two_sampling_rates        out {out.dtype}{out.shape}")
+    fe1 = dict(Fs=Fs, ampImb=0.5, timeSkew=1e-12)
+    out = ref_dev.coherentReceiver(Es[:, 0].copy(), Elo, mk_param(**fe1), mk_param(**pd))
+    save("rx_coh_two_sampling_rates", Ei=Es[:, 0], Elo=Elo, out=out, cfg=cfg_json("coherentReceiver", dict(fe=fe1, pd=pd)))
+
+
 def tx_vectors():
     """WDM transmitter"""
     import optic.comm.modulation as ref_mod
@@ -567,6 +603,8 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "tx":      # only the transmitter vectors
         os.makedirs(OUT, exist_ok=True)
         tx_vectors()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rx_edges":   # only the receiver-side argument edges (round 4)
+        rx_edge_vectors()
     elif len(sys.argv) > 1 and sys.argv[1] == "rx":    # only the receiver-side vectors
         os.makedirs(OUT, exist_ok=True)
         rx_vectors()
