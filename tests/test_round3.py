@@ -291,6 +291,30 @@ def test_longest_fields_stay_on_the_hand_written_kernels(N):
     assert rel_l2(out, ref) <= 1e-10
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,engine", [(3000, "auto"), (1500, "auto"), (30030, "auto"), (1 << 12, "rocfft")])
+def test_run_sharded_falls_back_to_one_call_per_unit_where_a_plan_cannot_carry_units(N, engine):
+    """Small same-shape units are batched into one plan of independent units -- which only the natively split fused pipeline
+    takes (ssf_plan_set_units: SSF_ERR_UNSUPPORTED otherwise, 'the caller falls back to one call per unit', include/ssf.h).
+    Lengths that AUTO sends to rocFFT or to Bluestein / one-launch rows, and set_engine('rocfft'), must run all the same
+    (advisor, round 3: they raised RuntimeError), with the results of the stand-alone calls."""
+    import opticommpy_amd as oa
+    from helpers import make_param, rel_l2, synth_field
+    from opticommpy_amd import mgpu
+    from oracle import ssf_oracle as orc
+    fields = [synth_field(N, 2, 80 + u, 3.0 * u) for u in range(3)]
+    cfg = dict(UNIT_CFG, amp="ideal")
+    oa.set_engine(engine)
+    try:
+        outs = mgpu.run_sharded(fields, make_param(oa.parameters, cfg))
+        alone = [oa.manakovSSF(E, make_param(oa.parameters, cfg)) for E in fields]
+    finally:
+        oa.set_engine("auto")
+    for u in range(3):
+        assert np.array_equal(outs[u], alone[u]), u
+    assert rel_l2(outs[2], orc.manakovSSF(fields[2], make_param(orc.parameters, cfg))) <= 1e-10
+
+
 # ------------------------------------------------------------------------------------------ configs 4 and 5 at workload size
 def _check_units_against_the_reference(rec, which, log2n):
     """Every unit's (sum |E|^2, |<q, E>|, iterations) against what the REFERENCE produced for that unit (tests/golden/wl_units45_n*.npz,
