@@ -69,6 +69,8 @@ struct Ctrl {           // device-resident step state, double-buffered by launch
     int pcur, redo_;    // current Pch buffer; iterate 0 is being rebuilt as final
     int bound0;         // the pending lim_0 sums cover a sixteenth of the samples: a lower bound of lim_0
     int exact0;         // the next I stage of iterate 0 evaluates lim_0 on all samples (bound was inconclusive)
+    int gscale;         // G holds the column spectrum of the field DIVIDED by N1: the final I stage of the last step did not
+                        // rewrite it (see mk_col_stage); the next row stage multiplies its operator by N1
     long long pend0_idx;// trace row lim_0 belongs to
     double z, hz;
     long long steps, iterations, nonconv, trace_n;
@@ -535,6 +537,7 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
     const Ctrl &c = *a.cin;
     const int c_state = c.state, c_it = c.it, c_pend0 = c.pend0, c_pendn = c.pendn, c_cap0 = c.cap0, c_bound0 = c.bound0;
     int n_exact0 = c.exact0;
+    const int c_gscale = c.gscale;
     int n_state = c_state, n_final = c.final_, n_cap0 = c_cap0, n_hzv = c.hz_valid;
     int add_nonconv = 0, add_ahead = 0;
     double n_hz = c.hz;
@@ -604,6 +607,7 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
     } else if (act) {
         lo = c.lin;
     }
+    if (act && c_state == ST_AFTER_S && c_gscale) lo.mag *= (double)(1ll << a.log2N1);   // (G = spectrum / N1: mk_col_stage)
     if (act) n_state = c_state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
     if (lead) {
         ctrl_forward(a.cin, a.cout, (int)((new_lin ? offsetof(Ctrl, lin) : sizeof(Ctrl)) / 8));
@@ -615,6 +619,7 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
         n->cap0 = n_cap0;
         n->bound0 = 0;
         n->exact0 = n_exact0;
+        if (act && c_state == ST_AFTER_S) n->gscale = 0;
         n->hz_valid = n_hzv;
         n->hz = n_hz;
         n->nonconv = c.nonconv + add_nonconv;
@@ -1204,7 +1209,11 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
         op = 2;
         do_inv = true;
         more = c.z + c.hz < a.k.Lspan;                                // channels.py:441, 387
-        do_fwd = final_ ? more : true;
+        // The final stage only OBSERVES the field (stores it, takes the next step's Pch): its forward transform would rebuild
+        // the column spectrum it has just read -- G as the row stage left it is that spectrum / N1 (unnormalised transforms; N1
+        // is a power of two, so the factor is exact) -- and so it neither transforms nor rewrites G (one forward column
+        // transform and one write of the field less per step); the control block tells the next row stage (gscale).
+        do_fwd = final_ ? false : true;
     } else if (c.state == ST_REDO0) {
         op = 3;
         do_fwd = true;
@@ -1214,6 +1223,7 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
         Ctrl *n = a.cout;
         if (op == 0) {
             n->state = ST_AFTER_S;
+            n->gscale = 0;
             n->hz_valid = 0;
         } else if (op == 1) {
             n->state = ST_ROW_ITER;
@@ -1259,6 +1269,7 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
             }
             n->redo_ = 0;
             if (more) {
+                n->gscale = 1;
                 n->state = ST_AFTER_S;
                 n->pcur = c.pcur ^ 1;
                 if (a.k.adaptive) n->hz_valid = 0;

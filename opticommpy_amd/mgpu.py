@@ -20,6 +20,7 @@ barrier, bcast, send, recv, allgather, allreduce): the CPU tests drive it with a
 """
 import copy
 import ctypes as C
+import hashlib
 import os
 import pickle
 import stat
@@ -86,8 +87,23 @@ class RcclComm:
     # srun or mpirun with a daemon per rank.  The file is created with O_EXCL, mode 0600, and carries a magic word and
     # its creation time: readers ignore anything written before their own job could have started (a file a crashed run
     # left behind) and rank 0 unlinks it on every exit path.
-    _MAGIC = b"SSFRCCL1"
+    _MAGIC = b"SSFRCCL2"
     _STALE_S = 300.0
+
+    @staticmethod
+    def _nonce():
+        """16 bytes that identify THIS job, from $SSF_RCCL_NONCE (any string the launcher exports to every rank: bench.py --gpus N
+        and the tests do); zeros when there is none.  With a nonce an id file is this job's or it is not -- whenever it was
+        written (a rank that starts minutes after rank 0 still takes it; a file a killed run left under the same key seconds ago
+        is not taken).  Without one only freshness can be checked: the file must not be older than this rank's own start minus
+        _STALE_S (advisor, round 3)."""
+        n = os.environ.get("SSF_RCCL_NONCE")
+        return hashlib.md5(n.encode()).digest() if n else b"\0" * 16
+
+    @classmethod
+    def _pack(cls, raw, stamp=None, nonce=None):
+        return cls._MAGIC + np.array([time.time() if stamp is None else stamp], dtype=np.float64).tobytes() + \
+            (cls._nonce() if nonce is None else nonce) + raw
 
     @staticmethod
     def id_path():
@@ -113,7 +129,7 @@ class RcclComm:
             pass
         fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
         with os.fdopen(fd, "wb") as f:
-            f.write(cls._MAGIC + np.array([time.time()], dtype=np.float64).tobytes() + raw)
+            f.write(cls._pack(raw))
 
     @classmethod
     def _read_id(cls, path, not_before):
@@ -125,11 +141,14 @@ class RcclComm:
             if os.fstat(f.fileno()).st_uid != os.getuid():
                 raise RuntimeError("RCCL rendezvous: %s belongs to another user" % path)
             raw = f.read()
-        if len(raw) != 16 + _lib.COMM_ID_BYTES or raw[:8] != cls._MAGIC:
+        if len(raw) != 32 + _lib.COMM_ID_BYTES or raw[:8] != cls._MAGIC:
             return None                                        # not complete yet (or not ours)
-        if float(np.frombuffer(raw[8:16], dtype=np.float64)[0]) < not_before:
-            return None                                        # left behind by an earlier run
-        return raw[16:]
+        mine = cls._nonce()
+        if any(mine):                                          # a job nonce: identity, not age, decides
+            return raw[32:] if raw[16:32] == mine else None
+        if any(raw[16:32]) or float(np.frombuffer(raw[8:16], dtype=np.float64)[0]) < not_before:
+            return None                                        # another job's, or left behind by an earlier run
+        return raw[32:]
 
     @classmethod
     def from_env(cls, device=None, timeout=180.0):

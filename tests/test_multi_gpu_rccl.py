@@ -44,7 +44,7 @@ def _spawn(script_text, tmp_path, world=2, timeout=900):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), SSF_ROOT=ROOT, SSF_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1",
-                   SSF_RCCL_ID_FILE=str(tmp_path / "rccl.id"), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   SSF_RCCL_ID_FILE=str(tmp_path / "rccl.id"), SSF_RCCL_NONCE="test-%d" % port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=timeout)

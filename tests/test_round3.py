@@ -29,7 +29,7 @@ def test_rendezvous_file_is_private_fresh_and_keyed_by_the_job(tmp_path, monkeyp
     raw = bytes(range(128)) * (_lib.COMM_ID_BYTES // 128)
     # a file a crashed run left behind (valid layout, old time stamp) is not taken for this run's id
     with open(p, "wb") as f:
-        f.write(R._MAGIC + np.array([time.time() - 3600.0]).tobytes() + raw)
+        f.write(R._pack(raw, stamp=time.time() - 3600.0))
     assert R._read_id(p, mgpu._process_start_time() - R._STALE_S) is None
     # rank 0 replaces it: O_EXCL, 0600, fresh stamp
     R._publish_id(p, raw)
@@ -47,13 +47,31 @@ def test_rendezvous_times_out_with_a_stale_file(tmp_path, monkeypatch):
     """Rank 1 must not pick up an old id (it would hang in ncclCommInitRank): it reports the missing rendezvous."""
     from opticommpy_amd import _lib, mgpu
     p = tmp_path / "stale.id"
-    p.write_bytes(mgpu.RcclComm._MAGIC + np.array([time.time() - 7200.0]).tobytes() + b"\0" * _lib.COMM_ID_BYTES)
+    p.write_bytes(mgpu.RcclComm._pack(b"\0" * _lib.COMM_ID_BYTES, stamp=time.time() - 7200.0))
     for k, v in dict(SSF_RCCL_ID_FILE=str(p), RANK="1", WORLD_SIZE="2", LOCAL_RANK="1").items():
         monkeypatch.setenv(k, v)
     if not os.path.exists(os.path.join(ROOT, "opticommpy_amd", "libssf_hip.so")):
         pytest.skip("library not built")
     with pytest.raises(TimeoutError, match="no fresh id"):
         mgpu.RcclComm.from_env(timeout=0.3)
+
+
+def test_rendezvous_job_nonce_decides_identity_not_age(tmp_path, monkeypatch):
+    """With $SSF_RCCL_NONCE (bench.py --gpus N exports one per launch) a rank takes exactly its own job's id: an hour-old file of
+    this job is taken (a rank may start long after rank 0), a fresh file of another job -- a killed run under the same key -- is
+    not (advisor, round 3)."""
+    from opticommpy_amd import _lib, mgpu
+    R = mgpu.RcclComm
+    raw = bytes(range(128)) * (_lib.COMM_ID_BYTES // 128)
+    p = str(tmp_path / "n.id")
+    monkeypatch.setenv("SSF_RCCL_NONCE", "job-A")
+    with open(p, "wb") as f:
+        f.write(R._pack(raw, stamp=time.time() - 3600.0))
+    assert R._read_id(p, time.time()) == raw                      # old, but ours
+    monkeypatch.setenv("SSF_RCCL_NONCE", "job-B")
+    assert R._read_id(p, 0.0) is None                             # fresh enough for any clock, but another job's
+    monkeypatch.delenv("SSF_RCCL_NONCE")
+    assert R._read_id(p, 0.0) is None                             # a rank without a nonce does not take a nonce'd job's id
 
 
 def test_unit_checksum_tells_equal_power_units_apart():
