@@ -7,15 +7,27 @@ from helpers import make_param, rel_l2, synth_field
 from oracle import ssf_oracle as orc
 
 
-def test_receiver_rejects_two_different_sampling_rates():
-    """ssf_rx_params carries one Fs; the reference uses paramPD.Fs for the photodiodes and paramFE.Fs for IQ mixing."""
+def test_receiver_passes_both_sampling_rates(monkeypatch):
+    """The reference uses paramPD.Fs for the photodiode model (noise scale, low-pass design) and paramFE.Fs for the polarisation
+    delay / IQ mixing / skew (optic/models/devices.py:331-353, 562-571): ssf_rx_params carries both (Fs, Fs_pd; 0 = the same).
+    Round 3 refused two different rates; the numbers are checked against reference-generated vectors on the emulator and the GPU
+    (rx_pdm_two_sampling_rates, rx_coh_two_sampling_rates)."""
+    from opticommpy_amd import rx as rxmod
+    seen = []
+
+    class Recorder:
+        def rx(self, mode, N, nmodes, p, ip, lp, up, out):
+            seen.append((float(p.Fs), float(p.Fs_pd)))
+
+    monkeypatch.setattr(rxmod, "_backend", Recorder())
     E = np.ones(64, complex)
     fe, pd = oa.parameters(), oa.parameters()
     fe.Fs, pd.Fs, pd.B = 64e9, 128e9, 20e9
-    with pytest.raises(ValueError, match="differs from paramFE.Fs"):
-        oa.coherentReceiver(E, E, fe, pd)
-    with pytest.raises(ValueError, match="differs from paramFE.Fs"):
-        oa.pdmCoherentReceiver(np.ones((64, 2), complex), E, fe, pd)
+    oa.coherentReceiver(E, E, fe, pd)
+    oa.pdmCoherentReceiver(np.ones((64, 2), complex), E, fe, pd)
+    pd.Fs = 64e9
+    oa.coherentReceiver(E, E, fe, pd)
+    assert seen == [(64e9, 128e9), (64e9, 128e9), (64e9, 0.0)]
 
 
 @pytest.mark.gpu
