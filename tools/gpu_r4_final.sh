@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 4: the whole GPU suite, the driver's command (three runs), fuzzing and the full-size configurations on the final binary
+cd "$(dirname "$0")/.."
+O=gpurun_out/r4z; mkdir -p $O
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -5 $O/smoke.log
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
+for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_cmd_$i.json 2> $O/driver_cmd_$i.err; python -c "
+import json; d=json.loads(open('$O/driver_cmd_$i.json').read().strip().splitlines()[-1]); print('driver command run $i:', round(d['value'],1), round(d['roofline']['frac'],4), d['parity']['ok'], {k: (round(v['value'],1), round(v['roofline_frac'],3), v['parity']['ok']) for k, v in d['also'].items()})"; done | tee $O/driver_cmd.txt
+timeout 400 python tests/tools/fuzz_gpu.py 300 71 > $O/fuzz_71.log 2>&1; echo "rc=$?" >> $O/fuzz_71.log; tail -2 $O/fuzz_71.log
+timeout 400 python tests/tools/fuzz_gpu.py 300 73 > $O/fuzz_73.log 2>&1; echo "rc=$?" >> $O/fuzz_73.log; tail -2 $O/fuzz_73.log
+timeout 300 python tests/tools/soak_gpu.py 20 > $O/soak.log 2>&1; echo "rc=$?" >> $O/soak.log; tail -2 $O/soak.log
+timeout 400 python tests/tools/full_configs.py > $O/full_configs.log 2>&1; echo "rc=$?" >> $O/full_configs.log; grep -E "^C[1-5]|^   " $O/full_configs.log
+python bench.py --steps 1000 --warmup 50 --no-also > $O/bench_1000.json 2> $O/bench_1000.err; python -c "
+import json; d=json.loads(open('$O/bench_1000.json').read().strip().splitlines()[-1]); print('1000-step span:', round(d['value'],1), round(d['roofline']['frac'],4), d['config']['iterations_per_step'])"
