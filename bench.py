@@ -158,6 +158,7 @@ def self_launch(n):
     import tempfile
     tmp = tempfile.mkdtemp(prefix="ssf_bench_")
     port = str(free_port())
+    nonce = "%s-%d-%.6f" % (port, os.getpid(), time.time())       # ONE job identity for all ranks (mgpu.RcclComm._nonce)
     procs = []
 
     def die_with_parent():                                      # a killed launcher must not leave ranks behind
@@ -169,7 +170,7 @@ def self_launch(n):
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SSF_RCCL_ID_FILE=os.path.join(tmp, "rccl.id"),
-                       SSF_RCCL_NONCE="%s-%d-%.6f" % (port, os.getpid(), time.time()),
+                       SSF_RCCL_NONCE=nonce,
                        HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, preexec_fn=die_with_parent))

@@ -23,7 +23,7 @@
  *                                        sharded over the GPUs of one node, SURVEY.md 8e
  *   ssf_plan_set_units                   (no reference equivalent) several independent fields per launch
  *   ssf_plan_set_lanes                   (no reference equivalent) this plan shares the GPU with others
- *   ssf_set_coupling                     np.max(phiRot) / scipy.linalg.norm over ALL rows of a K > 1 batch
+ *   ssf_set_coupling[_comm]              np.max(phiRot) / scipy.linalg.norm over ALL rows of a K > 1 batch
  *                                        (channels.py:394, 517-519) when the rows live in several plans
  *   ssf_comm_*                           (no reference equivalent) one process per GPU: RCCL
  *                                        broadcast / scatter / gather of parameters, inputs and
@@ -241,6 +241,13 @@ const char *ssf_comm_last_error(const ssf_comm *comm);       /* never NULL; comm
  * on the fused engine (its control flow lives on the device; independent units need no coupling). */
 typedef int (*ssf_reduce_fn)(void *ctx, double *values, int32_t n, int32_t op);
 int  ssf_set_coupling(ssf_plan *plan, ssf_reduce_fn reduce, void *ctx);
+/* The same coupling for the device-resident pipeline (SSF_PIPE_DEVICE: natively split lengths on the fused engine), host out
+ * of the loop: between the column launch that leaves the partial sums / maxima and the row launch that uses them the plan's stream
+ * carries one ncclAllGather of 40 bytes over `comm` and every rank reduces the gathered values in rank order (identical bits, hence
+ * identical step sizes and iteration counts, on every rank).  Every rank of `comm` must run the same call with its own pairs.
+ * comm = NULL detaches.  SSF_ERR_UNSUPPORTED on the host-driven pipelines (use ssf_set_coupling there) and for plans of
+ * independent units; SSF_ERR_BAD_ARG if the communicator lives on another device. */
+int  ssf_set_coupling_comm(ssf_plan *plan, ssf_comm *comm);
 
 /* ---- which pipeline a plan runs on (ssf_stats.engine says SSF_ENGINE_FUSED for everything on the hand-written kernels) ----
  *   SSF_PIPE_DEVICE     natively split length: device-resident control flow, no host synchronisation inside a span

@@ -96,6 +96,7 @@ SYMBOLS = {
     "ssf_mgpu_run": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "ssf_set_coupling": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ssf_set_coupling_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ssf_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "ssf_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "ssf_overlap_save": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

@@ -242,3 +242,15 @@ int ssf_comm_rank(const ssf_comm *c) { return c ? c->rank : SSF_ERR_BAD_ARG; }
 int ssf_comm_size(const ssf_comm *c) { return c ? c->nranks : SSF_ERR_BAD_ARG; }
 
 }  // extern "C"
+
+namespace ssf {
+// all-gather of device buffers enqueued on the CALLER's stream, no synchronisation: the coupled fused engine puts it between the
+// column launch that leaves its partial sums and the row launch that uses them (ssf_set_coupling_comm)
+int comm_allgather_on(ssf_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank, hipStream_t st) {
+    if (!c || !send_dev || !recv_dev || bytes_per_rank < 1) return SSF_ERR_BAD_ARG;
+    return c->nccl(api().AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, c->comm, st), "ncclAllGather");
+}
+int comm_nranks(const ssf_comm *c) { return c ? c->nranks : 0; }
+int comm_device(const ssf_comm *c) { return c ? c->device : -1; }
+const char *comm_error(const ssf_comm *c) { return c ? c->err.c_str() : ""; }
+}  // namespace ssf

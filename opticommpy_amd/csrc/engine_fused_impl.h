@@ -115,6 +115,47 @@ template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT) k_ols(co
 #include "fused_experiments.h"      // persistent span kernels (measured slower at every size: DESIGN.md appendix)
 #endif
 
+// ---- coupled batch across ranks (ssf_set_coupling_comm; reference optic/models/channels.py:394, 517-519) --------------------------------
+// The column stage leaves per-workgroup partials (sums of lim_0 / lim_i, maxima of phi); the row stage reduces them in a fixed
+// order.  When the pairs of ONE coupled call are spread over several ranks, the partials are first reduced per rank
+// (k_couple_local: the row stage's own order, one workgroup), all-gathered (40 bytes per rank, on the plan's stream) and reduced
+// over the ranks in rank order (k_couple_finish): every rank ends up with the same five doubles and the row stage reads those
+// (npart = 1) -- same decisions, same step sizes, same iteration counts on every rank, no host in the loop.
+struct CoupleArgs {
+    const double *pnum0, *pden0, *pnum, *pden, *pmax;
+    int npart;
+    double *out;              // [5]: sum pnum0, sum pden0, sum pnum, sum pden, max pmax
+};
+__global__ void __launch_bounds__(256) k_couple_local(const CoupleArgs a) {
+    __shared__ double sh[5][256];
+    double s[5] = {0, 0, 0, 0, -INFINITY};
+    for (int i = (int)threadIdx.x; i < a.npart; i += 256) {
+        s[0] += a.pnum0[i];
+        s[1] += a.pden0[i];
+        s[2] += a.pnum[i];
+        s[3] += a.pden[i];
+        s[4] = a.pmax[i] > s[4] ? a.pmax[i] : s[4];
+    }
+    for (int q = 0; q < 5; ++q) sh[q][threadIdx.x] = s[q];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int q = (int)threadIdx.x;
+        double r = sh[q][0];
+        for (int i = 1; i < 256; ++i) r = q == 4 ? (sh[q][i] > r ? sh[q][i] : r) : r + sh[q][i];
+        a.out[q] = r;
+    }
+}
+__global__ void k_couple_finish(const double *gathered, int nranks, double *out) {
+    const int q = (int)threadIdx.x;
+    if (q >= 5) return;
+    double r = gathered[q];
+    for (int i = 1; i < nranks; ++i) {
+        const double x = gathered[5 * i + q];
+        r = q == 4 ? (x > r ? x : r) : r + x;
+    }
+    out[q] = r;
+}
+
 template <typename T> using RowFn = void (*)(const RowArgs<T>);
 template <typename T> using ColFn = void (*)(const ColArgs<T>);
 
@@ -414,6 +455,26 @@ struct HipBackend {
 #else
     static constexpr bool kCanPersist = false;
 #endif
+    // partial sums / maxima of this rank -> the same five values on every rank of `comm`, on the plan's stream (see k_couple_local)
+    static constexpr bool kCanCouple = true;
+    int couple(void *comm, const double *part, size_t stride, int npart, double *work) {
+        ssf_comm *c = (ssf_comm *)comm;
+        const int nr = comm_nranks(c);
+        CoupleArgs a{part + 3 * stride, part + 4 * stride, part + stride, part + 2 * stride, part, npart, work};   // (col_args' layout)
+        k_couple_local<<<1, 256, 0, pl->stream>>>(a);
+        chk(hipGetLastError(), "launch k_couple_local");
+        int rc = comm_allgather_on(c, work, work + 8, 5 * sizeof(double), pl->stream);
+        if (rc) {
+            if (first_err == hipSuccess) {
+                first_err = hipErrorUnknown;
+                where = std::string("coupled batch: ") + comm_error(c);
+            }
+            return rc;
+        }
+        k_couple_finish<<<1, 64, 0, pl->stream>>>(work + 8, nr, work);
+        chk(hipGetLastError(), "launch k_couple_finish");
+        return SSF_OK;
+    }
     bool sink_active() const { return pl->sink.active(); }
     template <typename C> void sink_capture(const C *soa, long long N, int nrows) {
         chk(pl->sink.capture(soa, N, nrows, pl->stream), "snapshot sink");
@@ -468,6 +529,12 @@ template <typename T> class FusedEngine final : public Engine {
         return SSF_OK;
     }
     int unit_stats(int u, ssf_stats *out) override { return core.unit_stats(u, out) ? SSF_OK : SSF_ERR_BAD_ARG; }
+    int set_coupling_comm(ssf_comm *comm) override {
+        if (comm && (core.N2mix || core.units > 1)) return SSF_ERR_UNSUPPORTED;
+        int rc = core.set_couple(comm, comm ? comm_nranks(comm) : 0);
+        if (core.pk && rc == SSF_OK) rc = core.pk->set_couple(comm, comm ? comm_nranks(comm) : 0);
+        return rc;
+    }
 };
 
 template <typename T> class FusedConvImpl final : public FusedConv {

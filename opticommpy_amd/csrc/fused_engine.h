@@ -139,6 +139,8 @@ template <typename T, class Backend> class FusedCore {
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
     S *P = nullptr, *Theta = nullptr;
     bool own_G = true;           // the packed core works in the float core's exchange buffer
+    void *cpl_comm = nullptr;    // coupled batch across ranks (ssf_set_coupling_comm): the communicator ...
+    double *cpl_work = nullptr;  // ... and 8 + 5 x ranks doubles: [0, 5) this rank's / the reduced values, [8, ...) the gathered ones
     std::unique_ptr<FusedCore<pf2, Backend>> pk;     // float core: the packed-pair Manakov pipeline (created on first use)
     bool use_packed = true;      // SSF_C64_PACKED=0: complex64 Manakov on the one-row-per-polarisation kernels (A/B runs)
     bool lim0_bound = true;       // SSF_LIM0_BOUND=0: always evaluate lim_0 on all samples (A/B runs)
@@ -307,6 +309,7 @@ template <typename T, class Backend> class FusedCore {
     }
     ~FusedCore() {
         if (!own_G) G = nullptr;
+        if (cpl_work) be.free(cpl_work);
         for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)Theta, (void *)ctrl, (void *)linops, (void *)gbar,
                         (void *)part, (void *)wtab, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
             if (p) be.free(p);
@@ -314,6 +317,15 @@ template <typename T, class Backend> class FusedCore {
     }
 
     C *Tcur() { return cur ? T1 : T0; }
+    int set_couple(void *comm, int nranks) {
+        if (cpl_work) be.free(cpl_work);
+        cpl_work = nullptr;
+        cpl_comm = nullptr;
+        if (!comm) return SSF_OK;
+        if (!(cpl_work = (double *)be.alloc(sizeof(double) * (size_t)(8 + 5 * nranks)))) return oom();
+        cpl_comm = comm;
+        return SSF_OK;
+    }
 
     int upload(const void *field, bool aos) {
         if constexpr (kPacked) return SSF_ERR_UNSUPPORTED;
@@ -591,6 +603,17 @@ template <typename T, class Backend> class FusedCore {
         a.pnum0 = part + 3 * ps;
         a.pden0 = part + 4 * ps;
         a.npart = col_grid_mk;
+        if constexpr (Backend::kCanCouple) {
+            if (cpl_comm) {                            // the pairs of a coupled batch live on several ranks: all-rank sums / maxima
+                if (be.couple(cpl_comm, part, ps, col_grid_mk, cpl_work)) return;
+                a.pnum0 = cpl_work;
+                a.pden0 = cpl_work + 1;
+                a.pnum = cpl_work + 2;
+                a.pden = cpl_work + 3;
+                a.pmax = cpl_work + 4;
+                a.npart = 1;
+            }
+        }
         be.launch_row(a, row_grid, row_block, row_lds, units);
         ++seq;
     }

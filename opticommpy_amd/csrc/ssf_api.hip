@@ -294,6 +294,15 @@ int ssf_set_coupling(ssf_plan *plan, ssf_reduce_fn reduce, void *ctx) {
     return rc ? fail(plan, rc, "coupled batches need the general-length engine (create the plan with SSF_ENGINE_ROCFFT)") : SSF_OK;
 }
 
+int ssf_set_coupling_comm(ssf_plan *plan, ssf_comm *comm) {
+    if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
+    SSF_NEED_ENGINE(plan);
+    if (comm && ssf::comm_device(comm) != plan->device) return fail(plan, SSF_ERR_BAD_ARG, "ssf_set_coupling_comm: the communicator lives on another device");
+    if (comm && plan->units > 1) return fail(plan, SSF_ERR_UNSUPPORTED, "ssf_set_coupling_comm: a plan of independent units is not a coupled batch");
+    int rc = plan->engine->set_coupling_comm(comm);
+    return rc ? fail(plan, rc, "device-side coupling needs the device-resident fused pipeline (else: ssf_set_coupling on SSF_ENGINE_ROCFFT)") : SSF_OK;
+}
+
 int ssf_set_profiling(ssf_plan *plan, int32_t enable) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     SSF_NEED_ENGINE(plan);

@@ -37,6 +37,12 @@ struct TraceSink {
     }
 };
 
+// comm_rccl.hip: device-buffer all-gather on the caller's stream (no synchronisation)
+int comm_allgather_on(ssf_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank, hipStream_t st);
+int comm_nranks(const ssf_comm *c);
+int comm_device(const ssf_comm *c);
+const char *comm_error(const ssf_comm *c);
+
 class Engine {
   public:
     virtual ~Engine() {}
@@ -51,6 +57,7 @@ class Engine {
     virtual int unit_stats(int, ssf_stats *) { return SSF_ERR_UNSUPPORTED; }
     virtual int set_lanes(int) { return SSF_OK; }
     virtual int set_coupling(ssf_reduce_fn, void *) { return SSF_ERR_UNSUPPORTED; }
+    virtual int set_coupling_comm(ssf_comm *) { return SSF_ERR_UNSUPPORTED; }
     virtual int set_profiling(int) { return SSF_ERR_UNSUPPORTED; }
     virtual int kernel_times(ssf_kernel_times *) { return SSF_ERR_UNSUPPORTED; }
 };

@@ -408,8 +408,17 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
                          "with more than one polarisation pair set param.saveSpanN = []")
     Nspans = int(np.floor(param.Ltotal / param.Lspan))
     prec = _prec_code(param.prec)
+    dev_coupling = False
     if _coupling is not None:                 # rows of ONE reference call spread over several processes (mgpu.run_coupled):
-        pl = _get_plan(N, ncols, prec, engine=_lib.ENGINE_ROCFFT)                  # host-driven control flow
+        # an RCCL communicator + a natively split length: the device-resident pipeline all-gathers its partial sums on the plan's
+        # stream (ssf_set_coupling_comm, no host in the loop); anything else: the host-driven engine with a reducer callback
+        ch = getattr(_coupling, "h", None)
+        if ch is not None and _state["engine"] != _lib.ENGINE_ROCFFT:
+            pl = _get_plan(N, ncols, prec)
+            dev_coupling = pl.lib.ssf_plan_pipeline(pl.h) == 0 and pl.lib.ssf_set_coupling_comm(pl.h, ch) == 0
+            pl.lib.ssf_set_coupling_comm(pl.h, None)                               # (attached for the run inside the try below)
+        if not dev_coupling:
+            pl = _get_plan(N, ncols, prec, engine=_lib.ENGINE_ROCFFT)              # host-driven control flow
     else:
         pl = _get_plan(N, ncols, prec, units=_units)
     # the reference's own layout goes over the bus; the (N, 2K) -> (2K, N) conversion runs on the GPU
@@ -446,7 +455,9 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
     try:                                      # (whatever fails below, the cached plan keeps no sink and no reducer)
         if save_list:
             sink = _open_sink(pl, on_dev, N, ncols, len(save_list), len(captured))
-        if _coupling is not None:
+        if dev_coupling:
+            pl.check(pl.lib.ssf_set_coupling_comm(pl.h, ch))
+        if _coupling is not None and not dev_coupling:
             def _reduce(_ctx, vals, n, op):   # called by the engine with the partial sums / maxima it is about to use
                 try:
                     a = np.ctypeslib.as_array(vals, shape=(n,))
@@ -460,6 +471,8 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
     finally:
         if reducer is not None:
             pl.lib.ssf_set_coupling(pl.h, None, None)
+        if dev_coupling:
+            pl.lib.ssf_set_coupling_comm(pl.h, None)
         if save_list:
             _close_sink(pl, len(captured))
     for _ in range(int(st.nonconverged_steps)):

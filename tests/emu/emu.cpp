@@ -167,6 +167,7 @@ struct EmuBackend {
         else run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_body<T, 0>(c, a); });
     }
     static constexpr bool kCanPersist = false;         // (no grid barrier between the emulator's sequential workgroups)
+    static constexpr bool kCanCouple = false;          // (no communicator)
     bool sink_active() const { return false; }
     template <typename C> void sink_capture(const C *, long long, int) {}
     void launch_repack(const ssf::fused::RepackArgs &a, int grid, int block) {

@@ -106,6 +106,12 @@ with mgpu.RcclComm.from_env(device=rank) as comm:
     out = mgpu.run_coupled(np.ascontiguousarray(E[:, 2 * rank: 2 * rank + 2]), make_param(oa.parameters, cfgc), comm)
     np.save(os.path.join(os.environ["SSF_OUT"], f"coupled_rank{rank}.npy"), out)
     np.save(os.path.join(os.environ["SSF_OUT"], f"steps_rank{rank}.npy"), np.array([models.last_run["steps"], models.last_run["iterations"]]))
+    assert models.last_run["pipeline"] == "fused-device"             # device-side coupling (ssf_set_coupling_comm), host out of the loop
+    # ... and the host-driven engine with the reducer callback (what other lengths and the gloo stand-in use)
+    oa.set_engine("rocfft")
+    out_h = mgpu.run_coupled(np.ascontiguousarray(E[:, 2 * rank: 2 * rank + 2]), make_param(oa.parameters, cfgc), comm)
+    oa.set_engine("auto")
+    np.save(os.path.join(os.environ["SSF_OUT"], f"coupled_host_rank{rank}.npy"), out_h)
 '''
 
 
@@ -125,6 +131,8 @@ def test_run_sharded_and_run_coupled_over_rccl_on_two_devices(tmp_path):
     ref = orc.manakovSSF(E, make_param(orc.parameters, cfgc), trace=tr)
     got = np.concatenate([np.load(tmp_path / f"coupled_rank{r}.npy") for r in range(2)], axis=1)
     assert rel_l2(got, ref) <= 1e-10
+    got_h = np.concatenate([np.load(tmp_path / f"coupled_host_rank{r}.npy") for r in range(2)], axis=1)
+    assert rel_l2(got_h, ref) <= 1e-10
     for r in range(2):
         s = np.load(tmp_path / f"steps_rank{r}.npy")
         assert int(s[0]) == tr["steps"] and int(s[1]) == tr["iterations"]

@@ -333,6 +333,44 @@ def test_run_sharded_falls_back_to_one_call_per_unit_where_a_plan_cannot_carry_u
     assert rel_l2(outs[2], orc.manakovSSF(fields[2], make_param(orc.parameters, cfg))) <= 1e-10
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["complex128", "complex64"])
+def test_device_side_coupling_over_a_one_rank_rccl_communicator(monkeypatch, prec):
+    """ssf_set_coupling_comm: the device-resident pipeline reduces its partial sums / maxima per rank, all-gathers them over RCCL on
+    the plan's stream and reduces over the ranks, host out of the loop (round 4; two ranks: tests/test_multi_gpu_rccl.py).  With
+    ONE rank the gathered value is the rank's own: the K = 2 coupled call must come out as without a communicator -- same step
+    and iteration counts, field to rounding (the sums are taken in another order) -- adaptive and fixed step, and against the oracle."""
+    import opticommpy_amd as oa
+    from helpers import make_param, rel_l2, synth_field
+    from opticommpy_amd import mgpu, models
+    from oracle import ssf_oracle as orc
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    dt = np.dtype(prec)
+    E = np.concatenate([synth_field(1 << 13, 2, 11, 3.0), synth_field(1 << 13, 2, 12, 12.0)], axis=1).astype(dt)
+    with mgpu.RcclComm.from_env() as comm:
+        for adaptive in (True, False):
+            cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=8, Lspan=4, hz=0.5,
+                       nlprMethod=adaptive, maxNlinPhaseRot=1e-2, amp="ideal", saveSpanN=[], prec=prec)
+            plain = oa.manakovSSF(E, make_param(oa.parameters, cfg))
+            run0 = (models.last_run["steps"], models.last_run["iterations"], models.last_run["pipeline"])
+            out = oa.manakovSSF(E, make_param(oa.parameters, cfg), _coupling=comm)
+            run1 = (models.last_run["steps"], models.last_run["iterations"], models.last_run["pipeline"])
+            assert run1 == run0 and run1[2] == "fused-device"
+            assert rel_l2(out, plain) <= (1e-12 if prec == "complex128" else 1e-6)
+            if prec == "complex128":
+                tr = {}
+                ref = orc.manakovSSF(E, make_param(orc.parameters, cfg), trace=tr)
+                assert rel_l2(out, ref) <= 1e-10 and run1[:2] == (tr["steps"], tr["iterations"])
+        # lengths without a native split keep the host-driven engine + reducer callback
+        E3 = np.concatenate([synth_field(3000, 2, 11, 3.0), synth_field(3000, 2, 12, 12.0)], axis=1)
+        cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=4, Lspan=4, hz=0.5,
+                   nlprMethod=True, maxNlinPhaseRot=1e-2, amp="ideal", saveSpanN=[])
+        out3 = oa.manakovSSF(E3, make_param(oa.parameters, cfg), _coupling=comm)
+        assert rel_l2(out3, orc.manakovSSF(E3, make_param(orc.parameters, cfg))) <= 1e-10
+
+
 # ------------------------------------------------------------------------------------------ configs 4 and 5 at workload size
 def _check_units_against_the_reference(rec, which, log2n):
     """Every unit's (sum |E|^2, |<q, E>|, iterations) against what the REFERENCE produced for that unit (tests/golden/wl_units45_n*.npz,
