@@ -124,6 +124,8 @@ typedef struct {
                                  /*   evaluated one iteration in advance (all but the    */
                                  /*   first of every step)                               */
     int64_t rebuilt_iterates;    /* fused engine: iterates rebuilt as final (lim_0<tol)  */
+    int64_t recovered_fields;    /* fused engine: step-start fields recovered from E_hd  */
+                                 /*   for an exact lim_0 (three launches each)           */
 } ssf_stats;
 
 /* Optional per-step trace (for parity checks of the data-dependent control flow).

@@ -31,7 +31,8 @@ class Stats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("iterations", C.c_int64), ("transforms", C.c_int64),
                 ("nonconverged_steps", C.c_int64), ("device_ms", C.c_double),
                 ("bytes_algorithmic", C.c_double), ("engine", C.c_int32), ("n_snapshots", C.c_int32),
-                ("decided_ahead", C.c_int64), ("rebuilt_iterates", C.c_int64)]
+                ("decided_ahead", C.c_int64), ("rebuilt_iterates", C.c_int64),
+                ("recovered_fields", C.c_int64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}

@@ -775,6 +775,7 @@ template <typename T, class Backend> class FusedCore {
             us.nonconverged_steps += c.nonconv;
             us.decided_ahead += c.n_ahead;
             us.rebuilt_iterates += c.n_rebuilt;
+            us.recovered_fields += c.n_recovered;
             us.transforms += (int64_t)(kPacked ? 2 * rows_u() : rows_u()) * (2 * c.steps + 2 * c.iterations);
         }
         for (const Ctrl &c : cs) {
@@ -783,6 +784,7 @@ template <typename T, class Backend> class FusedCore {
             st->nonconverged_steps += c.nonconv;
             st->decided_ahead += c.n_ahead;
             st->rebuilt_iterates += c.n_rebuilt;
+            st->recovered_fields += c.n_recovered;
             st->transforms += (int64_t)(kPacked ? 2 * rows_u() : rows_u()) * (2 * c.steps + 2 * c.iterations);
         }
         return SSF_OK;

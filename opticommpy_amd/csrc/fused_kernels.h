@@ -52,7 +52,14 @@ enum {
     ST_NEED_I = 4,     // Col: E_fd(it).  Not final: next iterate + sums of lim_{it+1}            -> ROW_ITER
                        //      final: field out, next step's Pch + forward FFT         -> AFTER_S | SPAN_DONE
     ST_SPAN_DONE = 6,
-    ST_REDO0 = 7       // Col: rebuild iterate 0 as the final one (lim_0 < tol)                   -> ROW_ITER
+    ST_REDO0 = 7,      // Col: rebuild iterate 0 as the final one (lim_0 < tol)                   -> ROW_ITER
+    // The final stage of a step that another step follows stores the field at ONE sample in sixteen -- all that the next step's
+    // bound of lim_0 reads (Ctrl::t_sparse).  If that bound cannot exclude convergence at iterate 0 (the rounding-sized last step
+    // of a span: lim_0 ~ 1e-12), lim_0 has to be measured on every sample of the field at the step start, which is then
+    // recovered first: E(z) = Lin^-1(E_hd), one more column / row / column round, the last one also rebuilding iterate 0.
+    ST_RECOVER_A = 8,  // Col: E_hd -> forward column FFT                                         -> RECOVER_ROW
+    ST_RECOVER_ROW = 9,// Row: inverse half linear step                                           -> RECOVER_B
+    ST_RECOVER_B = 10  // Col: field at the step start out (all samples); then as REDO0           -> ROW_ITER
 };
 
 struct LinOp {          // exp(argLimOp * hz/2) / N evaluated from the bin index (row kernel)
@@ -69,12 +76,15 @@ struct Ctrl {           // device-resident step state, double-buffered by launch
     int pcur, redo_;    // current Pch buffer; iterate 0 is being rebuilt as final
     int bound0;         // the pending lim_0 sums cover a sixteenth of the samples: a lower bound of lim_0
     int exact0;         // the next I stage of iterate 0 evaluates lim_0 on all samples (bound was inconclusive)
+    int t_sparse;       // the field at the step start (T[cur]) holds one sample in sixteen only (see ST_RECOVER_A)
+    int dense;          // this step needed the exact lim_0: its final stage stores every sample
     int gscale;         // G holds the column spectrum of the field DIVIDED by N1: the final I stage of the last step did not
                         // rewrite it (see mk_col_stage); the next row stage multiplies its operator by N1
     long long pend0_idx;// trace row lim_0 belongs to
     double z, hz;
     long long steps, iterations, nonconv, trace_n;
     long long n_ahead, n_rebuilt;   // iterations decided in advance / iterates rebuilt
+    long long n_recovered;          // step-start fields recovered (ST_RECOVER_A)
     LinOp lin;
 };
 
@@ -537,13 +547,13 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
     const Ctrl &c = *a.cin;
     const int c_state = c.state, c_it = c.it, c_pend0 = c.pend0, c_pendn = c.pendn, c_cap0 = c.cap0, c_bound0 = c.bound0;
     int n_exact0 = c.exact0;
-    const int c_gscale = c.gscale;
+    const int c_gscale = c.gscale, c_sparse = c.t_sparse;
     int n_state = c_state, n_final = c.final_, n_cap0 = c_cap0, n_hzv = c.hz_valid;
     int add_nonconv = 0, add_ahead = 0;
     double n_hz = c.hz;
     double *red = (double *)(ctx.lds) + 64;
     const bool lead = ctx.bid == 0 && ctx.tid == 0;
-    bool act = c_state == ST_AFTER_S || c_state == ST_ROW_ITER;
+    bool act = c_state == ST_AFTER_S || c_state == ST_ROW_ITER || c_state == ST_RECOVER_ROW;
     if (c_pend0 || c_pendn) {             // every block reduces the sums in the same order
         double s0 = part[0][0] + part[1][0], s1 = part[0][1] + part[1][1];
         double s2 = part[0][2] + part[1][2], s3 = part[0][3] + part[1][3];
@@ -573,7 +583,7 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
         }
         if (c_pendn) {                                                // lim_it, known before iterate it exists
             if (redo) {
-                n_state = ST_REDO0;
+                n_state = (n_exact0 && c_sparse) ? ST_RECOVER_A : ST_REDO0;   // (exact lim_0 needs the whole field at the step start)
                 act = false;
             } else {
                 const double lim = sqrt(s2) / sqrt(s3);
@@ -604,11 +614,17 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
         if (lead) a.cout->lin = lsh[0];   // (straight from LDS: callers that only need cth / mag keep no copy)
         n_hzv = 1;
         ctx.sync();
+    } else if (act && c_state == ST_RECOVER_ROW) {                    // E(z) = Lin^-1(E_hd): the half step backwards (rare: once per span)
+        ctx.sync();
+        if (ctx.tid == 0) lsh[0] = make_linop(-c.hz / 2, a.k.lin_a, a.k.lin_b, a.k.w2, a.k.invN, a.k.log2N);
+        ctx.sync();
+        lo = lsh[0];
+        ctx.sync();
     } else if (act) {
         lo = c.lin;
     }
     if (act && c_state == ST_AFTER_S && c_gscale) lo.mag *= (double)(1ll << a.log2N1);   // (G = spectrum / N1: mk_col_stage)
-    if (act) n_state = c_state == ST_AFTER_S ? ST_NEED_H : ST_NEED_I;
+    if (act) n_state = c_state == ST_AFTER_S ? ST_NEED_H : c_state == ST_RECOVER_ROW ? ST_RECOVER_B : ST_NEED_I;
     if (lead) {
         ctrl_forward(a.cin, a.cout, (int)((new_lin ? offsetof(Ctrl, lin) : sizeof(Ctrl)) / 8));
         Ctrl *n = a.cout;
@@ -619,6 +635,7 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
         n->cap0 = n_cap0;
         n->bound0 = 0;
         n->exact0 = n_exact0;
+        if (n_exact0) n->dense = 1;
         if (act && c_state == ST_AFTER_S) n->gscale = 0;
         n->hz_valid = n_hzv;
         n->hz = n_hz;
@@ -1179,12 +1196,16 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
 }
 
 // What a Manakov column launch does, decided from the control block; the lead thread forwards the block with the
-// state advanced.  op: 0 = S (span start), 1 = H, 2 = I, 3 = rebuild of iterate 0, -1 = nothing to do.
+// state advanced.  op: 0 = S (span start), 1 = H, 2 = I, 3 = rebuild of iterate 0, 4 / 5 = recover the field at the step
+// start (ST_RECOVER_A / _B; 5 goes on as 3), -1 = nothing to do.
 struct MkColStage {
     bool do_inv = false, do_fwd = false, final_ = false, more = false, exact0 = true;
+    bool sparse = false;      // final stage: store the field at the samples the next step's bound of lim_0 reads only
     int op = -1;
     struct { int state, it, cur, pcur; double z, hz; } c{};
 };
+// the samples of a thread's V that the bound of lim_0 reads: one in sixteen = one cache line in sixteen
+template <int V> SSF_HD bool lim0_bound_sample(int idx, int b) { return idx == 0 && (V == 16 || !(b & 1)); }
 template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &a, MkColStage &st) {
     bool &do_inv = st.do_inv, &do_fwd = st.do_fwd, &final_ = st.final_, &more = st.more, &exact0 = st.exact0;
     int &op = st.op;
@@ -1214,9 +1235,20 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
         // is a power of two, so the factor is exact) -- and so it neither transforms nor rewrites G (one forward column
         // transform and one write of the field less per step); the control block tells the next row stage (gscale).
         do_fwd = final_ ? false : true;
+        // ... and the next step reads the stored field at one sample in sixteen (the bound of lim_0), unless lim_0 is always
+        // exact, the last step needed the exact one (weak nonlinearity: lim_0 < tol as a rule -- keep storing everything) or
+        // a fixed-step run is about to take its short last step (whose lim_0 is rounding-sized).
+        st.sparse = final_ && more && !a.k.exact_lim0 && !a.cin->dense &&
+                    (a.k.adaptive || pick_hz(a.k, c.z + c.hz, 0.0) == c.hz);
     } else if (c.state == ST_REDO0) {
         op = 3;
         do_fwd = true;
+    } else if (c.state == ST_RECOVER_A) {
+        op = 4;
+        do_fwd = true;
+    } else if (c.state == ST_RECOVER_B) {
+        op = 5;
+        do_inv = do_fwd = true;
     }
     if (ctx.bid == 0 && ctx.tid == 0) {                               // forward the control block
         ctrl_forward(a.cin, a.cout, (int)(sizeof(Ctrl) / 8));
@@ -1224,19 +1256,24 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
         if (op == 0) {
             n->state = ST_AFTER_S;
             n->gscale = 0;
+            n->t_sparse = n->dense = 0;
             n->hz_valid = 0;
         } else if (op == 1) {
             n->state = ST_ROW_ITER;
             n->it = 0;
             n->final_ = a.k.maxIter == 1;
             n->pend0 = n->pendn = 0;
-        } else if (op == 3) {
+        } else if (op == 4) {
+            n->state = ST_RECOVER_ROW;
+        } else if (op == 3 || op == 5) {
+            if (op == 5) n->t_sparse = 0;
             n->state = ST_ROW_ITER;
             n->it = 0;
             n->final_ = a.cin->exact0 ? 0 : 1;                        // (exact0: rebuilt to measure lim_0, not as final)
             n->redo_ = a.cin->exact0 ? 0 : 1;
             n->pend0 = n->pendn = 0;
             n->n_rebuilt = a.cin->n_rebuilt + 1;
+            if (op == 5) n->n_recovered = a.cin->n_recovered + 1;
         } else if (op == 2 && !final_) {
             n->state = ST_ROW_ITER;
             n->it = c.it + 1;
@@ -1268,6 +1305,8 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
                 n->exact0 = 0;
             }
             n->redo_ = 0;
+            n->t_sparse = st.sparse ? 1 : 0;
+            n->dense = 0;
             if (more) {
                 n->gscale = 1;
                 n->state = ST_AFTER_S;
@@ -1290,7 +1329,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     // ---- what does this launch do? ------------------------------------------------------
     bool do_inv = false, do_fwd = false;
     int op = -1;     // Manakov: 0 = S (span start), 1 = H, 2 = I, 3 = rebuild iterate 0
-    bool final_ = false, more = false, exact0 = true;
+    bool final_ = false, more = false, exact0 = true, sparse = false;
     struct { int state, it, cur, pcur; double z, hz; } c{};
     double *red = (double *)ctx.lds;
     ctx.mark(0);
@@ -1302,6 +1341,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
         final_ = st.final_;
         more = st.more;
         exact0 = st.exact0;
+        sparse = st.sparse;
         op = st.op;
         c.state = st.c.state;
         c.it = st.c.it;
@@ -1344,8 +1384,9 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
         ctx.mark(2);
         if (a.prio) ctx.template setprio<2>();
     } else if (!(kMk && op == 3)) {
+        const cx<T> *src = kMk && op == 4 ? a.Ehd : Tcur;
 #pragma unroll
-        for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
+        for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(src, g.rowbase + g.time_off(idx));
     }
 
     // ---- time-domain work ---------------------------------------------------------------
@@ -1360,7 +1401,8 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
         cx<T> *shC = (cx<T> *)(ctx.lds + 2 * V * (size_t)g.half * sizeof(T));
         if (op == 0) {                               // span start: Pch into the current buffer
             mk_step_start(ctx, g, a, v, Pcur, false);
-        } else if (op == 1 || op == 3) {             // H (channels.py:409-417) | rebuild of iterate 0
+        } else if (op == 4) {                        // (E_hd goes through the forward transform as it is)
+        } else if (op == 1 || op == 3 || op == 5) {  // H (channels.py:409-417) | rebuild of iterate 0 (5: after the recovered field is out)
             T ang[H];
 #pragma unroll
             for (int j = 0; j < H; ++j) {
@@ -1371,7 +1413,10 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
             for (int idx = 0; idx < V; ++idx) {
                 const long long t = g.time_off(idx);
                 if (op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
-                else v[idx] = g.ld(a.Ehd, g.rowbase + t);
+                else {
+                    if (op == 5) g.st(Tcur, g.rowbase + t, v[idx]);
+                    v[idx] = g.ld(a.Ehd, g.rowbase + t);
+                }
             }
             cx<T> rot[V];
             ctx.sync();                              // inverse transform's LDS reads are done
@@ -1384,7 +1429,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
             if (c.it == 0) {                         // lim_0 against the field at the step start
 #pragma unroll
                 for (int idx = 0; idx < V; ++idx) {
-                    if (exact0 || (idx == 0 && (V == 16 || !(g.b & 1)))) {   // (bound: one sample in sixteen = one cache line in sixteen)
+                    if (exact0 || lim0_bound_sample<V>(idx, g.b)) {
                         const cx<T> e = g.ld(Tcur, g.rowbase + g.time_off(idx));
                         const double dr = (double)v[idx].re - (double)e.re, di = (double)v[idx].im - (double)e.im;
                         n0 += dr * dr + di * di;
@@ -1394,7 +1439,8 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
             }
             if (final_) {                            // the field after this step (channels.py:438-439)
 #pragma unroll
-                for (int idx = 0; idx < V; ++idx) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
+                for (int idx = 0; idx < V; ++idx)
+                    if (!sparse || lim0_bound_sample<V>(idx, g.b)) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
             } else {
                 mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
                 if (!exact0) d0 = psum;              // exact denominator of the bound: sum Pch over the tile
@@ -1518,14 +1564,16 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
         fft_dif<+1, V>(ctx, p, g.b, v, lds, tws);
         ctx.mark(2);
     } else if (op != 3) {
+        const cx<T> *src = op == 4 ? a.Ehd : Tcur;
 #pragma unroll
-        for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
+        for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(src, g.rowbase + g.time_off(idx));
     }
 
     const float shz = (float)(a.k.sgn * st.c.hz), c8g = (float)a.k.c8g;
     if (op == 0) {                                           // span start: Pch into the current buffer
         pk_step_start(ctx, g, a, v, Pcur);
-    } else if (op == 1 || op == 3) {                         // H (channels.py:409-417) | rebuild of iterate 0
+    } else if (op == 4) {                                    // (E_hd goes through the forward transform as it is)
+    } else if (op == 1 || op == 3 || op == 5) {              // H (channels.py:409-417) | rebuild of iterate 0 (5: recovered field out first)
         float pw[V];
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) pw[idx] = g.ld(Pcur, g.pbase + g.time_off(idx));
@@ -1533,7 +1581,10 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
         for (int idx = 0; idx < V; ++idx) {
             const long long t = g.time_off(idx);
             if (op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
-            else v[idx] = g.ld(a.Ehd, g.rowbase + t);
+            else {
+                if (op == 5) g.st(Tcur, g.rowbase + t, v[idx]);
+                v[idx] = g.ld(a.Ehd, g.rowbase + t);
+            }
         }
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) v[idx] = tmul(v[idx], cis_t<float>(shz * (c8g * (pw[idx] + pw[idx]) / 2.0f)));
@@ -1544,7 +1595,7 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
         if (first) {                                         // lim_0 against the field at the step start
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) {
-                if (st.exact0 || (idx == 0 && (V == 16 || !(g.b & 1)))) {   // (bound: one sample in sixteen = one cache line in sixteen)
+                if (st.exact0 || lim0_bound_sample<V>(idx, g.b)) {
                     const cx<T> e = g.ld(Tcur, g.rowbase + g.time_off(idx));
 #pragma unroll
                     for (int l = 0; l < 2; ++l) {
@@ -1557,7 +1608,8 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
         }
         if (st.final_) {                                     // the field after this step (channels.py:438-439)
 #pragma unroll
-            for (int idx = 0; idx < V; ++idx) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
+            for (int idx = 0; idx < V; ++idx)
+                if (!st.sparse || lim0_bound_sample<V>(idx, g.b)) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
         } else {
             // next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
             // sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the note at the top of this file)

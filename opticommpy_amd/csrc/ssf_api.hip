@@ -181,6 +181,7 @@ int ssf_get_unit_stats(ssf_plan *plan, int32_t unit, ssf_stats *out) {
     out->nonconverged_steps = u.nonconverged_steps;
     out->decided_ahead = u.decided_ahead;
     out->rebuilt_iterates = u.rebuilt_iterates;
+    out->recovered_fields = u.recovered_fields;
     out->bytes_algorithmic = (double)u.transforms * 2.0 * (plan->precision == SSF_C128 ? 16.0 : 8.0) * (double)plan->N;
     return SSF_OK;
 }

@@ -231,6 +231,61 @@ def test_lim0_bound_that_cannot_exclude_convergence_is_rechecked_exactly():
     assert ia["rebuilt_iterates"] == 0 and 0 < ib["rebuilt_iterates"] <= ib["steps"]
 
 
+def test_final_stage_stores_one_sample_in_sixteen_and_the_field_is_recovered_when_lim0_must_be_exact(monkeypatch):
+    """Without a trace the final stage of a step leaves the field at one sample in sixteen (all the next step's bound of lim_0
+    reads).  When the bound cannot exclude convergence at iterate 0 the whole field at the step start is recovered from E_hd
+    (inverse half linear step: column / row / column launches) before lim_0 is measured on every sample; steps that follow one
+    that needed the exact lim_0 find the whole field (no second recovery in a row).  Same results, bit for bit, and the same
+    step / iteration counts as the traced run, which never stores sparsely; weak nonlinearity (lim_0 < tol at every step)
+    recovers nothing, a run whose bound always holds recovers nothing; the short last step of a fixed-step span is foreseen
+    (the step before it stores everything)."""
+    d, cfg = load_golden("mk_fix_p0_none")
+    _, it = eb.run("manakovSSF", d["Ei"], cfg)
+    lim0 = sorted(float(l[0]) for l in it["lims"])
+    hit = 0
+    for f in (0.27, 0.25, 0.22):                           # tol around the bound (~ lim_0 / 4): some steps need the exact lim_0
+        cfg2 = dict(cfg, tol=lim0[len(lim0) // 2] * f)
+        a, ia = eb.run("manakovSSF", d["Ei"], cfg2)
+        b, ib = eb.run("manakovSSF", d["Ei"], cfg2, trace=False)
+        assert np.array_equal(a, b)
+        assert (ia["steps"], ia["iterations"], ia["nonconverged_steps"]) == (ib["steps"], ib["iterations"], ib["nonconverged_steps"])
+        assert ia["recovered_fields"] == 0 and ib["recovered_fields"] <= ib["rebuilt_iterates"] < ib["steps"]
+        useful = 2 * (ib["steps"] + ib["iterations"] + ib["rebuilt_iterates"] + ib["recovered_fields"])
+        assert useful <= ib["launches"] <= 1.35 * useful + 64
+        hit += ib["recovered_fields"]
+    assert hit > 0
+    for v in ("8", "16"):                                  # both kernel families (the 8-value one samples every other workgroup)
+        monkeypatch.setenv("SSF_COL_V", v)
+        monkeypatch.setenv("SSF_ROW_V", v)
+        bv, iv = eb.run("manakovSSF", d["Ei"], cfg2, trace=False)
+        assert rel_l2(bv, b) <= 1e-13 and iv["iterations"] == ib["iterations"] and iv["recovered_fields"] > 0, v
+    monkeypatch.delenv("SSF_COL_V")
+    monkeypatch.delenv("SSF_ROW_V")
+    tr = {}
+    ref = orc.manakovSSF(d["Ei"], make_param(orc.parameters, cfg2), trace=tr)
+    assert rel_l2(b.T, ref) <= TOL_C128 and ib["iterations"] == sum(tr["iters"])
+    # the bound always holds / never holds / short last step (Lspan = 4.2 hz): nothing to recover
+    for name, extra in (("mk_fix_p8_ideal_2span", {}), ("mk_adp_p13_ideal_2span", {}), ("mk_fix_p8_ideal_2span", dict(hz=0.33))):
+        d, cfg = load_golden(name)
+        cfg = dict(cfg, **extra)
+        _, ib = eb.run(cfg["func"], d["Ei"], cfg, trace=False)
+        assert ib["recovered_fields"] == 0 and ib["rebuilt_iterates"] == 0, name
+    # complex64 (packed pairs): recovered to single precision, results inside the single-precision gate
+    E = synth_field(1 << 12, 2, 19, 0.0, np.complex64)
+    c64 = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5, prgsBar=False,
+               Ltotal=4, Lspan=4, hz=0.25, nlprMethod=False, amp=None, saveSpanN=[], prec="complex64")
+    _, it = eb.run("manakovSSF", E, c64)
+    lim0 = sorted(float(l[0]) for l in it["lims"])
+    hit = 0
+    for f in (0.255, 0.2525):
+        c = dict(c64, tol=lim0[len(lim0) // 2] * f)
+        a, ia = eb.run("manakovSSF", E, c)
+        b, ib = eb.run("manakovSSF", E, c, trace=False)
+        assert ib["iterations"] == ia["iterations"] and rel_l2(b, a) <= 2e-6
+        hit += ib["recovered_fields"]
+    assert hit > 0
+
+
 @pytest.mark.parametrize("maxIter", [1, 2])
 def test_iteration_cap(maxIter):
     """maxIter = 1: the only iterate is final by the cap and lim_0 alone decides the warning count."""

@@ -325,6 +325,21 @@ def test_untraced_runs_bound_lim0_and_give_the_traced_result():
     assert list(models.last_run["iters"]) == tr["iters"] and rel_l2(a, ref) <= TOL_C128
     b = oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg2))
     assert np.array_equal(a, b) and 0 < models.last_run["rebuilt_iterates"] <= models.last_run["steps"]
+    # tol around the bound (~ lim_0 / 4): some steps need the exact lim_0 after steps that did not, whose final stage stored
+    # the field at one sample in sixteen only -- the whole field is recovered from E_hd first (fused_kernels.h: ST_RECOVER_A)
+    oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg), _trace=True)
+    mid = float(np.median([l[0] for l in models.last_run["lims"]]))
+    hit = 0
+    for f in (0.27, 0.25, 0.22):
+        cfg3 = dict(cfg, tol=mid * f)
+        a = oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg3), _trace=True)
+        ra = dict(models.last_run)
+        b = oa.manakovSSF(d["Ei"], make_param(oa.parameters, cfg3))
+        rb = dict(models.last_run)
+        assert np.array_equal(a, b) and (ra["steps"], ra["iterations"]) == (rb["steps"], rb["iterations"])
+        assert ra["recovered_fields"] == 0
+        hit += rb["recovered_fields"]
+    assert hit > 0
     oa.set_engine("auto")
 
 
