@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Differential fuzzing on the GPU through the public API: random sizes / fibre / solver parameters, both
 engines, traced and untraced runs, against the oracle (field and per-step iteration counts).
-Usage (GPU box): python tests/tools/fuzz_gpu.py [cases] [seed]"""
+Usage (GPU box): python tests/tools/fuzz_gpu.py [cases] [seed] [near]
+("near": the fused engine runs every Manakov case once more with tol placed around its own bound of lim_0, traced against untraced:
+the recovery of a sparsely stored step-start field, fused_kernels.h ST_RECOVER_A; both precisions.)"""
 import os
 import sys
 
@@ -22,7 +24,8 @@ ORC = {"ssfm": orc.ssfm, "manakovSSF": orc.manakovSSF, "manakovDBP": orc.manakov
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    bad = 0
+    near = len(sys.argv) > 3 and sys.argv[3] == "near"
+    bad = recovered = 0
     for case in range(cases):
         lg = int(rng.integers(8, 15))
         N = 1 << lg
@@ -76,10 +79,30 @@ def main():
                 bad += 1
                 print("MISMATCH case", case, eng, cfg, "N", N, "K", K, "p", p_dbm, "rel", rel_l2(out, ref), "untraced equal", np.array_equal(out, out2),
                       list(run.get("iters", []))[:8], tr.get("iters", [])[:8], flush=True)
+            if ok and near and eng == "fused" and func != "ssfm" and cfg["maxIter"] > 1 and cfg["gamma"] > 0 and len(run.get("lims", [])):
+                l0 = np.array([float(l[0]) for l in run["lims"] if len(l)])
+                l0 = l0[np.isfinite(l0) & (l0 > 0)]
+                if len(l0):
+                    cfg2 = dict(cfg, tol=float(rng.choice(l0)) * float(rng.uniform(0.2, 0.34)))
+                    a = FUNCS[func](E, make_param(oa.parameters, cfg2), _trace=True)
+                    ra = dict(models.last_run)
+                    b = FUNCS[func](E, make_param(oa.parameters, cfg2))
+                    rb = dict(models.last_run)
+                    recovered += rb["recovered_fields"]
+                    ok2 = np.array_equal(a, b) and (ra["steps"], ra["iterations"]) == (rb["steps"], rb["iterations"]) and ra["recovered_fields"] == 0
+                    if not c64:
+                        tr2 = {}
+                        with np.errstate(all="ignore"):
+                            ref2 = ORC[func](E, make_param(orc.parameters, cfg2), trace=tr2)
+                        ok2 = ok2 and list(ra["iters"]) == tr2["iters"] and rel_l2(a, ref2) <= gate
+                    if not ok2:
+                        bad += 1
+                        print("MISMATCH (tol near the bound) case", case, cfg2, "N", N, "K", K, "p", p_dbm, "equal", np.array_equal(a, b),
+                              (ra["steps"], ra["iterations"]), (rb["steps"], rb["iterations"]), "recovered", rb["recovered_fields"], flush=True)
         if case % 25 == 0:
             print(f"case {case} done ({func}, N={N}, K={K})", flush=True)
     oa.set_engine("auto")
-    print("done:", cases, "cases,", bad, "mismatches")
+    print("done:", cases, "cases,", bad, "mismatches" + (f", {recovered} recovered fields in the near-the-bound runs" if near else ""))
 
 
 if __name__ == "__main__":
