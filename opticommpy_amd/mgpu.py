@@ -116,8 +116,15 @@ class RcclComm:
         st = os.lstat(d)
         if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
             raise RuntimeError("RCCL rendezvous: %s is not a private directory of this user" % d)
-        job = env.get("TORCHELASTIC_RUN_ID") or env.get("SLURM_JOB_ID") or env.get("OMPI_MCA_ess_base_jobid") \
-            or env.get("PMIX_NAMESPACE") or "ppid%d" % os.getppid()
+        rid = env.get("TORCHELASTIC_RUN_ID")
+        if rid in ("", "none"):                                # torchrun's static rendezvous: every job on the node is "none"
+            rid = None
+        job = rid or env.get("SLURM_JOB_ID") or env.get("OMPI_MCA_ess_base_jobid") or env.get("PMIX_NAMESPACE")
+        if not job:
+            # no job id (or torchrun's "none"): the ranks of one single-node launch are children of one launcher process, whose
+            # pid tells this job from the one that ran a minute ago under the same MASTER_PORT (N = 1, 2, 4, 8 runs back to
+            # back) and may have left a file behind
+            job = "ppid%d" % os.getppid()
         key = "%s_%s_%s" % (env.get("MASTER_ADDR", "local"), env.get("MASTER_PORT", "0"), job)
         return os.path.join(d, "".join(c if c.isalnum() or c in "._-" else "_" for c in key) + ".id")
 

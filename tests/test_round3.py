@@ -23,6 +23,9 @@ def test_rendezvous_file_is_private_fresh_and_keyed_by_the_job(tmp_path, monkeyp
     d = os.path.dirname(p)
     assert os.stat(d).st_mode & 0o077 == 0 and os.stat(d).st_uid == os.getuid()
     assert "29511" in p and "job_7" in p and "ppid" not in p       # ranks of one job agree without sharing a parent
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")              # torchrun's static rendezvous names every job "none":
+    assert ("ppid%d" % os.getppid()) in R.id_path()                # the launcher's pid keys the file instead
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job/7")
     monkeypatch.setenv("SSF_RCCL_ID_FILE", str(tmp_path / "x.id"))
     p = R.id_path()
     assert p == str(tmp_path / "x.id")
