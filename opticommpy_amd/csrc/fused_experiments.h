@@ -135,6 +135,7 @@ template <typename T, int LGR, int LGC> __global__ void __launch_bounds__(256) k
             ColArgs<T> ca = a.col;
             ca.cin = lc;
             ca.cout = gout;
+            ctx.nblocks = a.col_grid;                                     // (the stage's own grid: Owned slots are keyed by it)
             for (int vb = me; vb < a.col_grid; vb += nwg) {
                 ctx.bid = vb;
                 col_body<T, LGC, CM_MK, false>(ctx, ca);
@@ -144,6 +145,7 @@ template <typename T, int LGR, int LGC> __global__ void __launch_bounds__(256) k
             RowArgs<T> ra = a.row;
             ra.cin = lc;
             ra.cout = gout;
+            ctx.nblocks = a.row_grid;
             for (int vb = me; vb < a.row_grid; vb += nwg) {
                 ctx.bid = vb;
                 row_body<T, LGR>(ctx, ra);

@@ -1509,6 +1509,38 @@ template <class Ctx> SSF_HD void repack_body(Ctx &ctx, const RepackArgs &a) {
     }
 }
 
+// P (step-start powers) and Theta (last phases) of the PACKED complex64 column stage are written and read by that stage only,
+// always by the thread that holds the sample (same kernel, same launch geometry in every launch of a plan): they are laid out by
+// owner instead of by sample, [16-byte chunk of the thread's values][workgroup][thread][chunk], so that a thread moves 16 bytes
+// and a wave 1 KiB per instruction.  (By sample, the four adjacent columns of a workgroup are 16 B: a wave instruction touches 16
+// cache lines for 256 bytes, and the three real-valued accesses per sample cost the memory pipeline as many line look-ups as the
+// three complex ones: +1.5 % at config 3.  The polarisation-split double-precision stage moves 64-byte segments by sample and
+// loses 0.7 % with this layout -- both in profiles/r4_ab_pk_owner_layout.txt -- so it keeps the by-sample one.)
+template <typename T, int NV, class Ctx> struct Owned {          // NV values of type T per thread
+    static constexpr int K = 16 / (int)sizeof(T), NQ = NV / K;
+    static_assert(NV % K == 0, "a thread's values are whole 16-byte chunks");
+    typedef T vec __attribute__((vector_size(16)));
+    long long me, stride;                                    // this thread's slot / slots per chunk index
+    SSF_HD Owned(const Ctx &ctx) : me((long long)ctx.bid * ctx.nthreads + ctx.tid), stride((long long)ctx.nblocks * ctx.nthreads) {}
+    SSF_HD void load(const T *buf, T *x) const {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const vec w = ((const vec *)buf)[q * stride + me];
+#pragma unroll
+            for (int l = 0; l < K; ++l) x[K * q + l] = w[l];
+        }
+    }
+    SSF_HD void store(T *buf, const T *x) const {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            vec w;
+#pragma unroll
+            for (int l = 0; l < K; ++l) w[l] = x[K * q + l];
+            ((vec *)buf)[q * stride + me] = w;
+        }
+    }
+};
+template <int V, class Ctx> using PkOwned = Owned<float, V, Ctx>;
 // |Ex|^2 and |Ey|^2 of a packed sample
 SSF_HD void pair_pow(cx<pf2> e, float &ax, float &ay) {
     const pf2 n = e.re * e.re + e.im * e.im;
@@ -1521,15 +1553,17 @@ SSF_HD void pk_step_start(Ctx &ctx, const G &g, const ColArgs<pf2> &a, const cx<
     constexpr int V = G::kV;
     const float c8g = (float)a.k.c8g;
     double m = -INFINITY;
+    float pws[V];
 #pragma unroll
     for (int idx = 0; idx < V; ++idx) {
         float ax, ay;
         pair_pow(v[idx], ax, ay);
         const float pw = ax + ay;
-        g.st(Pbuf, g.pbase + g.time_off(idx), pw);
+        pws[idx] = pw;
         const float phi = c8g * (pw + ax + ay) / 2.0f;
         m = (double)phi > m ? (double)phi : m;
     }
+    PkOwned<V, Ctx>(ctx).store(Pbuf, pws);
     if (a.k.adaptive) {
         m = block_max(ctx, m, (double *)ctx.lds);
         if (ctx.tid == 0) a.pmax[ctx.bid] = m;
@@ -1570,13 +1604,13 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
     }
 
     const float shz = (float)(a.k.sgn * st.c.hz), c8g = (float)a.k.c8g;
+    const PkOwned<V, Ctx> own(ctx);
     if (op == 0) {                                           // span start: Pch into the current buffer
         pk_step_start(ctx, g, a, v, Pcur);
     } else if (op == 4) {                                    // (E_hd goes through the forward transform as it is)
     } else if (op == 1 || op == 3 || op == 5) {              // H (channels.py:409-417) | rebuild of iterate 0 (5: recovered field out first)
         float pw[V];
-#pragma unroll
-        for (int idx = 0; idx < V; ++idx) pw[idx] = g.ld(Pcur, g.pbase + g.time_off(idx));
+        own.load(Pcur, pw);
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) {
             const long long t = g.time_off(idx);
@@ -1614,12 +1648,8 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
             // next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
             // sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the note at the top of this file)
             float pw[V], prev[V], pn[V];
-#pragma unroll
-            for (int idx = 0; idx < V; ++idx) {
-                const long long t = g.pbase + g.time_off(idx);
-                pw[idx] = g.ld(Pcur, t);
-                prev[idx] = first ? 0.0f : g.ld(a.Theta, t);
-            }
+            own.load(Pcur, pw);
+            if (!first) own.load(a.Theta, prev);
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) {
                 float ax, ay;
@@ -1631,8 +1661,7 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
             ctx.mark(6);
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
-#pragma unroll
-            for (int idx = 0; idx < V; ++idx) g.st(a.Theta, g.pbase + g.time_off(idx), pn[idx]);
+            own.store(a.Theta, pn);
             ctx.mark(7);
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) {
