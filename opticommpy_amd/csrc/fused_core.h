@@ -212,9 +212,21 @@ SSF_HD float kcos_f(float x) {
 }
 template <> SSF_HD cx<float> cis_t<float>(float a) {
     if (fabsf(a) <= (float)kQuarterPi) return mk<float>(kcos_f(a), ksin_f(a));
+#if defined(__HIP_DEVICE_COMPILE__)
+    // large |a| (rare: a nonlinear phase above 45 degrees per step): reduced to one turn in double, then sincospif -- sincosf's own
+    // large-argument reduction is ~340 instructions per call site, 16 sites unrolled per stage: a third of the packed column
+    // kernel's code for a path that never runs, and code that never runs still costs instruction-cache lines (config 3 + 3 %:
+    // profiles/r4_ab_code_size.txt)
+    double t = (double)a * 0.15915494309189533577;   // 1 / (2 pi)
+    t -= rint(t);
+    float s, c;
+    sincospif((float)(2.0 * t), &s, &c);
+    return mk<float>(c, s);
+#else
     float s, c;
     sincos_f(a, s, c);
     return mk<float>(c, s);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
