@@ -1,5 +1,9 @@
 // engine_fused_f64.hip -- the fused engine's kernels and classes for double fields: one of the two
 // translation units engine_fused_impl.h is compiled in (they build in parallel; engine_fused.hip dispatches on the precision).
+// Twiddle bases of this translation unit (cis of an exact fraction of a turn, two to four per thread and launch): own quarter-turn
+// reduction in front of the small-argument kernels instead of the library sincospi -- config 2 + 1.0 % in 4 of 4 interleaved
+// repetitions; in the single-precision unit the same is 1.3 % slower (profiles/r4_ab_code_size.txt), so only here.
+#define SSF_CIS2PI_OWN 1
 #include "engine_fused_impl.h"
 
 namespace ssf {

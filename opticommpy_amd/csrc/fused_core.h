@@ -93,9 +93,23 @@ template <> SSF_HD pf2 fma_s<pf2>(pf2 x, float a, pf2 c) {
 #endif
 }
 
+#ifndef SSF_CIS2PI_OWN
+#define SSF_CIS2PI_OWN 0
+#endif
+SSF_HD double ksin_d(double x);
+SSF_HD double kcos_d(double x);
 // cis(2*pi*frac) evaluated in double (frac is exact: integer / power of two)
 SSF_HD void cis2pi_d(double frac, double &c, double &s) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && SSF_CIS2PI_OWN
+    // |frac| < 1 exact (integer / power of two): the quarter-turn reduction is exact too
+    double t = frac - rint(frac);
+    const double qd = rint(4.0 * t);
+    const int q = (int)qd & 3;
+    const double x = (t - 0.25 * qd) * kTwoPi;
+    const double sx = ksin_d(x), cx_ = kcos_d(x);
+    s = q == 0 ? sx : q == 1 ? cx_ : q == 2 ? -sx : -cx_;
+    c = q == 0 ? cx_ : q == 1 ? -sx : q == 2 ? -cx_ : sx;
+#elif defined(__HIP_DEVICE_COMPILE__)
     sincospi(2.0 * frac, &s, &c);
 #else
     const double a = kTwoPi * frac;
