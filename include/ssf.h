@@ -273,7 +273,7 @@ int  ssf_plan_pipeline(const ssf_plan *plan);
  * ssf_upload (the engine is rebuilt, an uploaded field is dropped).  Natively split lengths of the fused engine only
  * (SSF_ERR_UNSUPPORTED otherwise: the caller falls back to one call per unit). */
 int  ssf_plan_set_units(ssf_plan *plan, int32_t n_units);
-/* steps / iterations / transforms / nonconverged_steps / decided_ahead / rebuilt_iterates of ONE unit since the last upload
+/* steps / iterations / transforms / nonconverged_steps / decided_ahead / rebuilt_iterates / recovered_fields of ONE unit since the last upload
  * (the Manakov models; the other fields of *out are those of the plan). */
 int  ssf_get_unit_stats(ssf_plan *plan, int32_t unit, ssf_stats *out);
 
