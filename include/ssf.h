@@ -33,7 +33,7 @@
  *                                                                          optic/dsp/equalization.py:113-117
  *   ssf_nlin_phase_rot                   nlinPhaseRot                     channels.py:471-493
  *   ssf_convergence_condition            convergenceCondition             channels.py:496-519
- *   ssf_fir_filter / ssf_delay_signal / ssf_decimate / ssf_rx_run   receiver side, see below
+ *   ssf_fir_filter / ssf_fir_long / ssf_delay_signal / ssf_decimate / ssf_rx_run   receiver side, see below
  *   ssf_device_malloc / ssf_device_free / ssf_device_memcpy         device-resident arrays, see below
  *   ssf_wdm_tx                           simpleWDMTx signal path          optic/models/tx.py:178-217
  *   ssf_device_copy_bandwidth            (no reference equivalent) measured memory ceiling
@@ -345,6 +345,15 @@ int  ssf_device_memcpy(int device, void *dst, const void *src, int64_t bytes);
 /* 'same'-mode convolution of every column with `ntaps` complex taps (1 <= ntaps <= 4096) */
 int  ssf_fir_filter(int device, int64_t sigLen, int32_t ncols, int32_t ntaps, const void *taps,
                     const void *sig_in, void *sig_out);
+/* FIR of ANY length, evaluated on the device: sig_out[n, m] = sum_t taps[t] * sig_in[n + shift - t, m] for n in [0, outLen),
+ * sig_in (inLen samples per column) extended with zeros on both sides; `shift` of either sign.  What it replaces:
+ * blockwiseFFTConv's result (optic/dsp/core.py:973-1046; shift = (ntaps - 1) / 2, outLen = inLen) for filters of more than
+ * 4096 taps -- edc over long links (optic/dsp/equalization.py:85-117), delaySignal with NFFT != 1024 (core.py:880-922: its
+ * zero padding, np.roll(-1) and [:N] cut are shift + 1 and outLen = N), firFilter with long responses.  The impulse response is
+ * cut into segments of 4096 taps, one overlap-save launch each, added in place: ceil(ntaps / 4096) passes over the signal.
+ * Host or device pointers; a device signal never leaves the device. */
+int  ssf_fir_long(int device, int64_t inLen, int64_t outLen, int32_t ncols, int64_t ntaps, const void *taps, int64_t shift,
+                  const void *sig_in, void *sig_out);
 /* one column delayed by `delay` seconds (NFFT = 1024 as the reference's default) */
 int  ssf_delay_signal(int device, int64_t N, double delay, double Fs, const void *sig_in, void *sig_out);
 /* The two helpers of the Manakov step the reference exports on their own (inside ssf_execute they are fused into

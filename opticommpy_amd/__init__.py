@@ -9,7 +9,7 @@ library or without a GPU every propagation call raises.
 """
 from .utils import parameters  # noqa: F401
 from .models import (  # noqa: F401
-    checkGPU, convergenceCondition, edc, edfa, linearFiberChannel, manakovDBP, manakovSSF, nlinPhaseRot,
+    blockwiseFFTConv, checkGPU, convergenceCondition, edc, edfa, linearFiberChannel, manakovDBP, manakovSSF, nlinPhaseRot,
     setPowerforParSSFM, ssfm,
     last_run, set_device, set_engine,
 )
@@ -20,8 +20,8 @@ from .rx import (  # noqa: F401
     pdmCoherentReceiver, photodiode,
 )
 
-from .wdm_tx import grayMapping, phaseNoise, pulseShape, simpleWDMTx  # noqa: F401
+from .wdm_tx import basicLaserModel, grayMapping, phaseNoise, pulseShape, simpleWDMTx  # noqa: F401
 
-__all__ = ["simpleWDMTx", "pulseShape", "phaseNoise", "grayMapping", "DeviceArray", "to_device", "firFilter", "lowPassFIR", "decimate", "delaySignal", "iqMixing", "pbs", "photodiode", "balancedPD",
-           "opticalHybrid2x4", "coherentReceiver", "pdmCoherentReceiver", "parameters", "ssfm", "manakovSSF", "manakovDBP", "nlinPhaseRot", "convergenceCondition", "edfa", "edc", "linearFiberChannel",
+__all__ = ["simpleWDMTx", "basicLaserModel", "pulseShape", "phaseNoise", "grayMapping", "DeviceArray", "to_device", "firFilter", "lowPassFIR", "decimate", "delaySignal", "iqMixing", "pbs", "photodiode", "balancedPD",
+           "opticalHybrid2x4", "coherentReceiver", "pdmCoherentReceiver", "parameters", "ssfm", "manakovSSF", "manakovDBP", "nlinPhaseRot", "convergenceCondition", "edfa", "edc", "blockwiseFFTConv", "linearFiberChannel",
            "setPowerforParSSFM", "checkGPU", "last_run", "set_device", "set_engine"]

@@ -106,6 +106,7 @@ SYMBOLS = {
     "ssf_device_free": (C.c_int, [C.c_int, C.c_void_p]),
     "ssf_device_memcpy": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     "ssf_fir_filter": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ssf_fir_long": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ssf_delay_signal": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "ssf_nlin_phase_rot": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ssf_convergence_condition": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

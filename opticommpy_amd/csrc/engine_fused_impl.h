@@ -68,10 +68,12 @@ template <typename T, int MAXT, int LG> __global__ void __launch_bounds__(MAXT, 
     row_body<T, LG, 8>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // Manakov column kernels run 512 threads (x half | y half); the single-row modes run 256
-template <typename T, int LG, int MODE>
+// CI > 0: the workgroup's CI columns interleaved in LDS (fused_kernels.h: lds_put) -- the launch geometry must give exactly CI
+// SG: the stage groups the instantiation carries (fused_kernels.h: stage_group)
+template <typename T, int LG, int MODE, int CI = 0, int SG = SG_ALL>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    col_body<T, LG, MODE, false>(ctx, unit_view(a, (int)blockIdx.y));
+    col_body<T, LG, MODE, false, 16, CI, SG>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // row lengths with factors 3 / 5 (mixed_fft.h): mixed-radix row stage, column stage with ragged last tiles
 template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT, MAXT <= 256 ? 2 : 1) k_row_mixed(const RowArgs<T> a) {
@@ -93,9 +95,9 @@ template <int LG> __global__ void __launch_bounds__(512, 4) k_col_pk8(const ColA
     col_pk_body<LG, 8>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // complex64 Manakov: packed polarisation pairs (fused_kernels.h: col_pk_body); up to 512 threads (8 columns of 1024)
-template <int LG> __global__ void __launch_bounds__(512) k_col_pk(const ColArgs<pf2> a) {
+template <int LG, int CI = 0, int SG = SG_ALL> __global__ void __launch_bounds__(512) k_col_pk(const ColArgs<pf2> a) {
     SSF_DEV_CTX(1);
-    col_pk_body<LG>(ctx, unit_view(a, (int)blockIdx.y));
+    col_pk_body<LG, 16, CI, SG>(ctx, unit_view(a, (int)blockIdx.y));
 }
 __global__ void __launch_bounds__(256) k_repack(const RepackArgs a) {
     SSF_DEV_CTX(1);
@@ -239,6 +241,48 @@ template <typename T> ColFn<T> pick_col8(int lg1, int mode) {
     default: return pick_col8_mode<T, 0>(mode);
     }
 }
+// Manakov column stage with the columns of a workgroup interleaved in LDS: the geometries the chip-filling fields get
+// (FusedCore::col_geometry: 8 columns of 256 / 512 per polarisation row in double precision)
+#if SSF_EXPERIMENTS
+template <typename T> ColFn<T> pick_col_il(int lg1, int cols) {
+    if constexpr (std::is_same<T, double>::value) {
+        if (cols == 8 && lg1 == 8) return k_col<T, 8, CM_MK, 8>;
+        if (cols == 8 && lg1 == 9) return k_col<T, 9, CM_MK, 8>;
+    }
+    return nullptr;
+}
+#else
+template <typename T> ColFn<T> pick_col_il(int, int) { return nullptr; }
+#endif
+// stage-specialised Manakov column kernels (fused_kernels.h: stage_group; FusedCore::run_span enqueues them along the predicted
+// stage sequence) for the geometries the chip-filling fields get (FusedCore::col_geometry): complex128 columns of 256 / 512 with 8
+// per workgroup and polarisation row (2^20 ... 2^22 samples), packed complex64 columns of 512 / 1024 (2^21 ... 2^23)
+template <typename T, int LG> ColFn<T> pick_col_sg_d(int sg) {
+    switch (sg) {
+    case SG_H | SG_RARE: return k_col<T, LG, CM_MK, 0, SG_H | SG_RARE>;
+    case SG_ADV: return k_col<T, LG, CM_MK, 0, SG_ADV>;
+    case SG_FIN: return k_col<T, LG, CM_MK, 0, SG_FIN>;
+    default: return nullptr;
+    }
+}
+template <int LG> ColFn<pf2> pick_col_sg_pk(int sg) {
+    switch (sg) {
+    case SG_H | SG_RARE: return k_col_pk<LG, 0, SG_H | SG_RARE>;
+    case SG_ADV: return k_col_pk<LG, 0, SG_ADV>;
+    case SG_FIN: return k_col_pk<LG, 0, SG_FIN>;
+    default: return nullptr;
+    }
+}
+template <typename T> ColFn<T> pick_col_sg(int lg1, int cols, int sg) {
+    if constexpr (std::is_same<T, double>::value) {
+        if (lg1 == 8 && cols == 8) return pick_col_sg_d<T, 8>(sg);
+        if (lg1 == 9 && cols == 8) return pick_col_sg_d<T, 9>(sg);
+    } else if constexpr (std::is_same<T, pf2>::value) {
+        if (lg1 == 10 && cols == 4) return pick_col_sg_pk<10>(sg);
+        if (lg1 == 9 && cols == 8) return pick_col_sg_pk<9>(sg);
+    }
+    return nullptr;
+}
 template <typename T> ColFn<T> pick_col(int lg1, int mode) {
     switch (lg1) {
     case 7: return pick_col_mode<T, 7>(mode);
@@ -255,6 +299,7 @@ struct HipBackend {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     int row_occ = 2;
+    bool col_il = false;     // interleaved LDS columns in the Manakov column stage (experiment builds: SSF_COL_IL=1; measured: no gain)
     // optional per-launch event timing (ssf_set_profiling)
     bool profiling = false;
     struct Stamp { hipEvent_t a, b; int cat; };
@@ -293,6 +338,7 @@ struct HipBackend {
     }
     explicit HipBackend(ssf_plan *p) : pl(p) {
         if (const char *s = tune_env("SSF_FUSED_ROW_OCC")) row_occ = atoi(s) == 1 ? 1 : 2;
+        if (const char *s = tune_env("SSF_COL_IL")) col_il = atoi(s) != 0;
         chk(hipEventCreate(&ev0), "hipEventCreate");
         chk(hipEventCreate(&ev1), "hipEventCreate");
     }
@@ -369,6 +415,7 @@ struct HipBackend {
     }
     template <typename T> void launch_col(const ColArgs<T> &a, int grid, int block, size_t lds, int units = 1) {
         ColFn<T> f;
+        const int cols = (block / a.npol) / ((1 << a.log2N1) / (a.vpt == 8 ? 8 : 16));      // columns per workgroup and polarisation row
         if constexpr (std::is_same<T, pf2>::value) {
             if (a.vpt == 8) {
                 switch (a.log2N1) {
@@ -381,17 +428,34 @@ struct HipBackend {
             switch (a.log2N1) {
             case 7: f = k_col_pk<7>; break;
             case 8: f = k_col_pk<8>; break;
+#if SSF_EXPERIMENTS
+            case 9: f = cols == 8 && col_il ? k_col_pk<9, 8> : k_col_pk<9>; break;
+            case 10: f = cols == 4 && col_il ? k_col_pk<10, 4> : k_col_pk<10>; break;
+#else
             case 9: f = k_col_pk<9>; break;
             case 10: f = k_col_pk<10>; break;
+#endif
             default: f = k_col_pk<0>; break;
             }
-        } else
+        } else {
             f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : a.vpt == 8 ? pick_col8<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
+            if (!a.N2 && a.vpt != 8 && a.mode == CM_MK && col_il)
+                if (ColFn<T> fi = pick_col_il<T>(a.log2N1, cols)) f = fi;
+        }
+        if (a.mode == CM_MK && a.sg && a.sg != SG_ALL && !a.N2 && a.vpt != 8)
+            if (ColFn<T> fs = pick_col_sg<T>(a.log2N1, cols, a.sg)) f = fs;
         arm((const void *)f);
         stamp_begin(a.mode == CM_MK ? 1 : 3);
         f<<<dim3((unsigned)grid, (unsigned)units), block, lds, pl->stream>>>(a);
         stamp_end();
         chk(hipGetLastError(), "launch k_col");
+    }
+    // are there stage-specialised column kernels for this geometry?  (run_span must not enqueue a pattern the launcher would
+    // silently serve with the general kernel: that one advances the state at EVERY launch, which is fine, but the pattern's
+    // chunk sizes assume idle launches)
+    template <typename T> bool can_split_cols(const ColArgs<T> &a, int block) const {
+        const int cols = (block / a.npol) / ((1 << a.log2N1) / (a.vpt == 8 ? 8 : 16));
+        return !a.N2 && a.vpt != 8 && pick_col_sg<T>(a.log2N1, cols, SG_FIN) != nullptr;
     }
     // raise the dynamic-LDS cap of a kernel the first time THIS backend (= this plan, hence this
     // device) launches it; the attribute is per device, so the record must not be shared

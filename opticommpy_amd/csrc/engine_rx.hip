@@ -281,6 +281,10 @@ int rx_run(int device, int mode, int64_t N, int nmodes, const ssf_rx_params *p, 
 int rx_fir(int device, int64_t sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out, std::string *err) {
     return with_core(device, err, [&](RxCore<Pooled> &c) { return c.fir(sigLen, ncols, ntaps, taps, in, out); });
 }
+int rx_fir_long(int device, int64_t inLen, int64_t outLen, int ncols, int64_t ntaps, const void *taps, int64_t shift, const void *in,
+                void *out, std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.fir_long(inLen, outLen, ncols, ntaps, taps, shift, in, out); });
+}
 int rx_overlap_save(int device, int64_t sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out,
                     std::string *err) {
     return with_core(device, err, [&](RxCore<Pooled> &c) { return c.overlap_save(sigLen, ncols, nfft, K, Hfft, in, out); });

@@ -157,6 +157,14 @@ template <typename T, class Backend> class FusedCore {
     int col_v = 16;              // values per thread of the column kernels (SSF_COL_V=8)
     bool underfilled = false;    // the field does not fill the chip: 8-value kernels, one row per workgroup (init)
     int lanes_hint = 1;          // plans that share the GPU concurrently (ssf_plan_set_lanes): > 1 turns the phase priorities off
+    // Stage-specialised column kernels (H | ADV | FIN, + the general one for the rare stages) along the predicted stage sequence
+    // (run_span; fused_kernels.h: stage_group): +1.5 ... 2.3 % steps/s at config 2, 3 of 3 (profiles/r5_ab_col_split.txt).2 = a
+    // transforming kernel (H, ADV, rare) and an observing one (FIN).  SSF_COL_SPLIT in experiment builds.
+    int col_split = 1;           // (experiment builds: SSF_COL_SPLIT=0 -- the general kernel at every launch)
+    bool split_ok = true;        // ... until rare stages turn out to be the rule in this call (then the general kernel for the rest of it
+    int split_penalty = 0;       //     and for the next kSplitPenalty calls of the plan)
+    static constexpr int kSplitPenalty = 8;
+    int hint_n_it = 0;           // iterations of the latest finished step of the previous call (0: unknown)
     int cur = 0;                 // which of T0/T1 holds the current field
     unsigned seq = 0;
     // launch geometry
@@ -215,6 +223,7 @@ template <typename T, class Backend> class FusedCore {
 
     int init() {
         if (const char *e = tune_env("SSF_LIM0_BOUND")) lim0_bound = std::atoi(e) != 0;
+        if (const char *e = tune_env("SSF_COL_SPLIT")) col_split = std::atoi(e);
         // Fields that do not fill the chip -- fewer than two 16-value waves per SIMD: rows x N <= 2^20 values per unit, i.e. up to
         // 2^19 samples for a complex128 pair, 2^20 for a packed complex64 pair -- run on the 8-value kernels (twice the waves
         // and workgroups, shorter dependent chains per thread) with one row per workgroup: measured +7 ... +75 % there
@@ -617,8 +626,9 @@ template <typename T, class Backend> class FusedCore {
         be.launch_row(a, row_grid, row_block, row_lds, units);
         ++seq;
     }
-    void launch_mk_col(const MkConst &k, int mode) {
+    void launch_mk_col(const MkConst &k, int mode, int sg = SG_ALL) {
         ColArgs<T> a = col_args(kPacked ? 1 : 2, mode);
+        a.sg = sg;
         a.cin = ctrl + (size_t)(seq & 1) * units;
         a.cout = ctrl + (size_t)((seq + 1) & 1) * units;
         a.k = k;
@@ -652,6 +662,7 @@ template <typename T, class Backend> class FusedCore {
     struct SpanRun {
         long long trace_n = 0;
         double avg_it = 3.0;
+        int n_it = 0;            // iterations of the latest finished step (0: none yet)
     };
     int run_span(const ssf_params &p, const MkConst &k, SpanRun &sr, ssf_stats *st) {
         std::vector<Ctrl> cs((size_t)units);
@@ -714,7 +725,21 @@ template <typename T, class Backend> class FusedCore {
         if (!persisted) {
         launch_mk_col(k, CM_MK);                                                       // first step start
         int guard = 0;
-        long long prev_steps = 0, prev_iters = 0;
+        long long prev_steps = 0, prev_iters = 0, prev_rare = 0;
+        // Stage-specialised column kernels (col_split; fused_kernels.h: stage_group): the host enqueues them along the sequence it
+        // predicts -- per step H, ADV x (iterations - 1), FIN, with the iteration count of the latest finished step
+        // (Ctrl::last_nit) -- and a kernel whose stage the state does not ask for does nothing, so a wrong guess (the 3 -> 2
+        // crossover of a lossy span: once per span) costs idle launches until the pattern meets the state again -- two per step
+        // when the guess is one too high, four when it is one too low, for the rest of one chunk -- never a wrong result.
+        // The rare stages (rebuilds of iterate 0, recoveries of the step-start field) ride in the H kernel: they wait for the
+        // next H slot (at most one predicted step).  A chunk without progress is followed by a short general chunk; where the
+        // rare stages are the rule (weak nonlinearity: lim_0 < tol at every step) the call goes back to the general kernel for
+        // good (and so do the next kSplitPenalty calls of the plan).
+        const bool can_split = col_split && split_penalty == 0 && units == 1 &&
+                               be.can_split_cols(col_args(kPacked ? 1 : 2, CM_MK), col_block_mk);
+        bool general_chunk = false;
+        int stalls = 0, pos = 0;                 // pos: position in the predicted pattern (kept from chunk to chunk)
+        long long idle_pairs = 0;                // pairs enqueued since a step last finished
         for (;;) {
             // [Row, Col] pairs still needed for this span: (1 + nIter) per step.  A surplus pair is a no-op launch
             // (~10 us); a chunk that ends short of the span costs a synchronising read and an idle stream (~100-150 us),
@@ -729,27 +754,55 @@ template <typename T, class Backend> class FusedCore {
                 else r = std::max(1.0, std::ceil((p.Lspan - c.z) / (c.hz > 0 ? c.hz : p.hz)));
                 steps_rem = std::max(steps_rem, r);
             }
-            double est = p.nlprMethod ? steps_rem * (1.0 + sr.avg_it) * 0.6 : steps_rem * (1.0 + sr.avg_it) + 3.0;
+            const bool use_split = can_split && split_ok && !general_chunk;
+            const int n_pred = std::max(1, std::min(p.maxIter, sr.n_it > 0 ? sr.n_it : (int)std::lround(sr.avg_it)));
+            double est = p.nlprMethod ? steps_rem * (1.0 + sr.avg_it) * 0.6
+                                      : steps_rem * (1.0 + (use_split ? std::max((double)n_pred, sr.avg_it) : sr.avg_it)) + 3.0;
             int chunk = (int)std::min(512.0, std::max(2.0, std::ceil(est)));
+            if (can_split && split_ok && general_chunk) chunk = std::min(chunk, 8);
+            else if (use_split && sr.n_it == 0) chunk = std::min(chunk, 4 * (n_pred + 1));     // nothing known yet: a short look first
             for (int i = 0; i < chunk; ++i) {
                 launch_mk_row(k);
-                launch_mk_col(k, CM_MK);
+                int sg = SG_ALL;
+                if (use_split) {
+                    sg = pos == 0 ? (SG_H | SG_RARE) : pos < n_pred ? SG_ADV : SG_FIN;
+                    pos = pos >= n_pred ? 0 : pos + 1;
+                }
+                launch_mk_col(k, CM_MK, sg);
             }
             be.d2h(cs.data(), ctrl + (size_t)(seq & 1) * units, cbytes);              // synchronising read
             if (!be.ok()) return hiperr();
-            long long steps = 0, iters = 0;
+            long long steps = 0, iters = 0, rare = 0;
             bool done = true;
             double worst = 0.0;
             for (const Ctrl &c : cs) {
                 steps += c.steps;
                 iters += c.iterations;
+                rare += c.n_rebuilt + c.n_recovered;
                 done = done && c.state == ST_SPAN_DONE && !c.pend0;
                 if (c.steps > 0) worst = std::max(worst, (double)c.iterations / (double)c.steps);
             }
-            if (steps > prev_steps)                                                   // iterations per step of the last chunk
+            if (steps > prev_steps) {                                                 // iterations per step of the last chunk
                 sr.avg_it = units == 1 ? (double)(iters - prev_iters) / (double)(steps - prev_steps) : worst;
+                sr.n_it = cs[0].last_nit;
+            }
+            if (can_split && split_ok && !done) {
+                // no step finished while the pattern went round twice: the pattern and the state do not meet (e.g. a run that
+                // converges at iterate 0 as a rule needs ADV then a rebuild where one iteration per step predicts H, FIN)
+                idle_pairs = steps == prev_steps ? idle_pairs + chunk : 0;
+                const bool stuck = idle_pairs >= 2 * (n_pred + 1) + 2;
+                if (general_chunk && !stuck) general_chunk = false;                   // the general kernel got it going: back to the pattern
+                else if (stuck) {
+                    general_chunk = true;
+                    if (++stalls >= 2) split_ok = false;
+                }
+                // rebuilds / recoveries wait for the next H slot: where they are the rule the general kernel is the faster one
+                if (rare - prev_rare > (steps - prev_steps) / 4 + 2) split_ok = false;
+                if (!split_ok) split_penalty = kSplitPenalty;
+            }
             prev_steps = steps;
             prev_iters = iters;
+            prev_rare = rare;
             if (done) break;
             if (++guard > (1 << 22)) {
                 err = "fused engine: span did not terminate";
@@ -816,6 +869,8 @@ template <typename T, class Backend> class FusedCore {
         if ((rc = prepare_trace(trace, p.maxIter))) return rc;
         const MkConst k = mk_const_for(p, d, trace);
         SpanRun sr;
+        sr.n_it = hint_n_it;                                          // (the previous call's iteration count: a guess, see run_span)
+        if (hint_n_it > 0) sr.avg_it = (double)hint_n_it;
         for (int span = s0; span <= s1; ++span) {
             if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))      // equalization.py:1090-1092
                 launch_amp(Tcur(), (S)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);
@@ -825,6 +880,7 @@ template <typename T, class Backend> class FusedCore {
         }
         be.sync();
         if (!be.ok()) return hiperr();
+        hint_n_it = sr.n_it;
         return fetch_trace(trace, sr.trace_n, p.maxIter);
     }
 
@@ -852,6 +908,8 @@ template <typename T, class Backend> class FusedCore {
             if ((rc = pk->prepare_trace(trace, p.maxIter))) return rc;
             const MkConst k = pk->mk_const_for(p, d, trace);
             typename FusedCore<pf2, Backend>::SpanRun sr;
+            sr.n_it = pk->hint_n_it;
+            if (pk->hint_n_it > 0) sr.avg_it = (double)pk->hint_n_it;
             for (int span = s0; span <= s1; ++span) {
                 if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))
                     launch_amp(Tcur(), (S)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);
@@ -867,6 +925,7 @@ template <typename T, class Backend> class FusedCore {
             }
             be.sync();
             if (!be.ok()) return hiperr();
+            pk->hint_n_it = sr.n_it;
             if ((rc = pk->fetch_trace(trace, sr.trace_n, p.maxIter))) err = pk->err;
             return rc;
         }
@@ -879,6 +938,12 @@ template <typename T, class Backend> class FusedCore {
             return SSF_ERR_BAD_ARG;
         }
         be.time_begin();
+        split_ok = true;
+        if (split_penalty > 0) --split_penalty;
+        if (pk) {
+            pk->split_ok = true;
+            if (pk->split_penalty > 0) --pk->split_penalty;
+        }
         int rc = p.model == SSF_MODEL_NLSE ? run_nlse(p, d, s0, s1, noise, st)
                  : packed_ok()             ? run_manakov_packed(p, d, s0, s1, noise, st, trace)
                                            : run_manakov(p, d, s0, s1, noise, st, trace);

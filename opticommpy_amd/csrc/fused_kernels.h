@@ -80,6 +80,7 @@ struct Ctrl {           // device-resident step state, double-buffered by launch
     int dense;          // this step needed the exact lim_0: its final stage stores every sample
     int gscale;         // G holds the column spectrum of the field DIVIDED by N1: the final I stage of the last step did not
                         // rewrite it (see mk_col_stage); the next row stage multiplies its operator by N1
+    int last_nit;       // iterations of the latest finished step (the host predicts the stage sequence from it: FusedCore::run_span)
     long long pend0_idx;// trace row lim_0 belongs to
     double z, hz;
     long long steps, iterations, nonconv, trace_n;
@@ -300,36 +301,44 @@ SSF_HD int reg_pos(const PassPlan &p, int i, int b, int idx) {
     return pass_pos(p, i, b + p.tpf * (idx >> lg), idx & ((1 << lg) - 1));
 }
 
-template <int V = 16, typename T> SSF_HD void lds_put(const PassPlan &p, int i, int b, const cx<T> *v, cx<T> *lds) {
+// CI = slot multiplier: 1 = the transform's slots are contiguous (rows; columns side by side, one after the other); CI = C > 1:
+// the C columns of a workgroup are INTERLEAVED, slot lds_slot(pos) * C + c (the caller's `lds` points at column c's slot 0).
+// Lane l of a wave works on column l % C and butterfly l / C, so the lanes of one LDS instruction then cover C consecutive
+// 16-byte slots per butterfly, and lds_slot() makes consecutive butterflies follow each other in every pass: the 8-lane
+// groups of ds_write_b128 (bank = slot mod 8) and the four 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...; bank =
+// slot mod 16) are conflict-free for C = 4, 8, 16 in every pass (tools/exp/lds_conflicts.py, MI355X_MICROARCH.md LDS table).
+// Side by side (slot = c * stride + lds_slot(pos)) no stride frees both: C = 8 reads were three-way conflicted (SQ_LDS_BANK_CONFLICT
+// 0.72 x SQ_ACTIVE_INST_LDS in k_col<double,8,3>), C = 4 writes two-way (1.18 x in k_col_pk<10>).
+template <int V = 16, int CI = 1, typename T> SSF_HD void lds_put(const PassPlan &p, int i, int b, const cx<T> *v, cx<T> *lds) {
 #pragma unroll
-    for (int idx = 0; idx < V; ++idx) lds[lds_slot(reg_pos(p, i, b, idx))] = v[idx];
+    for (int idx = 0; idx < V; ++idx) lds[lds_slot(reg_pos(p, i, b, idx)) * CI] = v[idx];
 }
-template <int V = 16, typename T> SSF_HD void lds_get(const PassPlan &p, int i, int b, cx<T> *v, const cx<T> *lds) {
+template <int V = 16, int CI = 1, typename T> SSF_HD void lds_get(const PassPlan &p, int i, int b, cx<T> *v, const cx<T> *lds) {
 #pragma unroll
-    for (int idx = 0; idx < V; ++idx) v[idx] = lds[lds_slot(reg_pos(p, i, b, idx))];
+    for (int idx = 0; idx < V; ++idx) v[idx] = lds[lds_slot(reg_pos(p, i, b, idx)) * CI];
 }
 
 // DIF transform: v holds pass-0 positions on entry, pass-(p-1) positions (digit-reversed) on exit
-template <int SIGN, int V = 16, bool TAB = false, typename T, class Ctx>
+template <int SIGN, int V = 16, bool TAB = false, int CI = 1, typename T, class Ctx>
 SSF_HD void fft_dif(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds, TwSrc<T> &src) {
     dif_pass<SIGN, V, TAB>(p, 0, b, v, src);
 #pragma unroll
     for (int i = 1; i < p.npass; ++i) {
-        lds_put<V>(p, i - 1, b, v, lds);
+        lds_put<V, CI>(p, i - 1, b, v, lds);
         ctx.sync();
-        lds_get<V>(p, i, b, v, lds);
+        lds_get<V, CI>(p, i, b, v, lds);
         dif_pass<SIGN, V, TAB>(p, i, b, v, src);
     }
 }
 // DIT transform: v holds pass-(p-1) positions on entry, pass-0 positions (natural) on exit
-template <int SIGN, int V = 16, bool TAB = false, typename T, class Ctx>
+template <int SIGN, int V = 16, bool TAB = false, int CI = 1, typename T, class Ctx>
 SSF_HD void fft_dit(Ctx &ctx, const PassPlan &p, int b, cx<T> *v, cx<T> *lds, TwSrc<T> &src) {
 #pragma unroll
     for (int i = p.npass - 1; i >= 1; --i) {
         dit_pass<SIGN, V, TAB>(p, i, b, v, src);
-        lds_put<V>(p, i, b, v, lds);
+        lds_put<V, CI>(p, i, b, v, lds);
         ctx.sync();
-        lds_get<V>(p, i - 1, b, v, lds);
+        lds_get<V, CI>(p, i - 1, b, v, lds);
     }
     dit_pass<SIGN, V, TAB>(p, 0, b, v, src);
 }
@@ -902,6 +911,7 @@ template <typename T> struct ColArgs {
     long long u_elems;        // independent units (see RowArgs): field elements per unit; P / Theta advance by 2 / 1 x ngroups x N
     int u_part;
     int prio;                 // see RowArgs
+    int sg;                   // Manakov: stage groups the launched kernel carries (0 = SG_ALL); read by the launcher only
 };
 
 // Arguments of unit u of a batch of independent units: every pointer moved to the unit's block.  The kernel bodies never
@@ -1206,7 +1216,13 @@ struct MkColStage {
 };
 // the samples of a thread's V that the bound of lim_0 reads: one in sixteen = one cache line in sixteen
 template <int V> SSF_HD bool lim0_bound_sample(int idx, int b) { return idx == 0 && (V == 16 || !(b & 1)); }
-template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &a, MkColStage &st) {
+// Stage groups: a column kernel instantiated for a subset SG of them carries only that subset's code and does NOTHING (forwards
+// the control block unchanged) when the state asks for another stage -- the host enqueues such kernels along the sequence it
+// predicts (H, ADV x (iterations - 1), FIN per step; FusedCore::run_span) and a wrong guess only costs idle launches: the next
+// kernel of the right group picks the state up.  SG_ALL = the one kernel that does whatever the state asks for.
+enum { SG_H = 1, SG_ADV = 2, SG_FIN = 4, SG_RARE = 8, SG_ALL = 15 };
+SSF_HD int stage_group(int op, bool final_) { return op == 1 ? SG_H : op == 2 ? (final_ ? SG_FIN : SG_ADV) : SG_RARE; }
+template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &a, MkColStage &st, int sg_mask = SG_ALL) {
     bool &do_inv = st.do_inv, &do_fwd = st.do_fwd, &final_ = st.final_, &more = st.more, &exact0 = st.exact0;
     int &op = st.op;
     auto &c = st.c;
@@ -1249,6 +1265,10 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
     } else if (c.state == ST_RECOVER_B) {
         op = 5;
         do_inv = do_fwd = true;
+    }
+    if (op >= 0 && !(stage_group(op, final_) & sg_mask)) {            // not this kernel's stage: nothing happens, the state stays
+        op = -1;
+        do_inv = do_fwd = false;
     }
     if (ctx.bid == 0 && ctx.tid == 0) {                               // forward the control block
         ctrl_forward(a.cin, a.cout, (int)(sizeof(Ctrl) / 8));
@@ -1293,6 +1313,7 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
             n->trace_n = tn + 1;
             n->steps = a.cin->steps + 1;
             n->iterations = a.cin->iterations + c.it + 1;
+            n->last_nit = c.it + 1;
             n->z = c.z + c.hz;
             n->cur = c.cur ^ 1;
             n->it = 0;
@@ -1323,9 +1344,15 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
 }
 
 // MODE is one of CM_*; the Manakov mode picks its stage from the Ctrl state.
-template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
+// CI > 0: the workgroup's CI columns (per polarisation row) are interleaved in LDS (lds_put); the launch must have exactly CI of them.
+// SG: the stage groups this instantiation carries (Manakov mode; see stage_group).
+template <typename T, int LG, int MODE, bool RAGGED, int V = 16, int CI = 0, int SG = SG_ALL, class Ctx>
+SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
     constexpr int H = V / 2;
+    constexpr int kCI = CI > 0 ? CI : 1;
     constexpr bool kMk = MODE == CM_MK;
+    constexpr bool kgH = (SG & SG_H) != 0, kgADV = (SG & SG_ADV) != 0, kgFIN = (SG & SG_FIN) != 0, kgRARE = (SG & SG_RARE) != 0;
+    constexpr bool kFwd = !kMk || kgH || kgADV || kgRARE;             // (the final stage never transforms forward)
     // ---- what does this launch do? ------------------------------------------------------
     bool do_inv = false, do_fwd = false;
     int op = -1;     // Manakov: 0 = S (span start), 1 = H, 2 = I, 3 = rebuild iterate 0
@@ -1335,10 +1362,10 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     ctx.mark(0);
     if (kMk) {
         MkColStage st;
-        mk_col_stage(ctx, a, st);
+        mk_col_stage(ctx, a, st, SG);
         do_inv = st.do_inv;
-        do_fwd = st.do_fwd;
-        final_ = st.final_;
+        do_fwd = kFwd && st.do_fwd;
+        final_ = kgFIN && (!kgADV || st.final_);
         more = st.more;
         exact0 = st.exact0;
         sparse = st.sparse;
@@ -1357,7 +1384,8 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 
     ColGeom<T, LG, Ctx, RAGGED, V> g(ctx, a);
     const PassPlan &p = g.p;
-    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
+    cx<T> *lds = CI > 0 ? (cx<T> *)ctx.lds + (size_t)g.pol * CI * lds_slots_per_fft(p.L) + g.c
+                        : (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
     cx<T> v[V];
 
     // buffers by role (Manakov)
@@ -1380,9 +1408,10 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
         ctx.mark(1);
         if (a.prio) ctx.template setprio<3>();
         global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v, gtw);
-        fft_dif<+1, V>(ctx, p, g.b, v, lds, tws);
+        fft_dif<+1, V, false, kCI>(ctx, p, g.b, v, lds, tws);
         ctx.mark(2);
         if (a.prio) ctx.template setprio<2>();
+    } else if (kMk && !kgRARE) {                     // (every other stage starts from the spectrum)
     } else if (!(kMk && op == 3)) {
         const cx<T> *src = kMk && op == 4 ? a.Ehd : Tcur;
 #pragma unroll
@@ -1399,10 +1428,10 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     } else if (kMk) {
         const T shz = (T)(a.k.sgn * c.hz), c8g = (T)a.k.c8g;
         cx<T> *shC = (cx<T> *)(ctx.lds + 2 * V * (size_t)g.half * sizeof(T));
-        if (op == 0) {                               // span start: Pch into the current buffer
+        if (kgRARE && op == 0) {                     // span start: Pch into the current buffer
             mk_step_start(ctx, g, a, v, Pcur, false);
-        } else if (op == 4) {                        // (E_hd goes through the forward transform as it is)
-        } else if (op == 1 || op == 3 || op == 5) {  // H (channels.py:409-417) | rebuild of iterate 0 (5: after the recovered field is out)
+        } else if (kgRARE && op == 4) {              // (E_hd goes through the forward transform as it is)
+        } else if ((kgH && op == 1) || (kgRARE && (op == 3 || op == 5))) {  // H (channels.py:409-417) | rebuild of iterate 0 (5: after the recovered field is out)
             T ang[H];
 #pragma unroll
             for (int j = 0; j < H; ++j) {
@@ -1412,7 +1441,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) {
                 const long long t = g.time_off(idx);
-                if (op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
+                if (!kgRARE || op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
                 else {
                     if (op == 5) g.st(Tcur, g.rowbase + t, v[idx]);
                     v[idx] = g.ld(a.Ehd, g.rowbase + t);
@@ -1424,7 +1453,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) v[idx] = v[idx] * rot[idx];
             ctx.sync();
-        } else {                                     // I: iterate `it` is in registers
+        } else if (kgADV || kgFIN) {                 // I: iterate `it` is in registers
             double n0 = 0, d0 = 0, n1 = 0, d1 = 0, psum = 0;
             if (c.it == 0) {                         // lim_0 against the field at the step start
 #pragma unroll
@@ -1441,7 +1470,7 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
 #pragma unroll
                 for (int idx = 0; idx < V; ++idx)
                     if (!sparse || lim0_bound_sample<V>(idx, g.b)) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
-            } else {
+            } else if (kgADV) {
                 mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
                 if (!exact0) d0 = psum;              // exact denominator of the bound: sum Pch over the tile
             }
@@ -1468,9 +1497,9 @@ template <typename T, int LG, int MODE, bool RAGGED, int V = 16, class Ctx> SSF_
     // ---- forward column transform: registers -> G -------------------------------------------
     ctx.mark(3);
     if (a.prio) ctx.template setprio<1>();
-    if (do_fwd) {
+    if (kFwd && do_fwd) {
         if (!kMk && do_inv) ctx.sync();              // (Manakov paths synchronised above)
-        fft_dit<-1, V>(ctx, p, g.b, v, lds, tws);
+        fft_dit<-1, V, false, kCI>(ctx, p, g.b, v, lds, tws);
         global_twiddle<-1, RAGGED>(g, a.log2N1 + a.log2N2, v, gtw);
         ctx.mark(4);
         if (a.prio) ctx.template setprio<0>();
@@ -1571,16 +1600,20 @@ SSF_HD void pk_step_start(Ctx &ctx, const G &g, const ColArgs<pf2> &a, const cx<
     ctx.sync();
 }
 
-template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2> &a) {
+template <int LG, int V = 16, int CI = 0, int SG = SG_ALL, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const ColArgs<pf2> &a) {
     using T = pf2;
+    constexpr int kCI = CI > 0 ? CI : 1;
+    constexpr bool kgH = (SG & SG_H) != 0, kgADV = (SG & SG_ADV) != 0, kgFIN = (SG & SG_FIN) != 0, kgRARE = (SG & SG_RARE) != 0;
+    constexpr bool kFwd = kgH || kgADV || kgRARE;                     // (the final stage never transforms forward)
     ctx.mark(0);
     MkColStage st;
-    mk_col_stage(ctx, a, st);
+    mk_col_stage(ctx, a, st, SG);
     if (st.op < 0) return;
     const int op = st.op;
+    const bool final_ = kgFIN && (!kgADV || st.final_);
     ColGeom<T, LG, Ctx, false, V> g(ctx, a);
     const PassPlan &p = g.p;
-    cx<T> *lds = (cx<T> *)ctx.lds + (size_t)g.c * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
+    cx<T> *lds = CI > 0 ? (cx<T> *)ctx.lds + g.c : (cx<T> *)ctx.lds + (size_t)g.c * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
     double *red = (double *)ctx.lds;
     cx<T> v[V];
     cx<T> *Tcur = st.c.cur ? a.T1 : a.T0;                    // field at the step start
@@ -1595,8 +1628,9 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
         for (int q = 0; q < V; ++q) v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
         ctx.mark(1);
         global_twiddle<+1, false>(g, a.log2N1 + a.log2N2, v, gtw);
-        fft_dif<+1, V>(ctx, p, g.b, v, lds, tws);
+        fft_dif<+1, V, false, kCI>(ctx, p, g.b, v, lds, tws);
         ctx.mark(2);
+    } else if (!kgRARE) {                                    // (every other stage starts from the spectrum)
     } else if (op != 3) {
         const cx<T> *src = op == 4 ? a.Ehd : Tcur;
 #pragma unroll
@@ -1605,16 +1639,16 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
 
     const float shz = (float)(a.k.sgn * st.c.hz), c8g = (float)a.k.c8g;
     const PkOwned<V, Ctx> own(ctx);
-    if (op == 0) {                                           // span start: Pch into the current buffer
+    if (kgRARE && op == 0) {                                 // span start: Pch into the current buffer
         pk_step_start(ctx, g, a, v, Pcur);
-    } else if (op == 4) {                                    // (E_hd goes through the forward transform as it is)
-    } else if (op == 1 || op == 3 || op == 5) {              // H (channels.py:409-417) | rebuild of iterate 0 (5: recovered field out first)
+    } else if (kgRARE && op == 4) {                          // (E_hd goes through the forward transform as it is)
+    } else if ((kgH && op == 1) || (kgRARE && (op == 3 || op == 5))) {   // H (channels.py:409-417) | rebuild of iterate 0 (5: recovered field out first)
         float pw[V];
         own.load(Pcur, pw);
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) {
             const long long t = g.time_off(idx);
-            if (op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
+            if (!kgRARE || op == 1) g.st(a.Ehd, g.rowbase + t, v[idx]);
             else {
                 if (op == 5) g.st(Tcur, g.rowbase + t, v[idx]);
                 v[idx] = g.ld(a.Ehd, g.rowbase + t);
@@ -1623,7 +1657,7 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) v[idx] = tmul(v[idx], cis_t<float>(shz * (c8g * (pw[idx] + pw[idx]) / 2.0f)));
         ctx.sync();                                          // the inverse transform's LDS reads are done
-    } else {                                                 // I: iterate `it` is in registers
+    } else if (kgADV || kgFIN) {                             // I: iterate `it` is in registers
         double n0 = 0, d0 = 0, n1 = 0, d1 = 0, psum = 0;
         const bool first = st.c.it == 0;
         if (first) {                                         // lim_0 against the field at the step start
@@ -1640,11 +1674,11 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
                 }
             }
         }
-        if (st.final_) {                                     // the field after this step (channels.py:438-439)
+        if (final_) {                                        // the field after this step (channels.py:438-439)
 #pragma unroll
             for (int idx = 0; idx < V; ++idx)
                 if (!st.sparse || lim0_bound_sample<V>(idx, g.b)) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
-        } else {
+        } else if (kgADV) {
             // next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
             // sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the note at the top of this file)
             float pw[V], prev[V], pn[V];
@@ -1685,7 +1719,7 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
                 a.pden0[ctx.bid] = d0;
             }
         }
-        if (!st.final_) {
+        if (!final_) {
             block_sum2(ctx, n1, d1, red);
             if (ctx.tid == 0) {
                 a.pnum[ctx.bid] = n1;
@@ -1699,8 +1733,8 @@ template <int LG, int V = 16, class Ctx> SSF_HD void col_pk_body(Ctx &ctx, const
     }
 
     ctx.mark(3);
-    if (st.do_fwd) {
-        fft_dit<-1, V>(ctx, p, g.b, v, lds, tws);
+    if (kFwd && st.do_fwd) {
+        fft_dit<-1, V, false, kCI>(ctx, p, g.b, v, lds, tws);
         global_twiddle<-1, false>(g, a.log2N1 + a.log2N2, v, gtw);
         ctx.mark(4);
 #pragma unroll
@@ -1776,6 +1810,10 @@ template <typename T> struct OlsArgs {
     int Hstride;          // 0: one filter for all columns; NFFT: column m uses H + m * NFFT
     int roll;             // np.roll(y, -roll) before the [:keep] cut (optic/dsp/core.py:920-922)
     int in_up;            // > 1: `in` holds every in_up-th sample, the others are zero (upsample, core.py:395-432)
+    // filters of any length, one segment of the impulse response per launch (RxCore::fir_long): output n takes the full
+    // convolution's sample n + D + Dx (Dx of either sign), the launch's first block is blk0, and the results are ADDED
+    long long Dx, blk0;
+    int acc;
 };
 template <typename T> SSF_HD void ols_defaults(OlsArgs<T> &a) {
     a.inLen = a.sigLen;
@@ -1784,6 +1822,8 @@ template <typename T> SSF_HD void ols_defaults(OlsArgs<T> &a) {
     a.Hstride = 0;
     a.roll = 0;
     a.in_up = 1;
+    a.Dx = a.blk0 = 0;
+    a.acc = 0;
 }
 template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T> &a) {
     const PassPlan p = make_plan(a.log2nfft);
@@ -1791,8 +1831,9 @@ template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T>
     const int f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
     const long long job = (long long)ctx.bid * fpw + f;
     const bool live = job < a.njobs;                     // idle threads still take part in the barriers
-    const long long blk = live ? job / a.nrows : 0;
-    const int m = live ? (int)(job - blk * a.nrows) : 0;
+    const long long jb = live ? job / a.nrows : 0;
+    const int m = live ? (int)(job - jb * a.nrows) : 0;
+    const long long blk = jb + a.blk0;
     cx<T> *l = (cx<T> *)ctx.lds + (size_t)f * lds_slots_per_fft(p.L);
     const cx<T> *H = a.H + (size_t)m * a.Hstride;
     cx<T> v[16];
@@ -1815,11 +1856,14 @@ template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T>
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int pos = b + p.tpf * q;
-        long long n = blk * a.d + pos - a.discard - a.D;
+        long long n = blk * a.d + pos - a.discard - a.D - a.Dx;
         if (live && pos >= a.discard && n >= 0 && n < a.sigLen) {
             n -= a.roll;
             if (n < 0) n += a.sigLen;
-            if (n < a.keep) a.out[n * a.out_ld + m] = v[q];
+            if (n < a.keep) {
+                cx<T> *o = a.out + n * a.out_ld + m;
+                *o = a.acc ? *o + v[q] : v[q];
+            }
         }
     }
 }

@@ -342,6 +342,52 @@ template <class Backend> struct RxCore {
         return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
     }
 
+    // FIR of any length, on the device: out[n, m] = sum_t taps[t] * in[n + shift - t, m] for n in [0, outLen), `in` (inLen samples
+    // per column) extended with zeros on both sides.  blockwiseFFTConv's result (optic/dsp/core.py:1043-1046) is shift =
+    // (K - 1) / 2, outLen = inLen; delaySignal's pad / roll(-1) / cut (core.py:905-922) is the same with shift + 1.  The impulse
+    // response is cut into segments h_p of at most kMaxNfft / 2 taps, conv(x, h)[k] = sum_p conv(x, h_p)[k - p0]: every segment is
+    // one overlap-save launch that adds its part in place (OlsArgs::acc), so the cost is ceil(K / 4096) passes over the signal.
+    int fir_long(long long inLen, long long outLen, int ncols, long long K, const void *taps, long long shift, const void *in,
+                 void *out) {
+        if (inLen < 1 || outLen < 1 || ncols < 1 || K < 1) return fail(SSF_ERR_BAD_ARG, "bad size");
+        Cd *a = dalloc((size_t)inLen * ncols), *acc = dalloc((size_t)outLen * ncols);
+        if (!a || !acc) return fail(SSF_ERR_OOM, "out of device memory");
+        be.h2d_big(a, in, sizeof(Cd) * (size_t)inLen * ncols);
+        be.memset(acc, 0, sizeof(Cd) * (size_t)outLen * ncols);
+        const long long S = kMaxNfft / 2;
+        for (long long p0 = 0; p0 < K; p0 += S) {
+            const int Kp = (int)std::min(S, K - p0);
+            const int nfft = K <= S ? fir_nfft(Kp) : kMaxNfft;
+            const long long sh = shift - p0;                         // out[n] += full_p[n + sh]
+            const long long d = nfft - Kp + 1;
+            const long long f_lo = std::max(0ll, sh), f_hi = std::min(outLen + sh, inLen + Kp - 1);
+            if (f_hi <= f_lo) continue;                              // this segment only meets the zero extension
+            Cd *dH = upload_filter(ols_filter_from_taps((const zc *)taps + p0, Kp, nfft));
+            if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
+            fused::OlsArgs<double> g{};
+            g.in = a;
+            g.out = acc;
+            g.H = dH;
+            g.sigLen = outLen;
+            g.nrows = ncols;
+            g.log2nfft = 0;
+            while ((1 << g.log2nfft) < nfft) ++g.log2nfft;
+            g.d = (int)d;
+            g.discard = Kp - 1;
+            g.D = 0;
+            fused::ols_defaults(g);
+            g.inLen = inLen;
+            g.Dx = sh;
+            g.blk0 = f_lo / d;
+            g.njobs = ((f_hi + d - 1) / d - g.blk0) * ncols;
+            g.acc = 1;
+            be.launch_ols(g);
+        }
+        be.sync();
+        be.d2h_big(out, acc, sizeof(Cd) * (size_t)outLen * ncols);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+
     // simpleWDMTx's signal path (tx.py:178-217) for all channels and polarisations; symbols (nCh, nPol, nSymbols),
     // taps (ntaps real), phi (nCh, N) or null, amp[nCh] = sqrt(Pch / nPol), deltaF[nCh]; out (N, nPol), N = nSymbols * SpS
     int wdm_tx(const ssf_tx_params &p, const void *symbols, const double *taps, const double *phi, const double *amp,

@@ -551,6 +551,15 @@ int ssf_fir_filter(int device, int64_t sigLen, int32_t ncols, int32_t ntaps, con
     return rc ? set_err(rc, "ssf_fir_filter: " + err) : SSF_OK;
 }
 
+int ssf_fir_long(int device, int64_t inLen, int64_t outLen, int32_t ncols, int64_t ntaps, const void *taps, int64_t shift,
+                 const void *in, void *out) {
+    if (!taps || !in || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_fir_long: NULL argument");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::rx_fir_long(device, inLen, outLen, ncols, ntaps, taps, shift, in, out, &err);
+    return rc ? set_err(rc, "ssf_fir_long: " + err) : SSF_OK;
+}
+
 int ssf_delay_signal(int device, int64_t N, double delay, double Fs, const void *in, void *out) {
     if (!in || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_delay_signal: NULL argument");
     if (int rc = rx_check_device(device)) return rc;

@@ -29,6 +29,16 @@ _POOL_CAP = 4 << 30
 _POOL_LOCK = threading.Lock()
 
 
+# Transfers between host and device memory made through DeviceArray.set / .get (tests count them: a chain of calls on
+# DeviceArrays must not go through the host in between, tests/test_chain.py, tests/test_gpu_device_arrays.py)
+_COUNTS = {"h2d": 0, "d2h": 0, "h2d_bytes": 0, "d2h_bytes": 0}
+
+
+def transfer_counts():
+    """Copy of the counters of DeviceArray.set (h2d) / .get (d2h) calls and bytes since the package was imported."""
+    return dict(_COUNTS)
+
+
 def release_pool():
     """Give the cached device blocks back to the driver."""
     lib = _lib.load()
@@ -101,12 +111,16 @@ class DeviceArray:
             raise ValueError(f"shape mismatch: {x.shape} vs {self.shape}")
         lib = _lib.load()
         _lib.raise_for(lib, None, lib.ssf_device_memcpy(self.device, self._ptr, x.ctypes.data_as(C.c_void_p), self.nbytes))
+        _COUNTS["h2d"] += 1
+        _COUNTS["h2d_bytes"] += self.nbytes
         return self
 
     def get(self):
         out = np.empty(self.shape, dtype=self.dtype)
         lib = _lib.load()
         _lib.raise_for(lib, None, lib.ssf_device_memcpy(self.device, out.ctypes.data_as(C.c_void_p), self._ptr, self.nbytes))
+        _COUNTS["d2h"] += 1
+        _COUNTS["d2h_bytes"] += self.nbytes
         return out
 
     def __array__(self, dtype=None, copy=None):

@@ -574,58 +574,46 @@ def _edc_filter(param, Fs):
     return NfilterCoeffs, Nfft, np.exp(-1j * (b2 / 2) * (w**2) * L)
 
 
-_OLS_MAX_TAPS = 4096          # longer impulse responses are convolved segment by segment (8192-point blocks, >= half output)
+_OLS_MAX_TAPS = 4096          # longer impulse responses are convolved segment by segment on the device (ssf_fir_long)
 
 
-def _ols_same_host(x, Hf):
-    """blockwiseFFTConv(x, Hf, freqDomainFilter=True) of the reference (optic/dsp/core.py:973-1046) for a host (n, ncols)
-    complex128 array and a K-sample frequency response centred at DC, any K: 'same'-mode linear convolution with the centred
-    impulse response (delay (K - 1) // 2), every block one LDS transform pair of ssf_overlap_save.  The block size of an
-    overlap-save evaluation does not change the convolution it computes, so the device kernel's own block sizes are used.
-    Impulse responses of more than _OLS_MAX_TAPS taps are cut into segments h_p: conv(x, h)[m] = sum_p conv(x, h_p)[m - p S],
-    every partial convolution one launch over the zero-extended signal, the partial results added with the segment's offset."""
-    lib = _lib.load()
-    x = np.ascontiguousarray(x, dtype=np.complex128)
-    n, ncols = x.shape
-    K = len(Hf)
-    h = np.fft.fftshift(np.fft.ifft(Hf))                          # core.py:1015-1016: centred impulse response, K taps
-    if K <= _OLS_MAX_TAPS:
-        nfft = 16
-        while nfft < min(4 * K, 8192) or nfft < K:
-            nfft *= 2
-        H = np.ascontiguousarray(np.fft.fft(np.pad(h, (0, nfft - K))), dtype=np.complex128)
-        out = np.empty_like(x)
-        rc = lib.ssf_overlap_save(_state["device"], n, ncols, _lib.SSF_C128, nfft, K, H.ctypes.data_as(C.c_void_p),
-                                  x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
-        _lib.raise_for(lib, None, rc)
-        return out
-    S, D = _OLS_MAX_TAPS, (K - 1) // 2
-    xp = np.zeros((n + 2 * K, ncols), dtype=np.complex128)        # zero-extended: every partial 'same' output we need exists
-    xp[K:K + n] = x
-    acc = np.zeros((n, ncols), dtype=np.complex128)
-    part = np.empty_like(xp)
-    nfft = 2 * S
-    for p0 in range(0, K, S):
-        hp = h[p0:p0 + S]
-        Kp, Dp = len(hp), (len(hp) - 1) // 2
-        H = np.ascontiguousarray(np.fft.fft(np.pad(hp, (0, nfft - Kp))), dtype=np.complex128)
-        rc = lib.ssf_overlap_save(_state["device"], xp.shape[0], ncols, _lib.SSF_C128, nfft, Kp, H.ctypes.data_as(C.c_void_p),
-                                  xp.ctypes.data_as(C.c_void_p), part.ctypes.data_as(C.c_void_p))
-        _lib.raise_for(lib, None, rc)
-        # part[i] = full_p[i + Dp] over the extended signal; y[j] = sum_p full_p[(j + K) + D - p0]
-        o = K + D - p0 - Dp
-        acc += part[o:o + n]
-    return acc
+def blockwiseFFTConv(x, h, NFFT=None, freqDomainFilter=False):
+    """Blockwise convolution by the overlap-and-save FFT method (optic/dsp/core.py:973-1046; cupy twin optic/dsp/coreGPU.py:81-170):
+    the 'same'-mode linear convolution of the 1-D signal ``x`` with the filter ``h`` -- an impulse response, or with
+    ``freqDomainFilter=True`` a frequency response centred at DC (turned into its centred impulse response as core.py:1015-1016
+    does) -- delay ``(len(h) - 1) // 2`` compensated, ``len(x)`` samples.  ``NFFT`` must not be smaller than the filter (the
+    reference's error); otherwise the block size of an overlap-save evaluation does not change the convolution it computes, and
+    the device kernel uses its own (LDS transforms of up to 8192 points; filters of more than 4096 taps segment by segment,
+    ceil(len(h) / 4096) passes over the signal).  numpy in, numpy out (real when ``x`` has no imaginary part, core.py:1043-1046);
+    a complex128 DeviceArray in, a DeviceArray out, never through the host."""
+    from . import rx as _rx
+    on_dev = _dev.is_device(x)
+    xs = x if on_dev else np.asarray(x)
+    if xs.ndim != 1:
+        raise ValueError("blockwiseFFTConv: x must be one-dimensional")
+    h = np.asarray(h)
+    sigLen, K = xs.shape[0], len(h)
+    if NFFT is None:
+        NFFT = 2 ** int(np.ceil(np.log2(np.max([sigLen, K]))))
+    if NFFT < K:
+        raise ValueError("FFT size is smaller than filter length")
+    ht = np.fft.fftshift(np.fft.ifft(h)) if freqDomainFilter else h
+    y = _rx._conv_shift(xs.reshape(sigLen, 1), ht, (K - 1) // 2, sigLen, on_dev).reshape(-1)
+    if on_dev:
+        return y
+    return y if np.any(np.iscomplex(xs)) else y.real
 
 
 def _edc_long(sigIn, sig2, one_d, on_dev, K, Hf):
-    """edc with an impulse response of more than _OLS_MAX_TAPS taps (_ols_same_host: segment by segment)."""
-    acc = _ols_same_host(sig2.get() if on_dev else sig2, Hf)
-    ncols = acc.shape[1]
+    """edc with an impulse response of more than _OLS_MAX_TAPS taps: blockwiseFFTConv(x, Hf, freqDomainFilter=True) of the
+    reference (optic/dsp/core.py:973-1046) for every column -- the centred impulse response (delay (K - 1) // 2), convolved on the
+    device segment by segment (ssf_fir_long); a DeviceArray stays on the device."""
+    from . import rx as _rx
+    h = np.fft.fftshift(np.fft.ifft(Hf))                          # core.py:1015-1016
+    acc = _rx._conv_shift(sig2, h, (K - 1) // 2, sig2.shape[0], on_dev)
     if on_dev:
-        out = _dev.empty(True, sig2.shape, np.complex128)
-        out.set(acc)
-        return out.reshape(-1) if one_d else out
+        return acc.reshape(-1) if one_d else acc
+    ncols = acc.shape[1]
     res = acc if np.iscomplexobj(sigIn) else acc.real
     if np.iscomplexobj(sigIn):
         for m_ in range(ncols):
@@ -658,7 +646,7 @@ def edc(sigIn, param):
     # kernel takes powers of two in [16, 8192], so any other request of the reference (Nfft = 2 for a 1 km link,
     # a non power of two, > 8192) is served with the smallest supported block that leaves >= 3/4 of each transform as
     # output.  Filters that leave less than half of an 8192-point block as output (> 4096 taps) are split into segments
-    # of the impulse response (_edc_long): the reference takes any length (core.py:973-1046).
+    # of the impulse response, on the device (_edc_long): the reference takes any length (core.py:973-1046).
     if K > _OLS_MAX_TAPS:
         return _edc_long(sigIn, sig2, one_d, on_dev, K, Hf)
     if Nfft < 16 or Nfft > 8192 or (Nfft & (Nfft - 1)):

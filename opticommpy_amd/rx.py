@@ -44,6 +44,10 @@ class _HipBackend:
         lib = _lib.load()
         _lib.raise_for(lib, None, lib.ssf_fir_filter(self._dev(), N, ncols, ntaps, taps, x, out))
 
+    def fir_long(self, inLen, outLen, ncols, ntaps, taps, shift, x, out):
+        lib = _lib.load()
+        _lib.raise_for(lib, None, lib.ssf_fir_long(self._dev(), int(inLen), int(outLen), int(ncols), int(ntaps), taps, int(shift), x, out))
+
     def delay(self, N, delay, Fs, x, out):
         lib = _lib.load()
         _lib.raise_for(lib, None, lib.ssf_delay_signal(self._dev(), N, float(delay), float(Fs), x, out))
@@ -96,16 +100,20 @@ def lowPassFIR(fc, fs, N, typeF="rect"):
 def firFilter(h, x, prec=None):
     """FIR filtering with the filter delay compensated: 'same'-mode convolution of every column of x
     with h (optic/dsp/core.py:87-125; ``prec`` as in the cupy twin optic/dsp/coreGPU.py:27-78).  One
-    overlap-save launch for all columns; at most 4096 taps.  A complex128 DeviceArray stays on the device."""
+    overlap-save launch for all columns up to 4096 taps, ceil(taps / 4096) launches beyond (ssf_fir_long).  A complex128
+    DeviceArray stays on the device."""
     on_dev = _dev.is_device(x)
     if not on_dev:
         x = np.asarray(x)
     taps = np.ascontiguousarray(h, dtype=np.complex128)
     input1D = x.ndim == 1
     x2 = x.reshape(len(x), 1) if input1D else x
-    xp, _keep = _dev.arg(x2, np.complex128)
-    y = _dev.empty(on_dev, x2.shape, np.complex128)
-    _backend.fir(x2.shape[0], x2.shape[1], len(taps), taps.ctypes.data_as(C.c_void_p), xp, _dev.out_ptr(y))
+    if len(taps) > _FIR_MAX_TAPS:
+        y = _conv_shift(x2, taps, (len(taps) - 1) // 2, x2.shape[0], on_dev)
+    else:
+        xp, _keep = _dev.arg(x2, np.complex128)
+        y = _dev.empty(on_dev, x2.shape, np.complex128)
+        _backend.fir(x2.shape[0], x2.shape[1], len(taps), taps.ctypes.data_as(C.c_void_p), xp, _dev.out_ptr(y))
     if on_dev:
         return y.reshape(-1) if input1D else y
     if prec is not None:
@@ -120,35 +128,28 @@ def firFilter(h, x, prec=None):
 _FIR_MAX_TAPS = 4096           # ssf_fir_filter: one LDS block pair per 8192-point block, at least half of it output
 
 
-def _conv_same_host(x, h):
-    """full[(K - 1) // 2 : (K - 1) // 2 + n] of the linear convolution of a host (n,) complex128 signal with K complex taps,
-    any K: what blockwiseFFTConv returns (optic/dsp/core.py:1043-1046).  The impulse response is cut into segments h_p of at
-    most _FIR_MAX_TAPS taps, conv(x, h)[m] = sum_p conv(x, h_p)[m - p S]; every partial convolution is one launch of the
-    overlap-save FIR kernel (ssf_fir_filter) over the zero-extended signal."""
-    n, K = len(x), len(h)
-    S, D = _FIR_MAX_TAPS, (K - 1) // 2
-    xp = np.zeros((n + 2 * K, 1), dtype=np.complex128)
-    xp[K:K + n, 0] = x
-    acc = np.zeros(n, dtype=np.complex128)
-    part = np.empty_like(xp)
-    for p0 in range(0, K, S):
-        hp = np.ascontiguousarray(h[p0:p0 + S], dtype=np.complex128)
-        Dp = (len(hp) - 1) // 2
-        _backend.fir(xp.shape[0], 1, len(hp), hp.ctypes.data_as(C.c_void_p), xp.ctypes.data_as(C.c_void_p), part.ctypes.data_as(C.c_void_p))
-        o = K + D - p0 - Dp                       # part[i] = full_p[i + Dp] over the extended signal
-        acc += part[o:o + n, 0]
-    return acc
+def _conv_shift(x2, h, shift, outLen, on_dev):
+    """out[n, m] = sum_t h[t] x2[n + shift - t, m], n in [0, outLen), x2 zero-extended on both sides: ssf_fir_long, any number of
+    taps, host or device signal -- a DeviceArray never leaves the device.  blockwiseFFTConv's result (optic/dsp/core.py:1043-1046)
+    is shift = (len(h) - 1) // 2, outLen = len(x2).  Cost: ceil(len(h) / 4096) overlap-save passes over the signal."""
+    taps = np.ascontiguousarray(h, dtype=np.complex128)
+    xp, _keep = _dev.arg(x2, np.complex128)
+    out = _dev.empty(on_dev, (int(outLen), x2.shape[1]), np.complex128)
+    _backend.fir_long(x2.shape[0], outLen, x2.shape[1], len(taps), taps.ctypes.data_as(C.c_void_p), shift, xp, _dev.out_ptr(out))
+    return out
 
 
 def delaySignal(sig, delay, Fs=1, NFFT=1024):
     """Fractional delay by FFT overlap-save filtering (optic/dsp/core.py:880-922).  NFFT = 1024 (the reference's default,
     a 512-tap delay filter) is one device call; any other NFFT -- an NFFT // 2-sample frequency response, or None = the next
-    power of two above the padded length -- builds the reference's filter on the host (a few thousand values) and runs the
-    same overlap-save kernel (_conv_same_host)."""
+    power of two above the padded length, i.e. about N / 2 taps -- builds the reference's impulse response on the host (NFFT // 2
+    values) and convolves on the device segment by segment (ssf_fir_long: ceil(NFFT / 8192) passes over the signal; at 2^20
+    samples and NFFT = None that is 64 passes, tens of milliseconds).  The reference's zero padding, np.roll(-1) and [:N] cut
+    are index arithmetic of that call.  A DeviceArray stays on the device (complex128 in, complex128 out)."""
     on_dev = _dev.is_device(sig)
     if NFFT != 1024:
-        s0 = np.asarray(sig.get() if on_dev else sig).reshape(-1)
-        N = len(s0)
+        s1 = sig.reshape(-1) if on_dev else np.asarray(sig).reshape(-1)
+        N = s1.shape[0]
         padLen = int(np.ceil(np.abs(delay * Fs)))                                  # core.py:905-909
         if NFFT is None:
             NFFT = 2 ** int(np.ceil(np.log2(N + padLen)))
@@ -157,13 +158,22 @@ def delaySignal(sig, delay, Fs=1, NFFT=1024):
         freq = np.fft.fftfreq(int(NFFT) // 2, d=1 / Fs)
         H = np.exp(-1j * 2 * np.pi * freq * delay)                                 # core.py:916
         h = np.fft.fftshift(np.fft.ifft(H))                                        # core.py:1015-1016: centred impulse response
-        y = _conv_same_host(np.pad(s0, (0, padLen)).astype(np.complex128), h)
-        y = np.roll(y, -1)[:N]                                                     # core.py:920-922
+        D = (len(h) - 1) // 2
+        # y = conv_same(sig zero-padded by padLen)[:N + padLen]; roll(y, -1)[:N] (core.py:920-922) = y[1 : N + 1] -- and with no
+        # padding the last sample wraps around to y[0]
+        x2 = s1.reshape(N, 1)
+        y = _conv_shift(x2, h, D + 1, N, on_dev)
+        if padLen == 0:
+            y0 = _conv_shift(x2, h, D, 1, on_dev)
+            if on_dev:
+                lib = _lib.load()
+                _lib.raise_for(lib, None, lib.ssf_device_memcpy(y.device, C.c_void_p(y.ptr.value + 16 * (N - 1)), y0.ptr, 16))
+            else:
+                y[N - 1] = y0[0]
+        y = y.reshape(-1)
         if on_dev:
-            out = _dev.empty(True, (N,), np.complex128)
-            out.set(y)
-            return out
-        return y if np.any(np.iscomplex(s0)) else y.real
+            return y
+        return y if np.any(np.iscomplex(s1)) else y.real
     if not on_dev:
         sig = np.asarray(sig)
     s1 = sig.reshape(-1)

@@ -129,6 +129,29 @@ def phaseNoise(lw, Nsamples, Ts, seed=None):
     return np.concatenate(([0.0], np.cumsum(steps)))[:Nsamples]
 
 
+def basicLaserModel(param=None):
+    """Laser with a Maxwellian random-walk phase and relative intensity noise (optic/models/devices.py:729-790): the receiver's
+    local oscillator in the coherent notebooks.  Parameters (defaults): P [10 dBm], lw [1e3 Hz], RIN_var [1e-20], Fs, Ns
+    [1000], seed [None], freqShift [0 Hz].  The seeded draws are the reference's ``np.random`` draws (phase walk with ``seed``,
+    intensity noise with ``seed + 73``), so with a seed the field equals the reference's; a host array, which
+    ``pdmCoherentReceiver`` uploads with the signal."""
+    from .models import gaussianComplexNoise
+    try:
+        Fs = param.Fs
+    except AttributeError:
+        raise AttributeError("basicLaserModel: simulation sampling frequency (param.Fs) not provided") from None
+    P = getattr(param, "P", 10)
+    lw = getattr(param, "lw", 1e3)
+    RIN_var = getattr(param, "RIN_var", 1e-20)
+    Ns = int(getattr(param, "Ns", 1000))
+    seed = getattr(param, "seed", None)
+    fshift = getattr(param, "freqShift", 0)
+    pn = phaseNoise(lw, Ns, 1 / Fs, None if seed is None else seed)
+    deltaP = gaussianComplexNoise(pn.shape, RIN_var, None if seed is None else seed + 73)
+    fo = 2 * np.pi * fshift * np.arange(Ns) / Fs if fshift != 0 else 0
+    return np.sqrt(1e-3 * 10 ** (P / 10) + deltaP) * np.exp(1j * (fo + pn))
+
+
 # ------------------------------------------------------------------ simpleWDMTx
 def simpleWDMTx(param, device_output=False):
     """Simple WDM transmitter (optic/models/tx.py:42-228).  Parameters (defaults): M [16], constType ['qam'], Rs

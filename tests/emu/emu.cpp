@@ -174,6 +174,7 @@ struct EmuBackend {
         ++launches;
         run_grid(std::min(grid, 8), block, 64, [&](EmuCtx &c) { ssf::fused::repack_body(c, a); });
     }
+    template <typename T> bool can_split_cols(const ssf::fused::ColArgs<T> &a, int) const { return !a.N2 && a.vpt != 8; }
     template <typename T> void launch_col(const ssf::fused::ColArgs<T> &a0, int grid, int block, size_t lds, int units = 1) {
         ++launches;
         for (int u = 0; u < units; ++u) {
@@ -185,7 +186,21 @@ struct EmuBackend {
         if (getenv("SSF_EMU_DEBUG") && launches < 8) fprintf(stderr, "emu col: vpt %d block %d grid %d lds %zu\n", a.vpt, block, grid, lds);
         using namespace ssf::fused;
         if constexpr (std::is_same<T, pf2>::value) {          // packed pair: only the Manakov stage exists
+            // (the HIP backend's choice: the columns of a workgroup interleaved in LDS where the chip-filling geometries have 4 / 8)
+            const int cols = (block / a.npol) / ((1 << a.log2N1) / (a.vpt == 8 ? 8 : 16));
+            const bool il = !getenv("SSF_COL_IL") || atoi(getenv("SSF_COL_IL")) != 0;
+            if (a.vpt != 8 && a.sg && a.sg != SG_ALL) {      // stage-specialised kernels (FusedCore::run_span, col_split)
+                switch (a.sg) {
+                case SG_H | SG_RARE: run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0, 16, 0, SG_H | SG_RARE>(c, a); }); break;
+                case SG_ADV: run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0, 16, 0, SG_ADV>(c, a); }); break;
+                case SG_FIN: run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0, 16, 0, SG_FIN>(c, a); }); break;
+                default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0, 16, 0, SG_ALL>(c, a); }); break;
+                }
+                return;
+            }
             if (a.vpt == 8) run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0, 8>(c, a); });
+            else if (il && cols == 4) run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0, 16, 4>(c, a); });
+            else if (il && cols == 8) run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0, 16, 8>(c, a); });
             else run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0>(c, a); });
             return;
         } else {
@@ -213,10 +228,23 @@ struct EmuBackend {
             if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST, true>(c, a); });
             else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_LAST, false>(c, a); });
             break;
-        case CM_MK:
+        case CM_MK: {
+            const int cols = (block / a.npol) / ((1 << a.log2N1) / 16);
+            const bool il = std::is_same<T, double>::value && cols == 8 && (!getenv("SSF_COL_IL") || atoi(getenv("SSF_COL_IL")) != 0);
+            if (!a.N2 && a.sg && a.sg != SG_ALL) {           // stage-specialised kernels (FusedCore::run_span, col_split)
+                switch (a.sg) {
+                case SG_H | SG_RARE: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false, 16, 0, SG_H | SG_RARE>(c, a); }); break;
+                case SG_ADV: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false, 16, 0, SG_ADV>(c, a); }); break;
+                case SG_FIN: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false, 16, 0, SG_FIN>(c, a); }); break;
+                default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false, 16, 0, SG_ALL>(c, a); }); break;
+                }
+                break;
+            }
             if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, true>(c, a); });
+            else if (il) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false, 16, 8>(c, a); });
             else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_MK, false>(c, a); });
             break;
+        }
         case CM_PLAIN_FWD:
             if (a.N2) run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD, true>(c, a); });
             else run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_PLAIN_FWD, false>(c, a); });
@@ -411,6 +439,11 @@ int emu_fir(int64_t sigLen, int ncols, int ntaps, const void *taps, const void *
     EmuBackend be;
     ssf::rx::RxCore<EmuBackend> core(be);
     return core.fir(sigLen, ncols, ntaps, taps, in, out);
+}
+int emu_fir_long(int64_t inLen, int64_t outLen, int ncols, int64_t ntaps, const void *taps, int64_t shift, const void *in, void *out) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    return core.fir_long(inLen, outLen, ncols, ntaps, taps, shift, in, out);
 }
 int emu_nlin_phase_rot(int64_t n, double gamma, const void *Ex, const void *Ey, const double *Pch, double *phi) {
     EmuBackend be;

@@ -170,6 +170,10 @@ class EmuRxBackend:
     def fir(self, N, ncols, ntaps, taps, x, out):
         self._check(self.e.emu_fir(N, ncols, ntaps, taps, x, out))
 
+    def fir_long(self, inLen, outLen, ncols, ntaps, taps, shift, x, out):
+        self.e.emu_fir_long.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        self._check(self.e.emu_fir_long(inLen, outLen, ncols, ntaps, taps, shift, x, out))
+
     def delay(self, N, delay, Fs, x, out):
         self._check(self.e.emu_delay(N, float(delay), float(Fs), x, out))
 

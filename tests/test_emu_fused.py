@@ -51,7 +51,7 @@ def test_linear_channel_c64_and_large():
     assert rel_l2(eb.linear_channel(E, 512e9, 193.1e12, 0.2, 16, 2.0), ref) < 1e-13
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith(("rx_", "tx_", "long_", "wl_"))])
+@pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith(("rx_", "tx_", "long_", "wl_", "chain_", "bfc_", "mix_"))])
 def test_golden_vectors_on_emulated_kernels(name):
     d, cfg = load_golden(name)
     N = d["Ei"].shape[0]
@@ -577,3 +577,36 @@ def test_three_pass_transforms_with_the_lds_twiddle_table_and_kept_bases(monkeyp
         assert rel_l2(eb.linear_channel(E, 512e9, 193.1e12, 0.2, 16, 3.0), orc.linearFiberChannel(E, p)) < 1e-13
     else:
         assert rel_l2(out.T, ref) <= 5e-5
+
+
+# ---- round 5: stage-specialised column kernels along the predicted stage sequence (FusedCore::run_span, fused_kernels.h: stage_group) ----
+@pytest.mark.parametrize("prec", ["complex128", "complex64"])
+@pytest.mark.parametrize("kw", [dict(), dict(nlprMethod=True, maxNlinPhaseRot=2e-3), dict(p=-20.0), dict(hz=0.3), dict(maxIter=1),
+                                dict(p=11.0, Lspan=6.0, Ltotal=6.0, alpha=2.0)],
+                         ids=["fixed", "adaptive", "weak_nonlinearity", "long_steps", "one_iteration", "iteration_count_falls"])
+def test_stage_specialised_column_kernels_follow_the_state(monkeypatch, prec, kw):
+    """The host enqueues H | ADV | FIN column kernels along the stage sequence it predicts from the latest step's iteration
+    count; a kernel whose stage the state does not ask for forwards the control block untouched.  Whatever the guess -- the
+    iteration count falling along a lossy span, convergence at iterate 0 as the rule (rebuilds ride in the H kernel; the call
+    falls back to the general kernel), the rounding-sized last step of a span -- the results are those of the one general
+    kernel (SSF_COL_SPLIT=0) bit for bit, with the same step and iteration counts, at a bounded cost in idle launches."""
+    monkeypatch.setenv("SSF_COL_V", "16")
+    monkeypatch.setenv("SSF_ROW_V", "16")
+    kw = dict(kw)
+    dt = np.complex64 if prec == "complex64" else np.complex128
+    E = synth_field(1 << 12, 2, 43, kw.pop("p", 8.4)).astype(dt)
+    cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5, prgsBar=False,
+               Ltotal=1.6, Lspan=0.8, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[], prec=prec)
+    cfg.update(kw)
+    res = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("SSF_COL_SPLIT", split)
+        res[split] = eb.run("manakovSSF", E, cfg, trace=False)
+    (a, ia), (b, ib) = res["0"], res["1"]
+    assert np.array_equal(a, b)
+    for k in ("steps", "iterations", "nonconverged_steps", "rebuilt_iterates", "recovered_fields"):
+        assert ia[k] == ib[k], k
+    assert ib["launches"] <= 1.5 * ia["launches"] + 96, (ia["launches"], ib["launches"])
+    if "alpha" in kw:                                   # the case is what it says: the iteration count changes inside the span
+        _, it = eb.run("manakovSSF", E, cfg)
+        assert len(set(it["iters"])) > 1

@@ -66,7 +66,7 @@ def _run_hip(cfg, Ei, **kw):
 
 
 @pytest.mark.parametrize("engine", ENGINES)
-@pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith(("edc_", "rx_", "tx_", "long_", "wl_"))])
+@pytest.mark.parametrize("name", [n for n in golden_names() if not n.startswith(("edc_", "rx_", "tx_", "long_", "wl_", "chain_", "bfc_", "mix_"))])
 def test_golden_vectors(name, engine):
     d, cfg = load_golden(name)
     _select(engine, d["Ei"].shape[0])

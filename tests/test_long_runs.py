@@ -160,24 +160,42 @@ def test_config3_first_steps_against_the_reference_at_full_size():
 
 
 @pytest.mark.gpu
-def test_config3_full_span_c64_vs_c128_at_full_size():
-    """BASELINE config 3's field (N = 2^22, complex64, seed 3, 8.4 dBm) over one full span (1001 steps)."""
+def test_config3_full_span_against_the_reference_at_full_size():
+    """BASELINE config 3's own field (N = 2^22, seed 3, 8.4 dBm, complex64 samples) over one FULL span -- 80 km, hz 0.08: 1001 passes
+    of the step loop, through the 3 -> 2 iteration crossover (step 493 of the reference in both precisions) -- against the
+    REFERENCE (tests/golden/long_c3_n22.npz, tools/gen_golden.py long_c3: 71 + 64 minutes of reference time).  HIP complex128: the
+    reference's iteration list step for step, every lim to 1e-6, the field to 1e-10 (decimated output, per-column power, a seeded
+    projection of all 2^23 output samples).  HIP complex64 (packed pairs): inside the 5e-4 gate of SURVEY 8c against the
+    reference's complex128 result AND its own complex64 result, power within 2e-4, the reference's iteration list up to a flip
+    at the crossover step (SURVEY 8c allows it in single precision; the totals are reported), and at least as close to the
+    complex128 truth as the reference's complex64 path (1.1e-4 here)."""
     import opticommpy_amd as oa
     from opticommpy_amd import models
-    N = 1 << 22
-    E = synth_field(N, 2, 3, 8.4, np.complex64)
-    cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False,
-               Ltotal=80, Lspan=80, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
-    outs, its = {}, {}
-    for prec in ("complex128", "complex64"):
-        outs[prec] = oa.manakovSSF(E.astype(prec), make_param(oa.parameters, dict(cfg, prec=prec)), _trace=True)
-        assert models.last_run["steps"] == 1001
-        its[prec] = np.asarray(models.last_run["iters"])
-    a, b = outs["complex64"].astype(np.complex128), outs["complex128"]
-    assert rel_l2(a, b) <= 5e-4
-    assert abs(np.sum(np.abs(a) ** 2) / np.sum(np.abs(b) ** 2) - 1) <= 2e-4
-    # a flip of the iteration count at the crossover step is allowed in single precision (SURVEY 8c), nothing else
-    assert np.count_nonzero(its["complex64"] != its["complex128"]) <= 2
+    d, cfg = load_golden("long_c3_n22")
+    dec, run = int(cfg["dec"]), _run_cfg(cfg)
+    E64 = _input(cfg, np.complex64)
+    out = oa.manakovSSF(E64.astype(np.complex128), make_param(oa.parameters, dict(run, prec="complex128")), _trace=True)
+    r128 = dict(models.last_run)
+    assert r128["engine"] == "fused" and r128["steps"] == int(cfg["steps"]) == 1001
+    assert list(r128["iters"]) == list(d["iters128"])
+    flat = np.concatenate([np.asarray(r, dtype=float) for r in r128["lims"]])
+    np.testing.assert_allclose(flat, d["lims128"], rtol=1e-6, atol=1e-15)
+    assert rel_l2(out[::dec], d["out128_dec"]) <= 1e-10
+    np.testing.assert_allclose(np.sum(np.abs(out) ** 2, axis=0), d["out128_power"], rtol=1e-9)
+    scale = np.sqrt(np.sum(d["out128_power"]))
+    assert np.max(np.abs(projection(out) - d["out128_proj"])) <= 1e-9 * scale
+    o64 = oa.manakovSSF(E64, make_param(oa.parameters, dict(run, prec="complex64")), _trace=True)
+    r64 = dict(models.last_run)
+    assert o64.dtype == np.complex64 and r64["steps"] == 1001
+    flips = int(np.count_nonzero(np.asarray(r64["iters"]) != d["iters64"]))
+    assert flips <= 2, flips
+    dev128, dev64 = rel_l2(o64[::dec], d["out128_dec"]), rel_l2(o64[::dec], d["out64_dec"])
+    print(f"config 3, one span: HIP c128 vs reference {rel_l2(out[::dec], d['out128_dec']):.2e}; HIP c64 vs reference c128 {dev128:.2e}, "
+          f"vs reference c64 {dev64:.2e} (reference c64 vs c128 {float(d['ref_c64_rel_l2_dec']):.2e}); iteration flips {flips}")
+    assert dev128 <= 5e-4 and dev64 <= 5e-4
+    assert dev128 <= max(float(d["ref_c64_rel_l2_dec"]), 5e-5)
+    assert np.max(np.abs(projection(o64) - d["out128_proj"])) <= 5e-4 * scale
+    np.testing.assert_allclose(np.sum(np.abs(o64.astype(np.complex128)) ** 2, axis=0), d["out128_power"], rtol=2e-4)
 
 
 @pytest.mark.gpu

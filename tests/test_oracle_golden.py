@@ -7,7 +7,7 @@ import pytest
 from helpers import golden_names, load_golden, make_param, split_iters
 from oracle import ssf_oracle as orc
 
-ALL = [n for n in golden_names() if not n.startswith(("rx_", "tx_", "long_", "wl_"))]   # rx_*, tx_*: their own test files
+ALL = [n for n in golden_names() if not n.startswith(("rx_", "tx_", "long_", "wl_", "chain_", "bfc_", "mix_"))]   # rx_*, tx_*: their own test files
 
 
 def _run(cfg, Ei, trace):

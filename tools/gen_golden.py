@@ -20,7 +20,7 @@ Output: tests/golden/<case>.npz, each holding
               output decimated by cfg["dec"], its per-column power and a seeded random projection of the full
               output (so an error anywhere in the array shows), see long_vectors()
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|rx_edges|tx|long|long20|cfg3|units45 [log2n]]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|rx_edges|tx|bfc|chain|long|long20|cfg3|long_c3 [128|64|merge]|units45 [log2n]]
 """
 import json
 import os
@@ -540,6 +540,122 @@ def cfg3_vector(steps=6):
     print(f"wl_cfg3_n22: reference complex64 vs complex128 after {steps} steps: {arrs['ref_c64_rel_l2']:.2e}  {sz/1024:.0f} KiB", flush=True)
 
 
+def long_c3_vector(which="both"):
+    """BASELINE config 3's own field (2^22 samples, seed 3, 8.4 dBm, complex64 samples) through the reference for ONE FULL
+    SPAN (80 km, hz 0.08: 1001 passes of the step loop, through the 3 -> 2 iteration crossover), in complex128 (samples cast
+    up) and in the reference's complex64 mode.  About an hour per precision: `which` = "128" /
+    "64" writes long_c3_n22_c128.part.npz / _c64.part.npz so that both can run side by side; "merge" joins them into
+    tests/golden/long_c3_n22.npz."""
+    import time
+    os.makedirs(OUT, exist_ok=True)
+    N, dec = 1 << 22, 2048
+    synth = (N, 2, 3, 8.4)
+    kw = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False,
+              Ltotal=80, Lspan=80, hz=0.08, nlprMethod=False, amp="ideal", saveSpanN=[])
+    part = lambda tag: os.path.join(OUT, "..", "..", "gpurun_out", "long_c3_n22_c%s.part.npz" % tag)
+    if which == "merge":
+        arrs = {}
+        for tag in ("128", "64"):
+            with np.load(part(tag)) as d:
+                arrs.update({k: d[k] for k in d.files})
+        # the reference's complex64 deviation from its complex128 result on what is stored (decimated output, projection)
+        a, b = arrs["out64_dec"].astype(np.complex128), arrs["out128_dec"]
+        arrs["ref_c64_rel_l2_dec"] = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        cfg = json.loads(cfg_json("manakovSSF", kw))
+        cfg["synth"], cfg["dec"], cfg["steps"] = list(synth), dec, int(len(arrs["iters128"]))
+        sz = save("long_c3_n22", cfg=json.dumps(cfg), **arrs)
+        print(f"long_c3_n22: steps {cfg['steps']}  iters128 {int(arrs['iters128'].sum())} iters64 {int(arrs['iters64'].sum())}  "
+              f"reference complex64 vs complex128 (decimated) {arrs['ref_c64_rel_l2_dec']:.2e}  {sz/1024:.0f} KiB", flush=True)
+        return
+    E64 = synth_field(*synth, np.complex64)
+    for tag, prec in (("128", np.complex128), ("64", np.complex64)):
+        if which not in ("both", tag):
+            continue
+        Ei = E64.astype(prec)
+        t0 = time.time()
+        p = mk_param(**dict(kw, prec=prec))
+        with Tracer(ref_ch) as tr:
+            out = ref_ch.manakovSSF(Ei, p)
+        assert out.dtype == np.dtype(prec) and out.shape == (N, 2)
+        iters = np.array(split_iters(tr.lims, p.tol, p.maxIter), dtype=np.int8)
+        o = out.astype(np.complex128)
+        np.savez(part(tag), **{"iters" + tag: iters, "lims" + tag: np.array(tr.lims), "out%s_dec" % tag: out[::dec].copy(),
+                               "out%s_power" % tag: np.sum(np.abs(o) ** 2, axis=0), "out%s_proj" % tag: projection(out)})
+        print(f"long_c3 complex{tag}: steps {len(iters)} iters {int(iters.sum())} "
+              f"({int(np.count_nonzero(np.diff(iters.astype(int))))} changes)  {time.time()-t0:.0f} s", flush=True)
+
+
+def chain_vector():
+    """The notebook chain end to end, in the order of examples/test_WDM_transmission.ipynb (cells 10, 14,
+    18, 20, 22, 23): simpleWDMTx(seed) -> manakovSSF -> basicLaserModel (LO) -> pdmCoherentReceiver -> firFilter (matched filter)
+    -> decimate -> edc, every stage the REFERENCE's own function fed with the previous stage's output.  simpleWDMTx's defaults
+    give 240 000 samples (60 000 bits, 16-QAM, 16 samples per symbol); the channel is two 50 km spans with amp='ideal' (the
+    deterministic amplifier) and the adaptive step of the notebook.  Stored: a projection of the symbols, every stage's decimated output and a
+    seeded projection of all of it, the channel's iteration list, the final output in full (30 000 x 2)."""
+    import time
+    import optic.dsp.core as ref_core
+    import optic.models.devices as ref_dev
+    import optic.models.tx as ref_tx
+    from optic.dsp.equalization import edc as ref_edc
+    os.makedirs(OUT, exist_ok=True)
+    t0 = time.time()
+    tx = dict(M=16, Rs=32e9, SpS=16, pulseType="rrc", nFilterTaps=1024, pulseRollOff=0.01, powerPerChannel=-2, nChannels=5,
+              Fc=193.1e12, laserLinewidth=100e3, wdmGridSpacing=37.5e9, nPolModes=2, nBits=60000, seed=123, prgsBar=False)
+    paramTx = mk_param(**tx)
+    sigTx, symbTx, paramTx = ref_tx.simpleWDMTx(paramTx)
+    Fs = paramTx.Rs * paramTx.SpS
+    ch = dict(Ltotal=100, Lspan=50, alpha=0.2, D=16, gamma=1.3, Fc=paramTx.Fc, hz=0.5, maxIter=5, tol=1e-5, nlprMethod=True,
+              maxNlinPhaseRot=2e-2, prgsBar=False, Fs=Fs, amp="ideal", saveSpanN=[])
+    pch = mk_param(**ch)
+    with Tracer(ref_ch) as tr:
+        sigCh = ref_ch.manakovSSF(sigTx, pch)
+    iters = np.array(split_iters(tr.lims, pch.tol, pch.maxIter), dtype=np.int8)
+    chIndex = int(np.floor(paramTx.nChannels / 2))
+    lo = dict(P=10, lw=100e3, RIN_var=0, Ns=len(sigCh), Fs=Fs, seed=789, freqShift=float(paramTx.wdmFreqGrid[chIndex]) - 128e6)
+    sigLO = ref_dev.basicLaserModel(mk_param(**lo))
+    fe = dict(Fs=Fs, polRotation=np.pi / 3, pdl=0, polDelay=3 / paramTx.Rs, phaseImbX=0.0, phaseImbY=0.0, ampImbX=0, ampImbY=0)
+    pd = dict(B=paramTx.Rs, Fs=Fs, ideal=True, seed=1011)
+    sigRx = ref_dev.pdmCoherentReceiver(sigCh, sigLO, mk_param(**fe), mk_param(**pd))
+    ps = dict(SpS=paramTx.SpS, nFilterTaps=paramTx.nFilterTaps, rollOff=paramTx.pulseRollOff, pulseType=paramTx.pulseType)
+    pulse = ref_core.pulseShape(mk_param(**ps))
+    sigMF = ref_core.firFilter(pulse, sigRx)
+    dec = dict(SpSin=paramTx.SpS, SpSout=2)
+    sigDec = ref_core.decimate(sigMF, mk_param(**dec))
+    ed = dict(L=pch.Ltotal, D=pch.D, Fc=pch.Fc, Rs=paramTx.Rs, Fs=2 * paramTx.Rs)
+    sigEDC = ref_edc(sigDec, mk_param(**ed))
+    d = 256
+    cfg = dict(func="chain", tx=tx, ch=ch, lo=lo, fe=fe, pd=pd, ps=ps, dec=dec, edc=ed, chIndex=chIndex, d=d)
+    sz = save("chain_wdm_240k", cfg=json.dumps(cfg), symb_head=symbTx[:64].copy(), symb_proj=projection(symbTx.reshape(len(symbTx), -1)),
+              freqGrid=paramTx.wdmFreqGrid, iters=iters, lims=np.array(tr.lims),
+              tx_dec=sigTx[::d].copy(), tx_proj=projection(sigTx), ch_dec=sigCh[::d].copy(), ch_proj=projection(sigCh),
+              lo_dec=sigLO[::d].copy(), rx_dec=sigRx[::d].copy(), rx_proj=projection(sigRx), mf_dec=sigMF[::d].copy(),
+              mf_proj=projection(sigMF), dec_proj=projection(sigDec), out=sigEDC, out_proj=projection(sigEDC))
+    print(f"chain_wdm_240k: N {sigTx.shape} steps {len(iters)} iters {int(iters.sum())}  out {sigEDC.dtype}{sigEDC.shape}  {sz/1024:.0f} KiB  {time.time()-t0:.0f} s")
+
+
+def bfc_vectors():
+    """blockwiseFFTConv itself (optic/dsp/core.py:973-1046), the overlap-save convolution under edc / delaySignal, as a callable
+    (missing #3): impulse responses and frequency responses, odd and even lengths, a filter longer than the
+    signal, a real signal, a 6001-tap filter (more than one 4096-tap segment on the device), NFFT given and None."""
+    import optic.dsp.core as ref_core
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(90)
+    cx = lambda n: (rng.normal(size=n) + 1j * rng.normal(size=n)) / np.sqrt(2)      # noqa: E731
+    f512 = np.fft.fftfreq(512, d=1 / 64e9)
+    cases = (
+        ("bfc_taps33_complex", cx(3000), cx(33) / 8, None, False),
+        ("bfc_taps64_real_nfft256", rng.normal(size=2048), rng.normal(size=64) / 8, 256, False),
+        ("bfc_freq512_nfft1024", cx(5000), np.exp(-1j * 2 * np.pi * f512 * 37.3e-12), 1024, True),
+        ("bfc_taps6001_nfft8192", cx(20000), cx(6001) / 64, 8192, False),
+        ("bfc_freq10000_nfft16384", cx(12000), np.exp(-1j * 0.5 * (2 * np.pi * np.fft.fftfreq(10000)) ** 2 * 9000.0), 16384, True),
+        ("bfc_taps255_longer_than_signal", cx(100), cx(255) / 16, None, False),
+    )
+    for name, x, h, nfft, fd in cases:
+        out = ref_core.blockwiseFFTConv(x, h, NFFT=nfft, freqDomainFilter=fd)
+        save(name, Ei=x, h=h, out=out, cfg=cfg_json("blockwiseFFTConv", dict(NFFT=nfft, freqDomainFilter=fd)))
+        print(f"{name:34s} x {x.dtype}{x.shape} h {h.dtype}{h.shape} NFFT {nfft} freq {fd} out {out.dtype}{out.shape}")
+
+
 def unit_checksum(out_cols, seed=4242):
     """bench.py's per-unit checksum of an (N, ncols) reference output: sum |E|^2 and <q, E> over the (ncols, N) SoA block
     with the seeded unit-variance complex vector q (bench.py: unit_checksum)."""
@@ -596,6 +712,12 @@ if __name__ == "__main__":
         long20_vector()
     elif len(sys.argv) > 1 and sys.argv[1] == "cfg3":    # config 3's own field, a few steps, complex128 and complex64
         cfg3_vector()
+    elif len(sys.argv) > 1 and sys.argv[1] == "bfc":     # blockwiseFFTConv as a callable
+        bfc_vectors()
+    elif len(sys.argv) > 1 and sys.argv[1] == "chain":   # the notebook chain end to end (transmitter -> channel -> receiver -> edc)
+        chain_vector()
+    elif len(sys.argv) > 1 and sys.argv[1] == "long_c3":  # config 3's own field over one full span (about an hour per precision)
+        long_c3_vector(sys.argv[2] if len(sys.argv) > 2 else "both")
     elif len(sys.argv) > 1 and sys.argv[1] == "units45":  # every unit of configs 4 / 5 at workload size
         units45_vector(log2n=int(sys.argv[2]) if len(sys.argv) > 2 else 20)
     elif len(sys.argv) > 1 and sys.argv[1] == "long":    # only the long-run vectors
