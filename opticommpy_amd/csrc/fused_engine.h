@@ -326,11 +326,14 @@ template <typename T, class Backend> class FusedCore {
     }
 
     C *Tcur() { return cur ? T1 : T0; }
+    int cpl_nranks = 0;
     int set_couple(void *comm, int nranks) {
         if (cpl_work) be.free(cpl_work);
         cpl_work = nullptr;
         cpl_comm = nullptr;
+        cpl_nranks = 0;
         if (!comm) return SSF_OK;
+        cpl_nranks = nranks;
         if (!(cpl_work = (double *)be.alloc(sizeof(double) * (size_t)(8 + 5 * nranks)))) return oom();
         cpl_comm = comm;
         return SSF_OK;
@@ -900,6 +903,13 @@ template <typename T, class Backend> class FusedCore {
                 pk.reset(new FusedCore<pf2, Backend>(be, N, nrows / 2, SSF_C128, (void *)G, units));
                 pk->lanes_hint = lanes_hint;
                 if ((rc = pk->init())) {
+                    err = pk->err;
+                    pk.reset();
+                    return rc;
+                }
+                // the packed core is created on first use: a coupling communicator attached before that (models._manakov attaches,
+                // then executes) must reach it too, or the first complex64 coupled call would reduce over this rank's pairs only
+                if (cpl_comm && (rc = pk->set_couple(cpl_comm, cpl_nranks))) {
                     err = pk->err;
                     pk.reset();
                     return rc;

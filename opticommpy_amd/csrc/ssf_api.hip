@@ -146,6 +146,9 @@ int ssf_plan_set_units(ssf_plan *plan, int32_t n_units) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     if (n_units < 1 || plan->nrows % n_units) return fail(plan, SSF_ERR_BAD_ARG, "ssf_plan_set_units: nrows must be a multiple of n_units");
     if (n_units == plan->units) return SSF_OK;
+    // (rebuilding the engine would silently drop an attached coupling communicator / reducer: the caller would go on believing
+    //  the plan is coupled -- and a plan of independent units is not a coupled batch anyway)
+    if (plan->coupled) return fail(plan, SSF_ERR_STATE, "ssf_plan_set_units: detach the coupling communicator / reducer first (ssf_set_coupling[_comm](plan, NULL))");
     if (plan->engine_id != SSF_ENGINE_FUSED || !fused_supports(plan->N, plan->nrows, plan->precision))
         return fail(plan, SSF_ERR_UNSUPPORTED, "independent units need the natively split fused engine");
     if (n_units > 65535) return fail(plan, SSF_ERR_BAD_ARG, "ssf_plan_set_units: at most 65535 units");
@@ -292,6 +295,7 @@ int ssf_set_coupling(ssf_plan *plan, ssf_reduce_fn reduce, void *ctx) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     SSF_NEED_ENGINE(plan);
     int rc = plan->engine->set_coupling(reduce, ctx);
+    if (rc == SSF_OK) plan->coupled = reduce != nullptr;
     return rc ? fail(plan, rc, "coupled batches need the general-length engine (create the plan with SSF_ENGINE_ROCFFT)") : SSF_OK;
 }
 
@@ -301,6 +305,7 @@ int ssf_set_coupling_comm(ssf_plan *plan, ssf_comm *comm) {
     if (comm && ssf::comm_device(comm) != plan->device) return fail(plan, SSF_ERR_BAD_ARG, "ssf_set_coupling_comm: the communicator lives on another device");
     if (comm && plan->units > 1) return fail(plan, SSF_ERR_UNSUPPORTED, "ssf_set_coupling_comm: a plan of independent units is not a coupled batch");
     int rc = plan->engine->set_coupling_comm(comm);
+    if (rc == SSF_OK) plan->coupled = comm != nullptr;
     return rc ? fail(plan, rc, "device-side coupling needs the device-resident fused pipeline (else: ssf_set_coupling on SSF_ENGINE_ROCFFT)") : SSF_OK;
 }
 

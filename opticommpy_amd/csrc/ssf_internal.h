@@ -70,6 +70,7 @@ struct ssf_plan {
     int nrows = 0;
     int units = 1;               // rows form `units` independent fields (ssf_plan_set_units)
     int lanes = 1;               // plans sharing this GPU concurrently (ssf_plan_set_lanes)
+    bool coupled = false;        // a coupling communicator / reducer is attached (ssf_set_coupling[_comm]): the engine must stay
     int precision = SSF_C128;
     int engine_id = 0;
     hipStream_t stream = nullptr;

@@ -86,7 +86,10 @@ class RcclComm:
     # port plus the launcher's run / job id (torchrun, srun, mpirun) -- not the parent pid, which differs per rank under
     # srun or mpirun with a daemon per rank.  The file is created with O_EXCL, mode 0600, and carries a magic word and
     # its creation time: readers ignore anything written before their own job could have started (a file a crashed run
-    # left behind) and rank 0 unlinks it on every exit path.
+    # left behind) and rank 0 unlinks it on every exit path.  Scope: ONE NODE.  The file lives in a local temporary directory, and
+    # without $SSF_RCCL_ID_FILE or a launcher job id the key falls back to the launcher's pid, which differs between the launchers
+    # of different nodes: a multi-node static rendezvous needs $SSF_RCCL_ID_FILE on a shared file system (otherwise the other
+    # nodes' ranks wait for a file that never appears and fail with the rendezvous timeout).
     _MAGIC = b"SSFRCCL2"
     _STALE_S = 300.0
 
@@ -445,8 +448,9 @@ def run_coupled(Ei_block, param, comm):
     base = int(getattr(param, "_rng_row_offset", 0))
     try:
         p._rng_row_offset = base + int(round(float(np.sum(counts[:comm.rank]))))
-    except AttributeError:
-        p = param
+    except AttributeError:                 # (a parameters object with __slots__: every rank would then draw the SAME Philox rows)
+        raise TypeError("run_coupled: the parameters object must accept new attributes (the rank's noise row offset is stored "
+                        "on a copy of it)") from None
     out = manakovSSF(Ei_block, p, _coupling=comm)
     if p is not param:                     # the reference writes defaults back onto the caller's object (channels.py:305-322)
         for k, v in vars(p).items():

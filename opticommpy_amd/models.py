@@ -412,51 +412,70 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
     if _coupling is not None:                 # rows of ONE reference call spread over several processes (mgpu.run_coupled):
         # an RCCL communicator + a natively split length: the device-resident pipeline all-gathers its partial sums on the plan's
         # stream (ssf_set_coupling_comm, no host in the loop); anything else: the host-driven engine with a reducer callback
+        # The ranks must agree on the mode -- one that fell back to the host reducer while the others enqueue ncclAllGather
+        # on their streams would leave the job waiting for the RCCL timeout -- so every rank attaches (once) and the outcome
+        # is reduced over the communicator before anything runs.
         ch = getattr(_coupling, "h", None)
+        attached = False
         if ch is not None and _state["engine"] != _lib.ENGINE_ROCFFT:
             pl = _get_plan(N, ncols, prec)
-            dev_coupling = pl.lib.ssf_plan_pipeline(pl.h) == 0 and pl.lib.ssf_set_coupling_comm(pl.h, ch) == 0
-            pl.lib.ssf_set_coupling_comm(pl.h, None)                               # (attached for the run inside the try below)
+            if pl.lib.ssf_plan_pipeline(pl.h) == 0:
+                rc = pl.lib.ssf_set_coupling_comm(pl.h, ch)
+                if rc == -1:                  # SSF_ERR_BAD_ARG: the communicator lives on another device than the plan
+                    raise ValueError("run_coupled: " + (pl.lib.ssf_last_error(pl.h) or b"bad argument").decode())
+                attached = rc == 0
+        try:
+            any_failed = float(_coupling.allreduce(np.array([0.0 if attached else 1.0]), "max")[0]) > 0.0
+        except Exception:
+            if attached:
+                pl.lib.ssf_set_coupling_comm(pl.h, None)
+            raise
+        dev_coupling = attached and not any_failed
+        if attached and not dev_coupling:
+            pl.lib.ssf_set_coupling_comm(pl.h, None)
         if not dev_coupling:
             pl = _get_plan(N, ncols, prec, engine=_lib.ENGINE_ROCFFT)              # host-driven control flow
     else:
         pl = _get_plan(N, ncols, prec, units=_units)
-    # the reference's own layout goes over the bus; the (N, 2K) -> (2K, N) conversion runs on the GPU
-    in_ptr, _keep = _dev.arg(Ei, pl.dtype)
+    try:                                      # (an argument error below must not leave the communicator on the cached plan)
+        # the reference's own layout goes over the bus; the (N, 2K) -> (2K, N) conversion runs on the GPU
+        in_ptr, _keep = _dev.arg(Ei, pl.dtype)
 
-    captured = _captured_spans(save_list, Nspans)
-    save_arr = np.array(captured, dtype=np.int32)
-    cp = _fill_params(_lib.MODEL_MANAKOV, direction, param, Fs, Nspans, save_arr)
+        captured = _captured_spans(save_list, Nspans)
+        save_arr = np.array(captured, dtype=np.int32)
+        cp = _fill_params(_lib.MODEL_MANAKOV, direction, param, Fs, Nspans, save_arr)
 
-    noise_fn = None
-    if direction > 0 and cp.amp == _lib.AMP_EDFA:
-        G = param.alpha * param.Lspan
-        assert G > 0, "EDFA gain should be a positive scalar"
-        assert param.NF >= 3, "The minimal EDFA noise figure is 3 dB"
-        _, p_noise = _edfa_noise_power(G, param.NF, param.Fc, Fs)
-        seed = param.seed
+        noise_fn = None
+        if direction > 0 and cp.amp == _lib.AMP_EDFA:
+            G = param.alpha * param.Lspan
+            assert G > 0, "EDFA gain should be a positive scalar"
+            assert param.NF >= 3, "The minimal EDFA noise figure is 3 dB"
+            _, p_noise = _edfa_noise_power(G, param.NF, param.Fc, Fs)
+            seed = param.seed
 
-        if _noise is not None:        # test hook: caller-supplied noise, (Nspans, 2K, N)
-            def noise_fn(span):
-                return np.ascontiguousarray(_noise[span - 1], dtype=pl.dtype)
-        elif _cpu_seed_policy:        # draw-for-draw the CPU reference's numpy stream (golden-vector tests)
-            def noise_fn(span):
-                return _span_noise(ncols, N, p_noise, seed, True, pl.dtype)
-        else:                         # product path: ASE generated on the device (Philox, per-span streams;
-            cp.rng_seed = _device_seed(seed)   # x and y rows get independent noise, unlike channels.py:444-445)
+            if _noise is not None:        # test hook: caller-supplied noise, (Nspans, 2K, N)
+                def noise_fn(span):
+                    return np.ascontiguousarray(_noise[span - 1], dtype=pl.dtype)
+            elif _cpu_seed_policy:        # draw-for-draw the CPU reference's numpy stream (golden-vector tests)
+                def noise_fn(span):
+                    return _span_noise(ncols, N, p_noise, seed, True, pl.dtype)
+            else:                         # product path: ASE generated on the device (Philox, per-span streams;
+                cp.rng_seed = _device_seed(seed)   # x and y rows get independent noise, unlike channels.py:444-445)
 
+    except BaseException:
+        if dev_coupling:
+            pl.lib.ssf_set_coupling_comm(pl.h, None)
+        raise
     logg.info("Running Manakov SSF model on GPU (HIP, %s)..." % ("forward" if direction > 0 else "DBP"))
-    pl.check(pl.lib.ssf_upload_aos(pl.h, in_ptr))
     if param.nlprMethod:
         hint = 1 << 16
     else:
         hint = int(np.ceil(param.Lspan / param.hz)) + 1
     sink, reducer = None, None
-    try:                                      # (whatever fails below, the cached plan keeps no sink and no reducer)
+    try:                                      # (whatever fails below, the cached plan keeps no sink, no reducer, no communicator)
+        pl.check(pl.lib.ssf_upload_aos(pl.h, in_ptr))
         if save_list:
             sink = _open_sink(pl, on_dev, N, ncols, len(save_list), len(captured))
-        if dev_coupling:
-            pl.check(pl.lib.ssf_set_coupling_comm(pl.h, ch))
         if _coupling is not None and not dev_coupling:
             def _reduce(_ctx, vals, n, op):   # called by the engine with the partial sums / maxima it is about to use
                 try:

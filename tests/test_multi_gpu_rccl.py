@@ -2,7 +2,8 @@
 
 RCCL refuses two ranks on one device, so on the one-GPU test box every test here SKIPS; on any box with two or more GPUs
 they are the first (and then regular) executions of ncclSend / ncclRecv / ncclAllGather / ncclBroadcast / ncclAllReduce
-between two devices in this project (missing item 1).  No SSF_BENCH_DEVICE / SSF_BENCH_COMM overrides: rank r
+between devices in this project (missing item 1) -- with W = min(devices, 8) ranks, so a 4- or 8-GPU box runs
+the 4- / 8-rank shapes of the driver's scaling runs.  No SSF_BENCH_DEVICE / SSF_BENCH_COMM overrides: rank r
 drives GPU r.  Unit definition: examples/test_NLC_withDBP_WDM_transmission.ipynb:660-675 (one independent field per
 launch power); coupling: optic/models/channels.py:394, 517-519."""
 import json
@@ -26,6 +27,7 @@ def _ndev():
 
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(_ndev() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")]
+W = max(2, min(_ndev(), 8))                       # ranks = GPUs of the box, at most eight
 
 
 def _free_port():
@@ -36,7 +38,8 @@ def _free_port():
     return port
 
 
-def _spawn(script_text, tmp_path, world=2, timeout=900):
+def _spawn(script_text, tmp_path, world=None, timeout=900):
+    world = world or W
     script = tmp_path / "worker.py"
     script.write_text(script_text)
     port = _free_port()
@@ -51,24 +54,31 @@ def _spawn(script_text, tmp_path, world=2, timeout=900):
         assert p.returncode == 0, out.decode(errors="replace")[-3000:]
 
 
-def test_bench_two_ranks_over_rccl_config4():
-    """bench.py --gpus 2 --config 4 as the driver runs it: rccl_ranks == 2, rank 0 synthesises and scatters all 16 units
+def _rank_counts():
+    return sorted({2, W} | ({4} if W >= 4 else set()))
+
+
+@pytest.mark.parametrize("ranks", _rank_counts())
+@pytest.mark.parametrize("cfg,units", [("4", 16), ("5", 8)])
+def test_bench_ranks_over_rccl_configs_4_and_5(ranks, cfg, units):
+    """bench.py --gpus N --config 4 / 5 as the driver runs them: rccl_ranks == N, rank 0 synthesises and scatters all units
     (ncclSend / ncclRecv), checksums all-gathered (ncclAllGather): every unit is the reference's."""
     from test_round3 import _bench, _check_units_against_the_reference
-    r, rec = _bench(["--gpus", "2", "--config", "4", "--steps", "8", "--warmup", "2", "--log2n", "16", "--no-kernel-times"])
+    r, rec = _bench(["--gpus", str(ranks), "--config", cfg, "--steps", "8", "--warmup", "2", "--log2n", "16", "--no-kernel-times"])
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
-    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["comm"].startswith("RCCL")
-    assert rec["config"]["units_total"] == 16 and rec["config"]["units_per_gpu"] == 8 and rec["scaling"] == "strong"
-    _check_units_against_the_reference(rec, "4", 16)
+    assert rec["n_gpus"] == ranks and rec["rccl_ranks"] == ranks and rec["comm"].startswith("RCCL")
+    assert rec["config"]["units_total"] == units and rec["config"]["units_per_gpu"] == units // ranks and rec["scaling"] == "strong"
+    _check_units_against_the_reference(rec, cfg, 16)
     assert rec["parity"]["ok"] and rec["value"] > 0
 
 
-def test_bench_two_ranks_over_rccl_weak_scaling():
+@pytest.mark.parametrize("ranks", _rank_counts())
+def test_bench_ranks_over_rccl_weak_scaling(ranks):
     from test_round3 import _bench
-    r, rec = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--log2n", "16", "--no-kernel-times"])
+    r, rec = _bench(["--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--log2n", "16", "--no-kernel-times"])
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
-    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["scaling"] == "weak" and len(rec["unit_checksums"]) == 2
-    assert rec["config"]["unit_steps_total"] == 12 and rec["parity"]["ok"]
+    assert rec["n_gpus"] == ranks and rec["rccl_ranks"] == ranks and rec["scaling"] == "weak" and len(rec["unit_checksums"]) == ranks
+    assert rec["config"]["unit_steps_total"] == 6 * ranks and rec["parity"]["ok"]
 
 
 SHARDED = r'''
@@ -78,12 +88,13 @@ sys.path.insert(0, os.environ["SSF_ROOT"]); sys.path.insert(0, os.path.join(os.e
 import opticommpy_amd as oa
 from opticommpy_amd import mgpu, models
 from helpers import synth_field, make_param
-rank = int(os.environ["RANK"])
+rank, W = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 oa.set_device(rank)
 with mgpu.RcclComm.from_env(device=rank) as comm:
-    assert comm.world == 2
+    assert comm.world == W
     comm.barrier()
-    assert comm.allreduce(np.array([float(rank + 1)]), "sum").tolist() == [3.0]
+    assert comm.allreduce(np.array([float(rank + 1)]), "sum").tolist() == [W * (W + 1) / 2.0]
+    assert comm.allreduce(np.array([float(rank)]), "max").tolist() == [W - 1.0]
     a = np.arange(4096, dtype=np.complex128) * (1 + 1j)
     got = comm.bcast(a.copy() if rank == 0 else np.zeros_like(a), 0)
     assert np.array_equal(got, a)
@@ -91,18 +102,26 @@ with mgpu.RcclComm.from_env(device=rank) as comm:
     comm.bcast(d, 0)
     assert np.array_equal(d.get(), a)
     ag = comm.allgather(np.full(8, float(rank)))
-    assert ag[0].tolist() == [0.0] * 8 and ag[1].tolist() == [1.0] * 8
+    assert all(ag[r].tolist() == [float(r)] * 8 for r in range(W))
     # independent units: rank 0 holds everything, inputs are scattered, results gathered on the root
-    U = 5
+    U = 2 * W + 1
     cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=2, Lspan=1, hz=0.25,
                nlprMethod=False, amp="ideal", saveSpanN=[])
     fields = [synth_field(1 << 13, 2, 100 + u, 8.4 - 0.5 * u) for u in range(U)] if rank == 0 else None
     outs = mgpu.run_sharded(fields, make_param(oa.parameters, cfg) if rank == 0 else None, comm=comm, root=0, gather="root")
     if rank == 0:
         np.save(os.path.join(os.environ["SSF_OUT"], "sharded.npy"), np.stack(outs))
-    # a coupled K = 2 batch, one pair per rank (8- and 16-byte all-reduces per step / iteration over RCCL)
-    E = np.concatenate([synth_field(4096, 2, 11, 3.0), synth_field(4096, 2, 12, 12.0)], axis=1)
+    # a coupled K = W batch, one pair per rank (the partial sums / maxima of every rank all-gathered on the plans' streams).
+    # complex64 FIRST, on fresh plans: the packed-pair core is created inside the first execute and must inherit the
+    # communicator attached before it (advisor, round 4: the first complex64 coupled call used to run uncoupled)
+    E = np.concatenate([synth_field(4096, 2, 11 + r, 3.0 + 9.0 * r / max(W - 1, 1)) for r in range(W)], axis=1)
     cfgc = dict(cfg, Ltotal=8, Lspan=4, hz=0.5, nlprMethod=True, maxNlinPhaseRot=1e-2)
+    for call in range(2):
+        out32 = mgpu.run_coupled(np.ascontiguousarray(E[:, 2 * rank: 2 * rank + 2]).astype(np.complex64),
+                                 make_param(oa.parameters, dict(cfgc, prec="complex64")), comm)
+        assert models.last_run["pipeline"] == "fused-device" and out32.dtype == np.complex64
+        np.save(os.path.join(os.environ["SSF_OUT"], f"steps32_call{call}_rank{rank}.npy"), np.array([models.last_run["steps"], models.last_run["iterations"]]))
+    np.save(os.path.join(os.environ["SSF_OUT"], f"coupled32_rank{rank}.npy"), out32)
     out = mgpu.run_coupled(np.ascontiguousarray(E[:, 2 * rank: 2 * rank + 2]), make_param(oa.parameters, cfgc), comm)
     np.save(os.path.join(os.environ["SSF_OUT"], f"coupled_rank{rank}.npy"), out)
     np.save(os.path.join(os.environ["SSF_OUT"], f"steps_rank{rank}.npy"), np.array([models.last_run["steps"], models.last_run["iterations"]]))
@@ -115,35 +134,41 @@ with mgpu.RcclComm.from_env(device=rank) as comm:
 '''
 
 
-def test_run_sharded_and_run_coupled_over_rccl_on_two_devices(tmp_path):
+def test_run_sharded_and_run_coupled_over_rccl_on_every_device(tmp_path):
     from helpers import make_param, rel_l2, synth_field
     from oracle import ssf_oracle as orc
     _spawn(SHARDED, tmp_path)
     cfg = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=2, Lspan=1, hz=0.25,
                nlprMethod=False, amp="ideal", saveSpanN=[])
     outs = np.load(tmp_path / "sharded.npy")
-    for u in range(5):
+    assert len(outs) == 2 * W + 1
+    for u in range(2 * W + 1):
         ref = orc.manakovSSF(synth_field(1 << 13, 2, 100 + u, 8.4 - 0.5 * u), make_param(orc.parameters, cfg))
         assert rel_l2(outs[u], ref) <= 1e-10, u
-    E = np.concatenate([synth_field(4096, 2, 11, 3.0), synth_field(4096, 2, 12, 12.0)], axis=1)
+    E = np.concatenate([synth_field(4096, 2, 11 + r, 3.0 + 9.0 * r / max(W - 1, 1)) for r in range(W)], axis=1)
     cfgc = dict(cfg, Ltotal=8, Lspan=4, hz=0.5, nlprMethod=True, maxNlinPhaseRot=1e-2)
     tr = {}
     ref = orc.manakovSSF(E, make_param(orc.parameters, cfgc), trace=tr)
-    got = np.concatenate([np.load(tmp_path / f"coupled_rank{r}.npy") for r in range(2)], axis=1)
+    got = np.concatenate([np.load(tmp_path / f"coupled_rank{r}.npy") for r in range(W)], axis=1)
     assert rel_l2(got, ref) <= 1e-10
-    got_h = np.concatenate([np.load(tmp_path / f"coupled_host_rank{r}.npy") for r in range(2)], axis=1)
+    got_h = np.concatenate([np.load(tmp_path / f"coupled_host_rank{r}.npy") for r in range(W)], axis=1)
     assert rel_l2(got_h, ref) <= 1e-10
-    for r in range(2):
+    got32 = np.concatenate([np.load(tmp_path / f"coupled32_rank{r}.npy") for r in range(W)], axis=1)
+    assert rel_l2(got32, ref) <= 5e-4
+    for r in range(W):
         s = np.load(tmp_path / f"steps_rank{r}.npy")
         assert int(s[0]) == tr["steps"] and int(s[1]) == tr["iterations"]
+        for call in range(2):                 # complex64: the first call on a fresh plan is coupled like the second (the single
+            s32 = np.load(tmp_path / f"steps32_call{call}_rank{r}.npy")     # call's step count; its iteration total up to a flip)
+            assert int(s32[0]) == tr["steps"] and abs(int(s32[1]) - tr["iterations"]) <= 2, (call, r, s32, tr["steps"], tr["iterations"])
 
 
-def test_ssf_mgpu_run_on_two_devices():
-    """The single-process entry point (host threads per device inside the library): 6 units over devices 0 and 1 are
+def test_ssf_mgpu_run_on_every_device():
+    """The single-process entry point (host threads per device inside the library): units over all W devices are
     bit-equal to the same units on device 0 alone."""
     from helpers import synth_field
     from opticommpy_amd import _lib, mgpu
-    N, U = 1 << 14, 6
+    N, U = 1 << 14, 2 * W + 2
     fields = np.stack([np.ascontiguousarray(synth_field(N, 2, 300 + u, 6.0 + 0.3 * u).T) for u in range(U)])
     cp = _lib.Params()
     cp.model, cp.direction = _lib.MODEL_MANAKOV, 1
@@ -151,7 +176,7 @@ def test_ssf_mgpu_run_on_two_devices():
     cp.Lspan, cp.Nspans, cp.hz, cp.maxIter, cp.tol = 1.6, 1, 0.08, 10, 1e-5
     cp.nlprMethod, cp.maxNlinPhaseRot, cp.NF, cp.amp = 0, 2e-2, 4.5, _lib.AMP_IDEAL
     cp.n_save, cp.save_spans = 0, None
-    two, st2 = mgpu.run_threads(fields, cp, [0, 1])
+    two, st2 = mgpu.run_threads(fields, cp, list(range(W)))
     one, st1 = mgpu.run_threads(fields, cp, [0])
     assert np.array_equal(two, one)
     assert [s["iterations"] for s in st2] == [s["iterations"] for s in st1]

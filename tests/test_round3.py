@@ -115,6 +115,25 @@ def test_bench_gpus_2_starts_two_ranks_by_itself_config4():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks,cfg,units", [(4, "5", 8), (8, "4", 16), (8, "5", 8)])
+def test_bench_with_four_and_eight_ranks_on_the_stand_in(ranks, cfg, units):
+    """The 4- and 8-process shapes of the driver's scaling runs (`bench.py --gpus 8 --config 4 / 5`), as far as ONE GPU can show
+    them: eight processes rendezvous, rank 0 synthesises every unit and scatters them, rank r owns the
+    contiguous block [r U / G, (r + 1) U / G) (2 / 1 units per rank at eight ranks), the checksums come back through the gather --
+    all ranks on this GPU (rank r on device r % count) over the gloo stand-in, because RCCL refuses several ranks on one device.
+    EVERY unit's (sum |E|^2, <q, E>, iterations) equals the reference's own run of that unit (wl_units45_n16).  No scaling curve
+    can be measured this way: the processes share one GPU."""
+    r, rec = _bench(["--gpus", str(ranks), "--config", cfg, "--steps", "8", "--warmup", "2", "--log2n", "16", "--no-kernel-times",
+                     "--no-cpu-baseline"], dict(SSF_BENCH_DEVICE="mod", SSF_BENCH_COMM="gloo"), timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    assert rec["n_gpus"] == ranks and rec["scaling"] == "strong"
+    assert rec["config"]["units_total"] == units and rec["config"]["units_per_gpu"] == units // ranks
+    assert len(rec["unit_checksums"]) == units
+    _check_units_against_the_reference(rec, cfg, 16)
+    assert rec["parity"]["ok"] and rec["value"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_gpus_2_weak_scaling_default_config():
     r, rec = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--log2n", "16", "--no-kernel-times"],
                     dict(SSF_BENCH_DEVICE="mod", SSF_BENCH_COMM="gloo"))
