@@ -378,15 +378,31 @@ def measure(env, cfg, m):
             lib.ssf_set_profiling(plans[u0], 0)
             bytes_per_launch = 2 * s * N * ncols                 # one transform-equivalent per row
             kernels = {}
-            for name, ms, n in (("row", kt.row_ms, kt.row_n), ("col", kt.col_ms, kt.col_n)):
+            # the final column stage only transforms backwards (it observes the field; the spectrum it read stays): half a
+            # transform-equivalent per row; every other launch is one
+            for name, ms, n, frac_tr in (("row", kt.row_ms, kt.row_n, 1.0), ("col", kt.col_ms, kt.col_n, 1.0),
+                                         ("col_H", kt.col_h_ms, kt.col_h_n, 1.0), ("col_ADV", kt.col_adv_ms, kt.col_adv_n, 1.0),
+                                         ("col_FIN", kt.col_fin_ms, kt.col_fin_n, 0.5)):
                 if n:
                     avg_us = ms / n * 1e3
-                    gbs = bytes_per_launch / (avg_us * 1e-6) / 1e9
-                    kernels[name] = {"launches": int(n), "avg_us": avg_us, "algorithmic_bytes_per_launch": bytes_per_launch,
+                    gbs = frac_tr * bytes_per_launch / (avg_us * 1e-6) / 1e9
+                    kernels[name] = {"launches": int(n), "avg_us": avg_us, "total_ms": ms,
+                                     "algorithmic_bytes_per_launch": frac_tr * bytes_per_launch,
                                      "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
-            kernels["what"] = {"row": "convergence decision + FFT.H.IFFT of the rows", "col": "Manakov column stage S | H | I "
-                               "(inverse + forward column transforms around the time-domain work)"}
+            kernels["what"] = {"row": "k_row: convergence decision + FFT.H.IFFT of the rows",
+                               "col": "all launches of the Manakov column stage (k_col / k_col_pk: inverse + forward column transforms "
+                                      "around the time-domain work), averaged; launches whose stage the state did not ask for included",
+                               "col_H": "stage-specialised kernel: half-dispersed field out, first rotation (+ the rare stages)",
+                               "col_ADV": "stage-specialised kernel: a non-final iterate -> the next one (phases, convergence sums)",
+                               "col_FIN": "stage-specialised kernel: the final iterate, observed and stored (inverse transform only)"}
             kernels["profiled_steps"] = int(stp[u0][1].steps)
+            names = [k for k in ("row", "col_H", "col_ADV", "col_FIN") if k in kernels] if "col_ADV" in kernels else [k for k in ("row", "col") if k in kernels]
+            if names:                                            # the kernel with the largest share of the device time
+                dom = max(names, key=lambda k: kernels[k]["total_ms"])
+                tot = sum(kernels[k]["total_ms"] for k in names)
+                kernels["dominant"] = {"name": dom, "share_of_kernel_time": kernels[dom]["total_ms"] / tot if tot else None,
+                                       "avg_us": kernels[dom]["avg_us"], "achieved_GBs": kernels[dom]["achieved_GBs"],
+                                       "frac": kernels[dom]["frac"]}
             rec["roofline"]["kernels"] = kernels
         # measured memory ceiling on this box: a kernel with the row stage's memory shape and no arithmetic
         probe = C.c_double(0.0)
@@ -404,7 +420,8 @@ def measure(env, cfg, m):
                     # PMC-measured HBM-side bytes per unit-step (separate rocprofv3 passes, see profiles/), NOT measured in this
                     # run: scaled from the profiled iteration count to this run's (linear in 1 + iterations/step)
                     scale = (1.0 + it_step) / (1.0 + t["iterations_per_step"])
-                    rec["roofline"]["traffic_profiled"] = t["bytes_per_step"] * scale
+                    rec["roofline"]["traffic"] = t["bytes_per_step"] * scale
+                    rec["roofline"]["traffic_profiled"] = t["bytes_per_step"] * scale       # (the key earlier rounds used)
                     rec["roofline"]["traffic_ratio"] = t["bytes_per_step"] * scale / (bytes_local / max(steps_local, 1))
                     rec["roofline"]["traffic_source"] = ("profiles/traffic_bytes_per_step.json[config%d] (%s: rocprofv3 --pmc FETCH_SIZE / "
                                                          "WRITE_SIZE, %d unit-steps at %.2f it/step)"

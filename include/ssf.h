@@ -290,10 +290,16 @@ int  ssf_plan_set_lanes(ssf_plan *plan, int32_t n_lanes);
  * Totals accumulate until ssf_upload.  Kernel classes of the fused pipeline:
  *   row   = (convergence decision,) FFT_rows . H . IFFT_rows   (one transform-equivalent per row)
  *   col   = Manakov column stage: inverse/forward column FFTs around the time-domain work
- *   other = scalar-NLSE / linear-channel column stages                                      */
+ *   other = scalar-NLSE / linear-channel column stages
+ * The Manakov column stage runs as stage-specialised kernels where the field fills the chip (H: half-dispersed field out + first
+ * rotation; ADV: a non-final iterate -> the next one; FIN: the final iterate, observed and stored; launches whose stage the state
+ * did not ask for do nothing and are counted where they were enqueued); col_* are included in col_ms / col_n, which also hold
+ * the general kernel's launches (span start, short fields, ragged tiles).                    */
 typedef struct {
     double  row_ms, col_ms, other_ms;
     int64_t row_n, col_n, other_n;
+    double  col_h_ms, col_adv_ms, col_fin_ms;
+    int64_t col_h_n, col_adv_n, col_fin_n;
 } ssf_kernel_times;
 int  ssf_set_profiling(ssf_plan *plan, int32_t enable);
 int  ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out);

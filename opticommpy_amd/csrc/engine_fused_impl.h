@@ -326,10 +326,18 @@ struct HipBackend {
         for (auto &s : stamps) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-                double *t = s.cat == 0 ? &kt.row_ms : s.cat == 1 ? &kt.col_ms : &kt.other_ms;
-                int64_t *n = s.cat == 0 ? &kt.row_n : s.cat == 1 ? &kt.col_n : &kt.other_n;
+                // categories: 0 row, 1 Manakov column stage (general kernel), 3 other, 4 / 5 / 6 the H / ADV / FIN kernels
+                const bool col = s.cat == 1 || s.cat >= 4;
+                double *t = s.cat == 0 ? &kt.row_ms : col ? &kt.col_ms : &kt.other_ms;
+                int64_t *n = s.cat == 0 ? &kt.row_n : col ? &kt.col_n : &kt.other_n;
                 *t += ms;
                 *n += 1;
+                if (s.cat >= 4) {
+                    double *ts = s.cat == 4 ? &kt.col_h_ms : s.cat == 5 ? &kt.col_adv_ms : &kt.col_fin_ms;
+                    int64_t *ns = s.cat == 4 ? &kt.col_h_n : s.cat == 5 ? &kt.col_adv_n : &kt.col_fin_n;
+                    *ts += ms;
+                    *ns += 1;
+                }
             }
             pool.push_back(s.a);
             pool.push_back(s.b);
@@ -442,10 +450,14 @@ struct HipBackend {
             if (!a.N2 && a.vpt != 8 && a.mode == CM_MK && col_il)
                 if (ColFn<T> fi = pick_col_il<T>(a.log2N1, cols)) f = fi;
         }
+        int cat = a.mode == CM_MK ? 1 : 3;
         if (a.mode == CM_MK && a.sg && a.sg != SG_ALL && !a.N2 && a.vpt != 8)
-            if (ColFn<T> fs = pick_col_sg<T>(a.log2N1, cols, a.sg)) f = fs;
+            if (ColFn<T> fs = pick_col_sg<T>(a.log2N1, cols, a.sg)) {
+                f = fs;
+                cat = (a.sg & SG_H) ? 4 : a.sg == SG_ADV ? 5 : 6;
+            }
         arm((const void *)f);
-        stamp_begin(a.mode == CM_MK ? 1 : 3);
+        stamp_begin(cat);
         f<<<dim3((unsigned)grid, (unsigned)units), block, lds, pl->stream>>>(a);
         stamp_end();
         chk(hipGetLastError(), "launch k_col");

@@ -28,21 +28,22 @@ template <int MAXT> __global__ void __launch_bounds__(MAXT) k_rx_ols(const fused
     SSF_RX_CTX();
     fused::ols_body<double>(ctx, a);
 }
-__global__ void __launch_bounds__(256) k_rx_pbs(const PbsArgs a) {
+// the coherent receivers' filters with the stages around them in their loads / stores (rx_kernels.h: rx_ols_body)
+template <int MAXT> __global__ void __launch_bounds__(MAXT) k_rx_ols_fused(const RxOlsArgs a) {
     SSF_RX_CTX();
-    pbs_body(ctx, a);
+    rx_ols_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_det(const DetKernelArgs a) {
+    SSF_RX_CTX();
+    det_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_iqf(const IqfArgs a) {
+    SSF_RX_CTX();
+    iqf_body(ctx, a);
 }
 __global__ void __launch_bounds__(256) k_rx_front(const FrontArgs a) {
     SSF_RX_CTX();
     front_body(ctx, a);
-}
-__global__ void __launch_bounds__(256) k_rx_iqmix(const IqMixArgs a) {
-    SSF_RX_CTX();
-    iqmix_body(ctx, a);
-}
-__global__ void __launch_bounds__(256) k_rx_combine(const CombineArgs a) {
-    SSF_RX_CTX();
-    combine_body(ctx, a);
 }
 __global__ void __launch_bounds__(256) k_nlin_phase(const NlinPhaseArgs a) {
     SSF_RX_CTX();
@@ -142,21 +143,33 @@ struct HipRxBackend {
         else k_rx_ols<1024><<<(unsigned)grid, block, lds, st>>>(a);
         chk(hipGetLastError(), "launch k_rx_ols");
     }
-    void launch_pbs(const PbsArgs &a) {
-        k_rx_pbs<<<ew_grid(a.N), 256, 0, st>>>(a);
-        chk(hipGetLastError(), "launch k_rx_pbs");
+    bool armed_fused = false;
+    void launch_rx_ols(const RxOlsArgs &a) {
+        const int nfft = 1 << a.o.log2nfft, tpf = nfft / 16;
+        const int block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
+        const long long grid = (a.o.njobs + fpw - 1) / fpw;
+        const size_t lds = (size_t)fpw * fused::lds_slots_per_fft(nfft) * sizeof(Cd);
+        if (!armed_fused) {
+            chk(hipFuncSetAttribute((const void *)k_rx_ols_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
+            chk(hipFuncSetAttribute((const void *)k_rx_ols_fused<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
+            armed_fused = true;
+        }
+        if (block <= 256) k_rx_ols_fused<256><<<(unsigned)grid, block, lds, st>>>(a);
+        else k_rx_ols_fused<1024><<<(unsigned)grid, block, lds, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_ols_fused");
     }
+    void launch_det(const DetKernelArgs &a) {
+        k_rx_det<<<ew_grid(a.det.N * a.det.nm), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_det");
+    }
+    void launch_iqf(const IqfArgs &a) {
+        k_rx_iqf<<<ew_grid(a.N * a.nm), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_iqf");
+    }
+    bool is_resident(const void *p) const { return on_device(p); }
     void launch_front(const FrontArgs &a) {
         k_rx_front<<<ew_grid(a.N), 256, 0, st>>>(a);
         chk(hipGetLastError(), "launch k_rx_front");
-    }
-    void launch_iqmix(const IqMixArgs &a) {
-        k_rx_iqmix<<<ew_grid(a.N), 256, 0, st>>>(a);
-        chk(hipGetLastError(), "launch k_rx_iqmix");
-    }
-    void launch_combine(const CombineArgs &a) {
-        k_rx_combine<<<ew_grid(a.N), 256, 0, st>>>(a);
-        chk(hipGetLastError(), "launch k_rx_combine");
     }
     void memset(void *d, int v, size_t n) { chk(hipMemsetAsync(d, v, n, st), "hipMemsetAsync"); }
     void launch_nlin_phase(const NlinPhaseArgs &a) {

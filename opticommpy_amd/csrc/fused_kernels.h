@@ -1825,7 +1825,11 @@ template <typename T> SSF_HD void ols_defaults(OlsArgs<T> &a) {
     a.Dx = a.blk0 = 0;
     a.acc = 0;
 }
-template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T> &a) {
+// pre(src, m): input sample `src` (an index into the unpadded, un-stuffed signal, 0 <= src < inLen) of column m;
+// post(n, m, v): output sample n (after roll and cut) of column m.  The receiver pipeline plugs the stages in front of and behind
+// a filter in here (rx_kernels.h: PBS rotation / detection in the loads, IQ mixing in the stores): one pass over the signal less each.
+template <typename T, class Ctx, class Pre, class Post>
+SSF_HD void ols_body_x(Ctx &ctx, const OlsArgs<T> &a, const Pre &pre, const Post &post) {
     const PassPlan p = make_plan(a.log2nfft);
     const int fpw = ctx.nthreads / p.tpf;
     const int f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
@@ -1846,7 +1850,7 @@ template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T>
             src = i / a.in_up;
             have = have && src * a.in_up == i;
         }
-        v[q] = have ? a.in[src * a.in_ld + m] : mk<T>((T)0, (T)0);
+        v[q] = have ? pre(src, m) : mk<T>((T)0, (T)0);
     }
     fft_dif<-1>(ctx, p, b, v, l);
     const int last = p.npass - 1;
@@ -1860,12 +1864,17 @@ template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T>
         if (live && pos >= a.discard && n >= 0 && n < a.sigLen) {
             n -= a.roll;
             if (n < 0) n += a.sigLen;
-            if (n < a.keep) {
-                cx<T> *o = a.out + n * a.out_ld + m;
-                *o = a.acc ? *o + v[q] : v[q];
-            }
+            if (n < a.keep) post(n, m, v[q]);
         }
     }
+}
+template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T> &a) {
+    ols_body_x<T>(
+        ctx, a, [&](long long src, int m) { return a.in[src * a.in_ld + m]; },
+        [&](long long n, int m, cx<T> v) {
+            cx<T> *o = a.out + n * a.out_ld + m;
+            *o = a.acc ? *o + v : v;
+        });
 }
 
 }  // namespace fused

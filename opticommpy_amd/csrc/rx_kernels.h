@@ -22,21 +22,6 @@ using fused::cx;
 using fused::mk;
 typedef cx<double> Cd;
 
-// ---- polarisation beam splitter: (N, 2) field -> rotated (N, 2) field, E @ [[c, -s], [s, c]]
-struct PbsArgs {
-    const Cd *in;      // (N, 2)
-    Cd *out;           // (N, 2)
-    long long N;
-    double c, s;
-};
-template <class Ctx> SSF_HD void pbs_body(Ctx &ctx, const PbsArgs &a) {
-    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
-        const Cd e0 = a.in[2 * n], e1 = a.in[2 * n + 1];
-        a.out[2 * n] = mk<double>(e0.re * a.c + e1.re * a.s, e0.im * a.c + e1.im * a.s);
-        a.out[2 * n + 1] = mk<double>(e1.re * a.c - e0.re * a.s, e1.im * a.c - e0.im * a.s);
-    }
-}
-
 // ---- photodiode model shared by every detection mode (devices.py:352-399, without the filter)
 struct PdModel {
     double R, IpdSat;
@@ -68,14 +53,12 @@ SSF_HD double pd_current(const PdModel &m, Cd e, long long n, long long N, int p
     return pd_current_pw(m, e.re * e.re + e.im * e.im, n, N, pd);
 }
 
-enum { RX_PHOTODIODE = 0, RX_BALANCED = 1, RX_COHERENT = 2, RX_PDM = 3 };
+enum { RX_PHOTODIODE = 0, RX_BALANCED = 1 };
 
-// ---- detection stage.  Output s: (N, nout) complex, before the photodiodes' low-pass filter
+// ---- detection stage of photodiode / balancedPD.  Output s: (N, 1) complex, before the photodiodes' low-pass filter
 //   RX_PHOTODIODE  in0 = (N, nm) field; out (N, 1): R * sum_modes |E|^2 (+ noise), imaginary part 0
 //   RX_BALANCED    in0 = (N, 2): columns E1, E2; out (N, 1): i1 - i2
-//   RX_COHERENT    in0 = (N, 1) signal, lo = (N,); out (N, 1): sI + j sQ
-//   RX_PDM         in0 = (N, 2) signal after the PBS (and PDL), lo = (N,); out (N, 2)
-// Subtracting before the (linear, common) filter instead of after it is exact.
+// Subtracting before the (linear, common) filter instead of after it is exact.  (The coherent receivers: det_sample below.)
 struct FrontArgs {
     const Cd *in0;
     const Cd *lo;
@@ -105,58 +88,123 @@ template <class Ctx> SSF_HD void front_body(Ctx &ctx, const FrontArgs &a) {
             const double i1 = pd_current(a.pd, a.in0[2 * n], n, a.N, 0);
             const double i2 = pd_current(a.pd, a.in0[2 * n + 1], n, a.N, 1);
             a.out[n] = mk<double>(i1 - i2, 0.0);
-        } else {
-            const int nm = a.mode == RX_PDM ? 2 : 1;
-            for (int p = 0; p < nm; ++p) {
-                Cd es = a.in0[n * nm + p], lo = a.lo[n];
-                es = mk<double>(es.re * a.es_scale[p], es.im * a.es_scale[p]);
-                lo = mk<double>(lo.re * a.lo_scale[p], lo.im * a.lo_scale[p]);
-                // 2x4 90-degree hybrid, T @ [Es, 0, 0, Elo] (devices.py:487-499)
-                const Cd e0 = mk<double>(0.5 * es.re - 0.5 * lo.re, 0.5 * es.im - 0.5 * lo.im);      //  Es/2 -  Elo/2
-                const Cd e1 = mk<double>(-0.5 * es.im - 0.5 * lo.im, 0.5 * es.re + 0.5 * lo.re);     // jEs/2 + jElo/2
-                const Cd e2 = mk<double>(-0.5 * es.im - 0.5 * lo.re, 0.5 * es.re - 0.5 * lo.im);     // jEs/2 -  Elo/2
-                const Cd e3 = mk<double>(-0.5 * es.re - 0.5 * lo.im, -0.5 * es.im + 0.5 * lo.re);    // -Es/2 + jElo/2
-                // balanced pairs (devices.py:562-563); photodiode slots: I pair = (e1, e0), Q pair = (e2, e3)
-                const int base = 4 * p;
-                const double sI = pd_current(a.pd, e1, n, a.N, base) - pd_current(a.pd, e0, n, a.N, base + 1);
-                const double sQ = pd_current(a.pd, e2, n, a.N, base + 2) - pd_current(a.pd, e3, n, a.N, base + 3);
-                a.out[n * nm + p] = mk<double>(sI, sQ);
-            }
         }
     }
 }
 
-// ---- IQ imbalance (core.py:952-960): s' = k1 s + k2 conj(s); real and imaginary parts go to
-// separate columns because each gets its own skew filter afterwards (core.py:963-966)
-struct IqMixArgs {
-    const Cd *in;      // (N, nm)
-    Cd *out;           // (N, 2 nm): column 2p = Re s'_p, 2p + 1 = Im s'_p (imaginary parts 0)
+// =====================================================================================================
+// The coherent receivers as at most three launches (round 5).  Every stage that is not a filter rides in the loads or the stores
+// of the filter next to it (fused_kernels.h: ols_body_x) -- or, where no filter follows, in one element-wise kernel:
+//   [PBS rotation -> polarisation delay filters]                 rx_ols_body, PRE_PBS                       (paramFE.polDelay != 0)
+//   [PBS, PDL, LO split,] hybrid, photodiodes, balanced pairs -> [low-pass FIR] -> IQ imbalance
+//                                                                rx_ols_body, PRE_DET (+ POST_IQF), or det_body without a filter
+//   IQ imbalance -> skew filters of I and Q -> S = I + j Q        rx_ols_body, PRE_IQ + POST_PART            (a timeSkew != 0)
+// Before: pbs, delay filter, front, low-pass filter, iqmix, two skew filters, combine -- eight launches and as many passes.
+struct DetArgs {
+    const Cd *in0;            // (N, nm) signal: before the PBS when `pbs` is set, behind it (and the delay filters) otherwise
+    const Cd *lo;             // (N,)
+    long long N;
+    int nm;                   // 1: coherentReceiver, 2: pdmCoherentReceiver
+    int pbs;                  // rotate the two columns here, E @ [[c, -s], [s, c]] (devices.py:223-260)
+    double c, s;
+    double es_scale[2];       // PDL (devices.py:660-662)
+    double lo_scale[2];       // LO split by the PBS at pi / 4 (devices.py:653): cos, -sin; (1, 1) for one polarisation
+    PdModel pd;
+};
+// the detected sample sI + j sQ of polarisation p at time n (devices.py:487-499, 562-563; photodiode slots as front_body)
+SSF_HD Cd det_sample(const DetArgs &a, long long n, int p) {
+    Cd es;
+    if (a.pbs) {
+        const Cd e0 = a.in0[2 * n], e1 = a.in0[2 * n + 1];
+        es = p == 0 ? mk<double>(e0.re * a.c + e1.re * a.s, e0.im * a.c + e1.im * a.s)
+                    : mk<double>(e1.re * a.c - e0.re * a.s, e1.im * a.c - e0.im * a.s);
+    } else es = a.in0[n * a.nm + p];
+    Cd lo = a.lo[n];
+    es = mk<double>(es.re * a.es_scale[p], es.im * a.es_scale[p]);
+    lo = mk<double>(lo.re * a.lo_scale[p], lo.im * a.lo_scale[p]);
+    const Cd e0 = mk<double>(0.5 * es.re - 0.5 * lo.re, 0.5 * es.im - 0.5 * lo.im);      //  Es/2 -  Elo/2
+    const Cd e1 = mk<double>(-0.5 * es.im - 0.5 * lo.im, 0.5 * es.re + 0.5 * lo.re);     // jEs/2 + jElo/2
+    const Cd e2 = mk<double>(-0.5 * es.im - 0.5 * lo.re, 0.5 * es.re - 0.5 * lo.im);     // jEs/2 -  Elo/2
+    const Cd e3 = mk<double>(-0.5 * es.re - 0.5 * lo.im, -0.5 * es.im + 0.5 * lo.re);    // -Es/2 + jElo/2
+    const int base = 4 * p;
+    const double sI = pd_current(a.pd, e1, n, a.N, base) - pd_current(a.pd, e0, n, a.N, base + 1);
+    const double sQ = pd_current(a.pd, e2, n, a.N, base + 2) - pd_current(a.pd, e3, n, a.N, base + 3);
+    return mk<double>(sI, sQ);
+}
+// IQ imbalance (core.py:952-960): s' = k1 s + k2 conj(s)
+SSF_HD Cd iq_mix(Cd k1, Cd k2, Cd s) { return k1 * s + k2 * fused::conj(s); }
+
+enum { PRE_PLAIN = 0, PRE_PBS = 1, PRE_DET = 2, PRE_IQ = 3 };
+enum { POST_PLAIN = 0, POST_IQF = 1, POST_PART = 2 };
+struct RxOlsArgs {
+    fused::OlsArgs<double> o; // geometry, filters, o.in (PRE_PLAIN / PRE_IQ), o.out
+    int pre, post;
+    DetArgs det;              // PRE_PBS: in0, c, s;  PRE_DET: everything
+    Cd k1[2], k2[2];          // PRE_IQ / POST_IQF, per polarisation
+    int nm;                   // PRE_IQ / POST_PART: polarisations of the signal (columns of o.in / o.out)
+    int pol0;                 // ... the launch's columns are I and Q of the polarisations pol0, pol0 + 1, ...
+    long long N;              // POST_IQF: signal length -- the last sample is zero, as delaySignal's np.roll(-1) of an unpadded
+                              // signal leaves it when the skew is zero (core.py:905-922: y[N - 1] = conv[0] = x[-1] = 0)
+};
+template <class Ctx> SSF_HD void rx_ols_body(Ctx &ctx, const RxOlsArgs &a) {
+    fused::ols_body_x<double>(
+        ctx, a.o,
+        [&](long long src, int m) -> Cd {
+            if (a.pre == PRE_PBS) {
+                const Cd e0 = a.det.in0[2 * src], e1 = a.det.in0[2 * src + 1];
+                return m == 0 ? mk<double>(e0.re * a.det.c + e1.re * a.det.s, e0.im * a.det.c + e1.im * a.det.s)
+                              : mk<double>(e1.re * a.det.c - e0.re * a.det.s, e1.im * a.det.c - e0.im * a.det.s);
+            }
+            if (a.pre == PRE_DET) return det_sample(a.det, src, m);
+            if (a.pre == PRE_IQ) {                       // column m = 2 p + part: the real (I) or imaginary (Q) part of s'_p, as a real signal
+                const int pl = a.pol0 + (m >> 1);
+                const Cd t = iq_mix(a.k1[pl], a.k2[pl], a.o.in[src * a.nm + pl]);
+                return mk<double>((m & 1) ? t.im : t.re, 0.0);
+            }
+            return a.o.in[src * a.o.in_ld + m];
+        },
+        [&](long long n, int m, Cd v) {
+            if (a.post == POST_IQF) {
+                const Cd t = iq_mix(a.k1[m], a.k2[m], v);
+                a.o.out[n * a.o.out_ld + m] = n == a.N - 1 ? mk<double>(0.0, 0.0) : t;
+            } else if (a.post == POST_PART) {            // S_p = Re(filtered I) + j Re(filtered Q)   (core.py:963-968)
+                double *o = (double *)(a.o.out + n * a.nm + a.pol0 + (m >> 1));
+                o[m & 1] = v.re;
+            } else a.o.out[n * a.o.out_ld + m] = v;
+        });
+}
+// detection without a filter behind it (ideal photodiodes / bandwidthLimitation off): one element-wise pass
+struct DetKernelArgs {
+    DetArgs det;
+    Cd *out;                  // (N, nm)
+    int iqf;                  // apply the IQ imbalance and the zero-skew rule here (nothing follows)
+    Cd k1[2], k2[2];
+};
+template <class Ctx> SSF_HD void det_body(Ctx &ctx, const DetKernelArgs &a) {
+    const long long total = a.det.N * a.det.nm;
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < total; i += (long long)ctx.nblocks * ctx.nthreads) {
+        const long long n = i / a.det.nm;
+        const int p = (int)(i - n * a.det.nm);
+        Cd v = det_sample(a.det, n, p);
+        if (a.iqf) v = n == a.det.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(a.k1[p], a.k2[p], v);
+        a.out[i] = v;
+    }
+}
+// iqMixing by itself with no skew: S = k1 s + k2 conj(s), last sample zero
+struct IqfArgs {
+    const Cd *in;
+    Cd *out;
     long long N;
     int nm;
     Cd k1[2], k2[2];
 };
-template <class Ctx> SSF_HD void iqmix_body(Ctx &ctx, const IqMixArgs &a) {
-    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
-        for (int p = 0; p < a.nm; ++p) {
-            const Cd s = a.in[n * a.nm + p];
-            const Cd t = a.k1[p] * s + a.k2[p] * fused::conj(s);
-            a.out[(n * a.nm + p) * 2] = mk<double>(t.re, 0.0);
-            a.out[(n * a.nm + p) * 2 + 1] = mk<double>(t.im, 0.0);
-        }
+template <class Ctx> SSF_HD void iqf_body(Ctx &ctx, const IqfArgs &a) {
+    const long long total = a.N * a.nm;
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < total; i += (long long)ctx.nblocks * ctx.nthreads) {
+        const long long n = i / a.nm;
+        const int p = (int)(i - n * a.nm);
+        a.out[i] = n == a.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(a.k1[p], a.k2[p], a.in[i]);
     }
-}
-
-// ---- S_p = Re(column 2p) + j Re(column 2p + 1)   (core.py:965-968)
-struct CombineArgs {
-    const Cd *in;      // (N, 2 nm)
-    Cd *out;           // (N, nm)
-    long long N;
-    int nm;
-};
-template <class Ctx> SSF_HD void combine_body(Ctx &ctx, const CombineArgs &a) {
-    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads)
-        for (int p = 0; p < a.nm; ++p)
-            a.out[n * a.nm + p] = mk<double>(a.in[(n * a.nm + p) * 2].re, a.in[(n * a.nm + p) * 2 + 1].re);
 }
 
 // ---- real part of a complex column as a float64 array (photocurrents: `return ipd.real`, devices.py:399)

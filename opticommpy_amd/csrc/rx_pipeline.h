@@ -197,14 +197,206 @@ template <class Backend> struct RxCore {
         return ols(in, ld, N, N + padLen, out, ld, N, ncols, dH, nfft, K, nfft, 1);
     }
 
+    // an input array where the kernels can read it: a device pointer as it is (no copy), a host array uploaded
+    const Cd *resident(const void *p, size_t n) {
+        if (be.is_resident(p)) return (const Cd *)p;
+        Cd *d = dalloc(n);
+        if (d) be.h2d_big(d, p, sizeof(Cd) * n);
+        return d;
+    }
+    static void iq_gains(const ssf_rx_params &p, int k, Cd *k1o, Cd *k2o) {      // core.py:952-959
+        const double amp = std::pow(10.0, p.ampImb[k] / 20) - 1, ph = p.phaseImb[k];
+        const zc ep(std::cos(ph / 2), std::sin(ph / 2)), em(std::cos(ph / 2), -std::sin(ph / 2));
+        const zc k1 = (1 - amp) * ep / 2.0 + (1 + amp) * em / 2.0, k2 = (1 - amp) * em / 2.0 - (1 + amp) * ep / 2.0;
+        *k1o = mk<double>(k1.real(), k1.imag());
+        *k2o = mk<double>(k2.real(), k2.imag());
+    }
+    RxOlsArgs rx_ols_args(long long inLen, long long sigLen, Cd *out, int out_ld, long long keep, int ncols, const Cd *H, int Hstride,
+                          int K, int nfft, int roll) {
+        const OlsGeom g = ols_geometry(sigLen, K, nfft);
+        RxOlsArgs r{};
+        fused::OlsArgs<double> &a = r.o;
+        a.out = out;
+        a.H = H;
+        a.sigLen = sigLen;
+        a.njobs = g.numBlocks * ncols;
+        a.nrows = ncols;
+        a.log2nfft = g.lg;
+        a.d = g.d;
+        a.discard = g.discard;
+        a.D = g.D;
+        a.inLen = inLen;
+        a.keep = keep;
+        a.in_ld = ncols;
+        a.out_ld = out_ld;
+        a.Hstride = Hstride;
+        a.roll = roll;
+        a.in_up = 1;
+        return r;
+    }
+    // coherentReceiver / pdmCoherentReceiver / iqMixing in at most three launches (rx_kernels.h: rx_ols_body); device inputs are
+    // read where they are and a device result is written where it belongs
+    int run_coherent(int mode, long long N, const ssf_rx_params &p, const void *in0, const void *lo, const double *un, void *out) {
+        const bool iq_only = mode == SSF_RX_IQ_MIXING;
+        const int nm = mode == SSF_RX_PDM_COHERENT ? 2 : iq_only ? 1 : 1;
+        const bool quiet = p.ideal != 0;
+        const bool noisy = !iq_only && !quiet && (p.shotNoise || p.thermalNoise);
+        const bool lowpass = !iq_only && !quiet && p.bandwidthLimitation;
+        const double fs_pd = p.Fs_pd > 0 ? p.Fs_pd : p.Fs;
+        int ntaps = p.N;
+        if (ntaps % 2 == 0) ++ntaps;                                 // devices.py:361-365
+        const Cd *sig = resident(in0, (size_t)N * nm);
+        const Cd *dlo = iq_only ? nullptr : resident(lo, (size_t)N);
+        Cd *result = be.is_resident(out) ? (Cd *)out : dalloc((size_t)N * nm);
+        if (!sig || (!iq_only && !dlo) || !result) return fail(SSF_ERR_OOM, "out of device memory");
+        double *dun = nullptr;
+        if (noisy && un) {
+            const int npd = 4 * nm;
+            dun = (double *)be.alloc(sizeof(double) * (size_t)N * npd * 2);
+            if (!dun) return fail(SSF_ERR_OOM, "out of device memory");
+            owned.push_back(dun);
+            be.h2d_big(dun, un, sizeof(double) * (size_t)N * npd * 2);
+        }
+        Cd k1[2], k2[2];
+        bool skew = false;
+        for (int k = 0; k < nm; ++k) {
+            iq_gains(p, k, &k1[k], &k2[k]);
+            skew = skew || p.timeSkew[k] != 0;
+        }
+        const Cd *detected = sig;                                    // iqMixing by itself: the input is the detected signal
+        if (!iq_only) {
+            DetArgs det{};
+            det.in0 = sig;
+            det.lo = dlo;
+            det.N = N;
+            det.nm = nm;
+            det.es_scale[0] = det.es_scale[1] = 1.0;
+            det.lo_scale[0] = det.lo_scale[1] = 1.0;
+            if (mode == SSF_RX_PDM_COHERENT) {
+                det.pbs = 1;
+                det.c = std::cos(p.polRotation);
+                det.s = std::sin(p.polRotation);
+                if (p.pdl != 0) {
+                    det.es_scale[0] = std::pow(10.0, -(p.pdl / 2) / 20);
+                    det.es_scale[1] = std::pow(10.0, (p.pdl / 2) / 20);
+                }
+                det.lo_scale[0] = std::cos(kPi / 4);
+                det.lo_scale[1] = -std::sin(kPi / 4);
+                if (p.polDelay != 0) {                               // devices.py:656-658: x delayed by -polDelay/2, y by +polDelay/2
+                    const int K = 512, nfft = 4096;                  // (delay_pair's filter and block size)
+                    const double dl[2] = {-p.polDelay / 2, p.polDelay / 2};
+                    const long long padLen = (long long)std::ceil(std::fabs(dl[0] * p.Fs));
+                    std::vector<zc> H;
+                    for (int c = 0; c < 2; ++c) {
+                        const std::vector<zc> h = ols_filter_from_delay(dl[c], p.Fs, K, nfft);
+                        H.insert(H.end(), h.begin(), h.end());
+                    }
+                    Cd *dH = upload_filter(H), *fld = dalloc((size_t)N * 2);
+                    if (!dH || !fld) return fail(SSF_ERR_OOM, "out of device memory");
+                    RxOlsArgs r = rx_ols_args(N, N + padLen, fld, 2, N, 2, dH, nfft, K, nfft, 1);
+                    r.pre = PRE_PBS;
+                    r.det = det;
+                    be.launch_rx_ols(r);
+                    det.in0 = fld;
+                    det.pbs = 0;
+                }
+            }
+            const double q = 1.602176634e-19, kB = 1.380649e-23;     // scipy.constants (CODATA 2018, exact)
+            det.pd.R = p.R;
+            det.pd.IpdSat = p.IpdSat;
+            det.pd.saturate = !quiet && p.currentSaturation;
+            det.pd.shot = !quiet && p.shotNoise;
+            det.pd.thermal = !quiet && p.thermalNoise;
+            det.pd.shot_k = fs_pd * q;
+            det.pd.Id = p.Id;
+            det.pd.thermal_sigma = std::sqrt(fs_pd * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
+            det.pd.seed = (unsigned long long)p.rng_seed;
+            det.pd.un = dun;
+            Cd *dst = skew ? dalloc((size_t)N * nm) : result;
+            if (!dst) return fail(SSF_ERR_OOM, "out of device memory");
+            if (lowpass) {
+                const std::vector<double> h = low_pass_fir(p.B, fs_pd, ntaps, p.fType);
+                std::vector<zc> hz(h.begin(), h.end());
+                const int nfft = fir_nfft(ntaps);
+                Cd *dH = upload_filter(ols_filter_from_taps(hz.data(), ntaps, nfft));
+                if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
+                RxOlsArgs r = rx_ols_args(N, N, dst, nm, N, nm, dH, 0, ntaps, nfft, 0);
+                r.pre = PRE_DET;
+                r.det = det;
+                r.post = skew ? POST_PLAIN : POST_IQF;
+                r.N = N;
+                for (int k = 0; k < nm; ++k) {
+                    r.k1[k] = k1[k];
+                    r.k2[k] = k2[k];
+                }
+                be.launch_rx_ols(r);
+            } else {
+                DetKernelArgs d{};
+                d.det = det;
+                d.out = dst;
+                d.iqf = skew ? 0 : 1;
+                for (int k = 0; k < nm; ++k) {
+                    d.k1[k] = k1[k];
+                    d.k2[k] = k2[k];
+                }
+                be.launch_det(d);
+            }
+            detected = dst;
+        }
+        if (skew) {                                                  // iqMixing with a skew (core.py:962-968)
+            // sI delayed by -skew/2, sQ by +skew/2; the zero padding of delaySignal (core.py:905-909) differs between the
+            // polarisations when their skews do: then one launch per polarisation
+            long long pad[2] = {0, 0};
+            for (int k = 0; k < nm; ++k) pad[k] = (long long)std::ceil(std::fabs(p.timeSkew[k] / 2 * p.Fs));
+            const bool together = nm == 1 || pad[0] == pad[1];
+            const int K = 512, nfft = 4096;
+            std::vector<zc> H;
+            for (int k = 0; k < nm; ++k)
+                for (int part = 0; part < 2; ++part) {
+                    const std::vector<zc> h = ols_filter_from_delay((part ? 1.0 : -1.0) * p.timeSkew[k] / 2, p.Fs, K, nfft);
+                    H.insert(H.end(), h.begin(), h.end());
+                }
+            Cd *dH = upload_filter(H);
+            if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
+            for (int k = 0; k < (together ? 1 : nm); ++k) {
+                const int ncols = together ? 2 * nm : 2;
+                RxOlsArgs r = rx_ols_args(N, N + pad[k], result, nm, N, ncols, dH + (together ? 0 : (size_t)2 * k * nfft), nfft, K, nfft, 1);
+                r.pre = PRE_IQ;
+                r.post = POST_PART;
+                r.o.in = detected;
+                r.nm = nm;
+                r.pol0 = together ? 0 : k;
+                for (int q2 = 0; q2 < nm; ++q2) {
+                    r.k1[q2] = k1[q2];
+                    r.k2[q2] = k2[q2];
+                }
+                be.launch_rx_ols(r);
+            }
+        } else if (iq_only) {
+            IqfArgs f{};
+            f.in = detected;
+            f.out = result;
+            f.N = N;
+            f.nm = nm;
+            for (int k = 0; k < nm; ++k) {
+                f.k1[k] = k1[k];
+                f.k2[k] = k2[k];
+            }
+            be.launch_iqf(f);
+        }
+        be.sync();
+        if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
+        if ((void *)result != out) be.d2h_big(out, result, sizeof(Cd) * (size_t)N * nm);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+
     // run one of the ssf_rx_mode pipelines; in0 / lo / un / out are HOST pointers
     int run(int mode, long long N, int nmodes, const ssf_rx_params &p, const void *in0, const void *lo, const double *un,
             void *out) {
         const bool coherent = mode == SSF_RX_COHERENT || mode == SSF_RX_PDM_COHERENT;
         const bool iq_only = mode == SSF_RX_IQ_MIXING;
         const int nin = mode == SSF_RX_PHOTODIODE ? nmodes : mode == SSF_RX_BALANCED_PD ? 2 : mode == SSF_RX_PDM_COHERENT ? 2 : 1;
-        const int nm = mode == SSF_RX_PDM_COHERENT ? 2 : 1;          // columns of the detected signal
-        const int npd = mode == SSF_RX_PHOTODIODE ? 1 : mode == SSF_RX_BALANCED_PD ? 2 : 4 * nm;
+        const int npd = mode == SSF_RX_PHOTODIODE ? 1 : 2;
         if (N < 1 || nin < 1) return fail(SSF_ERR_BAD_ARG, "bad size");
         if (!iq_only && !(p.R > 0)) return fail(SSF_ERR_BAD_ARG, "PD responsivity should be a positive scalar");
         const bool quiet = p.ideal != 0;
@@ -215,113 +407,56 @@ template <class Backend> struct RxCore {
         int ntaps = p.N;
         if (ntaps % 2 == 0) ++ntaps;                                 // devices.py:361-365
         if (lowpass && (ntaps < 1 || ntaps > kMaxNfft / 2)) return fail(SSF_ERR_UNSUPPORTED, "photodiode filter: 1 <= N <= 4096 taps");
+        if (coherent || iq_only) return run_coherent(mode, N, p, in0, lo, un, out);
 
-        Cd *a = dalloc((size_t)N * nin), *b = dalloc((size_t)N * (coherent || iq_only ? 2 * nm : 1) + 16);
-        Cd *dlo = coherent ? dalloc((size_t)N) : nullptr;
+        // photodiode / balancedPD: detection -> [low-pass FIR] -> real photocurrent
+        Cd *a = dalloc((size_t)N * nin), *b = dalloc((size_t)N + 16);
         double *dun = nullptr;
-        if (!a || !b || (coherent && !dlo)) return fail(SSF_ERR_OOM, "out of device memory");
+        if (!a || !b) return fail(SSF_ERR_OOM, "out of device memory");
         be.h2d_big(a, in0, sizeof(Cd) * (size_t)N * nin);
-        if (coherent) be.h2d_big(dlo, lo, sizeof(Cd) * (size_t)N);
         if (noisy && un) {
             dun = (double *)be.alloc(sizeof(double) * (size_t)N * npd * 2);
             if (!dun) return fail(SSF_ERR_OOM, "out of device memory");
             owned.push_back(dun);
             be.h2d_big(dun, un, sizeof(double) * (size_t)N * npd * 2);
         }
-        Cd *s = a;                                                   // detected signal (N, nm)
-        if (!iq_only) {
-            Cd *field = a;
-            if (mode == SSF_RX_PDM_COHERENT) {
-                PbsArgs pa{a, b, N, std::cos(p.polRotation), std::sin(p.polRotation)};
-                be.launch_pbs(pa);
-                field = b;
-                if (p.polDelay != 0) {                               // devices.py:656-658
-                    const double dl[2] = {-p.polDelay / 2, p.polDelay / 2};
-                    int rc = delay_pair(b, a, 2, N, dl, 2, p.Fs);
-                    if (rc) return rc;
-                    field = a;
-                }
-            }
-            Cd *det = field == a ? b : a;
-            FrontArgs fa{};
-            fa.in0 = field;
-            fa.lo = dlo;
-            fa.out = det;
-            fa.N = N;
-            fa.mode = mode == SSF_RX_PHOTODIODE ? RX_PHOTODIODE : mode == SSF_RX_BALANCED_PD ? RX_BALANCED
-                      : mode == SSF_RX_COHERENT ? RX_COHERENT : RX_PDM;
-            fa.nm = nin;
-            fa.es_scale[0] = fa.es_scale[1] = 1.0;
-            fa.lo_scale[0] = fa.lo_scale[1] = 1.0;
-            if (mode == SSF_RX_PDM_COHERENT) {
-                if (p.pdl != 0) {
-                    fa.es_scale[0] = std::pow(10.0, -(p.pdl / 2) / 20);
-                    fa.es_scale[1] = std::pow(10.0, (p.pdl / 2) / 20);
-                }
-                fa.lo_scale[0] = std::cos(kPi / 4);
-                fa.lo_scale[1] = -std::sin(kPi / 4);
-            }
-            const double q = 1.602176634e-19, kB = 1.380649e-23;     // scipy.constants (CODATA 2018, exact)
-            fa.pd.R = p.R;
-            fa.pd.IpdSat = p.IpdSat;
-            fa.pd.saturate = !quiet && p.currentSaturation;
-            fa.pd.shot = !quiet && p.shotNoise;
-            fa.pd.thermal = !quiet && p.thermalNoise;
-            fa.pd.shot_k = fs_pd * q;
-            fa.pd.Id = p.Id;
-            fa.pd.thermal_sigma = std::sqrt(fs_pd * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
-            fa.pd.seed = (unsigned long long)p.rng_seed;
-            fa.pd.un = dun;
-            be.launch_front(fa);
-            s = det;
-            if (lowpass) {
-                const std::vector<double> h = low_pass_fir(p.B, fs_pd, ntaps, p.fType);
-                std::vector<zc> hz(h.begin(), h.end());
-                const int nfft = fir_nfft(ntaps);
-                Cd *dH = upload_filter(ols_filter_from_taps(hz.data(), ntaps, nfft));
-                if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
-                Cd *flt = s == a ? b : a;
-                int rc = ols(s, nm, N, N, flt, nm, N, nm, dH, 0, ntaps, nfft, 0);
-                if (rc) return rc;
-                s = flt;
-            }
+        FrontArgs fa{};
+        fa.in0 = a;
+        fa.lo = nullptr;
+        fa.out = b;
+        fa.N = N;
+        fa.mode = mode == SSF_RX_PHOTODIODE ? RX_PHOTODIODE : RX_BALANCED;
+        fa.nm = nin;
+        fa.es_scale[0] = fa.es_scale[1] = 1.0;
+        fa.lo_scale[0] = fa.lo_scale[1] = 1.0;
+        const double q = 1.602176634e-19, kB = 1.380649e-23;         // scipy.constants (CODATA 2018, exact)
+        fa.pd.R = p.R;
+        fa.pd.IpdSat = p.IpdSat;
+        fa.pd.saturate = !quiet && p.currentSaturation;
+        fa.pd.shot = !quiet && p.shotNoise;
+        fa.pd.thermal = !quiet && p.thermalNoise;
+        fa.pd.shot_k = fs_pd * q;
+        fa.pd.Id = p.Id;
+        fa.pd.thermal_sigma = std::sqrt(fs_pd * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
+        fa.pd.seed = (unsigned long long)p.rng_seed;
+        fa.pd.un = dun;
+        be.launch_front(fa);
+        Cd *s = b;
+        if (lowpass) {
+            const std::vector<double> h = low_pass_fir(p.B, fs_pd, ntaps, p.fType);
+            std::vector<zc> hz(h.begin(), h.end());
+            const int nfft = fir_nfft(ntaps);
+            Cd *dH = upload_filter(ols_filter_from_taps(hz.data(), ntaps, nfft));
+            if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
+            int rc = ols(s, 1, N, N, a, 1, N, 1, dH, 0, ntaps, nfft, 0);
+            if (rc) return rc;
+            s = a;
         }
-        if (coherent || iq_only) {                                   // iqMixing (devices.py:568, core.py:925-970)
-            Cd *cols = dalloc((size_t)N * 2 * nm), *dly = dalloc((size_t)N * 2 * nm);
-            if (!cols || !dly) return fail(SSF_ERR_OOM, "out of device memory");
-            IqMixArgs ia{};
-            ia.in = s;
-            ia.out = cols;
-            ia.N = N;
-            ia.nm = nm;
-            for (int k = 0; k < nm; ++k) {
-                const double amp = std::pow(10.0, p.ampImb[k] / 20) - 1, ph = p.phaseImb[k];
-                const zc ep(std::cos(ph / 2), std::sin(ph / 2)), em(std::cos(ph / 2), -std::sin(ph / 2));
-                const zc k1 = (1 - amp) * ep / 2.0 + (1 + amp) * em / 2.0, k2 = (1 - amp) * em / 2.0 - (1 + amp) * ep / 2.0;
-                ia.k1[k] = mk<double>(k1.real(), k1.imag());
-                ia.k2[k] = mk<double>(k2.real(), k2.imag());
-            }
-            be.launch_iqmix(ia);
-            for (int k = 0; k < nm; ++k) {                           // sI delayed by -skew/2, sQ by +skew/2
-                const double dl[2] = {-p.timeSkew[k] / 2, p.timeSkew[k] / 2};
-                int rc = delay_pair(cols + 2 * k, dly + 2 * k, 2 * nm, N, dl, 2, p.Fs);
-                if (rc) return rc;
-            }
-            CombineArgs ca{dly, cols, N, nm};                        // (cols is free again: reuse it for the result)
-            be.launch_combine(ca);
-            s = cols;
-        }
+        double *re = (double *)(s == a ? b : a);                     // real photocurrent: (N,) float64 (the other buffer holds >= N complex values)
+        RealPartArgs ra{s, re, N};
+        be.launch_real_part(ra);
         be.sync();
-        if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
-        if (coherent || iq_only) {
-            be.d2h_big(out, s, sizeof(Cd) * (size_t)N * nm);
-        } else {                                                     // real photocurrent: (N,) float64
-            double *re = (double *)(s == a ? b : a);                 // (the other buffer holds >= N complex values)
-            RealPartArgs ra{s, re, N};
-            be.launch_real_part(ra);
-            be.sync();
-            be.d2h_big(out, re, sizeof(double) * (size_t)N);
-        }
+        be.d2h_big(out, re, sizeof(double) * (size_t)N);
         if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
         return SSF_OK;
     }

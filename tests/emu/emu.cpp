@@ -269,10 +269,17 @@ struct EmuBackend {
                  [&](EmuCtx &c) { ssf::fused::ols_body<double>(c, a); });
     }
     static int ew_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>(3, (n + 63) / 64)); }
-    void launch_pbs(const ssf::rx::PbsArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::pbs_body(c, a); }); }
+    void launch_rx_ols(const ssf::rx::RxOlsArgs &a) {
+        ++launches;
+        const int nfft = 1 << a.o.log2nfft, tpf = nfft / 16, block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
+        const long long grid = (a.o.njobs + fpw - 1) / fpw;
+        run_grid((int)grid, block, (size_t)fpw * ssf::fused::lds_slots_per_fft(nfft) * sizeof(ssf::fused::cx<double>),
+                 [&](EmuCtx &c) { ssf::rx::rx_ols_body(c, a); });
+    }
+    void launch_det(const ssf::rx::DetKernelArgs &a) { ++launches; run_grid(ew_grid(a.det.N * a.det.nm), 64, 64, [&](EmuCtx &c) { ssf::rx::det_body(c, a); }); }
+    void launch_iqf(const ssf::rx::IqfArgs &a) { ++launches; run_grid(ew_grid(a.N * a.nm), 64, 64, [&](EmuCtx &c) { ssf::rx::iqf_body(c, a); }); }
+    bool is_resident(const void *) const { return true; }      // (the emulator's "device" memory is the host's)
     void launch_front(const ssf::rx::FrontArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::front_body(c, a); }); }
-    void launch_iqmix(const ssf::rx::IqMixArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::iqmix_body(c, a); }); }
-    void launch_combine(const ssf::rx::CombineArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::combine_body(c, a); }); }
     void launch_nlin_phase(const ssf::rx::NlinPhaseArgs &a) { run_grid(ew_grid(a.n), 64, 64, [&](EmuCtx &c) { ssf::rx::nlin_phase_body(c, a); }); }
     void launch_conv_sums(const ssf::rx::ConvSumsArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::conv_sums_body(c, a); }); }
     void launch_absmax(const ssf::rx::AbsMaxArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::absmax_body(c, a); }); }
@@ -428,10 +435,13 @@ int emu_overlap_save(int64_t sigLen, int nrows, int lg, int K, const void *Hfft,
     return 0;
 }
 
+static long g_rx_launches = 0;
+long emu_rx_launches() { return g_rx_launches; }                   // kernel launches of the last emu_rx_run
 int emu_rx_run(int mode, int64_t N, int nmodes, const ssf_rx_params *p, const void *in0, const void *lo, const double *un, void *out) {
     EmuBackend be;
     ssf::rx::RxCore<EmuBackend> core(be);
     int rc = core.run(mode, N, nmodes, *p, in0, lo, un, out);
+    g_rx_launches = be.launches;
     if (rc) fprintf(stderr, "emu: %s\n", core.err.c_str());
     return rc;
 }

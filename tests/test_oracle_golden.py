@@ -89,3 +89,14 @@ def test_dbp_roundtrip_recovers_input():
     out, _ = _run(cfg, d["Ei"], {})
     err = np.linalg.norm(out - d["extra_orig"]) / np.linalg.norm(d["extra_orig"])
     assert err < 1e-6
+
+
+@pytest.mark.parametrize("name", golden_names("mix_"))
+def test_mixed_dtype_vectors_are_the_reference_on_the_cast_input(name):
+    """tests/golden/mix_*.npz (the GPU twin's mixed-dtype calls): the oracle on the input cast to prec, result cast as the twin does."""
+    d, cfg = load_golden(name)
+    prec = np.dtype(cfg["prec"]).type
+    tr = {}
+    out = orc.manakovSSF(d["Ei"].astype(prec), make_param(orc.parameters, cfg), trace=tr)
+    out = out.astype(d["Ei"].dtype) if not cfg["saveSpanN"] else out.astype(prec)
+    assert out.dtype == d["out"].dtype and np.array_equal(out, d["out"]) and tr["iters"] == list(d["iters"])

@@ -123,8 +123,8 @@ def test_bench_with_four_and_eight_ranks_on_the_stand_in(ranks, cfg, units):
     all ranks on this GPU (rank r on device r % count) over the gloo stand-in, because RCCL refuses several ranks on one device.
     EVERY unit's (sum |E|^2, <q, E>, iterations) equals the reference's own run of that unit (wl_units45_n16).  No scaling curve
     can be measured this way: the processes share one GPU."""
-    r, rec = _bench(["--gpus", str(ranks), "--config", cfg, "--steps", "8", "--warmup", "2", "--log2n", "16", "--no-kernel-times",
-                     "--no-cpu-baseline"], dict(SSF_BENCH_DEVICE="mod", SSF_BENCH_COMM="gloo"), timeout=900)
+    r, rec = _bench(["--gpus", str(ranks), "--config", cfg, "--steps", "8", "--warmup", "2", "--log2n", "16", "--no-kernel-times"],
+                    dict(SSF_BENCH_DEVICE="mod", SSF_BENCH_COMM="gloo"), timeout=900)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
     assert rec["n_gpus"] == ranks and rec["scaling"] == "strong"
     assert rec["config"]["units_total"] == units and rec["config"]["units_per_gpu"] == units // ranks

@@ -20,7 +20,7 @@ Output: tests/golden/<case>.npz, each holding
               output decimated by cfg["dec"], its per-column power and a seeded random projection of the full
               output (so an error anywhere in the array shows), see long_vectors()
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|rx_edges|tx|bfc|chain|long|long20|cfg3|long_c3 [128|64|merge]|units45 [log2n]]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|rx_edges|tx|bfc|mixed|chain|long|long20|cfg3|long_c3 [128|64|merge]|units45 [log2n]]
 """
 import json
 import os
@@ -656,6 +656,30 @@ def bfc_vectors():
         print(f"{name:34s} x {x.dtype}{x.shape} h {h.dtype}{h.shape} NFFT {nfft} freq {fd} out {out.dtype}{out.shape}")
 
 
+def mixed_dtype_vectors():
+    """The GPU twin's mixed-dtype calls (missing #4): optic/models/modelsGPU.py:214-226, 402-404 casts the input
+    to `prec` (`Ei_ = cp.asarray(Ei).astype(prec)`), computes everything in `prec`, and returns either the snapshots in `prec`
+    (:376-377) or `Ech = Ei.copy(); Ech[:, 0::2] = ...` (:505-507), i.e. the result cast back to the INPUT's dtype.  The twin itself
+    cannot be imported here (no cupy); what it computes is the CPU reference on the cast input ("CPU semantics + the cast",
+    SURVEY.md 8c), which is what is run: complex64 samples with the default prec (complex128 arithmetic, complex64 out) and
+    complex128 samples with prec = complex64 (the reference's complex64 mode, complex128 out), each with saveSpanN = [] and [1]."""
+    os.makedirs(OUT, exist_ok=True)
+    base = dict(Fs=512e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, maxIter=10, tol=1e-5, prgsBar=False, Ltotal=2, Lspan=1, hz=0.25,
+                nlprMethod=False, amp="ideal")
+    for name, in_dt, prec in (("mix_c64in_prec128", np.complex64, np.complex128), ("mix_c128in_prec64", np.complex128, np.complex64)):
+        Ei = synth_field(1 << 10, 2, 77, 8.4, in_dt)
+        for tag, save in (("final", []), ("span1", [1])):
+            kw = dict(base, saveSpanN=save, prec=prec)
+            p = mk_param(**kw)
+            with Tracer(ref_ch) as tr:
+                out = ref_ch.manakovSSF(Ei.astype(prec), p)
+            out = out.astype(in_dt) if not save else out.astype(prec)
+            iters = np.array(split_iters(tr.lims, p.tol, p.maxIter))
+            save_name = f"{name}_{tag}"
+            globals()["save"](save_name, Ei=Ei, out=out, iters=iters, cfg=cfg_json("manakovSSF", kw))
+            print(f"{save_name:30s} in {Ei.dtype} prec {np.dtype(prec).name} out {out.dtype}{out.shape} iters {int(iters.sum())}")
+
+
 def unit_checksum(out_cols, seed=4242):
     """bench.py's per-unit checksum of an (N, ncols) reference output: sum |E|^2 and <q, E> over the (ncols, N) SoA block
     with the seeded unit-variance complex vector q (bench.py: unit_checksum)."""
@@ -712,6 +736,8 @@ if __name__ == "__main__":
         long20_vector()
     elif len(sys.argv) > 1 and sys.argv[1] == "cfg3":    # config 3's own field, a few steps, complex128 and complex64
         cfg3_vector()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mixed":   # the GPU twin's mixed-dtype calls
+        mixed_dtype_vectors()
     elif len(sys.argv) > 1 and sys.argv[1] == "bfc":     # blockwiseFFTConv as a callable
         bfc_vectors()
     elif len(sys.argv) > 1 and sys.argv[1] == "chain":   # the notebook chain end to end (transmitter -> channel -> receiver -> edc)
