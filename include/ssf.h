@@ -25,6 +25,7 @@
  *   ssf_plan_set_lanes                   (no reference equivalent) this plan shares the GPU with others
  *   ssf_set_coupling[_comm]              np.max(phiRot) / scipy.linalg.norm over ALL rows of a K > 1 batch
  *                                        (channels.py:394, 517-519) when the rows live in several plans
+ *   ssf_couple_reduce_selftest           (test aid) the rank-order reduction behind ssf_set_coupling_comm
  *   ssf_comm_*                           (no reference equivalent) one process per GPU: RCCL
  *                                        broadcast / scatter / gather of parameters, inputs and
  *                                        results of independent units, SURVEY.md 8e
@@ -284,6 +285,14 @@ int  ssf_get_unit_stats(ssf_plan *plan, int32_t unit, ssf_stats *out);
  * interleaving it costs 4 %: profiles/r3_lanes_prio_wt.txt).  Default 1; may be called at any time between executes. */
 int  ssf_plan_set_lanes(ssf_plan *plan, int32_t n_lanes);
 
+/* ---- the device-side reduction of a coupled batch by itself (test aid) ------------------------
+ * ssf_set_coupling_comm reduces every rank's per-workgroup partials on the device, all-gathers five doubles per rank and reduces
+ * those in rank order, so that every rank takes identical decisions (channels.py:394, 517-519 evaluated over ALL rows).  This
+ * entry runs exactly that arithmetic on synthetic partials, without a communicator: `parts` = [nranks][5][npart] doubles, per rank
+ * the arrays (max phi, sum lim_i numerator, denominator, lim_0 numerator, denominator) of npart workgroups; out5 = (sum num0, sum
+ * den0, sum num, sum den, max) as the row stage of every rank would read them. */
+int  ssf_couple_reduce_selftest(int device, int32_t nranks, int32_t npart, const double *parts, double *out5);
+
 /* ---- per-kernel timing (measurement aid; fused engine only) ------------------------------ */
 /* With profiling enabled every kernel launch of ssf_execute is bracketed by HIP events on the
  * plan's stream (costs a few microseconds per launch: do not enable for the headline timing).
@@ -424,6 +433,12 @@ typedef struct {
     double  Fs, mzmScale;
     int64_t nSymbols;
     int32_t SpS, nChannels, nPolModes, ntaps;
+    /* laser phase noise generated ON THE DEVICE (used when `phi` is NULL and pn_seed != 0): per channel a random walk
+     * phi[0] = 0, phi[k] = phi[k - 1] + N(0, pn_sigma^2), pn_sigma = sqrt(2 pi linewidth / Fs) (optic/dsp/core.py:792-826), from
+     * Philox4x32-10 keyed by pn_seed (statistical parity: what a call WITHOUT a seed can promise; with a seed the host passes the
+     * reference's own np.random draws in `phi`).  No N-sample array crosses the bus then. */
+    double   pn_sigma;
+    uint64_t pn_seed;
 } ssf_tx_params;
 int  ssf_wdm_tx(int device, const ssf_tx_params *params, const void *symbols, const double *taps, const double *phi,
                 const double *amp, const double *deltaF, void *sig_out, double *power_out);

@@ -65,7 +65,8 @@ class RxParams(C.Structure):
 class TxParams(C.Structure):
     """ssf_tx_params (include/ssf.h)."""
     _fields_ = [("Fs", C.c_double), ("mzmScale", C.c_double), ("nSymbols", C.c_int64), ("SpS", C.c_int32),
-                ("nChannels", C.c_int32), ("nPolModes", C.c_int32), ("ntaps", C.c_int32)]
+                ("nChannels", C.c_int32), ("nPolModes", C.c_int32), ("ntaps", C.c_int32),
+                ("pn_sigma", C.c_double), ("pn_seed", C.c_uint64)]
 
 
 class DeviceInfo(C.Structure):
@@ -108,6 +109,7 @@ SYMBOLS = {
     "ssf_device_free": (C.c_int, [C.c_int, C.c_void_p]),
     "ssf_device_memcpy": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     "ssf_fir_filter": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ssf_couple_reduce_selftest": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ssf_fir_long": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ssf_delay_signal": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "ssf_nlin_phase_rot": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -10,6 +10,9 @@ namespace ssf {
 Engine *make_fused_engine_f64(ssf_plan *plan) { return make_fused_engine_t<double>(plan); }
 FusedConv *make_fused_conv_f64(ssf_plan *plan, int64_t M, int nrows) { return make_fused_conv_t<double>(plan, M, nrows); }
 FusedRows *make_fused_rows_f64(ssf_plan *plan, int64_t N, int nrows) { return make_fused_rows_t<double>(plan, N, nrows); }
+int fused_couple_reduce_selftest(int nranks, int npart, const double *parts, double *out5, std::string *err) {
+    return couple_reduce_selftest_impl(nranks, npart, parts, out5, err);
+}
 int fused_overlap_save_f64(int64_t sigLen, int nrows, int log2nfft, int K, const void *Hfft, const void *in, void *out, std::string *err) {
     return overlap_save_t<double>(sigLen, nrows, log2nfft, K, Hfft, in, out, err);
 }

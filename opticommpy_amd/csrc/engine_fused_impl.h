@@ -802,6 +802,38 @@ int overlap_save_t(int64_t sigLen, int nrows, int lg, int K, const void *Hfft, c
     return SSF_OK;
 }
 
+// The device-side reduction of a coupled batch by itself (ssf_couple_reduce_selftest): `parts` holds, per rank, the five arrays of
+// per-workgroup partials in col_args' order (pmax, pnum, pden, pnum0, pden0), npart values each -- what the column stage of that
+// rank would have left.  Every rank's block goes through k_couple_local into the slot the all-gather would put it in, then
+// k_couple_finish reduces the slots in rank order: out5 = (sum pnum0, sum pden0, sum pnum, sum pden, max pmax), the five values
+// the row stage of EVERY rank reads.  No communicator involved: this is the arithmetic that must give identical bits on all ranks.
+inline int couple_reduce_selftest_impl(int nranks, int npart, const double *parts, double *out5, std::string *err) {
+    if (nranks < 1 || npart < 1 || !parts || !out5) return SSF_ERR_BAD_ARG;
+    double *d = nullptr, *work = nullptr;
+    const size_t n = (size_t)nranks * 5 * (size_t)npart;
+    hipError_t e = hipMalloc(&d, sizeof(double) * n);
+    if (e == hipSuccess) e = hipMalloc(&work, sizeof(double) * (size_t)(8 + 5 * nranks));
+    if (e == hipSuccess) e = hipMemcpy(d, parts, sizeof(double) * n, hipMemcpyHostToDevice);
+    for (int r = 0; r < nranks && e == hipSuccess; ++r) {
+        const double *b = d + (size_t)r * 5 * npart;
+        CoupleArgs a{b + 3 * (size_t)npart, b + 4 * (size_t)npart, b + (size_t)npart, b + 2 * (size_t)npart, b, npart, work + 8 + 5 * r};
+        k_couple_local<<<1, 256>>>(a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        k_couple_finish<<<1, 64>>>(work + 8, nranks, work);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out5, work, sizeof(double) * 5, hipMemcpyDeviceToHost);
+    if (d) (void)hipFree(d);
+    if (work) (void)hipFree(work);
+    if (e != hipSuccess) {
+        *err = std::string("ssf_couple_reduce_selftest: ") + hipGetErrorString(e);
+        return SSF_ERR_HIP;
+    }
+    return SSF_OK;
+}
+
 // entry points of this translation unit (one per precision; engine_fused.hip dispatches)
 template <typename T> Engine *make_fused_engine_t(ssf_plan *plan) {
     auto *x = new FusedEngine<T>(plan);

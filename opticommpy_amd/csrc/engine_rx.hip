@@ -2,6 +2,7 @@
 // bodies of rx_kernels.h / ols_body and the Backend that RxCore (rx_pipeline.h) drives.  One
 // stream per call; stages are enqueued back to back and nothing is read back between them (the
 // decimator's sampling-phase decision is the one exception: 8 x SpSin doubles).
+#include <cstring>
 #include <string>
 #include <utility>
 #include <vector>
@@ -56,6 +57,10 @@ __global__ void __launch_bounds__(256) k_conv_sums(const ConvSumsArgs a) {
 __global__ void __launch_bounds__(256) k_tx_absmax(const AbsMaxArgs a) {
     SSF_RX_CTX();
     absmax_body(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_tx_phase_noise(const PnArgs a) {
+    SSF_RX_CTX();
+    pn_body(ctx, a);
 }
 __global__ void __launch_bounds__(256) k_tx_iqm(const IqmArgs a) {
     SSF_RX_CTX();
@@ -185,6 +190,10 @@ struct HipRxBackend {
         k_tx_absmax<<<(unsigned)nblocks, 256, 4096, st>>>(a);
         chk(hipGetLastError(), "launch k_tx_absmax");
     }
+    void launch_pn(const PnArgs &a, int nchunks) {
+        k_tx_phase_noise<<<(unsigned)nchunks, 256, 256 * sizeof(double), st>>>(a);
+        chk(hipGetLastError(), "launch k_tx_phase_noise");
+    }
     void launch_iqm(const IqmArgs &a, int nblocks) {
         k_tx_iqm<<<(unsigned)nblocks, 256, 4096, st>>>(a);
         chk(hipGetLastError(), "launch k_tx_iqm");
@@ -218,6 +227,33 @@ struct Pooled : HipRxBackend {
     };
     std::vector<Block> blocks;
     static constexpr size_t kPoolBytes = (size_t)2 << 30;
+    // device images of filters, kept between calls (RxCore::cached_filter); dropped all at once between two calls when there are
+    // too many (never inside a call: its launches may still read them)
+    struct Filter {
+        std::string key;
+        void *p;
+    };
+    std::vector<Filter> filters;
+    static constexpr size_t kMaxFilters = 128;
+    void *filter_lookup(const void *key, size_t n) {
+        for (auto &f : filters)
+            if (f.key.size() == n && std::memcmp(f.key.data(), key, n) == 0) return f.p;
+        return nullptr;
+    }
+    void *filter_store(const void *key, size_t n, const void *host, size_t bytes) {
+        void *p = HipRxBackend::alloc(bytes);
+        if (!p) {
+            first_err = hipSuccess;                 // (no room for a cache entry is not an error: the caller uploads per call)
+            return nullptr;
+        }
+        h2d(p, host, bytes);
+        filters.push_back(Filter{std::string((const char *)key, n), p});
+        return p;
+    }
+    void drop_filters() {
+        for (auto &f : filters) (void)hipFree(f.p);
+        filters.clear();
+    }
     void *alloc(size_t n) {
         Block *best = nullptr;
         for (auto &b : blocks)
@@ -250,7 +286,10 @@ struct Pooled : HipRxBackend {
             } else ++i;
         }
     }
-    ~Pooled() { trim(0); }
+    ~Pooled() {
+        trim(0);
+        drop_filters();
+    }
 };
 
 Pooled *backend_for(int device, std::string *err) {
@@ -274,6 +313,7 @@ Pooled *backend_for(int device, std::string *err) {
 template <class F> int with_core(int device, std::string *err, F &&f) {
     Pooled *be = backend_for(device, err);
     if (!be) return SSF_ERR_HIP;
+    if (be->filters.size() > Pooled::kMaxFilters) be->drop_filters();
     int rc;
     {
         RxCore<Pooled> core(*be);

@@ -322,6 +322,52 @@ template <class Ctx> SSF_HD void iqm_body(Ctx &ctx, const IqmArgs &a) {
     if (ctx.tid == 0) a.part[ctx.bid] = acc;
 }
 
+// ---- laser phase noise on the device (ssf_tx_params::pn_seed): phi[0] = 0, phi[k] = phi[k - 1] + sigma * g_k, g_k ~ N(0, 1) from
+// Philox (counter = k / 2, row = channel: two normals per draw).  A chunk of kPnChunk samples per workgroup; pass 1 leaves every
+// chunk's sum, the host turns the (few hundred) sums into offsets, pass 2 writes offset + prefix.
+constexpr int kPnChunk = 4096;
+struct PnArgs {
+    double *phi;              // (N,) pass 2; null in pass 1
+    double *csum;             // pass 1: the chunks' sums out;  pass 2: the chunks' offsets in
+    long long N;
+    double sigma;
+    unsigned long long seed;
+    unsigned channel;
+};
+SSF_HD double pn_increment(const PnArgs &a, long long k) {      // the step INTO sample k (k >= 1)
+    double g0, g1;
+    gauss_pair((unsigned long long)(k >> 1), a.channel, 0x504Eu, a.seed, 1.0, g0, g1);
+    return a.sigma * ((k & 1) ? g1 : g0);
+}
+template <class Ctx> SSF_HD void pn_body(Ctx &ctx, const PnArgs &a) {
+    const int per = kPnChunk / ctx.nthreads;                     // consecutive samples per thread
+    const long long k0 = (long long)ctx.bid * kPnChunk + (long long)ctx.tid * per;
+    double loc = 0;
+    for (int j = 0; j < per; ++j) {
+        const long long k = k0 + j;
+        if (k >= 1 && k < a.N) loc += pn_increment(a, k);
+    }
+    double *sh = (double *)ctx.lds;
+    sh[ctx.tid] = loc;
+    ctx.sync();
+    if (!a.phi) {                                                // pass 1: the chunk's sum, in thread order (as pass 2 adds them up)
+        if (ctx.tid == 0) {
+            double s = 0;
+            for (int t = 0; t < ctx.nthreads; ++t) s += sh[t];
+            a.csum[ctx.bid] = s;
+        }
+        return;
+    }
+    double run = a.csum[ctx.bid];                                // pass 2: offset of the chunk + the threads before this one
+    for (int t = 0; t < ctx.tid; ++t) run += sh[t];
+    for (int j = 0; j < per; ++j) {
+        const long long k = k0 + j;
+        if (k >= a.N) break;
+        if (k >= 1) run += pn_increment(a, k);
+        a.phi[k] = run;
+    }
+}
+
 // acc[n, mode] += amp * (x[n] / rms) * exp(j w t_n),  t_n = n * (1 / Fs), w = 2 pi deltaF  (core.py:1050-1073)
 struct ShiftAddArgs {
     const Cd *in;

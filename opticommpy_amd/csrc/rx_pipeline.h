@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -187,12 +188,7 @@ template <class Backend> struct RxCore {
         // used here (4096: 87 % of every transform is output, 50 % with 1024)
         const int K = 512, nfft = 4096;
         const long long padLen = (long long)std::ceil(std::fabs(dl[0] * Fs));
-        std::vector<zc> H;
-        for (int c = 0; c < ncols; ++c) {
-            const std::vector<zc> h = ols_filter_from_delay(dl[c], Fs, K, nfft);
-            H.insert(H.end(), h.begin(), h.end());
-        }
-        Cd *dH = upload_filter(H);
+        Cd *dH = delay_filters(dl, ncols, Fs, K, nfft);
         if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
         return ols(in, ld, N, N + padLen, out, ld, N, ncols, dH, nfft, K, nfft, 1);
     }
@@ -203,6 +199,66 @@ template <class Backend> struct RxCore {
         Cd *d = dalloc(n);
         if (d) be.h2d_big(d, p, sizeof(Cd) * n);
         return d;
+    }
+    // ... and a result where it belongs: a device destination is written by the kernels themselves (unless it is the input:
+    // the filters read their neighbourhood), a host destination gets a scratch block that is downloaded at the end
+    Cd *result_buffer(void *out, const void *in, size_t n) {
+        if (be.is_resident(out) && out != in) return (Cd *)out;
+        return dalloc(n);
+    }
+    int finish(void *out, const Cd *res, size_t n) {
+        be.sync();
+        if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
+        if ((const void *)res != out) be.d2h_big(out, res, sizeof(Cd) * n);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+    // filters derived from a few numbers (delays, the photodiodes' low-pass) or from taps the caller passes again and again (a
+    // matched filter): the backend may keep their device images between calls (host FFT + a synchronising upload per filter cost
+    // as much as the kernels of a 2^20-sample call)
+    struct FilterKey {
+        int kind, K, nfft, x;
+        double a, b;
+        unsigned long long h;
+        bool operator==(const FilterKey &o) const {
+            return kind == o.kind && K == o.K && nfft == o.nfft && x == o.x && a == o.a && b == o.b && h == o.h;
+        }
+    };
+    template <class Gen> Cd *cached_filter(const FilterKey &k, Gen &&gen) {
+        if (void *d = be.filter_lookup(&k, sizeof(k))) return (Cd *)d;
+        const std::vector<zc> H = gen();
+        if (void *d = be.filter_store(&k, sizeof(k), H.data(), sizeof(Cd) * H.size())) return (Cd *)d;
+        return upload_filter(H);
+    }
+    Cd *delay_filters(const double *dl, int n, double Fs, int K, int nfft) {         // n delay filters side by side
+        FilterKey k{1, K, nfft, n, dl[0], Fs, 0};
+        for (int c = 1; c < n; ++c) {
+            unsigned long long bits;
+            std::memcpy(&bits, &dl[c], 8);
+            k.h = k.h * 1099511628211ull + bits;
+        }
+        return cached_filter(k, [&] {
+            std::vector<zc> H;
+            for (int c = 0; c < n; ++c) {
+                const std::vector<zc> h = ols_filter_from_delay(dl[c], Fs, K, nfft);
+                H.insert(H.end(), h.begin(), h.end());
+            }
+            return H;
+        });
+    }
+    Cd *lowpass_filter(double B, double fs, int ntaps, int fType, int nfft) {
+        FilterKey k{2, ntaps, nfft, fType, B, fs, 0};
+        return cached_filter(k, [&] {
+            const std::vector<double> h = low_pass_fir(B, fs, ntaps, fType);
+            std::vector<zc> hz(h.begin(), h.end());
+            return ols_filter_from_taps(hz.data(), ntaps, nfft);
+        });
+    }
+    Cd *taps_filter(const zc *taps, int K, int nfft) {
+        unsigned long long h = 1469598103934665603ull;
+        const unsigned char *b = (const unsigned char *)taps;
+        for (size_t i = 0; i < sizeof(zc) * (size_t)K; ++i) h = (h ^ b[i]) * 1099511628211ull;
+        FilterKey k{3, K, nfft, 0, 0.0, 0.0, h};
+        return cached_filter(k, [&] { return ols_filter_from_taps(taps, K, nfft); });
     }
     static void iq_gains(const ssf_rx_params &p, int k, Cd *k1o, Cd *k2o) {      // core.py:952-959
         const double amp = std::pow(10.0, p.ampImb[k] / 20) - 1, ph = p.phaseImb[k];
@@ -286,12 +342,7 @@ template <class Backend> struct RxCore {
                     const int K = 512, nfft = 4096;                  // (delay_pair's filter and block size)
                     const double dl[2] = {-p.polDelay / 2, p.polDelay / 2};
                     const long long padLen = (long long)std::ceil(std::fabs(dl[0] * p.Fs));
-                    std::vector<zc> H;
-                    for (int c = 0; c < 2; ++c) {
-                        const std::vector<zc> h = ols_filter_from_delay(dl[c], p.Fs, K, nfft);
-                        H.insert(H.end(), h.begin(), h.end());
-                    }
-                    Cd *dH = upload_filter(H), *fld = dalloc((size_t)N * 2);
+                    Cd *dH = delay_filters(dl, 2, p.Fs, K, nfft), *fld = dalloc((size_t)N * 2);
                     if (!dH || !fld) return fail(SSF_ERR_OOM, "out of device memory");
                     RxOlsArgs r = rx_ols_args(N, N + padLen, fld, 2, N, 2, dH, nfft, K, nfft, 1);
                     r.pre = PRE_PBS;
@@ -315,10 +366,8 @@ template <class Backend> struct RxCore {
             Cd *dst = skew ? dalloc((size_t)N * nm) : result;
             if (!dst) return fail(SSF_ERR_OOM, "out of device memory");
             if (lowpass) {
-                const std::vector<double> h = low_pass_fir(p.B, fs_pd, ntaps, p.fType);
-                std::vector<zc> hz(h.begin(), h.end());
                 const int nfft = fir_nfft(ntaps);
-                Cd *dH = upload_filter(ols_filter_from_taps(hz.data(), ntaps, nfft));
+                Cd *dH = lowpass_filter(p.B, fs_pd, ntaps, p.fType, nfft);
                 if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
                 RxOlsArgs r = rx_ols_args(N, N, dst, nm, N, nm, dH, 0, ntaps, nfft, 0);
                 r.pre = PRE_DET;
@@ -350,13 +399,10 @@ template <class Backend> struct RxCore {
             for (int k = 0; k < nm; ++k) pad[k] = (long long)std::ceil(std::fabs(p.timeSkew[k] / 2 * p.Fs));
             const bool together = nm == 1 || pad[0] == pad[1];
             const int K = 512, nfft = 4096;
-            std::vector<zc> H;
+            double dls[4];
             for (int k = 0; k < nm; ++k)
-                for (int part = 0; part < 2; ++part) {
-                    const std::vector<zc> h = ols_filter_from_delay((part ? 1.0 : -1.0) * p.timeSkew[k] / 2, p.Fs, K, nfft);
-                    H.insert(H.end(), h.begin(), h.end());
-                }
-            Cd *dH = upload_filter(H);
+                for (int part = 0; part < 2; ++part) dls[2 * k + part] = (part ? 1.0 : -1.0) * p.timeSkew[k] / 2;
+            Cd *dH = delay_filters(dls, 2 * nm, p.Fs, K, nfft);
             if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
             for (int k = 0; k < (together ? 1 : nm); ++k) {
                 const int ncols = together ? 2 * nm : 2;
@@ -443,10 +489,8 @@ template <class Backend> struct RxCore {
         be.launch_front(fa);
         Cd *s = b;
         if (lowpass) {
-            const std::vector<double> h = low_pass_fir(p.B, fs_pd, ntaps, p.fType);
-            std::vector<zc> hz(h.begin(), h.end());
             const int nfft = fir_nfft(ntaps);
-            Cd *dH = upload_filter(ols_filter_from_taps(hz.data(), ntaps, nfft));
+            Cd *dH = lowpass_filter(p.B, fs_pd, ntaps, p.fType, nfft);
             if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
             int rc = ols(s, 1, N, N, a, 1, N, 1, dH, 0, ntaps, nfft, 0);
             if (rc) return rc;
@@ -466,15 +510,13 @@ template <class Backend> struct RxCore {
         if (sigLen < 1 || ncols < 1 || ntaps < 1) return fail(SSF_ERR_BAD_ARG, "bad size");
         if (ntaps > kMaxNfft / 2) return fail(SSF_ERR_UNSUPPORTED, "firFilter: at most 4096 taps");
         const int nfft = fir_nfft(ntaps);
-        Cd *a = dalloc((size_t)sigLen * ncols), *b = dalloc((size_t)sigLen * ncols);
-        Cd *dH = upload_filter(ols_filter_from_taps((const zc *)taps, ntaps, nfft));
+        const size_t n = (size_t)sigLen * ncols;
+        const Cd *a = resident(in, n);
+        Cd *b = result_buffer(out, in, n), *dH = taps_filter((const zc *)taps, ntaps, nfft);
         if (!a || !b || !dH) return fail(SSF_ERR_OOM, "out of device memory");
-        be.h2d_big(a, in, sizeof(Cd) * (size_t)sigLen * ncols);
         int rc = ols(a, ncols, sigLen, sigLen, b, ncols, sigLen, ncols, dH, 0, ntaps, nfft, 0);
         if (rc) return rc;
-        be.sync();
-        be.d2h_big(out, b, sizeof(Cd) * (size_t)sigLen * ncols);
-        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+        return finish(out, b, n);
     }
 
     // FIR of any length, on the device: out[n, m] = sum_t taps[t] * in[n + shift - t, m] for n in [0, outLen), `in` (inLen samples
@@ -485,9 +527,9 @@ template <class Backend> struct RxCore {
     int fir_long(long long inLen, long long outLen, int ncols, long long K, const void *taps, long long shift, const void *in,
                  void *out) {
         if (inLen < 1 || outLen < 1 || ncols < 1 || K < 1) return fail(SSF_ERR_BAD_ARG, "bad size");
-        Cd *a = dalloc((size_t)inLen * ncols), *acc = dalloc((size_t)outLen * ncols);
+        const Cd *a = resident(in, (size_t)inLen * ncols);
+        Cd *acc = result_buffer(out, in, (size_t)outLen * ncols);
         if (!a || !acc) return fail(SSF_ERR_OOM, "out of device memory");
-        be.h2d_big(a, in, sizeof(Cd) * (size_t)inLen * ncols);
         be.memset(acc, 0, sizeof(Cd) * (size_t)outLen * ncols);
         const long long S = kMaxNfft / 2;
         for (long long p0 = 0; p0 < K; p0 += S) {
@@ -518,9 +560,7 @@ template <class Backend> struct RxCore {
             g.acc = 1;
             be.launch_ols(g);
         }
-        be.sync();
-        be.d2h_big(out, acc, sizeof(Cd) * (size_t)outLen * ncols);
-        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+        return finish(out, acc, (size_t)outLen * ncols);
     }
 
     // simpleWDMTx's signal path (tx.py:178-217) for all channels and polarisations; symbols (nCh, nPol, nSymbols),
@@ -539,10 +579,16 @@ template <class Backend> struct RxCore {
         double *dpart = (double *)be.alloc(sizeof(double) * nblocks), *dphi = nullptr;
         if (dpart) owned.push_back(dpart);
         if (!dH || !dsym || !sig || !mod || !acc || !dpart) return fail(SSF_ERR_OOM, "out of device memory");
-        if (phi) {
+        const bool dev_pn = !phi && p.pn_seed != 0 && p.pn_sigma > 0;          // random walk generated on the device
+        const int pn_chunks = (int)((N + kPnChunk - 1) / kPnChunk);
+        double *dcs = nullptr;
+        std::vector<double> cs((size_t)pn_chunks);
+        if (phi || dev_pn) {
             dphi = (double *)be.alloc(sizeof(double) * (size_t)N);
-            if (!dphi) return fail(SSF_ERR_OOM, "out of device memory");
-            owned.push_back(dphi);
+            if (dev_pn) dcs = (double *)be.alloc(sizeof(double) * (size_t)pn_chunks);
+            if (dphi) owned.push_back(dphi);
+            if (dcs) owned.push_back(dcs);
+            if (!dphi || (dev_pn && !dcs)) return fail(SSF_ERR_OOM, "out of device memory");
         }
         be.h2d_big(dsym, symbols, sizeof(Cd) * (size_t)nCh * nPol * nS);
         be.memset(acc, 0, sizeof(Cd) * (size_t)N * nPol);
@@ -550,6 +596,21 @@ template <class Backend> struct RxCore {
         const double erLin = std::pow(10.0, 60.0 / 10), gamma = 2 * std::sqrt(erLin) / (erLin + 1);   // devices.py:185-188 defaults
         for (int ch = 0; ch < nCh; ++ch) {
             if (phi) be.h2d_big(dphi, phi + (size_t)ch * N, sizeof(double) * (size_t)N);
+            if (dev_pn) {
+                PnArgs pa{nullptr, dcs, N, p.pn_sigma, (unsigned long long)p.pn_seed, (unsigned)ch};
+                be.launch_pn(pa, pn_chunks);
+                be.sync();
+                be.d2h(cs.data(), dcs, sizeof(double) * (size_t)pn_chunks);
+                double run = 0;                                      // exclusive scan of the chunk sums (a few hundred values)
+                for (int c = 0; c < pn_chunks; ++c) {
+                    const double v = cs[(size_t)c];
+                    cs[(size_t)c] = run;
+                    run += v;
+                }
+                be.h2d(dcs, cs.data(), sizeof(double) * (size_t)pn_chunks);
+                pa.phi = dphi;
+                be.launch_pn(pa, pn_chunks);
+            }
             for (int mode = 0; mode < nPol; ++mode) {
                 const Cd *sym = dsym + ((size_t)ch * nPol + mode) * nS;
                 int rc = ols(sym, 1, N, N, sig, 1, N, 1, dH, 0, K, nfft, 0, p.SpS);
@@ -599,11 +660,11 @@ template <class Backend> struct RxCore {
         const int nthreads = 256 / nclass * nclass;                  // every thread keeps one (phase, column) class
         // the grid stride must keep the class too: nblocks * nthreads is a multiple of nclass by construction
         const int nblocks = (int)std::max<long long>(1, std::min<long long>(512, (N * ncols + 4 * nthreads - 1) / (4 * nthreads)));
-        Cd *a = dalloc((size_t)N * ncols), *b = dalloc((size_t)Nout * ncols), *dmean = dalloc((size_t)nclass);
+        const Cd *a = resident(in, (size_t)N * ncols);
+        Cd *b = result_buffer(out, in, (size_t)Nout * ncols), *dmean = dalloc((size_t)nclass);
         double *dpart = (double *)be.alloc(sizeof(double) * 2 * (size_t)nblocks * nclass);
         if (dpart) owned.push_back(dpart);
         if (!a || !b || !dmean || !dpart) return fail(SSF_ERR_OOM, "out of device memory");
-        be.h2d_big(a, in, sizeof(Cd) * (size_t)N * ncols);
         std::vector<double> part(2 * (size_t)nblocks * nclass);
         std::vector<zc> mean((size_t)nclass);
         std::vector<double> var((size_t)nclass);
@@ -645,9 +706,7 @@ template <class Backend> struct RxCore {
             if (sampDelay_out) sampDelay_out[c] = best;
         }
         be.launch_dec_gather(ga);
-        be.sync();
-        be.d2h_big(out, b, sizeof(Cd) * (size_t)Nout * ncols);
-        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+        return finish(out, b, (size_t)Nout * ncols);
     }
 
     // blockwiseFFTConv with a caller-supplied frequency response (edc: ssf_overlap_save); Hfft = fft(zero-padded
@@ -655,14 +714,13 @@ template <class Backend> struct RxCore {
     int overlap_save(long long sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out) {
         std::vector<zc> H((size_t)nfft);
         for (int i = 0; i < nfft; ++i) H[(size_t)i] = ((const zc *)Hfft)[i] / (double)nfft;    // the ifft's 1/NFFT folded in
-        Cd *a = dalloc((size_t)sigLen * ncols), *b = dalloc((size_t)sigLen * ncols), *dH = upload_filter(H);
+        const size_t n = (size_t)sigLen * ncols;
+        const Cd *a = resident(in, n);
+        Cd *b = result_buffer(out, in, n), *dH = upload_filter(H);
         if (!a || !b || !dH) return fail(SSF_ERR_OOM, "out of device memory");
-        be.h2d_big(a, in, sizeof(Cd) * (size_t)sigLen * ncols);
         int rc = ols(a, ncols, sigLen, sigLen, b, ncols, sigLen, ncols, dH, 0, K, nfft, 0);
         if (rc) return rc;
-        be.sync();
-        be.d2h_big(out, b, sizeof(Cd) * (size_t)sigLen * ncols);
-        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+        return finish(out, b, n);
     }
 
     // delaySignal (core.py:880-922) of one column
@@ -707,15 +765,13 @@ template <class Backend> struct RxCore {
     }
     int delay(long long N, double delay_s, double Fs, const void *in, void *out) {
         if (N < 1 || !(Fs > 0)) return fail(SSF_ERR_BAD_ARG, "bad size");
-        Cd *a = dalloc((size_t)N), *b = dalloc((size_t)N);
+        const Cd *a = resident(in, (size_t)N);
+        Cd *b = result_buffer(out, in, (size_t)N);
         if (!a || !b) return fail(SSF_ERR_OOM, "out of device memory");
-        be.h2d_big(a, in, sizeof(Cd) * (size_t)N);
         const double dl[1] = {delay_s};
         int rc = delay_pair(a, b, 1, N, dl, 1, Fs);
         if (rc) return rc;
-        be.sync();
-        be.d2h_big(out, b, sizeof(Cd) * (size_t)N);
-        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+        return finish(out, b, (size_t)N);
     }
 };
 

@@ -309,6 +309,15 @@ int ssf_set_coupling_comm(ssf_plan *plan, ssf_comm *comm) {
     return rc ? fail(plan, rc, "device-side coupling needs the device-resident fused pipeline (else: ssf_set_coupling on SSF_ENGINE_ROCFFT)") : SSF_OK;
 }
 
+static int rx_check_device(int device);
+int ssf_couple_reduce_selftest(int device, int32_t nranks, int32_t npart, const double *parts, double *out5) {
+    if (int rc = rx_check_device(device)) return rc;
+    if (hipSetDevice(device) != hipSuccess) return set_err(SSF_ERR_HIP, "hipSetDevice");
+    std::string err;
+    int rc = ssf::fused_couple_reduce_selftest(nranks, npart, parts, out5, &err);
+    return rc ? set_err(rc, err.empty() ? "ssf_couple_reduce_selftest: bad argument" : err) : SSF_OK;
+}
+
 int ssf_set_profiling(ssf_plan *plan, int32_t enable) {
     if (!plan) return set_err(SSF_ERR_BAD_ARG, "plan is NULL");
     SSF_NEED_ENGINE(plan);

@@ -89,6 +89,7 @@ namespace ssf {
 Engine *make_rocfft_engine(ssf_plan *plan);
 Engine *make_fused_engine(ssf_plan *plan);
 bool fused_supports(int64_t N, int nrows, int precision);
+int fused_couple_reduce_selftest(int nranks, int npart, const double *parts, double *out5, std::string *err);
 int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int log2nfft, int K, const void *Hfft,
                         const void *in, void *out, std::string *err);
 

@@ -192,7 +192,11 @@ def simpleWDMTx(param, device_output=False):
         raise ValueError("nBits must give the same symbol count for the source and the time axis")   # tx.py:112, 125
 
     symbols = np.empty((nCh, nPol, nSymbols), dtype=np.complex128)
-    phi = np.empty((nCh, N)) if param.laserLinewidth else None
+    # Laser phase noise.  With a seed the random walk is the reference's own np.random draws (phaseNoise below: host, N values
+    # per channel, uploaded); WITHOUT one nothing can be reproduced anyway, and the walk is generated on the device (Philox, two
+    # launches per channel: ssf_tx_params.pn_seed) -- no N-sample draw on the host, no N-sample upload.
+    device_pn = bool(param.laserLinewidth) and param.seed is None
+    phi = np.empty((nCh, N)) if (param.laserLinewidth and not device_pn) else None
     seed = param.seed
     for ch in range(nCh):                                          # the reference's draw order (tx.py:184-210)
         logg.info("channel %d\t fc : %3.4f THz" % (ch, (param.Fc + freqGrid[ch]) / 1e12))
@@ -201,13 +205,17 @@ def simpleWDMTx(param, device_output=False):
             symbols[ch, mode] = _symbol_source(nSymbols, param.M, param.constType, param.probDist, param.shapingFactor, seed)
             if param.seed is not None:
                 seed += 1
-            if mode == 0:
-                pn = phaseNoise(param.laserLinewidth, N, 1 / Fs, seed=param.seed)      # drawn even when the linewidth is 0
-                if phi is not None:
+            if mode == 0 and param.seed is not None:
+                pn = phaseNoise(param.laserLinewidth, N, 1 / Fs, seed=param.seed)      # drawn even when the linewidth is 0: the
+                if phi is not None:                                                     # draws move the seeded stream (tx.py:199)
                     phi[ch] = pn
 
     p = _lib.TxParams(Fs=Fs, mzmScale=float(param.mzmScale), nSymbols=nSymbols, SpS=int(param.SpS), nChannels=nCh,
                       nPolModes=nPol, ntaps=len(pulse))
+    if device_pn:
+        from .models import _device_seed
+        p.pn_sigma = float(np.sqrt(2 * np.pi * param.laserLinewidth / Fs))
+        p.pn_seed = _device_seed(None)
     amp = np.sqrt(Pch / nPol).astype(np.float64)
     power = np.zeros(nCh * nPol)
     sig = _dev.empty(device_output, (N, nPol), np.complex128)

@@ -77,3 +77,48 @@ def test_two_processes_reproduce_the_single_coupled_call(tmp_path):
     single = oa.manakovSSF(E, make_param(oa.parameters, cfg2))
     got2 = np.concatenate([np.load(tmp_path / f"edfa_rank{r}.npy") for r in range(2)], axis=1)
     assert rel_l2(got2, single) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks,npart", [(2, 512), (8, 128), (3, 777)])
+def test_rank_order_reduction_of_a_coupled_batch_on_synthetic_rank_buffers(nranks, npart):
+    """The arithmetic behind ssf_set_coupling_comm with partials that DIFFER between the ranks (with one RCCL
+    rank the gathered value is the rank's own): every rank's per-workgroup partials are reduced on the device (k_couple_local),
+    the per-rank results in rank order (k_couple_finish).  Checked bit for bit against a numpy model of exactly that order --
+    the property that makes every rank take the same decisions -- and to rounding against the single K-pair call's reduction
+    over all workgroups at once (the sums agree to ~1e-16 relative, the maximum exactly)."""
+    import ctypes as C
+    from opticommpy_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(nranks * 1000 + npart)
+    parts = rng.random((nranks, 5, npart)) * np.array([1e-2, 1e-9, 1e-3, 1e-9, 1e-3])[None, :, None]      # pmax, pnum, pden, pnum0, pden0
+    out = np.zeros(5)
+    _lib.raise_for(lib, None, lib.ssf_couple_reduce_selftest(0, nranks, npart, parts.ctypes.data_as(C.POINTER(C.c_double)),
+                                                            out.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def local(v, is_max):                       # k_couple_local: 256 threads stride the partials, thread 0..255 combined in order
+        lanes = []
+        for t in range(256):
+            x = v[t::256]
+            if is_max:
+                lanes.append(np.max(x) if len(x) else -np.inf)
+            else:
+                s = 0.0
+                for y in x:
+                    s += y
+                lanes.append(s)
+        r = lanes[0]
+        for y in lanes[1:]:
+            r = max(r, y) if is_max else r + y
+        return r
+    want = []
+    for q, src in enumerate((3, 4, 1, 2, 0)):   # out5 = (sum pnum0, sum pden0, sum pnum, sum pden, max pmax)
+        per_rank = [local(parts[r, src], q == 4) for r in range(nranks)]
+        r0 = per_rank[0]
+        for y in per_rank[1:]:
+            r0 = max(r0, y) if q == 4 else r0 + y
+        want.append(r0)
+    assert out.tolist() == want                 # bit for bit: the same on every rank, whatever its own partials are
+    single = [parts[:, 3].sum(), parts[:, 4].sum(), parts[:, 1].sum(), parts[:, 2].sum(), parts[:, 0].max()]
+    np.testing.assert_allclose(out, single, rtol=1e-14)
+    assert out[4] == single[4]

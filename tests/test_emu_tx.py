@@ -48,3 +48,33 @@ def test_errors():
         oa.simpleWDMTx(make_param(oa.parameters, dict(probDist="gaussian", prgsBar=False)))
     with pytest.raises(AssertionError):
         oa.simpleWDMTx(make_param(oa.parameters, dict(powerPerChannel=[0, 0], nChannels=3, nBits=1024, prgsBar=False)))
+
+
+def test_laser_phase_noise_is_generated_on_the_device_when_there_is_no_seed(monkeypatch):
+    """Without a seed nothing can be reproduced, so the laser's random walk (optic/dsp/core.py:792-826: phi[0] = 0, steps
+    N(0, 2 pi lw Ts)) is generated on the device (Philox, ssf_tx_params.pn_seed): no host draw, no N-sample upload.  One channel,
+    one polarisation, no modulation depth (mzmScale -> 0, a CW carrier): the transmitted field's phase IS the walk, so its
+    increments can be measured: zero mean, the right variance, uncorrelated, a different walk per key and per channel."""
+    lw, Fs = 5e6, 16 * 32e9
+    kw = dict(M=4, nBits=2 * 4096, SpS=16, nChannels=1, nPolModes=1, laserLinewidth=lw, mzmScale=1e-9, pulseType="nrz", prgsBar=False)
+    seen = []
+    monkeypatch.setattr(wdm_tx, "phaseNoise", lambda *a, **k: (_ for _ in ()).throw(AssertionError("host phase-noise draw")))
+    for key in (11, 12):
+        from opticommpy_amd import models
+        monkeypatch.setattr(models, "_device_seed", lambda seed, key=key: key)
+        sig, _, _ = oa.simpleWDMTx(make_param(oa.parameters, kw))
+        ph = np.unwrap(np.angle(sig[:, 0]))
+        ph -= ph[0]
+        inc = np.diff(ph)
+        s2 = 2 * np.pi * lw / Fs
+        assert abs(np.var(inc) / s2 - 1) < 0.02 and abs(np.mean(inc)) < 4 * np.sqrt(s2 / len(inc))
+        assert abs(np.corrcoef(inc[:-1], inc[1:])[0, 1]) < 0.02
+        assert np.max(np.abs(inc)) < 6 * np.sqrt(s2)          # ... also across the 4096-sample chunks the kernel works in: they join up
+        seen.append(inc)
+    assert np.max(np.abs(seen[0] - seen[1])) > 1e-6
+    # with a seed: the reference's own draws, on the host, as before
+    monkeypatch.undo()
+    monkeypatch.setattr(wdm_tx, "_backend", eb.EmuTxBackend())
+    a, _, _ = oa.simpleWDMTx(make_param(oa.parameters, dict(kw, seed=5)))
+    b, _, _ = oa.simpleWDMTx(make_param(oa.parameters, dict(kw, seed=5)))
+    assert np.array_equal(a, b)
