@@ -545,7 +545,58 @@ def also_configs(env, args):
     leg("config4_one_gpu_two_lanes", 4, steps=20, warmup=5, parity="fixture_units", no_kernel_times=True)
     leg("config5_one_gpu_two_lanes", 5, steps=20, warmup=5, parity="fixture_units", no_kernel_times=True)
     leg("config1_16_fields_per_launch", 1, steps=100, warmup=20, nfields=16, no_kernel_times=True)
+    try:
+        out["rx_chain_2^20"] = rx_chain_leg()
+    except Exception as e:
+        out["rx_chain_2^20"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
+
+
+def rx_chain_leg(reps=10):
+    """SURVEY.md 8f ranks 1 and 3 behind the channel, device-resident: pdmCoherentReceiver -> firFilter (1024-tap matched filter)
+    -> decimate 16 -> 2 -> edc (800 km) on a 2 x 2^20 field that sits in HBM (one upload before, one download after the timed
+    region), against the REFERENCE's output of the same chain (tests/golden/wl_rx_chain_n20.npz, tools/gen_golden.py
+    rx_chain20).  Algorithmic bytes: every stage reads its input and writes its output once (receiver 48 + 32 B per sample,
+    filter 32 + 32, decimation 32 + 4, compensation 4 + 4)."""
+    import opticommpy_amd as oa
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import synth_field
+    z = np.load(os.path.join(ROOT, "tests", "golden", "wl_rx_chain_n20.npz"))
+    c = json.loads(str(z["cfg"]))
+
+    def bag(cls, kw):
+        p = cls()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+    N = int(c["synth"][0])
+    E = synth_field(*[int(c["synth"][0]), int(c["synth"][1]), int(c["synth"][2]), float(c["synth"][3])])
+    lo = oa.basicLaserModel(bag(oa.parameters, c["lo"]))        # (seeded: the reference's own draws)
+    pulse = oa.pulseShape(bag(oa.parameters, c["ps"]))
+    Ed, Ld = oa.to_device(E), oa.to_device(lo)
+
+    def chain():
+        s = oa.pdmCoherentReceiver(Ed, Ld, bag(oa.parameters, c["fe"]), bag(oa.parameters, c["pd"]))
+        s = oa.firFilter(pulse, s)
+        s = oa.decimate(s, bag(oa.parameters, c["dec"]))
+        return oa.edc(s, bag(oa.parameters, c["edc"]))
+    out = chain().get()                                               # warm-up + the parity check
+    d = int(c["d"])
+    err = float(np.linalg.norm(out[::d] - z["out_dec"]) / np.linalg.norm(z["out_dec"]))
+    rng = np.random.default_rng(4242)
+    r = (rng.normal(size=out.shape[0]) + 1j * rng.normal(size=out.shape[0])) / np.sqrt(2)
+    perr = float(np.max(np.abs(out.T @ r - z["out_proj"])) / np.sqrt(np.sum(z["out_power"])))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        o = chain()
+    o.get()[:1]                                                       # (the calls are synchronous at return; one small read to be sure)
+    dt = (time.perf_counter() - t0) / reps
+    alg = N * (80 + 64 + 36 + 8)
+    return {"workload": "pdmCoherentReceiver (polarisation rotation + delay, ideal photodiodes) -> firFilter 1024 taps -> decimate 16 -> 2 -> "
+                        "edc 800 km, 2 x 2^20 complex128 samples resident in HBM", "ms_per_chain": dt * 1e3, "samples_per_s": N / dt,
+            "algorithmic_bytes": alg, "achieved_GBs": alg / dt / 1e9, "roofline_frac": alg / dt / 1e9 / HBM_PEAK_GBS, "reps": reps,
+            "parity": {"rel_l2_vs_reference": err, "projection_err": perr, "gate": 1e-9, "ok": bool(err <= 1e-9 and perr <= 1e-8),
+                       "what": "the reference's own output of this chain (reference-generated fixture wl_rx_chain_n20)"}}
 
 
 def main():

@@ -20,7 +20,7 @@ Output: tests/golden/<case>.npz, each holding
               output decimated by cfg["dec"], its per-column power and a seeded random projection of the full
               output (so an error anywhere in the array shows), see long_vectors()
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|rx_edges|tx|bfc|mixed|chain|long|long20|cfg3|long_c3 [128|64|merge]|units45 [log2n]]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|rx_edges|tx|bfc|mixed|rx_chain20|chain|long|long20|cfg3|long_c3 [128|64|merge]|units45 [log2n]]
 """
 import json
 import os
@@ -680,6 +680,38 @@ def mixed_dtype_vectors():
             print(f"{save_name:30s} in {Ei.dtype} prec {np.dtype(prec).name} out {out.dtype}{out.shape} iters {int(iters.sum())}")
 
 
+def rx_chain20_vector():
+    """The receiver side of the notebook chain at 2^20 samples for bench.py's "also" leg: the REFERENCE's
+    basicLaserModel (LO) -> pdmCoherentReceiver -> firFilter (1024-tap RRC matched filter) -> decimate (16 -> 2) -> edc (800 km) on
+    a seeded 2 x 2^20 field (the channel benchmarks' recipe: band-limited complex Gaussian, 0 dBm).  Stored: the decimated final
+    output, per-column power and a seeded projection of all of it (bench.py regenerates the input from the recipe)."""
+    import time
+    import optic.dsp.core as ref_core
+    import optic.models.devices as ref_dev
+    from optic.dsp.equalization import edc as ref_edc
+    os.makedirs(OUT, exist_ok=True)
+    t0 = time.time()
+    N, Fs, Rs = 1 << 20, 512e9, 32e9
+    synth = (N, 2, 9, 0.0)
+    E = synth_field(*synth)
+    lo = dict(P=10, lw=100e3, RIN_var=0, Ns=N, Fs=Fs, seed=789, freqShift=-128e6)
+    sigLO = ref_dev.basicLaserModel(mk_param(**lo))
+    fe = dict(Fs=Fs, polRotation=np.pi / 3, pdl=0, polDelay=3 / Rs, phaseImbX=0.0, phaseImbY=0.0, ampImbX=0, ampImbY=0)
+    pd = dict(B=Rs, Fs=Fs, ideal=True, seed=1011)
+    sigRx = ref_dev.pdmCoherentReceiver(E, sigLO, mk_param(**fe), mk_param(**pd))
+    ps = dict(SpS=16, nFilterTaps=1024, rollOff=0.01, pulseType="rrc")
+    sigMF = ref_core.firFilter(ref_core.pulseShape(mk_param(**ps)), sigRx)
+    dec = dict(SpSin=16, SpSout=2)
+    sigDec = ref_core.decimate(sigMF, mk_param(**dec))
+    ed = dict(L=800, D=16, Fc=193.1e12, Rs=Rs, Fs=2 * Rs)
+    out = ref_edc(sigDec, mk_param(**ed))
+    d = 64
+    cfg = dict(func="rx_chain", synth=list(synth), lo=lo, fe=fe, pd=pd, ps=ps, dec=dec, edc=ed, d=d)
+    sz = save("wl_rx_chain_n20", cfg=json.dumps(cfg), out_dec=out[::d].copy(), out_power=np.sum(np.abs(out) ** 2, axis=0), out_proj=projection(out),
+              rx_proj=projection(sigRx))
+    print(f"wl_rx_chain_n20: out {out.dtype}{out.shape}  {sz/1024:.0f} KiB  {time.time()-t0:.0f} s")
+
+
 def unit_checksum(out_cols, seed=4242):
     """bench.py's per-unit checksum of an (N, ncols) reference output: sum |E|^2 and <q, E> over the (ncols, N) SoA block
     with the seeded unit-variance complex vector q (bench.py: unit_checksum)."""
@@ -738,6 +770,8 @@ if __name__ == "__main__":
         cfg3_vector()
     elif len(sys.argv) > 1 and sys.argv[1] == "mixed":   # the GPU twin's mixed-dtype calls
         mixed_dtype_vectors()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rx_chain20":   # the receiver chain at 2^20 (bench.py's "also" leg)
+        rx_chain20_vector()
     elif len(sys.argv) > 1 and sys.argv[1] == "bfc":     # blockwiseFFTConv as a callable
         bfc_vectors()
     elif len(sys.argv) > 1 and sys.argv[1] == "chain":   # the notebook chain end to end (transmitter -> channel -> receiver -> edc)
