@@ -487,18 +487,37 @@ template <typename T> struct RowArgs {
 
 // linear operator for the V registers of a last-radix-V butterfly (V = 16 | 8): bins k0 + (N/V) q, signed q' = q or q - V;
 // phase cth (k0 + dk q')^2 = A * B^q' * C_|q'| with C_m = cis(cth dk^2 m^2) = the control block's table at 16/V * m
-template <int V = 16, typename T>
-SSF_HD void apply_lin16(const LinOp &lo, long long k0, int log2N, cx<T> *v) {
-    constexpr int lgV = V == 16 ? 4 : 3, H = V / 2, CS = 16 / V;
+// (the two sines / cosines of it by themselves: they depend on the thread's bins only, not on the data, so the row stage
+//  evaluates them while its row is still in flight -- SSF_EARLY_BASES)
+struct Lin16Bases {
+    cx<double> A, B1;       // A: the unit phasor cis(cth k0^2) (the magnitude is applied with the operator), B1 = cis(2 cth k0 dk)
+    double cth;             // the operator constant they were made for
+};
+template <int V = 16> SSF_HD Lin16Bases lin16_bases(double cth, long long k0, int log2N) {
+    constexpr int lgV = V == 16 ? 4 : 3;
     const double dk = (double)(1ll << (log2N - lgV));
     const double k0d = (double)k0;
     double s, c;
-    cis_rad_d(lo.cth * k0d * k0d, c, s);
-    const cx<double> A = mk<double>(lo.mag * c, lo.mag * s);
-    cis_rad_d(2.0 * lo.cth * k0d * dk, c, s);
+    Lin16Bases r;
+    cis_rad_d(cth * k0d * k0d, c, s);
+    r.A = mk<double>(c, s);
+    cis_rad_d(2.0 * cth * k0d * dk, c, s);
+    r.B1 = mk<double>(c, s);
+    r.cth = cth;
+    return r;
+}
+template <int V = 16, typename T> SSF_HD void apply_lin16(const LinOp &lo, const Lin16Bases &lb, cx<T> *v);
+template <int V = 16, typename T>
+SSF_HD void apply_lin16(const LinOp &lo, long long k0, int log2N, cx<T> *v) {
+    apply_lin16<V>(lo, lin16_bases<V>(lo.cth, k0, log2N), v);
+}
+template <int V, typename T>
+SSF_HD void apply_lin16(const LinOp &lo, const Lin16Bases &lb, cx<T> *v) {
+    constexpr int H = V / 2, CS = 16 / V;
+    const cx<double> A = mk<double>(lo.mag * lb.A.re, lo.mag * lb.A.im);
     cx<double> Bp[H + 1];
     Bp[0] = mk<double>(1.0, 0.0);
-    Bp[1] = mk<double>(c, s);
+    Bp[1] = lb.B1;
     Bp[2] = Bp[1] * Bp[1];
     Bp[3] = Bp[2] * Bp[1];
     Bp[4] = Bp[2] * Bp[2];
@@ -675,6 +694,12 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
     const cx<T> *gin = a.src ? a.src + rr * L : g;
     LinOp lo;
     double part[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#if SSF_EARLY_BASES
+    // the operator constant as the previous launch left it (a scalar load, ahead of everything: the vector loads of the whole
+    // operator inside row_ctrl queue up behind the row): the thread's operator bases are made from it while the row is in flight,
+    // and made again in the (rare) launch that derives a new operator
+    const double cth_pre = a.use_ctrl ? a.cin->lin.cth : (a.lin ? a.lin->cth : 0.0);
+#endif
     if (a.use_ctrl) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -750,6 +775,12 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
 #ifndef SSF_WT_ROWS
 #define SSF_WT_ROWS 3
 #endif
+#ifndef SSF_LOAD_ORDER
+#define SSF_LOAD_ORDER 1      // loads of a row in the order its first butterfly consumes them: + 0.5 ... 1.3 %, 8 of 8 (profiles/r5_ab_load_order.txt)
+#endif
+#ifndef SSF_EARLY_BASES
+#define SSF_EARLY_BASES 0
+#endif
 template <typename T> constexpr bool wt_rows() {
     return sizeof(scalar_t<T>) == 8 ? (SSF_WT_ROWS & 1) != 0 : sizeof(T) == 8 ? (SSF_WT_ROWS & 2) != 0 : (SSF_WT_ROWS & 4) != 0;
 }
@@ -807,6 +838,12 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     // makes the decision wait for the row: +2.5 us per launch.  Starting half of the workgroups
     // late, so that co-resident workgroups are out of phase, was measured and does not help.)
     double part[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#if SSF_EARLY_BASES
+    // the operator constant as the previous launch left it (a scalar load, ahead of everything: the vector loads of the whole
+    // operator inside row_ctrl queue up behind the row): the thread's operator bases are made from it while the row is in flight,
+    // and made again in the (rare) launch that derives a new operator
+    const double cth_pre = a.use_ctrl ? a.cin->lin.cth : (a.lin ? a.lin->cth : 0.0);
+#endif
     if (a.use_ctrl) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -820,8 +857,24 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
         }
         ctx.issue_fence();
     }
+#if SSF_LOAD_ORDER
+    // Experiment (appendix #43): the row's loads issued in the order the first butterfly consumes them (bit-reversed: dft16 starts
+    // with v[0] + v[8], v[4] + v[12], ...), in groups the scheduler may not merge, so that the waits can be per group and the first
+    // additions start while the rest of the row is still in flight.
+    {
+        constexpr int ord16[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+        constexpr int ord8[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int q = V == 16 ? ord16[i] : ord8[i & 7];
+            v[q] = g[b + p.tpf * q];
+            if ((i & 3) == 3) ctx.issue_fence();
+        }
+    }
+#else
 #pragma unroll
     for (int q = 0; q < V; ++q) v[q] = g[b + p.tpf * q];
+#endif
     // single precision: the next-to-last pass takes its hi + lo factors from a table in LDS, built while the row is in flight (TwSrc)
     constexpr bool kTab = (SSF_TW_TAB & 1) && sizeof(scalar_t<T>) == 4;
     TwSrc<T> tws;
@@ -848,11 +901,29 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
     // workgroup catches up while the early one is in a later phase: +3 % steps/s at config 2 (profiles/r3_ab_runs.txt);
     // off (a.prio = 0) when several plans share the GPU, where it costs 4 % (profiles/r3_lanes_prio_wt.txt).
     if (a.prio) ctx.template setprio<2>();
+    const int last = p.npass - 1;
+#if SSF_EARLY_BASES
+    // Everything that depends on the thread's position only -- the twiddle bases of all passes (one sincospi each; the inverse
+    // transform conjugates them) and the two sines / cosines of the linear operator -- is evaluated HERE, while the row is still
+    // in flight and the VALU has nothing else to do (appendix #44).
+    Lin16Bases lb{};
+    const bool lin16 = (a.use_ctrl || a.lin) && p.lg(last) == lgV;
+    {
+#pragma unroll
+        for (int i = 0; i < kTwMaxPass; ++i) {
+            if (i < p.npass && p.lgLn(i) > 0 && !(kTab && i == p.npass - 2)) {
+                tws.base[i] = tw_base(+1, pass_j(p, i, b), pass_lgLi(p, i));
+                tws.have[i] = true;
+            }
+        }
+        if (lin16) lb = lin16_bases<V>(cth_pre, k1 + ((long long)rev_pos(p, reg_pos(p, last, b, 0)) << a.log2N1), log2N);
+        ctx.issue_fence();
+    }
+#endif
     fft_dif<-1, V, kTab>(ctx, p, b, v, l, tws);
     ctx.mark(2);
     if (a.prio) ctx.template setprio<1>();
     // registers now hold pass-(p-1) positions; bin k = k1 + N1 * rev(pos)
-    const int last = p.npass - 1;
     if (!a.use_ctrl && !a.lin) {                 // fixed-kernel convolution: multiplier array in this kernel's spectrum order
         if (a.fwd_only) {
 #pragma unroll
@@ -863,8 +934,13 @@ template <typename T, int LG, int V = 16, class Ctx> SSF_HD void row_body(Ctx &c
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) v[idx] = v[idx] * h[reg_pos(p, last, b, idx)];
     } else if (p.lg(last) == lgV) {
+#if SSF_EARLY_BASES
+        if (lo.cth != lb.cth) lb = lin16_bases<V>(lo.cth, k1 + ((long long)rev_pos(p, reg_pos(p, last, b, 0)) << a.log2N1), log2N);
+        apply_lin16<V>(lo, lb, v);
+#else
         const long long k0 = k1 + ((long long)rev_pos(p, reg_pos(p, last, b, 0)) << a.log2N1);
         apply_lin16<V>(lo, k0, log2N, v);
+#endif
     } else {
 #pragma unroll
         for (int idx = 0; idx < V; ++idx) {
@@ -1404,7 +1480,12 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
     GTw gtw;
     if (do_inv) {
 #pragma unroll
-        for (int q = 0; q < V; ++q) v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+        for (int q = 0; q < V; ++q) {
+            v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+#if SSF_LOAD_ORDER
+            if ((q & 3) == 3) ctx.issue_fence();             // (appendix #43: the inter-pass twiddles are applied in this order, group by group)
+#endif
+        }
         ctx.mark(1);
         if (a.prio) ctx.template setprio<3>();
         global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v, gtw);
@@ -1625,7 +1706,12 @@ template <int LG, int V = 16, int CI = 0, int SG = SG_ALL, class Ctx> SSF_HD voi
     GTw gtw;
     if (st.do_inv) {
 #pragma unroll
-        for (int q = 0; q < V; ++q) v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+        for (int q = 0; q < V; ++q) {
+            v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+#if SSF_LOAD_ORDER
+            if ((q & 3) == 3) ctx.issue_fence();             // (appendix #43: the inter-pass twiddles are applied in this order, group by group)
+#endif
+        }
         ctx.mark(1);
         global_twiddle<+1, false>(g, a.log2N1 + a.log2N2, v, gtw);
         fft_dif<+1, V, false, kCI>(ctx, p, g.b, v, lds, tws);

@@ -24,6 +24,18 @@ def test_persistent_span_kernels_reproduce_the_launch_sequence(which):
 
 
 @pytest.mark.gpu
+def test_stage_specialised_column_kernels_against_the_general_kernel_at_chip_filling_sizes():
+    """tests/tools/split_check.py: the H | ADV | FIN kernels along the predicted sequence against the one general kernel on the GPU,
+    2^20 ... 2^22 samples, both precisions, ten regimes (iteration-count change, adaptive step, rebuilds at every step, maxIter = 1,
+    snapshots, back-propagation): same step and iteration counts, fields equal to rounding."""
+    if not os.path.exists(EXP):
+        pytest.skip("experiment library not built (make -C opticommpy_amd/csrc exp)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "split_check.py")],
+                       env=dict(os.environ, SSF_LIB=EXP), capture_output=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout.decode(errors="replace")[-3000:], r.stderr.decode(errors="replace")[-2000:])
+
+
+@pytest.mark.gpu
 def test_product_library_ignores_the_experiment_switches(monkeypatch):
     """SSF_ROW_V / SSF_COL_V / SSF_SPLIT_L1 / SSF_PERSIST ... are experiment-build knobs: one stray environment variable must
     not change what the shipped library runs (bit-equal result, same launch count)."""
