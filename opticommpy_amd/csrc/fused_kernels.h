@@ -544,12 +544,27 @@ SSF_HD cx<double> lin_at(const LinOp &lo, long long k, int log2N) {
     return mk<double>(lo.mag * c, lo.mag * s);
 }
 
-// Forward nwords 8-byte words of the control block (lead thread).  Eight words are fetched before any is stored:
-// copied one by one, every load waits for the store before it (the compiler must assume the blocks alias), i.e. 35
-// memory round trips in a row -- 3.5 us that the lead workgroup finishes late, a quarter of a launch at small N.
+// Forward nwords 8-byte words of the control block (lead thread).  ALL words are fetched before any is stored: copied one by
+// one, every load waits for the store before it (the compiler must assume the blocks alias), i.e. 35 memory round trips in a row
+// -- 3.5 us that the lead workgroup finishes late, a quarter of a launch at small N (round 2: groups of eight).  Round 5: the 38
+// words of the block were still four groups and six single words = ten dependent round trips in front of the lead workgroup's own
+// work, in EVERY launch (the generated code shows a load + s_waitcnt vmcnt(0) + store per word of the tail); now one round trip.
+#ifndef SSF_CTRL_WIDE
+#define SSF_CTRL_WIDE 1
+#endif
 SSF_HD void ctrl_forward(const Ctrl *cin, Ctrl *cout, int nwords) {
     const unsigned long long *src = (const unsigned long long *)cin;
     unsigned long long *dst = (unsigned long long *)cout;
+#if SSF_CTRL_WIDE
+    constexpr int kMax = (int)(sizeof(Ctrl) / 8);
+    unsigned long long w[kMax];
+#pragma unroll
+    for (int q = 0; q < kMax; ++q)
+        if (q < nwords) w[q] = src[q];
+#pragma unroll
+    for (int q = 0; q < kMax; ++q)
+        if (q < nwords) dst[q] = w[q];
+#else
     int i = 0;
     for (; i + 8 <= nwords; i += 8) {
         unsigned long long w[8];
@@ -559,6 +574,7 @@ SSF_HD void ctrl_forward(const Ctrl *cin, Ctrl *cout, int nwords) {
         for (int q = 0; q < 8; ++q) dst[i + q] = w[q];
     }
     for (; i < nwords; ++i) dst[i] = src[i];
+#endif
 }
 
 // Control-block handling of a Manakov Row launch: evaluates the convergence sums the last column stage left
@@ -578,6 +594,7 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
     const int c_gscale = c.gscale, c_sparse = c.t_sparse;
     int n_state = c_state, n_final = c.final_, n_cap0 = c_cap0, n_hzv = c.hz_valid;
     int add_nonconv = 0, add_ahead = 0;
+    const long long c_nonconv = c.nonconv, c_ahead = c.n_ahead;      // (read before the block is forwarded: see mk_col_stage)
     double n_hz = c.hz;
     double *red = (double *)(ctx.lds) + 64;
     const bool lead = ctx.bid == 0 && ctx.tid == 0;
@@ -667,8 +684,8 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
         if (act && c_state == ST_AFTER_S) n->gscale = 0;
         n->hz_valid = n_hzv;
         n->hz = n_hz;
-        n->nonconv = c.nonconv + add_nonconv;
-        n->n_ahead = c.n_ahead + add_ahead;
+        n->nonconv = c_nonconv + add_nonconv;
+        n->n_ahead = c_ahead + add_ahead;
     }
     return act;
 }
@@ -1312,6 +1329,12 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
     c.hz = a.cin->hz;
     final_ = a.cin->final_ != 0;
     exact0 = a.k.exact_lim0 || a.cin->exact0 != 0;
+    // everything the lead thread's patches of the forwarded block need, read HERE (scalar loads next to the ones above): read
+    // after the block's stores they are vector loads the compiler must wait for one by one (cin and cout may alias for all it
+    // knows) -- up to five more memory round trips in front of the lead workgroup's own work
+    const int c_exact0 = a.cin->exact0, c_redo = a.cin->redo_;
+    const long long c_trace_n = a.cin->trace_n, c_steps = a.cin->steps, c_iters = a.cin->iterations;
+    const long long c_rebuilt = a.cin->n_rebuilt, c_recovered = a.cin->n_recovered;
     if (c.state == ST_NEED_S) {
         op = 0;
         do_fwd = true;
@@ -1365,30 +1388,30 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
             if (op == 5) n->t_sparse = 0;
             n->state = ST_ROW_ITER;
             n->it = 0;
-            n->final_ = a.cin->exact0 ? 0 : 1;                        // (exact0: rebuilt to measure lim_0, not as final)
-            n->redo_ = a.cin->exact0 ? 0 : 1;
+            n->final_ = c_exact0 ? 0 : 1;                        // (exact0: rebuilt to measure lim_0, not as final)
+            n->redo_ = c_exact0 ? 0 : 1;
             n->pend0 = n->pendn = 0;
-            n->n_rebuilt = a.cin->n_rebuilt + 1;
-            if (op == 5) n->n_recovered = a.cin->n_recovered + 1;
+            n->n_rebuilt = c_rebuilt + 1;
+            if (op == 5) n->n_recovered = c_recovered + 1;
         } else if (op == 2 && !final_) {
             n->state = ST_ROW_ITER;
             n->it = c.it + 1;
             n->pendn = 1;
             if (c.it == 0) {
                 n->pend0 = 1;
-                n->pend0_idx = a.cin->trace_n;
+                n->pend0_idx = c_trace_n;
                 n->bound0 = exact0 ? 0 : 1;
                 n->exact0 = 0;
             }
         } else if (op == 2) {                                         // the step ends here
-            const long long tn = a.cin->trace_n;
+            const long long tn = c_trace_n;
             if (tn < a.k.trace_cap) {
                 if (a.k.tr_hz) a.k.tr_hz[tn] = c.hz;
                 if (a.k.tr_it) a.k.tr_it[tn] = c.it + 1;
             }
             n->trace_n = tn + 1;
-            n->steps = a.cin->steps + 1;
-            n->iterations = a.cin->iterations + c.it + 1;
+            n->steps = c_steps + 1;
+            n->iterations = c_iters + c.it + 1;
             n->last_nit = c.it + 1;
             n->z = c.z + c.hz;
             n->cur = c.cur ^ 1;
@@ -1397,7 +1420,7 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
             if (c.it == 0) {
                 n->pend0 = 1;
                 n->pend0_idx = tn;
-                n->cap0 = a.cin->redo_ ? 0 : 1;
+                n->cap0 = c_redo ? 0 : 1;
                 n->bound0 = exact0 ? 0 : 1;      // (only recorded in a trace, and a trace makes it exact)
                 n->exact0 = 0;
             }
@@ -1478,6 +1501,7 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
     // ---- inverse column transform: G -> time samples in registers -------------------------
     TwSrc<T> tws;
     GTw gtw;
+    cx<T> e_pre{};
     if (do_inv) {
 #pragma unroll
         for (int q = 0; q < V; ++q) {
@@ -1486,6 +1510,10 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
             if ((q & 3) == 3) ctx.issue_fence();             // (appendix #43: the inter-pass twiddles are applied in this order, group by group)
 #endif
         }
+        // the one sample per thread that the bound of lim_0 compares with the field at the step start: fetched here, behind the
+        // spectrum, instead of where it is used -- there the load was issued and waited for on the spot (s_waitcnt vmcnt(0) right
+        // behind it: a whole memory round trip exposed in the middle of the first iterate's launch of every step)
+        if (kMk && (kgADV || kgFIN) && op == 2 && c.it == 0 && !exact0 && lim0_bound_sample<V>(0, g.b)) e_pre = g.ld(Tcur, g.rowbase + g.time_off(0));
         ctx.mark(1);
         if (a.prio) ctx.template setprio<3>();
         global_twiddle<+1, RAGGED>(g, a.log2N1 + a.log2N2, v, gtw);
@@ -1537,13 +1565,19 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
         } else if (kgADV || kgFIN) {                 // I: iterate `it` is in registers
             double n0 = 0, d0 = 0, n1 = 0, d1 = 0, psum = 0;
             if (c.it == 0) {                         // lim_0 against the field at the step start
+                // (exact: all samples, fetched together -- loaded where they are used, one by one, every load was waited for on
+                //  the spot: sixteen memory round trips in a row in the traced / maxIter = 1 / weak-nonlinearity runs)
+                cx<T> e[V];
+                if (exact0) {
+#pragma unroll
+                    for (int idx = 0; idx < V; ++idx) e[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
+                } else e[0] = e_pre;
 #pragma unroll
                 for (int idx = 0; idx < V; ++idx) {
                     if (exact0 || lim0_bound_sample<V>(idx, g.b)) {
-                        const cx<T> e = g.ld(Tcur, g.rowbase + g.time_off(idx));
-                        const double dr = (double)v[idx].re - (double)e.re, di = (double)v[idx].im - (double)e.im;
+                        const double dr = (double)v[idx].re - (double)e[idx].re, di = (double)v[idx].im - (double)e[idx].im;
                         n0 += dr * dr + di * di;
-                        d0 += (double)e.re * e.re + (double)e.im * e.im;
+                        d0 += (double)e[idx].re * e[idx].re + (double)e[idx].im * e[idx].im;
                     }
                 }
             }
@@ -1712,6 +1746,8 @@ template <int LG, int V = 16, int CI = 0, int SG = SG_ALL, class Ctx> SSF_HD voi
             if ((q & 3) == 3) ctx.issue_fence();             // (appendix #43: the inter-pass twiddles are applied in this order, group by group)
 #endif
         }
+        // (the sample of the lim_0 bound is NOT fetched ahead here as col_body does: in this kernel it costs -0.3 ... -2.1 %, 4 of 4,
+        //  where the double-precision stage gains +0.1 ... +1.3 %, 4 of 4: profiles/r5_ab_lim0_prefetch.txt)
         ctx.mark(1);
         global_twiddle<+1, false>(g, a.log2N1 + a.log2N2, v, gtw);
         fft_dif<+1, V, false, kCI>(ctx, p, g.b, v, lds, tws);
@@ -1747,15 +1783,19 @@ template <int LG, int V = 16, int CI = 0, int SG = SG_ALL, class Ctx> SSF_HD voi
         double n0 = 0, d0 = 0, n1 = 0, d1 = 0, psum = 0;
         const bool first = st.c.it == 0;
         if (first) {                                         // lim_0 against the field at the step start
+            cx<T> e[V];                                      // (exact: all samples fetched together, see col_body)
+            if (st.exact0) {
+#pragma unroll
+                for (int idx = 0; idx < V; ++idx) e[idx] = g.ld(Tcur, g.rowbase + g.time_off(idx));
+            } else if (lim0_bound_sample<V>(0, g.b)) e[0] = g.ld(Tcur, g.rowbase + g.time_off(0));
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) {
                 if (st.exact0 || lim0_bound_sample<V>(idx, g.b)) {
-                    const cx<T> e = g.ld(Tcur, g.rowbase + g.time_off(idx));
 #pragma unroll
                     for (int l = 0; l < 2; ++l) {
-                        const double dr = (double)v[idx].re[l] - (double)e.re[l], di = (double)v[idx].im[l] - (double)e.im[l];
+                        const double dr = (double)v[idx].re[l] - (double)e[idx].re[l], di = (double)v[idx].im[l] - (double)e[idx].im[l];
                         n0 += dr * dr + di * di;
-                        d0 += (double)e.re[l] * e.re[l] + (double)e.im[l] * e.im[l];
+                        d0 += (double)e[idx].re[l] * e[idx].re[l] + (double)e[idx].im[l] * e[idx].im[l];
                     }
                 }
             }
