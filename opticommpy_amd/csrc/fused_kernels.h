@@ -798,6 +798,9 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
 #ifndef SSF_EARLY_BASES
 #define SSF_EARLY_BASES 0
 #endif
+#ifndef SSF_SPEC_G
+#define SSF_SPEC_G 0
+#endif
 template <typename T> constexpr bool wt_rows() {
     return sizeof(scalar_t<T>) == 8 ? (SSF_WT_ROWS & 1) != 0 : sizeof(T) == 8 ? (SSF_WT_ROWS & 2) != 0 : (SSF_WT_ROWS & 4) != 0;
 }
@@ -1459,6 +1462,21 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
     struct { int state, it, cur, pcur; double z, hz; } c{};
     double *red = (double *)ctx.lds;
     ctx.mark(0);
+    ColGeom<T, LG, Ctx, RAGGED, V> g(ctx, a);
+    cx<T> v[V];
+#if SSF_SPEC_G
+    // The spectrum is fetched BEFORE the control block is looked at (its addresses do not depend on the state): the block was
+    // written by the previous launch on another XCD, so its first read at the start of a launch is a miss that 512 workgroups
+    // wait for before they know their stage -- one memory latency in front of every column launch's loads.  A launch that
+    // turns out to have nothing to do (or a rare stage that starts from the time-domain field) drops the values.
+    if (kMk) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+            if ((q & 3) == 3) ctx.issue_fence();
+        }
+    }
+#endif
     if (kMk) {
         MkColStage st;
         mk_col_stage(ctx, a, st, SG);
@@ -1481,11 +1499,9 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
         do_fwd = MODE == CM_NLSE_STEP || MODE == CM_NLSE_FIRST || MODE == CM_PLAIN_FWD;
     }
 
-    ColGeom<T, LG, Ctx, RAGGED, V> g(ctx, a);
     const PassPlan &p = g.p;
     cx<T> *lds = CI > 0 ? (cx<T> *)ctx.lds + (size_t)g.pol * CI * lds_slots_per_fft(p.L) + g.c
                         : (cx<T> *)ctx.lds + (size_t)(g.pol * g.C + g.c) * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
-    cx<T> v[V];
 
     // buffers by role (Manakov)
     cx<T> *Tcur = a.T0, *Tnew = a.T1;
@@ -1503,12 +1519,14 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
     GTw gtw;
     cx<T> e_pre{};
     if (do_inv) {
+        if (!(kMk && SSF_SPEC_G)) {
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-            v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+            for (int q = 0; q < V; ++q) {
+                v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
 #if SSF_LOAD_ORDER
-            if ((q & 3) == 3) ctx.issue_fence();             // (appendix #43: the inter-pass twiddles are applied in this order, group by group)
+                if ((q & 3) == 3) ctx.issue_fence();         // (appendix #43: the inter-pass twiddles are applied in this order, group by group)
 #endif
+            }
         }
         // the one sample per thread that the bound of lim_0 compares with the field at the step start: fetched here, behind the
         // spectrum, instead of where it is used -- there the load was issued and waited for on the spot (s_waitcnt vmcnt(0) right
@@ -1721,16 +1739,23 @@ template <int LG, int V = 16, int CI = 0, int SG = SG_ALL, class Ctx> SSF_HD voi
     constexpr bool kgH = (SG & SG_H) != 0, kgADV = (SG & SG_ADV) != 0, kgFIN = (SG & SG_FIN) != 0, kgRARE = (SG & SG_RARE) != 0;
     constexpr bool kFwd = kgH || kgADV || kgRARE;                     // (the final stage never transforms forward)
     ctx.mark(0);
+    ColGeom<T, LG, Ctx, false, V> g(ctx, a);
+    cx<T> v[V];
+#if SSF_SPEC_G
+#pragma unroll
+    for (int q = 0; q < V; ++q) {                            // (the spectrum ahead of the control block: see col_body)
+        v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
+        if ((q & 3) == 3) ctx.issue_fence();
+    }
+#endif
     MkColStage st;
     mk_col_stage(ctx, a, st, SG);
     if (st.op < 0) return;
     const int op = st.op;
     const bool final_ = kgFIN && (!kgADV || st.final_);
-    ColGeom<T, LG, Ctx, false, V> g(ctx, a);
     const PassPlan &p = g.p;
     cx<T> *lds = CI > 0 ? (cx<T> *)ctx.lds + g.c : (cx<T> *)ctx.lds + (size_t)g.c * lds_col_stride(p.L, g.C, (int)sizeof(cx<T>));
     double *red = (double *)ctx.lds;
-    cx<T> v[V];
     cx<T> *Tcur = st.c.cur ? a.T1 : a.T0;                    // field at the step start
     cx<T> *Tnew = st.c.cur ? a.T0 : a.T1;                    // receives the field at the step end
     const long long psz = g.N * a.ngroups;
@@ -1739,6 +1764,7 @@ template <int LG, int V = 16, int CI = 0, int SG = SG_ALL, class Ctx> SSF_HD voi
     TwSrc<T> tws;
     GTw gtw;
     if (st.do_inv) {
+#if !SSF_SPEC_G
 #pragma unroll
         for (int q = 0; q < V; ++q) {
             v[q] = g.ld(a.G, g.rowbase + g.freq_off(q));
@@ -1746,6 +1772,7 @@ template <int LG, int V = 16, int CI = 0, int SG = SG_ALL, class Ctx> SSF_HD voi
             if ((q & 3) == 3) ctx.issue_fence();             // (appendix #43: the inter-pass twiddles are applied in this order, group by group)
 #endif
         }
+#endif
         // (the sample of the lim_0 bound is NOT fetched ahead here as col_body does: in this kernel it costs -0.3 ... -2.1 %, 4 of 4,
         //  where the double-precision stage gains +0.1 ... +1.3 %, 4 of 4: profiles/r5_ab_lim0_prefetch.txt)
         ctx.mark(1);
