@@ -396,6 +396,7 @@ def measure(env, cfg, m):
                                "col_ADV": "stage-specialised kernel: a non-final iterate -> the next one (phases, convergence sums)",
                                "col_FIN": "stage-specialised kernel: the final iterate, observed and stored (inverse transform only)"}
             kernels["profiled_steps"] = int(stp[u0][1].steps)
+            kernels["outlier_launches_left_out"] = int(kt.outliers)   # (events more than 8 x their class median apart: a held-up stream)
             names = [k for k in ("row", "col_H", "col_ADV", "col_FIN") if k in kernels] if "col_ADV" in kernels else [k for k in ("row", "col") if k in kernels]
             if names:                                            # the kernel with the largest share of the device time
                 dom = max(names, key=lambda k: kernels[k]["total_ms"])

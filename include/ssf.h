@@ -309,6 +309,8 @@ typedef struct {
     int64_t row_n, col_n, other_n;
     double  col_h_ms, col_adv_ms, col_fin_ms;
     int64_t col_h_n, col_adv_n, col_fin_n;
+    int64_t outliers;       /* launches whose events were more than 8 x the median of their class apart (the stream was held up: a clock
+                               transition, the profiler, another process): counted here, left out of the sums above */
 } ssf_kernel_times;
 int  ssf_set_profiling(ssf_plan *plan, int32_t enable);
 int  ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out);

@@ -49,7 +49,7 @@ class KernelTimes(C.Structure):
     _fields_ = [("row_ms", C.c_double), ("col_ms", C.c_double), ("other_ms", C.c_double),
                 ("row_n", C.c_int64), ("col_n", C.c_int64), ("other_n", C.c_int64),
                 ("col_h_ms", C.c_double), ("col_adv_ms", C.c_double), ("col_fin_ms", C.c_double),
-                ("col_h_n", C.c_int64), ("col_adv_n", C.c_int64), ("col_fin_n", C.c_int64)]
+                ("col_h_n", C.c_int64), ("col_adv_n", C.c_int64), ("col_fin_n", C.c_int64), ("outliers", C.c_int64)]
 
 
 class RxParams(C.Structure):
