@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: the GPU suite, smoke and the driver's command on the final sources
+# GPU validation of a source tree: smoke(), the GPU suite, the driver's command three times.   gpurun --timeout 3000 -- "bash tools/gpu_validate.sh <tag>"
 cd "$(dirname "$0")/.."
 REPO=$PWD; O=$REPO/gpurun_out/${1:-r5_final}; mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/smoke.log
