@@ -35,7 +35,7 @@
  *   ssf_nlin_phase_rot                   nlinPhaseRot                     channels.py:471-493
  *   ssf_convergence_condition            convergenceCondition             channels.py:496-519
  *   ssf_fir_filter / ssf_fir_long / ssf_delay_signal / ssf_decimate / ssf_rx_run   receiver side, see below
- *   ssf_device_malloc / ssf_device_free / ssf_device_memcpy         device-resident arrays, see below
+ *   ssf_device_malloc / ssf_device_free / ssf_device_memcpy / ssf_device_axpy   device-resident arrays, see below
  *   ssf_wdm_tx                           simpleWDMTx signal path          optic/models/tx.py:178-217
  *   ssf_device_copy_bandwidth            (no reference equivalent) measured memory ceiling
  *   ssf_set_profiling / ssf_get_kernel_times   time.time() pairs around calls in
@@ -347,6 +347,9 @@ int  ssf_overlap_save(int device, int64_t sigLen, int32_t nrows, int32_t precisi
 int  ssf_device_malloc(int device, int64_t bytes, void **ptr);
 int  ssf_device_free(int device, void *ptr);
 int  ssf_device_memcpy(int device, void *dst, const void *src, int64_t bytes);
+/* y += alpha * x on n float64 values, host or device pointers (a device y is updated in place): balancedPD's i1 - i2
+ * (optic/models/devices.py:456-458) when the two photocurrents are device arrays */
+int  ssf_device_axpy(int device, int64_t n, double alpha, const double *x, double *y);
 
 /* ---- receiver side of the channel: FIR filtering, fractional delay,
  * decimation and the coherent front-end.  All arrays are host buffers, complex128 interleaved,

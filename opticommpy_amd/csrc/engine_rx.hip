@@ -38,6 +38,10 @@ __global__ void __launch_bounds__(256) k_rx_det(const DetKernelArgs a) {
     SSF_RX_CTX();
     det_body(ctx, a);
 }
+__global__ void __launch_bounds__(256) k_axpy(const AxpyArgs a) {
+    SSF_RX_CTX();
+    axpy_body(ctx, a);
+}
 __global__ void __launch_bounds__(256) k_rx_iqf(const IqfArgs a) {
     SSF_RX_CTX();
     iqf_body(ctx, a);
@@ -166,6 +170,10 @@ struct HipRxBackend {
     void launch_det(const DetKernelArgs &a) {
         k_rx_det<<<ew_grid(a.det.N * a.det.nm), 256, 0, st>>>(a);
         chk(hipGetLastError(), "launch k_rx_det");
+    }
+    void launch_axpy(const AxpyArgs &a) {
+        k_axpy<<<ew_grid(a.n), 256, 0, st>>>(a);
+        chk(hipGetLastError(), "launch k_axpy");
     }
     void launch_iqf(const IqfArgs &a) {
         k_rx_iqf<<<ew_grid(a.N * a.nm), 256, 0, st>>>(a);
@@ -337,6 +345,9 @@ int rx_fir(int device, int64_t sigLen, int ncols, int ntaps, const void *taps, c
 int rx_fir_long(int device, int64_t inLen, int64_t outLen, int ncols, int64_t ntaps, const void *taps, int64_t shift, const void *in,
                 void *out, std::string *err) {
     return with_core(device, err, [&](RxCore<Pooled> &c) { return c.fir_long(inLen, outLen, ncols, ntaps, taps, shift, in, out); });
+}
+int rx_axpy(int device, int64_t n, double alpha, const void *x, void *y, std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.axpy(n, alpha, x, y); });
 }
 int rx_overlap_save(int device, int64_t sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out,
                     std::string *err) {

@@ -217,6 +217,17 @@ template <class Ctx> SSF_HD void real_part_body(Ctx &ctx, const RealPartArgs &a)
     for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) a.out[n] = a.in[n].re;
 }
 
+// ---- y += alpha x on float64 arrays (balancedPD's i1 - i2 when the photocurrents are device arrays: devices.py:456-458)
+struct AxpyArgs {
+    const double *x;
+    double *y;
+    long long n;
+    double alpha;
+};
+template <class Ctx> SSF_HD void axpy_body(Ctx &ctx, const AxpyArgs &a) {
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < a.n; i += (long long)ctx.nblocks * ctx.nthreads) a.y[i] += a.alpha * a.x[i];
+}
+
 // =====================================================================================================
 // The two helpers of the Manakov step that the reference also exports on their own (SURVEY.md 8a rows 3, 4;
 // optic/models/channels.py:471-493 and 496-519, cupy twins optic/models/modelsGPU.py:514-561).  Inside

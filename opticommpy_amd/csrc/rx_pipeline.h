@@ -505,6 +505,22 @@ template <class Backend> struct RxCore {
         return SSF_OK;
     }
 
+    // y += alpha x, n float64 values, host or device pointers (a device y is updated in place)
+    int axpy(long long n, double alpha, const void *x, void *y) {
+        if (n < 1) return fail(SSF_ERR_BAD_ARG, "bad size");
+        const size_t nc = (size_t)(n + 1) / 2;                       // (dalloc counts complex values)
+        const double *dx = (const double *)resident(x, nc);
+        double *dy = be.is_resident(y) ? (double *)y : (double *)dalloc(nc);
+        if (!dx || !dy) return fail(SSF_ERR_OOM, "out of device memory");
+        if ((void *)dy != y) be.h2d_big(dy, y, sizeof(double) * (size_t)n);
+        AxpyArgs a{dx, dy, n, alpha};
+        be.launch_axpy(a);
+        be.sync();
+        if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
+        if ((void *)dy != y) be.d2h_big(y, dy, sizeof(double) * (size_t)n);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+
     // firFilter (core.py:87-125): 'same'-mode convolution of every column with the taps
     int fir(long long sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out) {
         if (sigLen < 1 || ncols < 1 || ntaps < 1) return fail(SSF_ERR_BAD_ARG, "bad size");

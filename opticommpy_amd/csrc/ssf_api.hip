@@ -574,6 +574,14 @@ int ssf_fir_long(int device, int64_t inLen, int64_t outLen, int32_t ncols, int64
     return rc ? set_err(rc, "ssf_fir_long: " + err) : SSF_OK;
 }
 
+int ssf_device_axpy(int device, int64_t n, double alpha, const double *x, double *y) {
+    if (!x || !y) return set_err(SSF_ERR_BAD_ARG, "ssf_device_axpy: NULL argument");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::rx_axpy(device, n, alpha, x, y, &err);
+    return rc ? set_err(rc, "ssf_device_axpy: " + err) : SSF_OK;
+}
+
 int ssf_delay_signal(int device, int64_t N, double delay, double Fs, const void *in, void *out) {
     if (!in || !out) return set_err(SSF_ERR_BAD_ARG, "ssf_delay_signal: NULL argument");
     if (int rc = rx_check_device(device)) return rc;

@@ -127,6 +127,7 @@ bool general_supports(int64_t N, int nrows, int precision);
 int rx_run(int device, int mode, int64_t N, int nmodes, const ssf_rx_params *p, const void *in0, const void *lo,
            const double *un, void *out, std::string *err);
 int rx_fir(int device, int64_t sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out, std::string *err);
+int rx_axpy(int device, int64_t n, double alpha, const void *x, void *y, std::string *err);
 int rx_fir_long(int device, int64_t inLen, int64_t outLen, int ncols, int64_t ntaps, const void *taps, int64_t shift, const void *in,
                 void *out, std::string *err);
 int rx_overlap_save(int device, int64_t sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out,

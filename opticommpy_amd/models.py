@@ -545,6 +545,7 @@ def edfa(Ei, param=None):
     assert G > 0, "EDFA gain should be a positive scalar"
     assert NF >= 3, "The minimal EDFA noise figure is 3 dB"
     G_lin, p_noise = _edfa_noise_power(G, NF, Fc, Fs)
+    _dev.host_only("edfa (by itself; inside ssfm / manakovSSF the amplifier runs on the device)", Ei)
     Ei = np.asarray(Ei)
     return Ei * np.sqrt(G_lin) + gaussianComplexNoise(Ei.shape, p_noise, seed)
 
@@ -559,6 +560,7 @@ def linearFiberChannel(Ei, param):
     param.D = getattr(param, "D", 17)
     param.Fc = getattr(param, "Fc", 193.1e12)
     param.returnParameters = getattr(param, "returnParameters", False)
+    _dev.host_only("linearFiberChannel (numpy in, numpy out: its field crosses the bus once each way)", Ei)
     Ei = np.asarray(Ei)
     N = Ei.shape[0]
     E2 = Ei.reshape(N, -1)

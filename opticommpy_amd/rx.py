@@ -213,6 +213,7 @@ def decimate(sigIn, param):
 def pbs(E, θ=0):
     """Polarisation beam splitter (optic/models/devices.py:223-260): 2x2 rotation, host glue.  Inside
     pdmCoherentReceiver the same rotation runs on the device."""
+    _dev.host_only("pbs", E)
     E = np.asarray(E)
     if E.ndim == 1:
         E = np.repeat(E, 2).reshape(-1, 2)
@@ -226,6 +227,7 @@ def pbs(E, θ=0):
 
 def opticalHybrid2x4(Es, Elo):
     """2x4 90-degree optical hybrid (optic/models/devices.py:462-500): constant 4x4 matrix, host glue."""
+    _dev.host_only("opticalHybrid2x4", Es, Elo)
     assert Es.shape == (len(Es),), "Es need to have a (N,) shape"
     assert Elo.shape == (len(Elo),), "Elo need to have a (N,) shape"
     assert Es.shape == Elo.shape, "Es and Elo need to have the same (N,) shape"
@@ -291,9 +293,11 @@ def photodiode(E, param=None, _unit_normals=None):
 def balancedPD(E1, E2, param=None, _unit_normals=None):
     """Balanced photodiode pair (optic/models/devices.py:402-459): i(E1) - i(E2)."""
     assert E1.shape == E2.shape, "E1 and E2 need to have the same shape"
-    if len(E1.shape) != 1:
+    if len(E1.shape) != 1 or _dev.is_device(E1) or _dev.is_device(E2):
         # (N, M) fields: each photodiode sums |E|^2 over its modes (devices.py:355-357), the second one with seed + 1
-        # (devices.py:447-456): two launches of the photodiode pipeline, the difference on the host / device
+        # (devices.py:447-456): two launches of the photodiode pipeline, the difference on the host / device.  Device arrays of any
+        # shape go this way too (the reference's own formulation, i1 - i2): stacking them for the one-launch path below would
+        # take them through the host
         param2 = param
         if param is not None and getattr(param, "seed", None) is not None:
             param2 = copy.copy(param)
@@ -301,10 +305,13 @@ def balancedPD(E1, E2, param=None, _unit_normals=None):
         un = _unit_normals
         i1 = photodiode(E1, param, None if un is None else un[0:1])
         i2 = photodiode(E2, param2, None if un is None else un[1:2])
-        if _dev.is_device(i1):
-            d = _dev.empty(True, i1.shape, np.float64)
-            d.set(i1.get() - i2.get())
-            return d
+        if _dev.is_device(i1) or _dev.is_device(i2):
+            if not _dev.is_device(i1):
+                i1 = _dev.to_device(i1)
+            xp, _keep = _dev.arg(i2, np.float64)
+            lib = _lib.load()
+            _lib.raise_for(lib, None, lib.ssf_device_axpy(i1.device, i1.size, -1.0, xp, i1.ptr))    # i1 -= i2, in HBM
+            return i1
         return i1 - i2
     p = _pd_fields(_lib.RxParams(), param)
     return _rx(_MODE["balancedPD"], len(E1), 2, p, np.stack([E1, E2], axis=1), None, _unit_normals, (len(E1),), np.float64, 2)

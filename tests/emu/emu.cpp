@@ -277,6 +277,7 @@ struct EmuBackend {
                  [&](EmuCtx &c) { ssf::rx::rx_ols_body(c, a); });
     }
     void launch_det(const ssf::rx::DetKernelArgs &a) { ++launches; run_grid(ew_grid(a.det.N * a.det.nm), 64, 64, [&](EmuCtx &c) { ssf::rx::det_body(c, a); }); }
+    void launch_axpy(const ssf::rx::AxpyArgs &a) { run_grid(ew_grid(a.n), 64, 64, [&](EmuCtx &c) { ssf::rx::axpy_body(c, a); }); }
     void launch_iqf(const ssf::rx::IqfArgs &a) { ++launches; run_grid(ew_grid(a.N * a.nm), 64, 64, [&](EmuCtx &c) { ssf::rx::iqf_body(c, a); }); }
     bool is_resident(const void *) const { return true; }      // (the emulator's "device" memory is the host's)
     void *filter_lookup(const void *, size_t) { return nullptr; }                  // (no filter cache: every call builds its own)

@@ -138,3 +138,15 @@ def test_set_power_for_par_ssfm():
     out = oa.setPowerforParSSFM(sig, np.array([0.0, 3.0]))
     pw = np.mean(np.abs(out) ** 2, axis=0)
     np.testing.assert_allclose(pw, [0.5e-3, 0.5e-3, 0.5e-3 * 10 ** 0.3, 0.5e-3 * 10 ** 0.3], rtol=1e-12)
+
+
+def test_host_glue_functions_refuse_device_arrays_instead_of_downloading_them_silently():
+    import numpy as np
+    import opticommpy_amd as oa
+    d = object.__new__(oa.DeviceArray)                      # (no GPU needed: the check is on the type)
+    d.shape, d.dtype, d.device, d._ptr, d._owner = (8, 2), np.dtype(np.complex128), 0, None, d
+    p = oa.parameters()
+    p.Fs = 1e9
+    for f in (lambda: oa.pbs(d), lambda: oa.opticalHybrid2x4(d, d), lambda: oa.edfa(d, p), lambda: oa.linearFiberChannel(d, p)):
+        with pytest.raises(TypeError, match="host glue|numpy in"):
+            f()

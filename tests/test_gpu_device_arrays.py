@@ -99,3 +99,28 @@ def test_chain_on_the_device_equals_chain_through_the_host(capsys):
     with capsys.disabled():
         print(f"\n[chain] 100-step channel + PDM receiver + EDC + decimate at N=2^20: through the host {th*1e3:.1f} ms, "
               f"device-resident {td*1e3:.1f} ms")
+
+
+def test_balanced_photodiodes_on_device_arrays_never_visit_the_host():
+    """balancedPD (optic/models/devices.py:402-459) with DeviceArray fields, 1-D and (N, M): i1 - i2 is formed on the device
+    (ssf_device_axpy); stacking the two fields or subtracting through numpy would have taken them through the host.  Same values as
+    the host-array call (the one-launch path subtracts before the common low-pass filter: equal to rounding)."""
+    from opticommpy_amd import device as odev
+    rng = np.random.default_rng(12)
+    N = 1 << 14
+    E1 = (rng.normal(size=N) + 1j * rng.normal(size=N)) * 0.03
+    E2 = (rng.normal(size=N) + 1j * rng.normal(size=N)) * 0.03
+    p = bag(Fs=128e9, B=30e9, shotNoise=False, thermalNoise=False)
+    ref = oa.balancedPD(E1, E2, p)
+    d1, d2 = oa.to_device(E1), oa.to_device(E2)
+    n0 = odev.transfer_counts()
+    out = oa.balancedPD(d1, d2, p)
+    assert odev.transfer_counts() == n0 and isinstance(out, oa.DeviceArray) and out.dtype == np.float64 and out.shape == (N,)
+    assert np.max(np.abs(out.get() - ref)) <= 1e-12 * np.max(np.abs(ref))
+    F1, F2 = np.stack([E1, E2], axis=1), np.stack([E2, E1], axis=1)
+    ref2 = oa.balancedPD(F1, F2, p)
+    n0 = odev.transfer_counts()
+    out2 = oa.balancedPD(oa.to_device(F1), oa.to_device(F2), p)
+    n1 = odev.transfer_counts()
+    assert n1["d2h"] == n0["d2h"] and isinstance(out2, oa.DeviceArray)
+    assert np.max(np.abs(out2.get() - ref2)) <= 1e-12 * np.max(np.abs(ref2))
