@@ -111,7 +111,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_amp(const AmpArgs
 
 template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT) k_ols(const OlsArgs<T> a) {
     SSF_DEV_CTX(1);
-    ols_body<T>(ctx, a);
+    ols_body<T, 0, 1>(ctx, a);
 }
 
 #if SSF_EXPERIMENTS
@@ -792,6 +792,7 @@ int overlap_save_t(int64_t sigLen, int nrows, int lg, int K, const void *Hfft, c
         Hs[(size_t)i].re = ((const Cc *)Hfft)[i].re / (T)nfft;
         Hs[(size_t)i].im = ((const Cc *)Hfft)[i].im / (T)nfft;
     }
+    ols_permute_filter(Hs.data(), lg);                                               // (the order ols_body_x reads)
     Stager stg;
     (void)stg.init();
     if ((e = stg.h2d(din, in, sig_bytes, st)) != hipSuccess) return fail_("upload", e);

@@ -3,6 +3,7 @@
 // stream per call; stages are enqueued back to back and nothing is read back between them (the
 // decimator's sampling-phase decision is the one exception: 8 x SpSin doubles).
 #include <cstring>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -25,14 +26,14 @@ struct RxCtx : DevCtxCore {
     extern __shared__ __attribute__((aligned(16))) char ssf_smem[];           \
     RxCtx ctx{{(int)threadIdx.x, (int)blockIdx.x, (int)blockDim.x, (int)gridDim.x, ssf_smem}}
 
-template <int MAXT> __global__ void __launch_bounds__(MAXT) k_rx_ols(const fused::OlsArgs<double> a) {
+template <int LG, int C> __global__ void __launch_bounds__(fused::ols_threads(LG, C)) k_rx_ols(const fused::OlsArgs<double> a) {
     SSF_RX_CTX();
-    fused::ols_body<double>(ctx, a);
+    fused::ols_body<double, LG, C>(ctx, a);
 }
 // the coherent receivers' filters with the stages around them in their loads / stores (rx_kernels.h: rx_ols_body)
-template <int MAXT> __global__ void __launch_bounds__(MAXT) k_rx_ols_fused(const RxOlsArgs a) {
+template <int LG, int C, int PRE, int NOISE> __global__ void __launch_bounds__(fused::ols_threads(LG, C)) k_rx_ols_fused(const RxOlsArgs a) {
     SSF_RX_CTX();
-    rx_ols_body(ctx, a);
+    rx_ols_body<LG, C, PRE, NOISE>(ctx, a);
 }
 __global__ void __launch_bounds__(256) k_rx_det(const DetKernelArgs a) {
     SSF_RX_CTX();
@@ -92,7 +93,6 @@ struct HipRxBackend {
     hipError_t first_err = hipSuccess;
     std::string where;
     Stager stg;
-    bool armed = false;
     void chk(hipError_t e, const char *what) {
         if (e != hipSuccess && first_err == hipSuccess) {
             first_err = e;
@@ -138,33 +138,30 @@ struct HipRxBackend {
         const long long g = (n + 255) / 256;
         return (unsigned)(g < 1 ? 1 : g > 4096 ? 4096 : g);
     }
+    // one instantiation per transform size and columns-per-group (fused_kernels.h: ols_launch / ols_dispatch); a kernel's
+    // dynamic-LDS limit is raised the first time this device launches it
+    std::set<const void *> armed;
+    template <class K> void arm(K kernel) {
+        if (!armed.insert((const void *)kernel).second) return;
+        chk(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
+    }
     void launch_ols(const fused::OlsArgs<double> &a) {
-        const int nfft = 1 << a.log2nfft, tpf = nfft / 16;
-        const int block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
-        const long long grid = (a.njobs + fpw - 1) / fpw;
-        const size_t lds = (size_t)fpw * fused::lds_slots_per_fft(nfft) * sizeof(Cd);
-        if (!armed) {
-            chk(hipFuncSetAttribute((const void *)k_rx_ols<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
-            chk(hipFuncSetAttribute((const void *)k_rx_ols<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
-            armed = true;
-        }
-        if (block <= 256) k_rx_ols<256><<<(unsigned)grid, block, lds, st>>>(a);
-        else k_rx_ols<1024><<<(unsigned)grid, block, lds, st>>>(a);
+        const fused::OlsLaunch o = fused::ols_launch(a.log2nfft, a.nrows, a.njobs);
+        fused::ols_dispatch(o, [&](auto lg, auto cc) {
+            constexpr int LG = decltype(lg)::value, C = decltype(cc)::value;
+            arm(k_rx_ols<LG, C>);
+            k_rx_ols<LG, C><<<(unsigned)o.grid, o.threads, o.lds_bytes, st>>>(a);
+        });
         chk(hipGetLastError(), "launch k_rx_ols");
     }
-    bool armed_fused = false;
     void launch_rx_ols(const RxOlsArgs &a) {
-        const int nfft = 1 << a.o.log2nfft, tpf = nfft / 16;
-        const int block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
-        const long long grid = (a.o.njobs + fpw - 1) / fpw;
-        const size_t lds = (size_t)fpw * fused::lds_slots_per_fft(nfft) * sizeof(Cd);
-        if (!armed_fused) {
-            chk(hipFuncSetAttribute((const void *)k_rx_ols_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
-            chk(hipFuncSetAttribute((const void *)k_rx_ols_fused<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
-            armed_fused = true;
-        }
-        if (block <= 256) k_rx_ols_fused<256><<<(unsigned)grid, block, lds, st>>>(a);
-        else k_rx_ols_fused<1024><<<(unsigned)grid, block, lds, st>>>(a);
+        const fused::OlsLaunch o = fused::ols_launch(a.o.log2nfft, a.o.nrows, a.o.njobs);
+        const bool found = rx_ols_dispatch(a, o, [&](auto lg, auto cc, auto pre, auto noise) {
+            constexpr int LG = decltype(lg)::value, C = decltype(cc)::value, PRE = decltype(pre)::value, NOISE = decltype(noise)::value;
+            arm(k_rx_ols_fused<LG, C, PRE, NOISE>);
+            k_rx_ols_fused<LG, C, PRE, NOISE><<<(unsigned)o.grid, o.threads, o.lds_bytes, st>>>(a);
+        });
+        if (!found) chk(hipErrorInvalidConfiguration, "k_rx_ols_fused: no kernel for this stage / transform size");
         chk(hipGetLastError(), "launch k_rx_ols_fused");
     }
     void launch_det(const DetKernelArgs &a) {

@@ -1981,22 +1981,34 @@ template <typename T> SSF_HD void ols_defaults(OlsArgs<T> &a) {
 // pre(src, m): input sample `src` (an index into the unpadded, un-stuffed signal, 0 <= src < inLen) of column m;
 // post(n, m, v): output sample n (after roll and cut) of column m.  The receiver pipeline plugs the stages in front of and behind
 // a filter in here (rx_kernels.h: PBS rotation / detection in the loads, IQ mixing in the stores): one pass over the signal less each.
-template <typename T, class Ctx, class Pre, class Post>
+//
+// LG > 0: the transform size is a compile-time constant (the pass plan, every register index and the twiddle bases fold; with
+// the plan read from the arguments -- LG = 0, kept for transforms below 256 points and the single-precision host path -- the
+// value array is indexed at run time and lives in scratch memory).  C: columns of ONE block handled side by side by neighbouring
+// lanes (lane = butterfly * C + column): the 16-byte samples of the C columns of a row of the (N, ld) signal are neighbours in
+// memory, so a wave's loads and stores cover whole rows instead of every C-th 16-byte piece; the C transforms are interleaved
+// in LDS (lds_put / lds_get's CI).  H is stored in REGISTER order (ols_permute_filter below): thread b's value idx reads
+// H[idx * tpf + b], consecutive lanes consecutive entries -- in natural order the digit-reversed positions of neighbouring
+// lanes are a transform-stride apart (sixteen 64-line gathers per thread).
+template <typename T, int LG, int C, class Ctx, class Pre, class Post>
 SSF_HD void ols_body_x(Ctx &ctx, const OlsArgs<T> &a, const Pre &pre, const Post &post) {
-    const PassPlan p = make_plan(a.log2nfft);
-    const int fpw = ctx.nthreads / p.tpf;
-    const int f = ctx.tid / p.tpf, b = ctx.tid % p.tpf;
-    const long long job = (long long)ctx.bid * fpw + f;
-    const bool live = job < a.njobs;                     // idle threads still take part in the barriers
-    const long long jb = live ? job / a.nrows : 0;
-    const int m = live ? (int)(job - jb * a.nrows) : 0;
+    const PassPlan p = make_plan(LG > 0 ? LG : a.log2nfft);
+    const int tpg = p.tpf * C;                               // threads per group = the C columns of one block
+    const int gpw = ctx.nthreads / tpg;
+    const int g = ctx.tid / tpg, r = ctx.tid - g * tpg, b = r / C, c = r - b * C;
+    const int ncg = a.nrows / C;                             // column groups per block (launchers: nrows % C == 0)
+    const long long job = (long long)ctx.bid * gpw + g;
+    const bool live = job < a.njobs / C;                     // idle threads still take part in the barriers
+    const long long jb = !live ? 0 : ncg == 1 ? job : job / ncg;
+    const int m = (live ? (int)(job - jb * ncg) * C : 0) + c;
     const long long blk = jb + a.blk0;
-    cx<T> *l = (cx<T> *)ctx.lds + (size_t)f * lds_slots_per_fft(p.L);
-    const cx<T> *H = a.H + (size_t)m * a.Hstride;
+    cx<T> *l = (cx<T> *)ctx.lds + (size_t)g * C * lds_slots_per_fft(p.L) + c;
+    const cx<T> *H = a.H + (size_t)m * a.Hstride + b;
+    const long long i0 = blk * a.d - a.discard;              // index of the block's first sample in the unpadded signal
     cx<T> v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const long long i = blk * a.d + (b + p.tpf * q) - a.discard;      // index into the unpadded signal
+        const long long i = i0 + (b + p.tpf * q);
         bool have = live && i >= 0 && i < a.inLen;
         long long src = i;
         if (a.in_up > 1) {                                                // zero-stuffed input, never materialised
@@ -2005,15 +2017,16 @@ SSF_HD void ols_body_x(Ctx &ctx, const OlsArgs<T> &a, const Pre &pre, const Post
         }
         v[q] = have ? pre(src, m) : mk<T>((T)0, (T)0);
     }
-    fft_dif<-1>(ctx, p, b, v, l);
-    const int last = p.npass - 1;
+    TwSrc<T> tws;                                            // the inverse transform conjugates the forward one's bases
+    fft_dif<-1, 16, false, C>(ctx, p, b, v, l, tws);
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * H[rev_pos(p, reg_pos(p, last, b, idx))];
-    fft_dit<+1>(ctx, p, b, v, l);
+    for (int idx = 0; idx < 16; ++idx) v[idx] = v[idx] * H[idx * p.tpf];
+    fft_dit<+1, 16, false, C>(ctx, p, b, v, l, tws);
+    const long long n0 = i0 - a.D - a.Dx;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int pos = b + p.tpf * q;
-        long long n = blk * a.d + pos - a.discard - a.D - a.Dx;
+        long long n = n0 + pos;
         if (live && pos >= a.discard && n >= 0 && n < a.sigLen) {
             n -= a.roll;
             if (n < 0) n += a.sigLen;
@@ -2021,13 +2034,66 @@ SSF_HD void ols_body_x(Ctx &ctx, const OlsArgs<T> &a, const Pre &pre, const Post
         }
     }
 }
-template <typename T, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T> &a) {
-    ols_body_x<T>(
+template <typename T, int LG, int C, class Ctx> SSF_HD void ols_body(Ctx &ctx, const OlsArgs<T> &a) {
+    ols_body_x<T, LG, C>(
         ctx, a, [&](long long src, int m) { return a.in[src * a.in_ld + m]; },
         [&](long long n, int m, cx<T> v) {
             cx<T> *o = a.out + n * a.out_ld + m;
             *o = a.acc ? *o + v : v;
         });
+}
+
+// natural order -> the order ols_body_x reads (host side, where a filter is built): out[idx * tpf + b] = H[k(b, idx)], k the
+// frequency index that value idx of thread b holds after the forward (DIF) transform
+template <typename Z> inline void ols_permute_filter(Z *H, int log2nfft) {
+    const PassPlan p = make_plan(log2nfft);
+    const int last = p.npass - 1;
+    Z *tmp = new Z[(size_t)p.L];
+    for (int b = 0; b < p.tpf; ++b)
+        for (int idx = 0; idx < 16; ++idx) tmp[(size_t)idx * p.tpf + b] = H[rev_pos(p, reg_pos(p, last, b, idx))];
+    for (int i = 0; i < p.L; ++i) H[i] = tmp[i];
+    delete[] tmp;
+}
+
+// Launch geometry of the complex128 overlap-save kernels, shared by the HIP backend and the test emulator.  Transforms of
+// 256 ... 8192 points get their own instantiation; an even number of columns is taken two at a time while two transforms fit the
+// LDS (4096 points: 2 x 68 KiB).
+constexpr int kOlsMinLg = 8, kOlsMaxLg = 13, kOlsMaxPairLg = 12;
+struct OlsLaunch {
+    int lg, C, threads;          // lg = 0: the run-time plan
+    long long grid;
+    size_t lds_bytes;
+};
+inline OlsLaunch ols_launch(int log2nfft, int nrows, long long njobs) {
+    OlsLaunch o;
+    const int nfft = 1 << log2nfft, tpf = nfft / 16;
+    o.lg = log2nfft >= kOlsMinLg && log2nfft <= kOlsMaxLg ? log2nfft : 0;
+    o.C = o.lg && o.lg <= kOlsMaxPairLg && nrows % 2 == 0 ? 2 : 1;
+    o.threads = o.C * tpf > 256 ? o.C * tpf : 256;
+    const int gpw = o.threads / (o.C * tpf);
+    o.grid = (njobs / o.C + gpw - 1) / gpw;
+    o.lds_bytes = (size_t)gpw * o.C * lds_slots_per_fft(nfft) * sizeof(cx<double>);
+    return o;
+}
+constexpr int ols_threads(int LG, int C) { return LG == 0 ? 256 : (C << (LG - 4)) > 256 ? (C << (LG - 4)) : 256; }
+// f(integral_constant<LG>, integral_constant<C>) for the instantiation a launch needs
+template <class F> inline void ols_dispatch(const OlsLaunch &o, F &&f) {
+    using std::integral_constant;
+#define SSF_OLS_CASE(L)                                                       \
+    case L:                                                                   \
+        if (o.C == 2) f(integral_constant<int, L>{}, integral_constant<int, 2>{}); \
+        else f(integral_constant<int, L>{}, integral_constant<int, 1>{});     \
+        break;
+    switch (o.lg) {
+        SSF_OLS_CASE(8)
+        SSF_OLS_CASE(9)
+        SSF_OLS_CASE(10)
+        SSF_OLS_CASE(11)
+        SSF_OLS_CASE(12)
+    case 13: f(integral_constant<int, 13>{}, integral_constant<int, 1>{}); break;
+    default: f(integral_constant<int, 0>{}, integral_constant<int, 1>{}); break;
+    }
+#undef SSF_OLS_CASE
 }
 
 }  // namespace fused

@@ -22,6 +22,9 @@ using fused::cx;
 using fused::mk;
 typedef cx<double> Cd;
 
+// element i (0 or 1) of a two-entry kernel-argument array: a run-time subscript would move the whole argument block into scratch
+template <typename V> SSF_HD V sel2(const V (&a)[2], int i) { return i ? a[1] : a[0]; }
+
 // ---- photodiode model shared by every detection mode (devices.py:352-399, without the filter)
 struct PdModel {
     double R, IpdSat;
@@ -32,10 +35,12 @@ struct PdModel {
     unsigned long long seed;       // device noise (Philox), used when `un` is null
     const double *un;    // host-supplied unit normals, [(pd * 2 + kind) * N + n], or null
 };
-SSF_HD double pd_current_pw(const PdModel &m, double pw, long long n, long long N, int pd) {
+// NOISE: 0 = the caller knows that neither noise source is on (the generator is not even compiled in: the fused receiver
+// kernels unroll sixteen of these per thread), 1 / 2 = look at the model
+template <int NOISE = 2> SSF_HD double pd_current_pw(const PdModel &m, double pw, long long n, long long N, int pd) {
     double i = m.R * pw;
     if (m.saturate && i > m.IpdSat) i = m.IpdSat;
-    if (m.shot || m.thermal) {
+    if (NOISE != 0 && (m.shot || m.thermal)) {
         double us, ut;
         if (m.un) {
             us = m.un[(size_t)(pd * 2) * N + n];
@@ -49,8 +54,8 @@ SSF_HD double pd_current_pw(const PdModel &m, double pw, long long n, long long 
     return i;
 }
 
-SSF_HD double pd_current(const PdModel &m, Cd e, long long n, long long N, int pd) {
-    return pd_current_pw(m, e.re * e.re + e.im * e.im, n, N, pd);
+template <int NOISE = 2> SSF_HD double pd_current(const PdModel &m, Cd e, long long n, long long N, int pd) {
+    return pd_current_pw<NOISE>(m, e.re * e.re + e.im * e.im, n, N, pd);
 }
 
 enum { RX_PHOTODIODE = 0, RX_BALANCED = 1 };
@@ -112,7 +117,7 @@ struct DetArgs {
     PdModel pd;
 };
 // the detected sample sI + j sQ of polarisation p at time n (devices.py:487-499, 562-563; photodiode slots as front_body)
-SSF_HD Cd det_sample(const DetArgs &a, long long n, int p) {
+template <int NOISE = 2> SSF_HD Cd det_sample(const DetArgs &a, long long n, int p) {
     Cd es;
     if (a.pbs) {
         const Cd e0 = a.in0[2 * n], e1 = a.in0[2 * n + 1];
@@ -120,15 +125,16 @@ SSF_HD Cd det_sample(const DetArgs &a, long long n, int p) {
                     : mk<double>(e1.re * a.c - e0.re * a.s, e1.im * a.c - e0.im * a.s);
     } else es = a.in0[n * a.nm + p];
     Cd lo = a.lo[n];
-    es = mk<double>(es.re * a.es_scale[p], es.im * a.es_scale[p]);
-    lo = mk<double>(lo.re * a.lo_scale[p], lo.im * a.lo_scale[p]);
+    const double ks = sel2(a.es_scale, p), kl = sel2(a.lo_scale, p);
+    es = mk<double>(es.re * ks, es.im * ks);
+    lo = mk<double>(lo.re * kl, lo.im * kl);
     const Cd e0 = mk<double>(0.5 * es.re - 0.5 * lo.re, 0.5 * es.im - 0.5 * lo.im);      //  Es/2 -  Elo/2
     const Cd e1 = mk<double>(-0.5 * es.im - 0.5 * lo.im, 0.5 * es.re + 0.5 * lo.re);     // jEs/2 + jElo/2
     const Cd e2 = mk<double>(-0.5 * es.im - 0.5 * lo.re, 0.5 * es.re - 0.5 * lo.im);     // jEs/2 -  Elo/2
     const Cd e3 = mk<double>(-0.5 * es.re - 0.5 * lo.im, -0.5 * es.im + 0.5 * lo.re);    // -Es/2 + jElo/2
     const int base = 4 * p;
-    const double sI = pd_current(a.pd, e1, n, a.N, base) - pd_current(a.pd, e0, n, a.N, base + 1);
-    const double sQ = pd_current(a.pd, e2, n, a.N, base + 2) - pd_current(a.pd, e3, n, a.N, base + 3);
+    const double sI = pd_current<NOISE>(a.pd, e1, n, a.N, base) - pd_current<NOISE>(a.pd, e0, n, a.N, base + 1);
+    const double sQ = pd_current<NOISE>(a.pd, e2, n, a.N, base + 2) - pd_current<NOISE>(a.pd, e3, n, a.N, base + 3);
     return mk<double>(sI, sQ);
 }
 // IQ imbalance (core.py:952-960): s' = k1 s + k2 conj(s)
@@ -146,32 +152,57 @@ struct RxOlsArgs {
     long long N;              // POST_IQF: signal length -- the last sample is zero, as delaySignal's np.roll(-1) of an unpadded
                               // signal leaves it when the skew is zero (core.py:905-922: y[N - 1] = conv[0] = x[-1] = 0)
 };
-template <class Ctx> SSF_HD void rx_ols_body(Ctx &ctx, const RxOlsArgs &a) {
-    fused::ols_body_x<double>(
+// PRE (and, for the detection, whether the photodiodes are noisy) are compile-time: the load loop of ols_body_x carries sixteen
+// copies of the stage, and with every stage's code in every kernel the compiler gave up unrolling it (the value array then
+// lived in scratch memory)
+template <int LG, int C, int PRE, int NOISE, class Ctx> SSF_HD void rx_ols_body(Ctx &ctx, const RxOlsArgs &a) {
+    fused::ols_body_x<double, LG, C>(
         ctx, a.o,
         [&](long long src, int m) -> Cd {
-            if (a.pre == PRE_PBS) {
+            if constexpr (PRE == PRE_PBS) {
                 const Cd e0 = a.det.in0[2 * src], e1 = a.det.in0[2 * src + 1];
                 return m == 0 ? mk<double>(e0.re * a.det.c + e1.re * a.det.s, e0.im * a.det.c + e1.im * a.det.s)
                               : mk<double>(e1.re * a.det.c - e0.re * a.det.s, e1.im * a.det.c - e0.im * a.det.s);
-            }
-            if (a.pre == PRE_DET) return det_sample(a.det, src, m);
-            if (a.pre == PRE_IQ) {                       // column m = 2 p + part: the real (I) or imaginary (Q) part of s'_p, as a real signal
+            } else if constexpr (PRE == PRE_DET) {
+                return det_sample<NOISE>(a.det, src, m);
+            } else if constexpr (PRE == PRE_IQ) {        // column m = 2 p + part: the real (I) or imaginary (Q) part of s'_p, as a real signal
                 const int pl = a.pol0 + (m >> 1);
-                const Cd t = iq_mix(a.k1[pl], a.k2[pl], a.o.in[src * a.nm + pl]);
+                const Cd t = iq_mix(sel2(a.k1, pl), sel2(a.k2, pl), a.o.in[src * a.nm + pl]);
                 return mk<double>((m & 1) ? t.im : t.re, 0.0);
-            }
-            return a.o.in[src * a.o.in_ld + m];
+            } else return a.o.in[src * a.o.in_ld + m];
         },
         [&](long long n, int m, Cd v) {
             if (a.post == POST_IQF) {
-                const Cd t = iq_mix(a.k1[m], a.k2[m], v);
+                const Cd t = iq_mix(sel2(a.k1, m), sel2(a.k2, m), v);
                 a.o.out[n * a.o.out_ld + m] = n == a.N - 1 ? mk<double>(0.0, 0.0) : t;
             } else if (a.post == POST_PART) {            // S_p = Re(filtered I) + j Re(filtered Q)   (core.py:963-968)
                 double *o = (double *)(a.o.out + n * a.nm + a.pol0 + (m >> 1));
                 o[m & 1] = v.re;
             } else a.o.out[n * a.o.out_ld + m] = v;
         });
+}
+// f(LG, C, PRE, NOISE) -- integral constants -- for the instantiation a fused launch needs; false: no such kernel (the pipeline
+// only asks for the delay-filter geometry, kDelayNfft points and two columns at a time, around PRE_PBS / PRE_IQ)
+template <class F> inline bool rx_ols_dispatch(const RxOlsArgs &a, const fused::OlsLaunch &o, F &&f) {
+    using std::integral_constant;
+    if (o.lg == 0) return false;
+    if (a.pre == PRE_DET) {
+        const bool noisy = a.det.pd.shot || a.det.pd.thermal;
+        fused::ols_dispatch(o, [&](auto lg, auto cc) {
+            if (noisy) f(lg, cc, integral_constant<int, PRE_DET>{}, integral_constant<int, 1>{});
+            else f(lg, cc, integral_constant<int, PRE_DET>{}, integral_constant<int, 0>{});
+        });
+        return true;
+    }
+    if (o.C != 2 || (o.lg != 11 && o.lg != 12)) return false;
+    auto stage = [&](auto lg) {
+        if (a.pre == PRE_PBS) f(lg, integral_constant<int, 2>{}, integral_constant<int, PRE_PBS>{}, integral_constant<int, 0>{});
+        else f(lg, integral_constant<int, 2>{}, integral_constant<int, PRE_IQ>{}, integral_constant<int, 0>{});
+    };
+    if (a.pre != PRE_PBS && a.pre != PRE_IQ) return false;
+    if (o.lg == 11) stage(integral_constant<int, 11>{});
+    else stage(integral_constant<int, 12>{});
+    return true;
 }
 // detection without a filter behind it (ideal photodiodes / bandwidthLimitation off): one element-wise pass
 struct DetKernelArgs {
@@ -186,7 +217,7 @@ template <class Ctx> SSF_HD void det_body(Ctx &ctx, const DetKernelArgs &a) {
         const long long n = i / a.det.nm;
         const int p = (int)(i - n * a.det.nm);
         Cd v = det_sample(a.det, n, p);
-        if (a.iqf) v = n == a.det.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(a.k1[p], a.k2[p], v);
+        if (a.iqf) v = n == a.det.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(sel2(a.k1, p), sel2(a.k2, p), v);
         a.out[i] = v;
     }
 }
@@ -203,7 +234,7 @@ template <class Ctx> SSF_HD void iqf_body(Ctx &ctx, const IqfArgs &a) {
     for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < total; i += (long long)ctx.nblocks * ctx.nthreads) {
         const long long n = i / a.nm;
         const int p = (int)(i - n * a.nm);
-        a.out[i] = n == a.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(a.k1[p], a.k2[p], a.in[i]);
+        a.out[i] = n == a.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(sel2(a.k1, p), sel2(a.k2, p), a.in[i]);
     }
 }
 

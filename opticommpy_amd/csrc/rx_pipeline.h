@@ -88,6 +88,9 @@ inline std::vector<zc> ols_filter_from_taps(const zc *taps, int K, int nfft) {
     for (int i = 0; i < K; ++i) h[(size_t)i] = taps[i];
     host_fft(h, -1);
     for (auto &v : h) v /= (double)nfft;
+    int lg = 0;
+    while ((1 << lg) < nfft) ++lg;
+    fused::ols_permute_filter(h.data(), lg);                         // the order the kernel reads (fused_kernels.h: ols_body_x)
     return h;
 }
 
@@ -127,9 +130,14 @@ inline OlsGeom ols_geometry(long long sigLen, int K, int nfft) {
 inline int fir_nfft(int K) {
     int nfft = 256;
     while (nfft < 8 * K && nfft < 4096) nfft <<= 1;
+    while (nfft < 2 * K && nfft < 8192) nfft <<= 1;          // (2049 ... 4096 taps: 4096-point blocks would advance by a few samples)
     while (nfft < K) nfft <<= 1;
     return nfft;
 }
+#ifndef SSF_DELAY_NFFT
+#define SSF_DELAY_NFFT 4096
+#endif
+constexpr int kDelayNfft = SSF_DELAY_NFFT;   // block size of the 512-tap fractional-delay filters (delaySignal, polarisation delay, IQ skew)
 constexpr int kMaxNfft = 8192;            // c128 rows of the LDS transform (engine_fused_impl.h: k_ols)
 
 template <class Backend> struct RxCore {
@@ -186,7 +194,7 @@ template <class Backend> struct RxCore {
         // the reference's filter: NFFT = 1024 -> a 512-tap impulse response (core.py:880, 909-916).  The block
         // size of the overlap-save evaluation does not change the convolution, so larger blocks are
         // used here (4096: 87 % of every transform is output, 50 % with 1024)
-        const int K = 512, nfft = 4096;
+        const int K = 512, nfft = kDelayNfft;
         const long long padLen = (long long)std::ceil(std::fabs(dl[0] * Fs));
         Cd *dH = delay_filters(dl, ncols, Fs, K, nfft);
         if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
@@ -339,7 +347,7 @@ template <class Backend> struct RxCore {
                 det.lo_scale[0] = std::cos(kPi / 4);
                 det.lo_scale[1] = -std::sin(kPi / 4);
                 if (p.polDelay != 0) {                               // devices.py:656-658: x delayed by -polDelay/2, y by +polDelay/2
-                    const int K = 512, nfft = 4096;                  // (delay_pair's filter and block size)
+                    const int K = 512, nfft = kDelayNfft;                  // (delay_pair's filter and block size)
                     const double dl[2] = {-p.polDelay / 2, p.polDelay / 2};
                     const long long padLen = (long long)std::ceil(std::fabs(dl[0] * p.Fs));
                     Cd *dH = delay_filters(dl, 2, p.Fs, K, nfft), *fld = dalloc((size_t)N * 2);
@@ -398,7 +406,7 @@ template <class Backend> struct RxCore {
             long long pad[2] = {0, 0};
             for (int k = 0; k < nm; ++k) pad[k] = (long long)std::ceil(std::fabs(p.timeSkew[k] / 2 * p.Fs));
             const bool together = nm == 1 || pad[0] == pad[1];
-            const int K = 512, nfft = 4096;
+            const int K = 512, nfft = kDelayNfft;
             double dls[4];
             for (int k = 0; k < nm; ++k)
                 for (int part = 0; part < 2; ++part) dls[2 * k + part] = (part ? 1.0 : -1.0) * p.timeSkew[k] / 2;
@@ -730,6 +738,9 @@ template <class Backend> struct RxCore {
     int overlap_save(long long sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out) {
         std::vector<zc> H((size_t)nfft);
         for (int i = 0; i < nfft; ++i) H[(size_t)i] = ((const zc *)Hfft)[i] / (double)nfft;    // the ifft's 1/NFFT folded in
+        int lg = 0;
+        while ((1 << lg) < nfft) ++lg;
+        fused::ols_permute_filter(H.data(), lg);
         const size_t n = (size_t)sigLen * ncols;
         const Cd *a = resident(in, n);
         Cd *b = result_buffer(out, in, n), *dH = upload_filter(H);

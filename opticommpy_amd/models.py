@@ -576,6 +576,18 @@ def linearFiberChannel(Ei, param):
     return (Eo, param) if param.returnParameters else Eo
 
 
+def _ols_block(K):
+    """Transform size of the device's overlap-save kernel for a K-tap filter (rx_pipeline.h: fir_nfft)."""
+    nfft = 256
+    while nfft < 8 * K and nfft < 4096:
+        nfft *= 2
+    while nfft < 2 * K and nfft < 8192:
+        nfft *= 2
+    while nfft < K:
+        nfft *= 2
+    return nfft
+
+
 def _edc_filter(param, Fs):
     """(NfilterCoeffs, Nfft, H) as optic/dsp/equalization.py:85-110 derives them."""
     L = getattr(param, "L", 50)
@@ -663,17 +675,15 @@ def edc(sigIn, param):
         raise ValueError("FFT size is smaller than filter length")
     logg.info("Running CD compensation...")
     logg.info(f"CD filter length: {K} taps, FFT size: {Nfft}")
-    # The block size of an overlap-save evaluation does not change the linear convolution it computes: the device
-    # kernel takes powers of two in [16, 8192], so any other request of the reference (Nfft = 2 for a 1 km link,
-    # a non power of two, > 8192) is served with the smallest supported block that leaves >= 3/4 of each transform as
-    # output.  Filters that leave less than half of an 8192-point block as output (> 4096 taps) are split into segments
-    # of the impulse response, on the device (_edc_long): the reference takes any length (core.py:973-1046).
+    # The block size of an overlap-save evaluation does not change the linear convolution it computes, only how much of every
+    # transform is overlap: the reference's default Nfft (the next power of two above the filter length) leaves as little as a
+    # fifth of each block as output.  The device kernel takes powers of two in [16, 8192]; the block is chosen like firFilter's
+    # (rx_pipeline.h: fir_nfft): eight times the taps up to 4096 points, 8192 above 2048 taps.  Filters that leave less than
+    # half of an 8192-point block as output (> 4096 taps) are split into segments of the impulse response, on the device
+    # (_edc_long): the reference takes any length (core.py:973-1046).
     if K > _OLS_MAX_TAPS:
         return _edc_long(sigIn, sig2, one_d, on_dev, K, Hf)
-    if Nfft < 16 or Nfft > 8192 or (Nfft & (Nfft - 1)):
-        Nfft = 16
-        while Nfft < min(4 * K, 8192) or Nfft < K:
-            Nfft *= 2
+    Nfft = _ols_block(K)
     # core.py:1015-1020: centred impulse response, zero-padded to the FFT size, back to frequency
     h = np.pad(np.fft.fftshift(np.fft.ifft(Hf)), (0, Nfft - K), mode="constant")
     H = np.ascontiguousarray(np.fft.fft(h), dtype=np.complex128)

@@ -263,18 +263,24 @@ struct EmuBackend {
     // receiver pipeline (rx_pipeline.h)
     void launch_ols(const ssf::fused::OlsArgs<double> &a) {
         ++launches;
-        const int nfft = 1 << a.log2nfft, tpf = nfft / 16, block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
-        const long long grid = (a.njobs + fpw - 1) / fpw;
-        run_grid((int)grid, block, (size_t)fpw * ssf::fused::lds_slots_per_fft(nfft) * sizeof(ssf::fused::cx<double>),
-                 [&](EmuCtx &c) { ssf::fused::ols_body<double>(c, a); });
+        const ssf::fused::OlsLaunch o = ssf::fused::ols_launch(a.log2nfft, a.nrows, a.njobs);
+        ssf::fused::ols_dispatch(o, [&](auto lg, auto cc) {
+            run_grid((int)o.grid, o.threads, o.lds_bytes, [&](EmuCtx &c) { ssf::fused::ols_body<double, decltype(lg)::value, decltype(cc)::value>(c, a); });
+        });
     }
     static int ew_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>(3, (n + 63) / 64)); }
     void launch_rx_ols(const ssf::rx::RxOlsArgs &a) {
         ++launches;
-        const int nfft = 1 << a.o.log2nfft, tpf = nfft / 16, block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
-        const long long grid = (a.o.njobs + fpw - 1) / fpw;
-        run_grid((int)grid, block, (size_t)fpw * ssf::fused::lds_slots_per_fft(nfft) * sizeof(ssf::fused::cx<double>),
-                 [&](EmuCtx &c) { ssf::rx::rx_ols_body(c, a); });
+        const ssf::fused::OlsLaunch o = ssf::fused::ols_launch(a.o.log2nfft, a.o.nrows, a.o.njobs);
+        const bool found = ssf::rx::rx_ols_dispatch(a, o, [&](auto lg, auto cc, auto pre, auto noise) {
+            run_grid((int)o.grid, o.threads, o.lds_bytes, [&](EmuCtx &c) {
+                ssf::rx::rx_ols_body<decltype(lg)::value, decltype(cc)::value, decltype(pre)::value, decltype(noise)::value>(c, a);
+            });
+        });
+        if (!found) {
+            fprintf(stderr, "emu: no fused overlap-save kernel for this stage / transform size\n");
+            abort();
+        }
     }
     void launch_det(const ssf::rx::DetKernelArgs &a) { ++launches; run_grid(ew_grid(a.det.N * a.det.nm), 64, 64, [&](EmuCtx &c) { ssf::rx::det_body(c, a); }); }
     void launch_axpy(const ssf::rx::AxpyArgs &a) { run_grid(ew_grid(a.n), 64, 64, [&](EmuCtx &c) { ssf::rx::axpy_body(c, a); }); }
@@ -421,6 +427,7 @@ int emu_overlap_save(int64_t sigLen, int nrows, int lg, int K, const void *Hfft,
         Hs[(size_t)i].re = ((const Cc *)Hfft)[i].re / nfft;
         Hs[(size_t)i].im = ((const Cc *)Hfft)[i].im / nfft;
     }
+    ols_permute_filter(Hs.data(), lg);
     OlsArgs<double> a{};
     a.in = (const Cc *)in;
     a.out = (Cc *)out;
@@ -433,9 +440,10 @@ int emu_overlap_save(int64_t sigLen, int nrows, int lg, int K, const void *Hfft,
     a.discard = K - 1;
     a.D = (K - 1) / 2;
     ols_defaults(a);
-    const int tpf = nfft / 16, block = tpf >= 256 ? tpf : 256, fpw = block / tpf;
-    const long long grid = (a.njobs + fpw - 1) / fpw;
-    run_grid((int)grid, block, (size_t)fpw * lds_slots_per_fft(nfft) * sizeof(Cc), [&](EmuCtx &c) { ols_body<double>(c, a); });
+    const OlsLaunch o = ols_launch(lg, nrows, a.njobs);
+    ols_dispatch(o, [&](auto lgc, auto cc) {
+        run_grid((int)o.grid, o.threads, o.lds_bytes, [&](EmuCtx &c) { ols_body<double, decltype(lgc)::value, decltype(cc)::value>(c, a); });
+    });
     return 0;
 }
 

@@ -134,6 +134,7 @@ def edc(sigIn, param):
     one_d = sigIn.ndim == 1
     sig2 = sigIn.reshape(sigIn.size, 1) if one_d else sigIn
     K, Nfft, Hf = models._edc_filter(param, param.Fs)
+    Nfft = models._ols_block(K)                      # (the product's block size: models.edc)
     h = np.pad(np.fft.fftshift(np.fft.ifft(Hf)), (0, Nfft - K), mode="constant")
     H = np.ascontiguousarray(np.fft.fft(h), dtype=np.complex128)
     x = np.ascontiguousarray(sig2, dtype=np.complex128)

@@ -171,3 +171,38 @@ def test_error_conventions():
     dp.SpSin, dp.SpSout = 16, 2
     with pytest.raises(ValueError):
         oa.decimate(np.zeros(100), dp)                                                        # 100 % 16 != 0
+
+
+@pytest.mark.parametrize("lg", [4, 6, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("ncols", [1, 2, 3, 4])
+def test_every_overlap_save_instantiation(lg, ncols):
+    """One kernel per transform size (256 ... 8192 points) and per columns-side-by-side (two for an even column count up to 4096
+    points), the run-time plan below 256 points, the filter in register order (fused_kernels.h: ols_body_x, ols_permute_filter):
+    all against np.convolve -- blockwiseFFTConv's definition (optic/dsp/core.py:973-1046) with a random impulse response."""
+    import ctypes as C
+    emu = eb.load()
+    rng = np.random.default_rng(100 * lg + ncols)
+    nfft = 1 << lg
+    K = max(2, nfft // 5) | 1
+    N = 3 * nfft + 37
+    x = np.ascontiguousarray(rng.normal(size=(N, ncols)) + 1j * rng.normal(size=(N, ncols)))
+    h = rng.normal(size=K) + 1j * rng.normal(size=K)
+    H = np.ascontiguousarray(np.fft.fft(np.pad(h, (0, nfft - K))))
+    out = np.empty_like(x)
+    assert emu.emu_overlap_save(N, ncols, lg, K, H.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
+                                out.ctypes.data_as(C.c_void_p)) == 0
+    D = (K - 1) // 2
+    want = np.stack([np.convolve(x[:, c], h)[D:D + N] for c in range(ncols)], axis=1)
+    assert rel_l2(out, want) <= 1e-13
+
+
+@pytest.mark.parametrize("ntaps", [2049, 4096])
+def test_fir_filter_with_more_than_2048_taps_uses_8192_point_blocks(ntaps):
+    """(4096-point blocks would advance by 4096 - ntaps + 1 samples: one sample per block at 4096 taps)"""
+    rng = np.random.default_rng(ntaps)
+    N = 20000
+    x = rng.normal(size=(N, 2)) + 1j * rng.normal(size=(N, 2))
+    h = rng.normal(size=ntaps)
+    y = oa.firFilter(h, x)                                   # (the autouse fixture routes the kernels to the emulator)
+    want = np.stack([np.convolve(x[:, c], h, mode="same") for c in range(2)], axis=1)
+    assert rel_l2(y, want) <= 1e-13

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Receiver / transmitter side with everything resident in HBM (DeviceArray in, DeviceArray out): time per call and the
 algorithmic bytes it has to move at least (inputs once in, outputs once out), for the kernel summaries under profiles/
-(run under `rocprofv3 --kernel-trace --stats`).    python tools/bench_rx_device.py [log2n ...] [--reps R] [--json]"""
+(run under `rocprofv3 --kernel-trace --stats`).    python tools/bench_rx_device.py [log2n ...] [--reps R] [--json] [--cases a,b]
+(cases: pdm_notebook pdm_impaired pdm_defaults firFilter255 decimate16to2 edc800km simpleWDMTx11ch; default all)"""
 import json
 import os
 import sys
@@ -50,9 +51,18 @@ CASES = {
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 10
+    argv = sys.argv[1:]
+    opt = {}
+    for k in ("--reps", "--cases"):                      # options with a value
+        if k in argv:
+            i = argv.index(k)
+            opt[k] = argv[i + 1]
+            del argv[i:i + 2]
+    args = [a for a in argv if not a.startswith("--")]
+    reps = int(opt.get("--reps", 10))
     out = {}
+    only = opt["--cases"].split(",") if "--cases" in opt else None
+    want = lambda name: only is None or name in only  # noqa: E731
     rng = np.random.default_rng(1)
     for lg in [int(a) for a in args] or [20, 22]:
         N = 1 << lg
@@ -60,19 +70,26 @@ def main():
         Es = oa.to_device((rng.normal(size=(N, 2)) + 1j * rng.normal(size=(N, 2))) * 0.02)
         Elo = oa.to_device(np.full(N, np.sqrt(8e-3), dtype=complex))
         for name, (fe, pd) in CASES.items():
+            if not want(name):
+                continue
             t, r = timeit(lambda: oa.pdmCoherentReceiver(Es, Elo, bag(Fs=Fs, **fe), bag(Fs=Fs, **pd)), reps)
             alg = (2 + 1 + 2) * 16 * N                       # signal and LO in, detected signal out
             out["%s_2^%d" % (name, lg)] = dict(ms=t * 1e3, alg_MiB=alg / 2**20, GBs=alg / t / 1e9, frac=alg / t / 8e12)
         h = oa.lowPassFIR(25e9, Fs, 255)
-        t, _ = timeit(lambda: oa.firFilter(h, Es), reps)
-        out["firFilter255_2^%d" % lg] = dict(ms=t * 1e3, alg_MiB=64 * N / 2**20, GBs=64 * N / t / 1e9, frac=64 * N / t / 8e12)
-        t, _ = timeit(lambda: oa.decimate(Es, bag(SpSin=16, SpSout=2)), reps)
-        alg = (32 + 4) * N
-        out["decimate16to2_2^%d" % lg] = dict(ms=t * 1e3, alg_MiB=alg / 2**20, GBs=alg / t / 1e9, frac=alg / t / 8e12)
-        p = bag(L=800, D=16, Fc=193.1e12, Rs=32e9, Fs=64e9)
-        t, _ = timeit(lambda: oa.edc(Es, p), reps)
-        out["edc800km_2^%d" % lg] = dict(ms=t * 1e3, alg_MiB=64 * N / 2**20, GBs=64 * N / t / 1e9, frac=64 * N / t / 8e12)
+        if want("firFilter255"):
+            t, _ = timeit(lambda: oa.firFilter(h, Es), reps)
+            out["firFilter255_2^%d" % lg] = dict(ms=t * 1e3, alg_MiB=64 * N / 2**20, GBs=64 * N / t / 1e9, frac=64 * N / t / 8e12)
+        if want("decimate16to2"):
+            t, _ = timeit(lambda: oa.decimate(Es, bag(SpSin=16, SpSout=2)), reps)
+            alg = (32 + 4) * N
+            out["decimate16to2_2^%d" % lg] = dict(ms=t * 1e3, alg_MiB=alg / 2**20, GBs=alg / t / 1e9, frac=alg / t / 8e12)
+        if want("edc800km"):
+            p = bag(L=800, D=16, Fc=193.1e12, Rs=32e9, Fs=64e9)
+            t, _ = timeit(lambda: oa.edc(Es, p), reps)
+            out["edc800km_2^%d" % lg] = dict(ms=t * 1e3, alg_MiB=64 * N / 2**20, GBs=64 * N / t / 1e9, frac=64 * N / t / 8e12)
         del Es, Elo
+        if not want("simpleWDMTx11ch"):
+            continue
         # transmitter: N = nSymbols * 16 samples, 11 channels x 2 polarisations accumulate into one (N, 2) field
         nb = 4 * (N // 16)
         tx = dict(M=16, Rs=32e9, SpS=16, nBits=nb, nChannels=11, nPolModes=2, seed=123, laserLinewidth=100e3, wdmGridSpacing=37.5e9, prgsBar=False)
@@ -82,6 +99,12 @@ def main():
         t = time.perf_counter() - t0
         alg = 32 * N * 11 * 2                                 # every channel / polarisation: one modulated field written, read and added once
         out["simpleWDMTx11ch_2^%d" % lg] = dict(ms=t * 1e3, alg_MiB=alg / 2**20, GBs=alg / t / 1e9, frac=alg / t / 8e12, note="wall time incl. the host draws")
+        # unseeded: the laser phase-noise walks are generated on the device (Philox); the host still draws the bits
+        t0 = time.perf_counter()
+        sig, _, _ = oa.simpleWDMTx(bag(**dict(tx, seed=None)), device_output=True)
+        sync()
+        t = time.perf_counter() - t0
+        out["simpleWDMTx11ch_unseeded_2^%d" % lg] = dict(ms=t * 1e3, alg_MiB=alg / 2**20, GBs=alg / t / 1e9, frac=alg / t / 8e12, note="wall time; phase noise on the device")
     if "--json" in sys.argv:
         print(json.dumps(out))
     else:
