@@ -194,15 +194,17 @@ template <class F> inline bool rx_ols_dispatch(const RxOlsArgs &a, const fused::
         });
         return true;
     }
-    if (o.C != 2 || (o.lg != 11 && o.lg != 12)) return false;
-    auto stage = [&](auto lg) {
-        if (a.pre == PRE_PBS) f(lg, integral_constant<int, 2>{}, integral_constant<int, PRE_PBS>{}, integral_constant<int, 0>{});
-        else f(lg, integral_constant<int, 2>{}, integral_constant<int, PRE_IQ>{}, integral_constant<int, 0>{});
+    if ((o.lg != 11 && o.lg != 12) || (a.pre != PRE_PBS && a.pre != PRE_IQ)) return false;
+    auto stage = [&](auto lg, auto cc) {
+        if (a.pre == PRE_PBS) f(lg, cc, integral_constant<int, PRE_PBS>{}, integral_constant<int, 0>{});
+        else f(lg, cc, integral_constant<int, PRE_IQ>{}, integral_constant<int, 0>{});
     };
-    if (a.pre != PRE_PBS && a.pre != PRE_IQ) return false;
-    if (o.lg == 11) stage(integral_constant<int, 11>{});
-    else stage(integral_constant<int, 12>{});
-    return true;
+    if (o.C == 2) {
+        if (o.lg == 11) stage(integral_constant<int, 11>{}, integral_constant<int, 2>{});
+        else stage(integral_constant<int, 12>{}, integral_constant<int, 2>{});
+        return true;
+    }
+    return false;
 }
 // detection without a filter behind it (ideal photodiodes / bandwidthLimitation off): one element-wise pass
 struct DetKernelArgs {

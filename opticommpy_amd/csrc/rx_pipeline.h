@@ -127,15 +127,19 @@ inline OlsGeom ols_geometry(long long sigLen, int K, int nfft) {
     return g;
 }
 // transform size for a K-tap 'same' filter: the block advance nfft - K + 1 should be most of the block
+// Measured (profiles/r5_rx_ab.txt): a 2048-point block with two columns side by side is a 256-thread workgroup with 68 KiB of LDS,
+// two per CU; a 4096-point pair needs 512 threads and 136 KiB, one per CU, and is ~30 % slower per byte -- so 2048 points up to
+// 682 taps (two thirds of the block is output), 4096 up to 2048 taps, 8192 above
 inline int fir_nfft(int K) {
     int nfft = 256;
-    while (nfft < 8 * K && nfft < 4096) nfft <<= 1;
+    while (nfft < 8 * K && nfft < 2048) nfft <<= 1;
+    while (nfft < 3 * K && nfft < 4096) nfft <<= 1;
     while (nfft < 2 * K && nfft < 8192) nfft <<= 1;          // (2049 ... 4096 taps: 4096-point blocks would advance by a few samples)
     while (nfft < K) nfft <<= 1;
     return nfft;
 }
 #ifndef SSF_DELAY_NFFT
-#define SSF_DELAY_NFFT 4096
+#define SSF_DELAY_NFFT 2048
 #endif
 constexpr int kDelayNfft = SSF_DELAY_NFFT;   // block size of the 512-tap fractional-delay filters (delaySignal, polarisation delay, IQ skew)
 constexpr int kMaxNfft = 8192;            // c128 rows of the LDS transform (engine_fused_impl.h: k_ols)
@@ -193,7 +197,8 @@ template <class Backend> struct RxCore {
     int delay_pair(const Cd *in, Cd *out, int ld, long long N, const double *dl, int ncols, double Fs) {
         // the reference's filter: NFFT = 1024 -> a 512-tap impulse response (core.py:880, 909-916).  The block
         // size of the overlap-save evaluation does not change the convolution, so larger blocks are
-        // used here (4096: 87 % of every transform is output, 50 % with 1024)
+        // used here (kDelayNfft = 2048: 75 % of every transform is output, 50 % with 1024; 4096-point
+        // blocks measured slower, see fir_nfft)
         const int K = 512, nfft = kDelayNfft;
         const long long padLen = (long long)std::ceil(std::fabs(dl[0] * Fs));
         Cd *dH = delay_filters(dl, ncols, Fs, K, nfft);
@@ -743,7 +748,11 @@ template <class Backend> struct RxCore {
         fused::ols_permute_filter(H.data(), lg);
         const size_t n = (size_t)sigLen * ncols;
         const Cd *a = resident(in, n);
-        Cd *b = result_buffer(out, in, n), *dH = upload_filter(H);
+        unsigned long long hh = 1469598103934665603ull;              // (edc designs the same filter call after call)
+        const unsigned char *hb = (const unsigned char *)Hfft;
+        for (size_t i = 0; i < sizeof(zc) * (size_t)nfft; ++i) hh = (hh ^ hb[i]) * 1099511628211ull;
+        const FilterKey key{4, K, nfft, 0, 0.0, 0.0, hh};
+        Cd *b = result_buffer(out, in, n), *dH = cached_filter(key, [&] { return H; });
         if (!a || !b || !dH) return fail(SSF_ERR_OOM, "out of device memory");
         int rc = ols(a, ncols, sigLen, sigLen, b, ncols, sigLen, ncols, dH, 0, K, nfft, 0);
         if (rc) return rc;

@@ -579,7 +579,9 @@ def linearFiberChannel(Ei, param):
 def _ols_block(K):
     """Transform size of the device's overlap-save kernel for a K-tap filter (rx_pipeline.h: fir_nfft)."""
     nfft = 256
-    while nfft < 8 * K and nfft < 4096:
+    while nfft < 8 * K and nfft < 2048:
+        nfft *= 2
+    while nfft < 3 * K and nfft < 4096:
         nfft *= 2
     while nfft < 2 * K and nfft < 8192:
         nfft *= 2
@@ -678,7 +680,7 @@ def edc(sigIn, param):
     # The block size of an overlap-save evaluation does not change the linear convolution it computes, only how much of every
     # transform is overlap: the reference's default Nfft (the next power of two above the filter length) leaves as little as a
     # fifth of each block as output.  The device kernel takes powers of two in [16, 8192]; the block is chosen like firFilter's
-    # (rx_pipeline.h: fir_nfft): eight times the taps up to 4096 points, 8192 above 2048 taps.  Filters that leave less than
+    # (rx_pipeline.h: fir_nfft): eight times the taps up to 2048 points, 4096 above 682 taps, 8192 above 2048.  Filters that leave less than
     # half of an 8192-point block as output (> 4096 taps) are split into segments of the impulse response, on the device
     # (_edc_long): the reference takes any length (core.py:973-1046).
     if K > _OLS_MAX_TAPS:

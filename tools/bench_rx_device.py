@@ -53,13 +53,16 @@ CASES = {
 def main():
     argv = sys.argv[1:]
     opt = {}
-    for k in ("--reps", "--cases"):                      # options with a value
+    for k in ("--reps", "--cases", "--edc-block"):       # options with a value
         if k in argv:
             i = argv.index(k)
             opt[k] = argv[i + 1]
             del argv[i:i + 2]
     args = [a for a in argv if not a.startswith("--")]
     reps = int(opt.get("--reps", 10))
+    if "--edc-block" in opt:                             # experiment: edc's overlap-save block size (models._ols_block)
+        from opticommpy_amd import models
+        models._ols_block = lambda K, _n=int(opt["--edc-block"]): _n
     out = {}
     only = opt["--cases"].split(",") if "--cases" in opt else None
     want = lambda name: only is None or name in only  # noqa: E731
