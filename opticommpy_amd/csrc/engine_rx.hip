@@ -83,6 +83,10 @@ __global__ void __launch_bounds__(256) k_rx_dec_sum(const DecSumArgs a) {
     SSF_RX_CTX();
     dec_sum_body(ctx, a);
 }
+__global__ void __launch_bounds__(256) k_rx_dec_finish(const DecFinishArgs a) {
+    SSF_RX_CTX();
+    dec_finish_body(ctx, a);
+}
 __global__ void __launch_bounds__(256) k_rx_dec_gather(const DecGatherArgs a) {
     SSF_RX_CTX();
     dec_gather_body(ctx, a);
@@ -214,6 +218,10 @@ struct HipRxBackend {
     void launch_dec_sum(const DecSumArgs &a, int nblocks, int nthreads) {
         k_rx_dec_sum<<<(unsigned)nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, st>>>(a);
         chk(hipGetLastError(), "launch k_rx_dec_sum");
+    }
+    void launch_dec_finish(const DecFinishArgs &a) {
+        k_rx_dec_finish<<<1, 256, sizeof(double) * 256, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_dec_finish");
     }
     void launch_dec_gather(const DecGatherArgs &a) {
         k_rx_dec_gather<<<ew_grid(a.Nout * a.ncols), 256, 0, st>>>(a);

@@ -35,28 +35,33 @@ struct PdModel {
     unsigned long long seed;       // device noise (Philox), used when `un` is null
     const double *un;    // host-supplied unit normals, [(pd * 2 + kind) * N + n], or null
 };
-// NOISE: 0 = the caller knows that neither noise source is on (the generator is not even compiled in: the fused receiver
-// kernels unroll sixteen of these per thread), 1 / 2 = look at the model
-template <int NOISE = 2> SSF_HD double pd_current_pw(const PdModel &m, double pw, long long n, long long N, int pd) {
+// unit normals (shot, thermal) of `cnt` consecutive photodiodes starting at pd0 (even) at sample n: z[2 k] / z[2 k + 1] for
+// photodiode pd0 + k.  Supplied by the host ([(pd * 2 + kind) * N + n]: seeded parity runs) or generated, two photodiodes per call.
+SSF_HD void pd_normals(const PdModel &m, long long n, long long N, int pd0, int cnt, double *z) {
+    if (m.un) {
+        for (int k = 0; k < 2 * cnt; ++k) z[k] = m.un[(size_t)(pd0 * 2 + k) * N + n];
+    } else {
+        for (int k = 0; k < cnt; k += 2) {
+            float g[4];
+            gauss_quad((unsigned long long)n, (unsigned)((pd0 + k) >> 1), 0x5044u, m.seed, g);
+            z[2 * k] = g[0];
+            z[2 * k + 1] = g[1];
+            if (k + 1 < cnt) {
+                z[2 * k + 2] = g[2];
+                z[2 * k + 3] = g[3];
+            }
+        }
+    }
+}
+// photocurrent from the optical power and the photodiode's two unit normals (devices.py:367-390)
+SSF_HD double pd_current_pw(const PdModel &m, double pw, double us, double ut) {
     double i = m.R * pw;
     if (m.saturate && i > m.IpdSat) i = m.IpdSat;
-    if (NOISE != 0 && (m.shot || m.thermal)) {
-        double us, ut;
-        if (m.un) {
-            us = m.un[(size_t)(pd * 2) * N + n];
-            ut = m.un[(size_t)(pd * 2 + 1) * N + n];
-        } else {
-            gauss_pair((unsigned long long)n, (unsigned)pd, 0x5044u, m.seed, 1.0, us, ut);   // one Philox draw: two normals
-        }
-        if (m.shot) i += sqrt(m.shot_k * (i + m.Id)) * us;
-        if (m.thermal) i += m.thermal_sigma * ut;
-    }
+    if (m.shot) i += sqrt(m.shot_k * (i + m.Id)) * us;
+    if (m.thermal) i += m.thermal_sigma * ut;
     return i;
 }
-
-template <int NOISE = 2> SSF_HD double pd_current(const PdModel &m, Cd e, long long n, long long N, int pd) {
-    return pd_current_pw<NOISE>(m, e.re * e.re + e.im * e.im, n, N, pd);
-}
+SSF_HD double pd_current(const PdModel &m, Cd e, double us, double ut) { return pd_current_pw(m, e.re * e.re + e.im * e.im, us, ut); }
 
 enum { RX_PHOTODIODE = 0, RX_BALANCED = 1 };
 
@@ -76,22 +81,20 @@ struct FrontArgs {
 };
 template <class Ctx> SSF_HD void front_body(Ctx &ctx, const FrontArgs &a) {
     for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
+        const bool noisy = a.pd.shot || a.pd.thermal;
+        double z[4] = {0, 0, 0, 0};
         if (a.mode == RX_PHOTODIODE) {
-            double i = 0;
-            if (a.nm == 1) {
-                i = pd_current(a.pd, a.in0[n], n, a.N, 0);
-            } else {                            // devices.py:356-359: one photocurrent from the summed mode powers
-                double pw = 0;
-                for (int k = 0; k < a.nm; ++k) {
-                    const Cd e = a.in0[n * a.nm + k];
-                    pw += e.re * e.re + e.im * e.im;
-                }
-                i = pd_current_pw(a.pd, pw, n, a.N, 0);
+            if (noisy) pd_normals(a.pd, n, a.N, 0, 1, z);
+            double pw = 0;                              // devices.py:356-359: one photocurrent from the summed mode powers
+            for (int k = 0; k < a.nm; ++k) {
+                const Cd e = a.in0[n * a.nm + k];
+                pw += e.re * e.re + e.im * e.im;
             }
-            a.out[n] = mk<double>(i, 0.0);
+            a.out[n] = mk<double>(pd_current_pw(a.pd, pw, z[0], z[1]), 0.0);
         } else if (a.mode == RX_BALANCED) {
-            const double i1 = pd_current(a.pd, a.in0[2 * n], n, a.N, 0);
-            const double i2 = pd_current(a.pd, a.in0[2 * n + 1], n, a.N, 1);
+            if (noisy) pd_normals(a.pd, n, a.N, 0, 2, z);
+            const double i1 = pd_current(a.pd, a.in0[2 * n], z[0], z[1]);
+            const double i2 = pd_current(a.pd, a.in0[2 * n + 1], z[2], z[3]);
             a.out[n] = mk<double>(i1 - i2, 0.0);
         }
     }
@@ -132,9 +135,10 @@ template <int NOISE = 2> SSF_HD Cd det_sample(const DetArgs &a, long long n, int
     const Cd e1 = mk<double>(-0.5 * es.im - 0.5 * lo.im, 0.5 * es.re + 0.5 * lo.re);     // jEs/2 + jElo/2
     const Cd e2 = mk<double>(-0.5 * es.im - 0.5 * lo.re, 0.5 * es.re - 0.5 * lo.im);     // jEs/2 -  Elo/2
     const Cd e3 = mk<double>(-0.5 * es.re - 0.5 * lo.im, -0.5 * es.im + 0.5 * lo.re);    // -Es/2 + jElo/2
-    const int base = 4 * p;
-    const double sI = pd_current<NOISE>(a.pd, e1, n, a.N, base) - pd_current<NOISE>(a.pd, e0, n, a.N, base + 1);
-    const double sQ = pd_current<NOISE>(a.pd, e2, n, a.N, base + 2) - pd_current<NOISE>(a.pd, e3, n, a.N, base + 3);
+    double z[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // NOISE = 0: the caller knows that neither noise source is on (the generator
+    if (NOISE != 0 && (a.pd.shot || a.pd.thermal)) pd_normals(a.pd, n, a.N, 4 * p, 4, z);   // is not compiled into those kernels)
+    const double sI = pd_current(a.pd, e1, z[0], z[1]) - pd_current(a.pd, e0, z[2], z[3]);
+    const double sQ = pd_current(a.pd, e2, z[4], z[5]) - pd_current(a.pd, e3, z[6], z[7]);
     return mk<double>(sI, sQ);
 }
 // IQ imbalance (core.py:952-960): s' = k1 s + k2 conj(s)
@@ -213,15 +217,19 @@ struct DetKernelArgs {
     int iqf;                  // apply the IQ imbalance and the zero-skew rule here (nothing follows)
     Cd k1[2], k2[2];
 };
-template <class Ctx> SSF_HD void det_body(Ctx &ctx, const DetKernelArgs &a) {
+template <int NOISE, class Ctx> SSF_HD void det_loop(Ctx &ctx, const DetKernelArgs &a) {
     const long long total = a.det.N * a.det.nm;
     for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < total; i += (long long)ctx.nblocks * ctx.nthreads) {
-        const long long n = i / a.det.nm;
+        const long long n = a.det.nm == 2 ? i >> 1 : i;
         const int p = (int)(i - n * a.det.nm);
-        Cd v = det_sample(a.det, n, p);
+        Cd v = det_sample<NOISE>(a.det, n, p);
         if (a.iqf) v = n == a.det.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(sel2(a.k1, p), sel2(a.k2, p), v);
         a.out[i] = v;
     }
+}
+template <class Ctx> SSF_HD void det_body(Ctx &ctx, const DetKernelArgs &a) {
+    if (a.det.pd.shot || a.det.pd.thermal) det_loop<1>(ctx, a);       // (two loops: the quiet one carries no generator code)
+    else det_loop<0>(ctx, a);
 }
 // iqMixing by itself with no skew: S = k1 s + k2 conj(s), last sample zero
 struct IqfArgs {
@@ -437,7 +445,7 @@ template <class Ctx> SSF_HD void shift_add_body(Ctx &ctx, const ShiftAddArgs &a)
 // (mean, then mean |x - mean|^2).  The (N, ncols) array is read as one flat stream: with a thread
 // count that is a multiple of nclass = sps * ncols every thread only ever sees one (phase, column)
 // class, so the per-class sums are plain register accumulations; each workgroup leaves its partial
-// sums (fixed order, deterministic) and the host adds the few hundred partials.
+// sums (fixed order, deterministic) and dec_finish_body adds the few hundred partials.
 struct DecSumArgs {
     const Cd *in;        // (N, ncols)
     const Cd *mean;      // nclass means for pass 2, null for pass 1
@@ -471,13 +479,42 @@ template <class Ctx> SSF_HD void dec_sum_body(Ctx &ctx, const DecSumArgs &a) {
         a.part[((size_t)ctx.bid * a.nclass + ctx.tid) * 2 + 1] = t1;
     }
 }
+// the partials of one pass added up on the device, in the workgroup order the host used to add them (one thread per class):
+// pass 1 leaves the class means, pass 2 the variances and, per column, the first phase of the largest variance (core.py:478) --
+// no host round trip between the passes
+struct DecFinishArgs {
+    const double *part;  // (nblocks, nclass, 2)
+    Cd *mean;            // pass 1: nclass means out; null in pass 2
+    int *delay;          // pass 2: ncols sampling phases out
+    int nblocks, nclass, ncols, SpS;
+    double M;            // samples per class
+};
+template <class Ctx> SSF_HD void dec_finish_body(Ctx &ctx, const DecFinishArgs &a) {
+    double *var = (double *)ctx.lds;               // nclass doubles
+    if (ctx.tid < a.nclass) {
+        double s0 = 0, s1 = 0;
+        for (int w = 0; w < a.nblocks; ++w) {
+            s0 += a.part[((size_t)w * a.nclass + ctx.tid) * 2];
+            s1 += a.part[((size_t)w * a.nclass + ctx.tid) * 2 + 1];
+        }
+        if (a.mean) a.mean[ctx.tid] = mk<double>(s0 / a.M, s1 / a.M);
+        else var[ctx.tid] = s0 / a.M;
+    }
+    ctx.sync();
+    if (!a.mean && ctx.tid < a.ncols) {            // flat index i = n * ncols + col: class = (n % SpS) * ncols + col
+        int best = 0;
+        for (int ph = 1; ph < a.SpS; ++ph)
+            if (var[ph * a.ncols + ctx.tid] > var[best * a.ncols + ctx.tid]) best = ph;
+        a.delay[ctx.tid] = best;
+    }
+}
 // out[j, col] = x[(j * dec + delay[col]) mod N, col]
 struct DecGatherArgs {
     const Cd *in;      // (N, ncols)
     Cd *out;           // (Nout, ncols)
     long long N, Nout;
     int ncols, dec;
-    int delay[8];
+    const int *delay;  // ncols sampling phases (device memory: dec_finish_body)
 };
 template <class Ctx> SSF_HD void dec_gather_body(Ctx &ctx, const DecGatherArgs &a) {
     const long long total = a.Nout * a.ncols;

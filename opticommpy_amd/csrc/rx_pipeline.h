@@ -692,34 +692,20 @@ template <class Backend> struct RxCore {
         const Cd *a = resident(in, (size_t)N * ncols);
         Cd *b = result_buffer(out, in, (size_t)Nout * ncols), *dmean = dalloc((size_t)nclass);
         double *dpart = (double *)be.alloc(sizeof(double) * 2 * (size_t)nblocks * nclass);
+        int *ddelay = (int *)be.alloc(sizeof(int) * 8);
         if (dpart) owned.push_back(dpart);
-        if (!a || !b || !dmean || !dpart) return fail(SSF_ERR_OOM, "out of device memory");
-        std::vector<double> part(2 * (size_t)nblocks * nclass);
-        std::vector<zc> mean((size_t)nclass);
-        std::vector<double> var((size_t)nclass);
-        const double M = (double)(N / SpSin);
+        if (ddelay) owned.push_back(ddelay);
+        if (!a || !b || !dmean || !dpart || !ddelay) return fail(SSF_ERR_OOM, "out of device memory");
+        // mean per (phase, column) class, then the variance about it (two passes, as np.var), each pass's partials added up by one
+        // small launch in the workgroup order: five launches back to back, no host round trip in between
         DecSumArgs sa{a, nullptr, dpart, N * ncols, nclass};
+        DecFinishArgs fa{dpart, dmean, ddelay, nblocks, nclass, ncols, SpSin, (double)(N / SpSin)};
         be.launch_dec_sum(sa, nblocks, nthreads);
-        be.sync();
-        be.d2h(part.data(), dpart, sizeof(double) * part.size());
-        for (int c = 0; c < nclass; ++c) {
-            double sr = 0, si = 0;
-            for (int w = 0; w < nblocks; ++w) {
-                sr += part[((size_t)w * nclass + c) * 2];
-                si += part[((size_t)w * nclass + c) * 2 + 1];
-            }
-            mean[(size_t)c] = zc(sr / M, si / M);
-        }
-        be.h2d(dmean, mean.data(), sizeof(Cd) * (size_t)nclass);
+        be.launch_dec_finish(fa);
         sa.mean = dmean;
+        fa.mean = nullptr;
         be.launch_dec_sum(sa, nblocks, nthreads);
-        be.sync();
-        be.d2h(part.data(), dpart, sizeof(double) * part.size());
-        for (int c = 0; c < nclass; ++c) {                           // flat index i = n * ncols + col: class = (n % SpSin) * ncols + col
-            double s = 0;
-            for (int w = 0; w < nblocks; ++w) s += part[((size_t)w * nclass + c) * 2];
-            var[(size_t)c] = s / M;
-        }
+        be.launch_dec_finish(fa);
         DecGatherArgs ga{};
         ga.in = a;
         ga.out = b;
@@ -727,14 +713,13 @@ template <class Backend> struct RxCore {
         ga.Nout = Nout;
         ga.ncols = ncols;
         ga.dec = decFactor;
-        for (int c = 0; c < ncols; ++c) {                            // first index of the maximum (core.py:478)
-            int best = 0;
-            for (int ph = 1; ph < SpSin; ++ph)
-                if (var[(size_t)ph * ncols + c] > var[(size_t)best * ncols + c]) best = ph;
-            ga.delay[c] = best;
-            if (sampDelay_out) sampDelay_out[c] = best;
-        }
+        ga.delay = ddelay;
         be.launch_dec_gather(ga);
+        if (sampDelay_out) {
+            int dl[8];
+            be.d2h(dl, ddelay, sizeof(int) * (size_t)ncols);         // (waits for the stream)
+            for (int c = 0; c < ncols; ++c) sampDelay_out[c] = dl[c];
+        }
         return finish(out, b, (size_t)Nout * ncols);
     }
 

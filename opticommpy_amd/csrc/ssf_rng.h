@@ -44,4 +44,26 @@ SSF_HD void gauss_pair(uint64_t sample, uint32_t row, uint32_t span, uint64_t se
     im = rad * s;
 }
 
+// four unit normals from ONE Philox call, Box-Muller in single precision (the photodiodes' shot and thermal noise: eight normals
+// per sample and polarisation -- in double precision, one pair per call, the generator was 85 % of the receiver's detection
+// launch).  32-bit uniforms bound the tails at 6.7 sigma either way; the hardware's log / sin / cos (inputs in turns) on the
+// device, libm in the CPU emulator: statistical parity.
+SSF_HD void gauss_quad(uint64_t sample, uint32_t row, uint32_t span, uint64_t seed, float z[4]) {
+    const Philox4 r = philox4x32_10(sample, ((uint64_t)span << 32) | row, seed);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float u1 = ((float)r.v[2 * j] + 0.5f) * (1.0f / 4294967296.0f);            // (0, 1]
+        const float u2 = (float)(r.v[2 * j + 1] >> 8) * (1.0f / 16777216.0f);            // [0, 1): 24 bits, exact
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float rad = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // -2 ln(u1) = -2 ln 2 * log2(u1)
+        z[2 * j] = rad * __builtin_amdgcn_cosf(u2);
+        z[2 * j + 1] = rad * __builtin_amdgcn_sinf(u2);
+#else
+        const float rad = sqrtf(-2.0f * logf(u1));
+        z[2 * j] = rad * cosf(6.283185307179586f * u2);
+        z[2 * j + 1] = rad * sinf(6.283185307179586f * u2);
+#endif
+    }
+}
+
 }  // namespace ssf
