@@ -220,7 +220,7 @@ struct HipRxBackend {
         chk(hipGetLastError(), "launch k_rx_dec_sum");
     }
     void launch_dec_finish(const DecFinishArgs &a) {
-        k_rx_dec_finish<<<1, 256, sizeof(double) * 256, st>>>(a);
+        k_rx_dec_finish<<<1, 256, sizeof(double) * 3 * 256, st>>>(a);
         chk(hipGetLastError(), "launch k_rx_dec_finish");
     }
     void launch_dec_gather(const DecGatherArgs &a) {

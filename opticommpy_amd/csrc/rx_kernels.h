@@ -346,11 +346,10 @@ struct IqmArgs {
 };
 SSF_HD Cd mzm_out(Cd e, double u, double Vb, double Vpi, double sp, double sm) {
     const double ang = ((u + Vb) / 2 / Vpi) * 3.14159265358979323846;
-    double c, s, c2, s2;
-    fused::cis_rad_d(ang, c, s);
-    fused::cis_rad_d(-(u + Vb) / 2 / Vpi * 3.14159265358979323846, c2, s2);
+    double c, s;
+    fused::cis_rad_d(ang, c, s);                            // (the lower arm's phase is the negative: the conjugate)
     const Cd h = mk<double>(e.re / 2, e.im / 2);
-    const Cd a = h * mk<double>(c, s), b = h * mk<double>(c2, s2);
+    const Cd a = h * mk<double>(c, s), b = h * mk<double>(c, -s);
     return mk<double>(sp * a.re + sm * b.re, sp * a.im + sm * b.im);
 }
 template <class Ctx> SSF_HD void iqm_body(Ctx &ctx, const IqmArgs &a) {
@@ -479,9 +478,10 @@ template <class Ctx> SSF_HD void dec_sum_body(Ctx &ctx, const DecSumArgs &a) {
         a.part[((size_t)ctx.bid * a.nclass + ctx.tid) * 2 + 1] = t1;
     }
 }
-// the partials of one pass added up on the device, in the workgroup order the host used to add them (one thread per class):
-// pass 1 leaves the class means, pass 2 the variances and, per column, the first phase of the largest variance (core.py:478) --
-// no host round trip between the passes
+// the partials of one pass added up on the device (one workgroup; fixed order: thread (class c, segment g) adds the partials of
+// workgroups g, g + nseg, ... -- consecutive threads read consecutive partials -- then the nseg segment sums of a class are added
+// in order): pass 1 leaves the class means, pass 2 the variances and, per column, the first phase of the largest variance
+// (core.py:478) -- no host round trip between the passes
 struct DecFinishArgs {
     const double *part;  // (nblocks, nclass, 2)
     Cd *mean;            // pass 1: nclass means out; null in pass 2
@@ -490,15 +490,37 @@ struct DecFinishArgs {
     double M;            // samples per class
 };
 template <class Ctx> SSF_HD void dec_finish_body(Ctx &ctx, const DecFinishArgs &a) {
-    double *var = (double *)ctx.lds;               // nclass doubles
-    if (ctx.tid < a.nclass) {
-        double s0 = 0, s1 = 0;
-        for (int w = 0; w < a.nblocks; ++w) {
-            s0 += a.part[((size_t)w * a.nclass + ctx.tid) * 2];
-            s1 += a.part[((size_t)w * a.nclass + ctx.tid) * 2 + 1];
+    double *red = (double *)ctx.lds;               // nthreads x 2 doubles, then nclass variances behind them
+    double *var = red + 2 * ctx.nthreads;
+    const int nseg = ctx.nthreads / a.nclass, used = nseg * a.nclass;
+    double s0 = 0, s1 = 0;
+    if (ctx.tid < used)
+        for (int w = ctx.tid / a.nclass; w < a.nblocks; w += 8 * nseg) {    // eight loads in flight, added in order
+            double v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ww = w + u * nseg;
+                const size_t i = ((size_t)(ww < a.nblocks ? ww : w) * a.nclass + ctx.tid % a.nclass) * 2;
+                v0[u] = ww < a.nblocks ? a.part[i] : 0.0;
+                v1[u] = ww < a.nblocks ? a.part[i + 1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s0 += v0[u];
+                s1 += v1[u];
+            }
         }
-        if (a.mean) a.mean[ctx.tid] = mk<double>(s0 / a.M, s1 / a.M);
-        else var[ctx.tid] = s0 / a.M;
+    red[2 * ctx.tid] = s0;
+    red[2 * ctx.tid + 1] = s1;
+    ctx.sync();
+    if (ctx.tid < a.nclass) {
+        double t0 = 0, t1 = 0;
+        for (int g = 0; g < nseg; ++g) {
+            t0 += red[2 * (g * a.nclass + ctx.tid)];
+            t1 += red[2 * (g * a.nclass + ctx.tid) + 1];
+        }
+        if (a.mean) a.mean[ctx.tid] = mk<double>(t0 / a.M, t1 / a.M);
+        else var[ctx.tid] = t0 / a.M;
     }
     ctx.sync();
     if (!a.mean && ctx.tid < a.ncols) {            // flat index i = n * ncols + col: class = (n % SpS) * ncols + col

@@ -266,11 +266,18 @@ template <class Backend> struct RxCore {
             return ols_filter_from_taps(hz.data(), ntaps, nfft);
         });
     }
-    Cd *taps_filter(const zc *taps, int K, int nfft) {
+    static unsigned long long content_hash(const zc *v, size_t n) {              // FNV-1a over the 64-bit words of the values
         unsigned long long h = 1469598103934665603ull;
-        const unsigned char *b = (const unsigned char *)taps;
-        for (size_t i = 0; i < sizeof(zc) * (size_t)K; ++i) h = (h ^ b[i]) * 1099511628211ull;
-        FilterKey k{3, K, nfft, 0, 0.0, 0.0, h};
+        for (size_t i = 0; i < n; ++i) {
+            unsigned long long w[2];
+            std::memcpy(w, &v[i], 16);
+            h = (h ^ w[0]) * 1099511628211ull;
+            h = (h ^ w[1]) * 1099511628211ull;
+        }
+        return h;
+    }
+    Cd *taps_filter(const zc *taps, int K, int nfft) {
+        FilterKey k{3, K, nfft, 0, 0.0, 0.0, content_hash(taps, (size_t)K)};
         return cached_filter(k, [&] { return ols_filter_from_taps(taps, K, nfft); });
     }
     static void iq_gains(const ssf_rx_params &p, int k, Cd *k1o, Cd *k2o) {      // core.py:952-959
@@ -733,10 +740,7 @@ template <class Backend> struct RxCore {
         fused::ols_permute_filter(H.data(), lg);
         const size_t n = (size_t)sigLen * ncols;
         const Cd *a = resident(in, n);
-        unsigned long long hh = 1469598103934665603ull;              // (edc designs the same filter call after call)
-        const unsigned char *hb = (const unsigned char *)Hfft;
-        for (size_t i = 0; i < sizeof(zc) * (size_t)nfft; ++i) hh = (hh ^ hb[i]) * 1099511628211ull;
-        const FilterKey key{4, K, nfft, 0, 0.0, 0.0, hh};
+        const FilterKey key{4, K, nfft, 0, 0.0, 0.0, content_hash((const zc *)Hfft, (size_t)nfft)};   // (edc designs the same filter call after call)
         Cd *b = result_buffer(out, in, n), *dH = cached_filter(key, [&] { return H; });
         if (!a || !b || !dH) return fail(SSF_ERR_OOM, "out of device memory");
         int rc = ols(a, ncols, sigLen, sigLen, b, ncols, sigLen, ncols, dH, 0, K, nfft, 0);

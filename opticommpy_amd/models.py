@@ -609,6 +609,23 @@ def _edc_filter(param, Fs):
     return NfilterCoeffs, Nfft, np.exp(-1j * (b2 / 2) * (w**2) * L)
 
 
+_EDC_H = {}
+
+
+def _edc_block_response(K, Nfft, Hf):
+    """core.py:1015-1020: centred impulse response, zero-padded to the block size, back to frequency.  A receiver loop designs the
+    same filter call after call: the last few responses are kept (keyed by the K frequency samples themselves)."""
+    key = (K, Nfft, Hf.tobytes())
+    H = _EDC_H.get(key)
+    if H is None:
+        h = np.pad(np.fft.fftshift(np.fft.ifft(Hf)), (0, Nfft - K), mode="constant")
+        H = np.ascontiguousarray(np.fft.fft(h), dtype=np.complex128)
+        if len(_EDC_H) >= 8:
+            _EDC_H.pop(next(iter(_EDC_H)))
+        _EDC_H[key] = H
+    return H
+
+
 _OLS_MAX_TAPS = 4096          # longer impulse responses are convolved segment by segment on the device (ssf_fir_long)
 
 
@@ -686,9 +703,7 @@ def edc(sigIn, param):
     if K > _OLS_MAX_TAPS:
         return _edc_long(sigIn, sig2, one_d, on_dev, K, Hf)
     Nfft = _ols_block(K)
-    # core.py:1015-1020: centred impulse response, zero-padded to the FFT size, back to frequency
-    h = np.pad(np.fft.fftshift(np.fft.ifft(Hf)), (0, Nfft - K), mode="constant")
-    H = np.ascontiguousarray(np.fft.fft(h), dtype=np.complex128)
+    H = _edc_block_response(K, Nfft, Hf)
     in_ptr, _keep = _dev.arg(sig2, np.complex128)
     out = _dev.empty(on_dev, sig2.shape, np.complex128)
     lib = _lib.load()

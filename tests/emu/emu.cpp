@@ -299,7 +299,7 @@ struct EmuBackend {
     void launch_dec_sum(const ssf::rx::DecSumArgs &a, int nblocks, int nthreads) {
         run_grid(nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, [&](EmuCtx &c) { ssf::rx::dec_sum_body(c, a); });
     }
-    void launch_dec_finish(const ssf::rx::DecFinishArgs &a) { run_grid(1, 256, sizeof(double) * 256, [&](EmuCtx &c) { ssf::rx::dec_finish_body(c, a); }); }
+    void launch_dec_finish(const ssf::rx::DecFinishArgs &a) { run_grid(1, 256, sizeof(double) * 3 * 256, [&](EmuCtx &c) { ssf::rx::dec_finish_body(c, a); }); }
     void launch_dec_gather(const ssf::rx::DecGatherArgs &a) {
         run_grid(ew_grid(a.Nout * a.ncols), 64, 64, [&](EmuCtx &c) { ssf::rx::dec_gather_body(c, a); });
     }

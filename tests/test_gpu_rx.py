@@ -111,6 +111,48 @@ def test_fir_filter_sizes_and_limits():
     np.testing.assert_allclose(yr, orx.firFilter(np.ones(5) / 5, xr), atol=1e-6)
 
 
+@pytest.mark.parametrize("lg", [4, 6, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("ncols", [1, 2, 3, 4])
+def test_every_overlap_save_instantiation_through_the_c_abi(lg, ncols):
+    """ssf_overlap_save (blockwiseFFTConv with a caller-supplied response, optic/dsp/core.py:973-1046) at every transform size the
+    kernel is instantiated for (256 ... 8192 points; the run-time plan below), one and two columns per transform, the filter in
+    register order: against np.convolve with a random impulse response.  (The same sweep on the emulator: tests/test_emu_rx.py.)"""
+    import ctypes as C
+    from opticommpy_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(100 * lg + ncols)
+    nfft = 1 << lg
+    K = max(2, nfft // 5) | 1
+    N = 3 * nfft + 37
+    x = np.ascontiguousarray(rng.normal(size=(N, ncols)) + 1j * rng.normal(size=(N, ncols)))
+    h = rng.normal(size=K) + 1j * rng.normal(size=K)
+    H = np.ascontiguousarray(np.fft.fft(np.pad(h, (0, nfft - K))))
+    out = np.empty_like(x)
+    rc = lib.ssf_overlap_save(0, N, ncols, _lib.SSF_C128, nfft, K, H.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
+                              out.ctypes.data_as(C.c_void_p))
+    _lib.raise_for(lib, None, rc)
+    D = (K - 1) // 2
+    want = np.stack([np.convolve(x[:, c], h)[D:D + N] for c in range(ncols)], axis=1)
+    assert rel_l2(out, want) <= 1e-13
+    if lg >= 6:                                                       # the single-precision instantiation (run-time plan, one column)
+        x32, H32, out32 = x.astype(np.complex64), H.astype(np.complex64), np.empty((N, ncols), dtype=np.complex64)
+        rc = lib.ssf_overlap_save(0, N, ncols, _lib.SSF_C64, nfft, K, H32.ctypes.data_as(C.c_void_p), x32.ctypes.data_as(C.c_void_p),
+                                  out32.ctypes.data_as(C.c_void_p))
+        _lib.raise_for(lib, None, rc)
+        assert rel_l2(out32, want) <= 2e-5
+
+
+@pytest.mark.parametrize("ntaps", [683, 2049, 4096])
+def test_fir_filter_block_sizes_above_682_taps(ntaps):
+    """2048-point blocks up to 682 taps, 4096 up to 2048, 8192 above (rx_pipeline.h: fir_nfft)"""
+    rng = np.random.default_rng(ntaps)
+    x = rng.normal(size=(30000, 2)) + 1j * rng.normal(size=(30000, 2))
+    h = rng.normal(size=ntaps)
+    y = oa.firFilter(h, x)
+    want = np.stack([np.convolve(x[:, c], h, mode="same") for c in range(2)], axis=1)
+    assert rel_l2(y, want) <= 1e-13
+
+
 def test_decimate_large_exact():
     rng = np.random.default_rng(10)
     N, sps = 1 << 20, 16
