@@ -15,8 +15,8 @@ values), the 2x2 / 4x4 constant matrices of ``pbs`` and ``opticalHybrid2x4`` whe
 on their own, dtype / shape handling.
 
 Noise: the reference seeds numpy's global generator per photodiode (devices.py:368-389); the
-device draws from counter-based Philox streams instead (one per photodiode, keyed by
-``param.seed``), so noisy runs agree with the reference statistically, not sample by sample
+device draws from counter-based Philox streams instead (one per pair of photodiodes, keyed by
+``param.seed``; Box-Muller in single precision), so noisy runs agree with the reference statistically, not sample by sample
 (same policy as the EDFA).  ``_unit_normals`` feeds host-supplied standard
 normals through the same arithmetic for exact checks."""
 import copy
