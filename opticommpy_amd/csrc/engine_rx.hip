@@ -75,10 +75,6 @@ __global__ void __launch_bounds__(256) k_tx_shift_add(const ShiftAddArgs a) {
     SSF_RX_CTX();
     shift_add_body(ctx, a);
 }
-__global__ void __launch_bounds__(256) k_rx_real_part(const RealPartArgs a) {
-    SSF_RX_CTX();
-    real_part_body(ctx, a);
-}
 __global__ void __launch_bounds__(256) k_rx_dec_sum(const DecSumArgs a) {
     SSF_RX_CTX();
     dec_sum_body(ctx, a);
@@ -182,7 +178,7 @@ struct HipRxBackend {
     }
     bool is_resident(const void *p) const { return on_device(p); }
     void launch_front(const FrontArgs &a) {
-        k_rx_front<<<ew_grid(a.N), 256, 0, st>>>(a);
+        k_rx_front<<<ew_grid(a.f.N), 256, 0, st>>>(a);
         chk(hipGetLastError(), "launch k_rx_front");
     }
     void memset(void *d, int v, size_t n) { chk(hipMemsetAsync(d, v, n, st), "hipMemsetAsync"); }
@@ -210,10 +206,6 @@ struct HipRxBackend {
     void launch_shift_add(const ShiftAddArgs &a) {
         k_tx_shift_add<<<ew_grid(a.N), 256, 0, st>>>(a);
         chk(hipGetLastError(), "launch k_tx_shift_add");
-    }
-    void launch_real_part(const RealPartArgs &a) {
-        k_rx_real_part<<<ew_grid(a.N), 256, 0, st>>>(a);
-        chk(hipGetLastError(), "launch k_rx_real_part");
     }
     void launch_dec_sum(const DecSumArgs &a, int nblocks, int nthreads) {
         k_rx_dec_sum<<<(unsigned)nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, st>>>(a);

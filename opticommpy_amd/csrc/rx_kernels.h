@@ -65,39 +65,43 @@ SSF_HD double pd_current(const PdModel &m, Cd e, double us, double ut) { return 
 
 enum { RX_PHOTODIODE = 0, RX_BALANCED = 1 };
 
-// ---- detection stage of photodiode / balancedPD.  Output s: (N, 1) complex, before the photodiodes' low-pass filter
-//   RX_PHOTODIODE  in0 = (N, nm) field; out (N, 1): R * sum_modes |E|^2 (+ noise), imaginary part 0
-//   RX_BALANCED    in0 = (N, 2): columns E1, E2; out (N, 1): i1 - i2
+// ---- detection stage of photodiode / balancedPD: the real photocurrent before the photodiodes' low-pass filter
+//   RX_PHOTODIODE  in0 = (N, nm) field: R * sum_modes |E|^2 (+ noise)             (devices.py:352-399)
+//   RX_BALANCED    in0 = (N, 2): columns E1, E2: i1 - i2                           (devices.py:402-459)
 // Subtracting before the (linear, common) filter instead of after it is exact.  (The coherent receivers: det_sample below.)
-struct FrontArgs {
+struct PdFront {
     const Cd *in0;
-    const Cd *lo;
-    Cd *out;
     long long N;
     int mode, nm;
-    double es_scale[2];       // PDL (devices.py:660-662)
-    double lo_scale[2];       // LO split by the PBS at pi/4 (devices.py:653): cos, -sin
     PdModel pd;
 };
-template <class Ctx> SSF_HD void front_body(Ctx &ctx, const FrontArgs &a) {
-    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) {
-        const bool noisy = a.pd.shot || a.pd.thermal;
-        double z[4] = {0, 0, 0, 0};
-        if (a.mode == RX_PHOTODIODE) {
-            if (noisy) pd_normals(a.pd, n, a.N, 0, 1, z);
-            double pw = 0;                              // devices.py:356-359: one photocurrent from the summed mode powers
-            for (int k = 0; k < a.nm; ++k) {
-                const Cd e = a.in0[n * a.nm + k];
-                pw += e.re * e.re + e.im * e.im;
-            }
-            a.out[n] = mk<double>(pd_current_pw(a.pd, pw, z[0], z[1]), 0.0);
-        } else if (a.mode == RX_BALANCED) {
-            if (noisy) pd_normals(a.pd, n, a.N, 0, 2, z);
-            const double i1 = pd_current(a.pd, a.in0[2 * n], z[0], z[1]);
-            const double i2 = pd_current(a.pd, a.in0[2 * n + 1], z[2], z[3]);
-            a.out[n] = mk<double>(i1 - i2, 0.0);
+template <int NOISE = 2> SSF_HD double pd_front_sample(const PdFront &a, long long n) {
+    const bool noisy = NOISE != 0 && (a.pd.shot || a.pd.thermal);
+    double z[4] = {0, 0, 0, 0};
+    if (a.mode == RX_PHOTODIODE) {
+        if (noisy) pd_normals(a.pd, n, a.N, 0, 1, z);
+        double pw = 0;                                  // devices.py:356-359: one photocurrent from the summed mode powers
+        for (int k = 0; k < a.nm; ++k) {
+            const Cd e = a.in0[n * a.nm + k];
+            pw += e.re * e.re + e.im * e.im;
         }
+        return pd_current_pw(a.pd, pw, z[0], z[1]);
     }
+    if (noisy) pd_normals(a.pd, n, a.N, 0, 2, z);
+    return pd_current(a.pd, a.in0[2 * n], z[0], z[1]) - pd_current(a.pd, a.in0[2 * n + 1], z[2], z[3]);
+}
+// without a filter behind it (ideal photodiodes / bandwidthLimitation off): one element-wise pass, (N,) float64 out
+struct FrontArgs {
+    PdFront f;
+    double *out;
+};
+template <int NOISE, class Ctx> SSF_HD void front_loop(Ctx &ctx, const FrontArgs &a) {
+    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.f.N; n += (long long)ctx.nblocks * ctx.nthreads)
+        a.out[n] = pd_front_sample<NOISE>(a.f, n);
+}
+template <class Ctx> SSF_HD void front_body(Ctx &ctx, const FrontArgs &a) {
+    if (a.f.pd.shot || a.f.pd.thermal) front_loop<1>(ctx, a);
+    else front_loop<0>(ctx, a);
 }
 
 // =====================================================================================================
@@ -144,12 +148,13 @@ template <int NOISE = 2> SSF_HD Cd det_sample(const DetArgs &a, long long n, int
 // IQ imbalance (core.py:952-960): s' = k1 s + k2 conj(s)
 SSF_HD Cd iq_mix(Cd k1, Cd k2, Cd s) { return k1 * s + k2 * fused::conj(s); }
 
-enum { PRE_PLAIN = 0, PRE_PBS = 1, PRE_DET = 2, PRE_IQ = 3 };
-enum { POST_PLAIN = 0, POST_IQF = 1, POST_PART = 2 };
+enum { PRE_PLAIN = 0, PRE_PBS = 1, PRE_DET = 2, PRE_IQ = 3, PRE_PD = 4 };
+enum { POST_PLAIN = 0, POST_IQF = 1, POST_PART = 2, POST_REAL = 3 };
 struct RxOlsArgs {
     fused::OlsArgs<double> o; // geometry, filters, o.in (PRE_PLAIN / PRE_IQ), o.out
     int pre, post;
     DetArgs det;              // PRE_PBS: in0, c, s;  PRE_DET: everything
+    PdFront front;            // PRE_PD: photodiode / balancedPD (one column: the photocurrent as a real signal; POST_REAL: o.out is (N,) float64)
     Cd k1[2], k2[2];          // PRE_IQ / POST_IQF, per polarisation
     int nm;                   // PRE_IQ / POST_PART: polarisations of the signal (columns of o.in / o.out)
     int pol0;                 // ... the launch's columns are I and Q of the polarisations pol0, pol0 + 1, ...
@@ -169,6 +174,8 @@ template <int LG, int C, int PRE, int NOISE, class Ctx> SSF_HD void rx_ols_body(
                               : mk<double>(e1.re * a.det.c - e0.re * a.det.s, e1.im * a.det.c - e0.im * a.det.s);
             } else if constexpr (PRE == PRE_DET) {
                 return det_sample<NOISE>(a.det, src, m);
+            } else if constexpr (PRE == PRE_PD) {
+                return mk<double>(pd_front_sample<NOISE>(a.front, src), 0.0);
             } else if constexpr (PRE == PRE_IQ) {        // column m = 2 p + part: the real (I) or imaginary (Q) part of s'_p, as a real signal
                 const int pl = a.pol0 + (m >> 1);
                 const Cd t = iq_mix(sel2(a.k1, pl), sel2(a.k2, pl), a.o.in[src * a.nm + pl]);
@@ -182,6 +189,8 @@ template <int LG, int C, int PRE, int NOISE, class Ctx> SSF_HD void rx_ols_body(
             } else if (a.post == POST_PART) {            // S_p = Re(filtered I) + j Re(filtered Q)   (core.py:963-968)
                 double *o = (double *)(a.o.out + n * a.nm + a.pol0 + (m >> 1));
                 o[m & 1] = v.re;
+            } else if (a.post == POST_REAL) {            // `return ipd.real` (devices.py:399)
+                ((double *)a.o.out)[n] = v.re;
             } else a.o.out[n * a.o.out_ld + m] = v;
         });
 }
@@ -195,6 +204,15 @@ template <class F> inline bool rx_ols_dispatch(const RxOlsArgs &a, const fused::
         fused::ols_dispatch(o, [&](auto lg, auto cc) {
             if (noisy) f(lg, cc, integral_constant<int, PRE_DET>{}, integral_constant<int, 1>{});
             else f(lg, cc, integral_constant<int, PRE_DET>{}, integral_constant<int, 0>{});
+        });
+        return true;
+    }
+    if (a.pre == PRE_PD) {                           // (one column)
+        if (o.C != 1) return false;
+        const bool noisy = a.front.pd.shot || a.front.pd.thermal;
+        fused::ols_dispatch(o, [&](auto lg, auto) {
+            if (noisy) f(lg, integral_constant<int, 1>{}, integral_constant<int, PRE_PD>{}, integral_constant<int, 1>{});
+            else f(lg, integral_constant<int, 1>{}, integral_constant<int, PRE_PD>{}, integral_constant<int, 0>{});
         });
         return true;
     }
@@ -246,16 +264,6 @@ template <class Ctx> SSF_HD void iqf_body(Ctx &ctx, const IqfArgs &a) {
         const int p = (int)(i - n * a.nm);
         a.out[i] = n == a.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(sel2(a.k1, p), sel2(a.k2, p), a.in[i]);
     }
-}
-
-// ---- real part of a complex column as a float64 array (photocurrents: `return ipd.real`, devices.py:399)
-struct RealPartArgs {
-    const Cd *in;
-    double *out;
-    long long N;
-};
-template <class Ctx> SSF_HD void real_part_body(Ctx &ctx, const RealPartArgs &a) {
-    for (long long n = (long long)ctx.bid * ctx.nthreads + ctx.tid; n < a.N; n += (long long)ctx.nblocks * ctx.nthreads) a.out[n] = a.in[n].re;
 }
 
 // ---- y += alpha x on float64 arrays (balancedPD's i1 - i2 when the photocurrents are device arrays: devices.py:456-458)

@@ -475,54 +475,52 @@ template <class Backend> struct RxCore {
         if (lowpass && (ntaps < 1 || ntaps > kMaxNfft / 2)) return fail(SSF_ERR_UNSUPPORTED, "photodiode filter: 1 <= N <= 4096 taps");
         if (coherent || iq_only) return run_coherent(mode, N, p, in0, lo, un, out);
 
-        // photodiode / balancedPD: detection -> [low-pass FIR] -> real photocurrent
-        Cd *a = dalloc((size_t)N * nin), *b = dalloc((size_t)N + 16);
+        // photodiode / balancedPD: detection -> [low-pass FIR] -> real photocurrent, ONE launch: the detection rides in the filter's
+        // loads, the real part is what its stores write (an element-wise launch when there is no filter); a device input is read
+        // where it is and a device result written where it belongs
+        const Cd *sig = resident(in0, (size_t)N * nin);
+        double *res = be.is_resident(out) ? (double *)out : (double *)dalloc((size_t)(N + 1) / 2);
         double *dun = nullptr;
-        if (!a || !b) return fail(SSF_ERR_OOM, "out of device memory");
-        be.h2d_big(a, in0, sizeof(Cd) * (size_t)N * nin);
+        if (!sig || !res) return fail(SSF_ERR_OOM, "out of device memory");
         if (noisy && un) {
             dun = (double *)be.alloc(sizeof(double) * (size_t)N * npd * 2);
             if (!dun) return fail(SSF_ERR_OOM, "out of device memory");
             owned.push_back(dun);
             be.h2d_big(dun, un, sizeof(double) * (size_t)N * npd * 2);
         }
-        FrontArgs fa{};
-        fa.in0 = a;
-        fa.lo = nullptr;
-        fa.out = b;
-        fa.N = N;
-        fa.mode = mode == SSF_RX_PHOTODIODE ? RX_PHOTODIODE : RX_BALANCED;
-        fa.nm = nin;
-        fa.es_scale[0] = fa.es_scale[1] = 1.0;
-        fa.lo_scale[0] = fa.lo_scale[1] = 1.0;
+        PdFront fr{};
+        fr.in0 = sig;
+        fr.N = N;
+        fr.mode = mode == SSF_RX_PHOTODIODE ? RX_PHOTODIODE : RX_BALANCED;
+        fr.nm = nin;
         const double q = 1.602176634e-19, kB = 1.380649e-23;         // scipy.constants (CODATA 2018, exact)
-        fa.pd.R = p.R;
-        fa.pd.IpdSat = p.IpdSat;
-        fa.pd.saturate = !quiet && p.currentSaturation;
-        fa.pd.shot = !quiet && p.shotNoise;
-        fa.pd.thermal = !quiet && p.thermalNoise;
-        fa.pd.shot_k = fs_pd * q;
-        fa.pd.Id = p.Id;
-        fa.pd.thermal_sigma = std::sqrt(fs_pd * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
-        fa.pd.seed = (unsigned long long)p.rng_seed;
-        fa.pd.un = dun;
-        be.launch_front(fa);
-        Cd *s = b;
+        fr.pd.R = p.R;
+        fr.pd.IpdSat = p.IpdSat;
+        fr.pd.saturate = !quiet && p.currentSaturation;
+        fr.pd.shot = !quiet && p.shotNoise;
+        fr.pd.thermal = !quiet && p.thermalNoise;
+        fr.pd.shot_k = fs_pd * q;
+        fr.pd.Id = p.Id;
+        fr.pd.thermal_sigma = std::sqrt(fs_pd * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
+        fr.pd.seed = (unsigned long long)p.rng_seed;
+        fr.pd.un = dun;
         if (lowpass) {
             const int nfft = fir_nfft(ntaps);
             Cd *dH = lowpass_filter(p.B, fs_pd, ntaps, p.fType, nfft);
             if (!dH) return fail(SSF_ERR_OOM, "out of device memory");
-            int rc = ols(s, 1, N, N, a, 1, N, 1, dH, 0, ntaps, nfft, 0);
-            if (rc) return rc;
-            s = a;
+            RxOlsArgs r = rx_ols_args(N, N, (Cd *)res, 1, N, 1, dH, 0, ntaps, nfft, 0);
+            r.pre = PRE_PD;
+            r.post = POST_REAL;
+            r.front = fr;
+            be.launch_rx_ols(r);
+        } else {
+            FrontArgs fa{fr, res};
+            be.launch_front(fa);
         }
-        double *re = (double *)(s == a ? b : a);                     // real photocurrent: (N,) float64 (the other buffer holds >= N complex values)
-        RealPartArgs ra{s, re, N};
-        be.launch_real_part(ra);
         be.sync();
-        be.d2h_big(out, re, sizeof(double) * (size_t)N);
         if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
-        return SSF_OK;
+        if ((void *)res != out) be.d2h_big(out, res, sizeof(double) * (size_t)N);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
     }
 
     // y += alpha x, n float64 values, host or device pointers (a device y is updated in place)

@@ -288,14 +288,13 @@ struct EmuBackend {
     bool is_resident(const void *) const { return true; }      // (the emulator's "device" memory is the host's)
     void *filter_lookup(const void *, size_t) { return nullptr; }                  // (no filter cache: every call builds its own)
     void *filter_store(const void *, size_t, const void *, size_t) { return nullptr; }
-    void launch_front(const ssf::rx::FrontArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::front_body(c, a); }); }
+    void launch_front(const ssf::rx::FrontArgs &a) { ++launches; run_grid(ew_grid(a.f.N), 64, 64, [&](EmuCtx &c) { ssf::rx::front_body(c, a); }); }
     void launch_nlin_phase(const ssf::rx::NlinPhaseArgs &a) { run_grid(ew_grid(a.n), 64, 64, [&](EmuCtx &c) { ssf::rx::nlin_phase_body(c, a); }); }
     void launch_conv_sums(const ssf::rx::ConvSumsArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::conv_sums_body(c, a); }); }
     void launch_absmax(const ssf::rx::AbsMaxArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::absmax_body(c, a); }); }
     void launch_pn(const ssf::rx::PnArgs &a, int nchunks) { run_grid(nchunks, 64, 64 * sizeof(double), [&](EmuCtx &c) { ssf::rx::pn_body(c, a); }); }
     void launch_iqm(const ssf::rx::IqmArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::iqm_body(c, a); }); }
     void launch_shift_add(const ssf::rx::ShiftAddArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::shift_add_body(c, a); }); }
-    void launch_real_part(const ssf::rx::RealPartArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::real_part_body(c, a); }); }
     void launch_dec_sum(const ssf::rx::DecSumArgs &a, int nblocks, int nthreads) {
         run_grid(nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, [&](EmuCtx &c) { ssf::rx::dec_sum_body(c, a); });
     }

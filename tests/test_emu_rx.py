@@ -119,6 +119,12 @@ def test_a_coherent_receiver_call_is_at_most_three_launches():
                          (dict(), dict(B=30e9, seed=2), 1), (dict(), dict(B=30e9, ideal=True), 1)):
         out = oa.pdmCoherentReceiver(Es, Elo, bag(dict(Fs=96e9, **fe)), bag(dict(Fs=96e9, **pd)))
         assert out.shape == (N, 2) and e.emu_rx_launches() == want, (fe, e.emu_rx_launches())
+    # photodiode / balancedPD: detection in the filter's loads, the real part in its stores (or one element-wise pass): 1 launch
+    for pd in (dict(B=30e9, seed=2), dict(B=30e9, ideal=True), dict(B=30e9, bandwidthLimitation=False, seed=3)):
+        i = oa.photodiode(Es, bag(dict(Fs=96e9, **pd)))
+        assert i.shape == (N,) and i.dtype == np.float64 and e.emu_rx_launches() == 1, (pd, e.emu_rx_launches())
+        i = oa.balancedPD(Es[:, 0], Es[:, 1], bag(dict(Fs=96e9, **pd)))
+        assert i.shape == (N,) and e.emu_rx_launches() == 1, (pd, e.emu_rx_launches())
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 17])

@@ -2,7 +2,7 @@
 """Receiver / transmitter side with everything resident in HBM (DeviceArray in, DeviceArray out): time per call and the
 algorithmic bytes it has to move at least (inputs once in, outputs once out), for the kernel summaries under profiles/
 (run under `rocprofv3 --kernel-trace --stats`).    python tools/bench_rx_device.py [log2n ...] [--reps R] [--json] [--cases a,b]
-(cases: pdm_notebook pdm_impaired pdm_defaults firFilter255 decimate16to2 edc800km simpleWDMTx11ch; default all)"""
+(cases: pdm_notebook pdm_impaired pdm_defaults photodiode firFilter255 decimate16to2 edc800km simpleWDMTx11ch; default all)"""
 import json
 import os
 import sys
@@ -78,6 +78,10 @@ def main():
             t, r = timeit(lambda: oa.pdmCoherentReceiver(Es, Elo, bag(Fs=Fs, **fe), bag(Fs=Fs, **pd)), reps)
             alg = (2 + 1 + 2) * 16 * N                       # signal and LO in, detected signal out
             out["%s_2^%d" % (name, lg)] = dict(ms=t * 1e3, alg_MiB=alg / 2**20, GBs=alg / t / 1e9, frac=alg / t / 8e12)
+        if want("photodiode"):                            # (N, 2) field -> one real photocurrent: defaults (noisy, band-limited) and ideal
+            for tag, kw in (("defaults", dict(B=30e9, seed=2)), ("ideal", dict(B=30e9, ideal=True))):
+                t, _ = timeit(lambda: oa.photodiode(Es, bag(Fs=Fs, **kw)), reps)
+                out["photodiode_%s_2^%d" % (tag, lg)] = dict(ms=t * 1e3, alg_MiB=40 * N / 2**20, GBs=40 * N / t / 1e9, frac=40 * N / t / 8e12)
         h = oa.lowPassFIR(25e9, Fs, 255)
         if want("firFilter255"):
             t, _ = timeit(lambda: oa.firFilter(h, Es), reps)
