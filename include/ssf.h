@@ -403,7 +403,7 @@ typedef struct {
     int32_t fType;                /* 0 'rect', 1 'gauss' */
     int32_t ideal, shotNoise, thermalNoise, currentSaturation, bandwidthLimitation;
     int32_t pad_;
-    int64_t rng_seed;             /* device noise streams (Philox4x32-10), one per photodiode */
+    int64_t rng_seed;             /* device noise streams (Philox4x32-10; one counter row per pair of photodiodes, single-precision Box-Muller) */
     double  Fs_pd;                /* sampling rate of the photodiode model -- noise scale, low-pass design, the Fs >= 2 B check:
                                    * paramPD.Fs of the reference (devices.py:331-353, 562-563) -- when it differs from Fs
                                    * (paramFE.Fs: polarisation delay, IQ skew); 0 = Fs */
