@@ -14,6 +14,7 @@ A DeviceArray is a typed, C-contiguous block of device memory (``ssf_device_mall
 recognises device pointers wherever it takes array arguments (include/ssf.h), so the same entry
 points serve both kinds of caller.  Functions return a DeviceArray when their main input is one."""
 import ctypes as C
+import math
 import threading
 
 import numpy as np
@@ -76,7 +77,7 @@ class DeviceArray:
     # ---- ndarray-like surface
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+        return math.prod(self.shape)                 # (np.prod costs microseconds per call: several per receiver-side call)
 
     @property
     def nbytes(self):
@@ -96,9 +97,9 @@ class DeviceArray:
     def reshape(self, *shape):
         """Same memory, another C-contiguous shape (a view: keeps the owner alive)."""
         shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
-        known = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
+        known = math.prod(int(s) for s in shape if s != -1)
         shape = tuple(self.size // known if s == -1 else int(s) for s in shape)
-        if int(np.prod(shape, dtype=np.int64)) != self.size:
+        if math.prod(shape) != self.size:
             raise ValueError(f"cannot reshape array of size {self.size} into shape {shape}")
         v = object.__new__(DeviceArray)
         v.shape, v.dtype, v.device, v._ptr, v._owner = shape, self.dtype, self.device, self._ptr, self
