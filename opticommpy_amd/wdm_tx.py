@@ -107,6 +107,9 @@ def _rc(t, alpha):
     return h
 
 
+_PULSES = {}
+
+
 def pulseShape(param):
     """Pulse-shaping filter taps, normalised to unit sum (optic/dsp/core.py:217-270): 'rect', 'nrz', 'rrc', 'rc'."""
     kind = getattr(param, "pulseType", "rrc")
@@ -119,8 +122,13 @@ def pulseShape(param):
         t = np.linspace(-2, 2, SpS)
         h = np.convolve(np.ones(SpS), 2 / np.sqrt(np.pi) * np.exp(-(t**2)), mode="full")
     elif kind in ("rrc", "rc"):
-        t = np.linspace(-n // 2, n // 2, n) * (1 / SpS)
-        h = _rrc(t, ro) if kind == "rrc" else _rc(t, ro)
+        key = (kind, SpS, n, ro)
+        if key not in _PULSES:                                     # (a thousand scalar evaluations: kept between calls)
+            t = np.linspace(-n // 2, n // 2, n) * (1 / SpS)
+            if len(_PULSES) >= 8:
+                _PULSES.pop(next(iter(_PULSES)))
+            _PULSES[key] = _rrc(t, ro) if kind == "rrc" else _rc(t, ro)
+        h = _PULSES[key]
     else:
         raise ValueError("pulseType must be 'rect', 'nrz', 'rrc' or 'rc'")
     return h / np.sum(h)
