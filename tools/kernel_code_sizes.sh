@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/../opticommpy_amd/csrc"
 T=$(mktemp -d)
 for u in f64 f32; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-pass-failed --cuda-device-only "$@" -c engine_fused_$u.hip -o $T/$u.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-pass-failed -mllvm -amdgpu-use-amdgpu-trackers=1 --cuda-device-only "$@" -c engine_fused_$u.hip -o $T/$u.o 2>/dev/null
   /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$T/$u.o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/$u.co 2>/dev/null
   /opt/rocm/lib/llvm/bin/llvm-readelf -sW $T/$u.co 2>/dev/null | awk '$4=="FUNC" {print $3, $8}' | sort -rn | c++filt |
     sed 's/ssf::(anonymous namespace):://; s/(ssf::fused::.*//; s/void //' | awk '{s=$1; $1=""; print s, $0}' | uniq

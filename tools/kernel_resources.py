@@ -19,7 +19,8 @@ def main():
             asm = (keep + "." + unit + ".s") if keep else os.path.join(td, unit + ".s")
             if not (keep and os.path.exists(asm)):
                 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                                       "-I" + CSRC, "-Wno-pass-failed", "--cuda-device-only", "-S"] + sys.argv[1:] +
+                                       "-I" + CSRC, "-Wno-pass-failed", "-mllvm", "-amdgpu-use-amdgpu-trackers=1",      # (the Makefile's FUSED_FLAGS)
+                                       "--cuda-device-only", "-S"] + sys.argv[1:] +
                                       [os.path.join(CSRC, unit + ".hip"), "-o", asm], stderr=subprocess.DEVNULL)
             txt += open(asm).read()
     rows = []
