@@ -59,7 +59,17 @@ struct DevCtx : DevCtxCore {
 // OCC = minimum waves per SIMD the register allocator must leave room for: 1 = up to 512
 // registers per lane and no spills (one 256-thread workgroup per CU), 2 = 256 registers
 // (two workgroups per CU).  LG = compile-time log2 of the transform length (0 = runtime).
-template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds__(MAXT, OCC) k_row(const RowArgs<T> a) {
+// experiment (appendix #42): SSF_WPE = 3 squeezes the 16-value kernels into the 168 registers three waves per SIMD would need (the
+// LDS tiles still allow two: this measures what the squeeze alone costs)
+#ifndef SSF_WPE
+#define SSF_WPE 0
+#endif
+#if SSF_WPE
+#define SSF_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SSF_WPE, SSF_WPE)))
+#else
+#define SSF_WPE_ATTR
+#endif
+template <typename T, int MAXT, int OCC, int LG> __global__ void __launch_bounds__(MAXT, OCC) SSF_WPE_ATTR k_row(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
     row_body<T, LG>(ctx, unit_view(a, (int)blockIdx.y));
 }
@@ -96,7 +106,7 @@ template <int LG> __global__ void __launch_bounds__(512, 4) k_col_pk8(const ColA
     col_pk_body<LG, 8>(ctx, unit_view(a, (int)blockIdx.y));
 }
 // complex64 Manakov: packed polarisation pairs (fused_kernels.h: col_pk_body); up to 512 threads (8 columns of 1024)
-template <int LG, int CI = 0, int SG = SG_ALL> __global__ void __launch_bounds__(512) k_col_pk(const ColArgs<pf2> a) {
+template <int LG, int CI = 0, int SG = SG_ALL> __global__ void __launch_bounds__(512) SSF_WPE_ATTR k_col_pk(const ColArgs<pf2> a) {
     SSF_DEV_CTX(1);
     col_pk_body<LG, 16, CI, SG>(ctx, unit_view(a, (int)blockIdx.y));
 }
