@@ -112,6 +112,8 @@ template <class Ctx> SSF_HD void front_body(Ctx &ctx, const FrontArgs &a) {
 //                                                                rx_ols_body, PRE_DET (+ POST_IQF), or det_body without a filter
 //   IQ imbalance -> skew filters of I and Q -> S = I + j Q        rx_ols_body, PRE_IQ + POST_PART            (a timeSkew != 0)
 // Before: pbs, delay filter, front, low-pass filter, iqmix, two skew filters, combine -- eight launches and as many passes.
+// photodiode / balancedPD the same way: pd_front_sample in the low-pass filter's loads, the real part in its stores
+//                                                                rx_ols_body, PRE_PD + POST_REAL, or front_body without a filter
 struct DetArgs {
     const Cd *in0;            // (N, nm) signal: before the PBS when `pbs` is set, behind it (and the delay filters) otherwise
     const Cd *lo;             // (N,)
