@@ -457,6 +457,7 @@ int emu_rx_run(int mode, int64_t N, int nmodes, const ssf_rx_params *p, const vo
     if (rc) fprintf(stderr, "emu: %s\n", core.err.c_str());
     return rc;
 }
+int emu_fir_nfft(int K) { return ssf::rx::fir_nfft(K); }                   // (the block-size rule: tests compare it with models._ols_block)
 int emu_fir(int64_t sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out) {
     EmuBackend be;
     ssf::rx::RxCore<EmuBackend> core(be);

@@ -212,3 +212,14 @@ def test_fir_filter_with_more_than_2048_taps_uses_8192_point_blocks(ntaps):
     y = oa.firFilter(h, x)                                   # (the autouse fixture routes the kernels to the emulator)
     want = np.stack([np.convolve(x[:, c], h, mode="same") for c in range(2)], axis=1)
     assert rel_l2(y, want) <= 1e-13
+
+
+def test_block_size_rule_is_the_same_on_both_sides_of_the_abi():
+    """edc picks its overlap-save block in Python (models._ols_block), firFilter / the photodiodes' low-pass in C++ (rx_pipeline.h:
+    fir_nfft): one rule -- 2048 points up to 682 taps, 4096 up to 2048, 8192 above, never smaller than the filter."""
+    from opticommpy_amd import models
+    e = eb.load()
+    for K in list(range(1, 700)) + [1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096]:
+        n = e.emu_fir_nfft(K)
+        assert n == models._ols_block(K) and n >= K and n & (n - 1) == 0, K
+    assert (e.emu_fir_nfft(255), e.emu_fir_nfft(682), e.emu_fir_nfft(683), e.emu_fir_nfft(2049)) == (2048, 2048, 4096, 8192)
