@@ -247,7 +247,8 @@ def measure(env, cfg, m):
     # warm-up steps and the timed ones
     dev_in = {}
     host_in = bool(os.environ.get("SSF_BENCH_HOST_INPUT"))     # (A/B switch: re-upload from host memory before every run, as rounds 1-2 did)
-    for u in mine:
+    t_h2d0 = time.perf_counter()                                # (what there is to measure beside the compute time of a
+    for u in mine:                                              #  sharded run is the host-side transfer of inputs and results)
         if host_in:
             dev_in[u] = fields[u].ctypes.data_as(C.c_void_p)
             continue
@@ -255,6 +256,8 @@ def measure(env, cfg, m):
         _lib.raise_for(lib, None, lib.ssf_device_malloc(local_rank, fields[u].nbytes, C.byref(q)))
         _lib.raise_for(lib, None, lib.ssf_device_memcpy(local_rank, q, fields[u].ctypes.data_as(C.c_void_p), fields[u].nbytes))
         dev_in[u] = q
+    h2d_ms = (time.perf_counter() - t_h2d0) * 1e3
+    h2d_bytes = 0 if host_in else sum(fields[u].nbytes for u in mine)
 
     # ---- one plan per unit (its field stays resident in HBM), units dealt to the lanes alternately
     plans = {}
@@ -314,10 +317,15 @@ def measure(env, cfg, m):
 
     # results: per-unit checksum, all-gathered ("gather of results only")
     outs = {}
+    t_d2h0 = time.perf_counter()
     for u in mine:
         o = np.empty_like(fields[u])
         _lib.raise_for(lib, plans[u], lib.ssf_download(plans[u], o.ctypes.data_as(C.c_void_p)))
         outs[u] = o
+    d2h_ms = (time.perf_counter() - t_d2h0) * 1e3
+    d2h_bytes = sum(o.nbytes for o in outs.values())
+    xfer = np.array([[h2d_ms, d2h_ms, dt_local * 1e3, float(h2d_bytes), float(d2h_bytes)]])
+    xfer_all = comm.allgather(xfer)[:, 0, :] if comm is not None else xfer
     per = max(len(mgpu.shard_range(U, world, r)) for r in range(world))
     cs = np.zeros((per, 3))
     for i, u in enumerate(mine):
@@ -352,6 +360,12 @@ def measure(env, cfg, m):
                        "pipeline": _lib.PIPELINE_NAMES.get(lib.ssf_plan_pipeline(plans[u0]), "?"),
                        "units_total": U, "units_per_gpu": len(mine), "lanes_per_gpu": lanes,
                        "unit_steps_total": steps_total, "iterations_per_step": it_step,
+                       # per rank, outside the timed region: inputs host -> HBM before the first run, results HBM -> host after the
+                       # timed one (pinned double-buffered staging, ssf_copy.h), beside that rank's timed compute time
+                       "h2d_ms": [float(x) for x in xfer_all[:, 0]], "d2h_ms": [float(x) for x in xfer_all[:, 1]],
+                       "compute_ms": [float(x) for x in xfer_all[:, 2]],
+                       "h2d_GBs": [float(b / max(t, 1e-9) / 1e6) for t, b in zip(xfer_all[:, 0], xfer_all[:, 3])],
+                       "d2h_GBs": [float(b / max(t, 1e-9) / 1e6) for t, b in zip(xfer_all[:, 1], xfer_all[:, 4])],
                        "transforms_per_step": sum(int(st.transforms) for st in sts.values()) / max(steps_local, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -550,6 +564,10 @@ def also_configs(env, args):
         out["rx_chain_2^20"] = rx_chain_leg()
     except Exception as e:
         out["rx_chain_2^20"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        out["reference_notebook"] = notebook_leg()
+    except Exception as e:
+        out["reference_notebook"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -600,6 +618,77 @@ def rx_chain_leg(reps=10):
                        "what": "the reference's own output of this chain (reference-generated fixture wl_rx_chain_n20)"}}
 
 
+def notebook_leg(sizes=(200_000, 800_000, 2_000_000), sample_km=12.0):
+    """The reference's own published GPU benchmark (/root/reference/examples/benchmarck_GPU_processing.ipynb cells 8 - 10:
+    `manakovSSF_GPU(sigWDM_Tx, paramCh)` timed with time.time() around the call, numpy in / numpy out): one 16-QAM channel,
+    2 polarisations, RRC 4096 taps, SpS 4 at 32 GBd (Fs = 128 GS/s), -2 dBm, Ltotal 500 / Lspan 50 km, ADAPTIVE step
+    (nlprMethod True, maxNlinPhaseRot 2e-2, maxIter 5, tol 1e-5, amp = the default 'edfa'), complex128, signal lengths
+    2e5 / 8e5 / 2e6 samples (the notebook's 5e4 / 2e5 / 5e5 symbols; its 17.5 - 25 x over the CPU is quoted for > 1e6 samples).
+    Per length: the wall time of the call as the notebook takes it, the same call on DeviceArrays, steps / iterations / pipeline,
+    and -- CPU baseline + parity -- the numpy oracle on the first `sample_km` km of the same field with amp='ideal' (a handful of
+    adaptive steps; a step's CPU time does not depend on its size) against the package on the same span."""
+    import opticommpy_amd as oa
+    from oracle import ssf_oracle as orc
+
+    def bag(cls, **kw):
+        q = cls()
+        for k, v in kw.items():
+            setattr(q, k, v)
+        return q
+    legs = {}
+    for N in sizes:
+        tx = bag(oa.parameters, M=16, Rs=32e9, SpS=4, nBits=int(N), pulseType="rrc", nFilterTaps=4096, pulseRollOff=0.01,
+                 powerPerChannel=-2, nChannels=1, Fc=193.1e12, laserLinewidth=100e3, wdmGridSpacing=37.5e9, nPolModes=2,
+                 seed=int(N) % 9973, prgsBar=False)
+        sig = oa.simpleWDMTx(tx)[0]
+        assert sig.shape == (N, 2), sig.shape
+
+        def ch(**kw):
+            return bag(oa.parameters, Ltotal=500, Lspan=50, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, hz=0.5, maxIter=5,
+                       tol=1e-5, nlprMethod=True, maxNlinPhaseRot=2e-2, prgsBar=False, Fs=32e9 * 4, seed=11, **kw)
+        oa.manakovSSF(sig, ch(Ltotal=50))                           # plan, kernels, clocks: one span, untimed
+        t0 = time.perf_counter()
+        out = oa.manakovSSF(sig, ch())                               # the notebook's timed statement
+        t_np = time.perf_counter() - t0
+        lr = dict(oa.last_run)
+        sig_d = oa.to_device(sig)
+        t0 = time.perf_counter()
+        out_d = oa.manakovSSF(sig_d, ch())
+        t_dev = time.perf_counter() - t0
+        lr_d = dict(oa.last_run)
+        assert out.shape == (N, 2) and np.all(np.isfinite(out)) and isinstance(out_d, oa.DeviceArray)
+        # CPU sample + parity on the first kilometres (deterministic amplifier)
+        pc = bag(orc.parameters, Ltotal=sample_km, Lspan=sample_km, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, hz=0.5, maxIter=5,
+                 tol=1e-5, nlprMethod=True, maxNlinPhaseRot=2e-2, prgsBar=False, Fs=32e9 * 4, amp="ideal", saveSpanN=[])
+        tr = {}
+        t0 = time.perf_counter()
+        ref = orc.manakovSSF(sig, pc, trace=tr)
+        t_cpu = time.perf_counter() - t0
+        got = oa.manakovSSF(sig, ch(Ltotal=sample_km, Lspan=sample_km, amp="ideal", saveSpanN=[]), _trace=True)
+        it_gpu = [int(x) for x in oa.last_run["iters"]]
+        err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        n_cpu = len(tr["iters"])
+        cpu_rate = n_cpu / t_cpu
+        ok = bool(err <= 1e-10) and it_gpu == [int(x) for x in tr["iters"]]
+        steps = int(lr["steps"])
+        legs[str(N)] = {
+            "samples": int(N), "pipeline": lr.get("pipeline"), "steps": steps, "iterations": int(lr["iterations"]),
+            "wall_s_numpy_in_numpy_out": t_np, "steps_per_s_numpy_in_numpy_out": steps / t_np,
+            "wall_s_device_resident": t_dev, "steps_per_s_device_resident": int(lr_d["steps"]) / t_dev,
+            "device_ms": float(lr.get("device_ms", 0.0)),
+            "algorithmic_GBs": float(lr.get("bytes_algorithmic", 0.0)) / max(float(lr.get("device_ms", 0.0)), 1e-9) / 1e6,
+            "cpu_oracle": {"steps_per_s": cpu_rate, "steps": n_cpu, "seconds": t_cpu, "cores": 1,
+                           "sample": "first %.0f km of the same field, amp='ideal' (numpy oracle, 1 thread)" % sample_km},
+            "speedup_vs_cpu_oracle_per_step": (steps / t_np) / cpu_rate,
+            "parity": {"rel_l2_vs_oracle": err, "steps": n_cpu, "iterations_equal": it_gpu == [int(x) for x in tr["iters"]],
+                       "gate": 1e-10, "ok": ok}}
+        del sig_d, out_d
+        oa.models.release_plans()
+    return {"workload": "reference notebook benchmarck_GPU_processing.ipynb cell 10: manakovSSF, 1 x 16-QAM channel, 2-pol, Fs 128 GS/s, "
+                        "-2 dBm, 10 x 50 km, adaptive step (maxNlinPhaseRot 2e-2, maxIter 5), amp='edfa' (device ASE), complex128",
+            "published": "GPU (cupy) 17.5 - 25 x the CPU at > 1e6 samples (Colab; notebook text below cell 13)", "lengths": legs}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -616,8 +705,12 @@ def main():
     ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-also", action="store_true", help="headline configuration only (no 'also' legs)")
     ap.add_argument("--parity", default="", help="parity leg: oracle (default) | fixture_cfg3 | fixture_units | none")
+    ap.add_argument("--notebook", action="store_true", help="only the reference notebook's benchmark (notebook_leg), as one JSON line")
     args = ap.parse_args()
 
+    if args.notebook:
+        print(json.dumps({"reference_notebook": notebook_leg()}), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher: be one (a launcher's environment wins)
         self_launch(args.gpus)
 

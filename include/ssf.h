@@ -322,7 +322,9 @@ int  ssf_get_kernel_times(ssf_plan *plan, ssf_kernel_times *out);
  * two buffers.  *gbs = (read + written bytes) / average launch time.  No reference equivalent. */
 int  ssf_device_copy_bandwidth(int device, int64_t bytes, int32_t launches, double *gbs);
 
-/* ---- linear channel (gamma = 0 closed form): one FFT . H . IFFT over the whole length */
+/* ---- linear channel (gamma = 0 closed form): one FFT . H . IFFT over the whole length.  field_in_soa == NULL: the field the plan
+ * already holds (ssf_upload / ssf_upload_aos -- the reference's own (N, ncols) layout, host or device pointer); field_out_soa ==
+ * NULL: the result stays in the plan (ssf_download / ssf_download_aos).  Reference: optic/models/channels.py:30-109. */
 int  ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, double D,
                         double L, const void *field_in_soa, void *field_out_soa);
 
@@ -390,6 +392,22 @@ int  ssf_convergence_condition(int device, int64_t n, const void *Ex_fd, const v
  * ncols <= 8; sig_out: (ceil(N / decFactor), ncols); sampDelay (may be NULL): ncols phases */
 int  ssf_decimate(int device, int64_t N, int32_t ncols, int32_t SpSin, int32_t decFactor,
                   const void *sig_in, void *sig_out, int32_t *sampDelay);
+
+/* ---- the amplifier and the passive optics by themselves: element-wise device passes, complex128, host or device pointers (a
+ * device array never leaves the device; an in-place ssf_edfa -- field_out == field_in -- is allowed).
+ *   ssf_edfa                edfa              optic/models/devices.py:671-726 (GPU twin optic/models/modelsGPU.py:56-114)
+ *       field_out = field_in * sqrt(G_lin) + noise over `n` complex values laid out (samples, ncols) row-major.  noise != NULL:
+ *       the caller's n complex values (the reference's seeded np.random draws, draw for draw); noise == NULL and rng_seed != 0:
+ *       CN(0, p_noise) from Philox4x32-10 (counter = sample, rng_row_offset + column), statistical parity like the span epilogue
+ *       of ssf_execute; both absent: gain only.  G_lin / p_noise as the reference derives them (devices.py:712-722).
+ *   ssf_pbs                 pbs               optic/models/devices.py:223-260
+ *       (Ex, Ey) = [ex, ey] @ [[cos t, -sin t], [sin t, cos t]] for a field of shape (N, 2), or (N,) taken as [ex, 0]
+ *   ssf_optical_hybrid_2x4  opticalHybrid2x4  optic/models/devices.py:462-500
+ *       Eo (4, N) = T @ [Es, 0, 0, Elo] with the 90-degree hybrid's transfer matrix T */
+int  ssf_edfa(int device, int64_t n, int32_t ncols, double G_lin, double p_noise, int64_t rng_seed, int32_t rng_row_offset,
+              const void *field_in, const void *noise, void *field_out);
+int  ssf_pbs(int device, int64_t N, int32_t ncols, double theta, const void *E, void *Ex, void *Ey);
+int  ssf_optical_hybrid_2x4(int device, int64_t N, const void *Es, const void *Elo, void *Eo);
 
 typedef struct {
     double  Fs;

@@ -113,6 +113,9 @@ SYMBOLS = {
     "ssf_device_axpy": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_void_p]),
     "ssf_fir_long": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ssf_delay_signal": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "ssf_edfa": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ssf_pbs": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ssf_optical_hybrid_2x4": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ssf_nlin_phase_rot": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ssf_convergence_condition": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.POINTER(C.c_double)]),

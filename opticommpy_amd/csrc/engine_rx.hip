@@ -51,6 +51,10 @@ __global__ void __launch_bounds__(256) k_rx_front(const FrontArgs a) {
     SSF_RX_CTX();
     front_body(ctx, a);
 }
+__global__ void __launch_bounds__(256) k_optics(const OpticsArgs a) {
+    SSF_RX_CTX();
+    optics_body(ctx, a);
+}
 __global__ void __launch_bounds__(256) k_nlin_phase(const NlinPhaseArgs a) {
     SSF_RX_CTX();
     nlin_phase_body(ctx, a);
@@ -182,6 +186,10 @@ struct HipRxBackend {
         chk(hipGetLastError(), "launch k_rx_front");
     }
     void memset(void *d, int v, size_t n) { chk(hipMemsetAsync(d, v, n, st), "hipMemsetAsync"); }
+    void launch_optics(const OpticsArgs &a) {
+        k_optics<<<ew_grid(a.n), 256, 64, st>>>(a);
+        chk(hipGetLastError(), "launch k_optics");
+    }
     void launch_nlin_phase(const NlinPhaseArgs &a) {
         const long long nb = (a.n + 255) / 256;
         k_nlin_phase<<<(unsigned)std::min<long long>(nb, 16384), 256, 64, st>>>(a);
@@ -246,9 +254,10 @@ struct Pooled : HipRxBackend {
         return nullptr;
     }
     void *filter_store(const void *key, size_t n, const void *host, size_t bytes) {
+        const hipError_t before = first_err;        // (an earlier error of this call stays recorded whatever happens here)
         void *p = HipRxBackend::alloc(bytes);
         if (!p) {
-            first_err = hipSuccess;                 // (no room for a cache entry is not an error: the caller uploads per call)
+            first_err = before;                     // (no room for a cache entry is not an error: the caller uploads per call)
             return nullptr;
         }
         h2d(p, host, bytes);
@@ -267,10 +276,11 @@ struct Pooled : HipRxBackend {
             best->used = true;
             return best->p;
         }
+        const hipError_t before = first_err;
         void *p = HipRxBackend::alloc(n);
         if (!p) {                                   // out of memory: drop the idle blocks and try once more
             trim(0);
-            first_err = hipSuccess;
+            first_err = before;
             p = HipRxBackend::alloc(n);
         }
         if (p) blocks.push_back(Block{p, n, true});
@@ -356,6 +366,10 @@ int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, voi
 int tx_wdm(int device, const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
            const double *deltaF, void *out, double *power_out, std::string *err) {
     return with_core(device, err, [&](RxCore<Pooled> &c) { return c.wdm_tx(*p, symbols, taps, phi, amp, deltaF, out, power_out); });
+}
+int rx_optics(int device, int op, int64_t n, int ncols, double p0, double p1, unsigned long long seed, unsigned row0, const void *a,
+              const void *b, void *o0, void *o1, std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) { return c.optics(op, n, ncols, p0, p1, seed, row0, a, b, o0, o1); });
 }
 int mk_nlin_phase(int device, int64_t n, double gamma, const void *Ex, const void *Ey, const double *Pch, double *phi,
                   std::string *err) {

@@ -738,7 +738,10 @@ template <typename T, class Backend> class FusedCore {
         // next H slot (at most one predicted step).  A chunk without progress is followed by a short general chunk; where the
         // rare stages are the rule (weak nonlinearity: lim_0 < tol at every step) the call goes back to the general kernel for
         // good (and so do the next kSplitPenalty calls of the plan).
-        const bool can_split = col_split && split_penalty == 0 && units == 1 &&
+        // (a coupled batch across ranks: every row launch carries an all-gather, so all ranks must enqueue the SAME launches.  The
+        //  pattern, the prediction and the chunk size depend on per-rank state -- column geometry by pairs per rank, plan history --
+        //  so a coupled span runs the general kernel, in chunks derived from the rank-identical control block only: run_manakov)
+        const bool can_split = col_split && split_penalty == 0 && units == 1 && !cpl_comm &&
                                be.can_split_cols(col_args(kPacked ? 1 : 2, CM_MK), col_block_mk);
         bool general_chunk = false;
         int stalls = 0, pos = 0;                 // pos: position in the predicted pattern (kept from chunk to chunk)
@@ -872,8 +875,10 @@ template <typename T, class Backend> class FusedCore {
         if ((rc = prepare_trace(trace, p.maxIter))) return rc;
         const MkConst k = mk_const_for(p, d, trace);
         SpanRun sr;
-        sr.n_it = hint_n_it;                                          // (the previous call's iteration count: a guess, see run_span)
-        if (hint_n_it > 0) sr.avg_it = (double)hint_n_it;
+        if (!cpl_comm) {                                              // (coupled ranks: no per-plan history in the launch count)
+            sr.n_it = hint_n_it;                                      // (the previous call's iteration count: a guess, see run_span)
+            if (hint_n_it > 0) sr.avg_it = (double)hint_n_it;
+        }
         for (int span = s0; span <= s1; ++span) {
             if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))      // equalization.py:1090-1092
                 launch_amp(Tcur(), (S)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);
@@ -918,8 +923,10 @@ template <typename T, class Backend> class FusedCore {
             if ((rc = pk->prepare_trace(trace, p.maxIter))) return rc;
             const MkConst k = pk->mk_const_for(p, d, trace);
             typename FusedCore<pf2, Backend>::SpanRun sr;
-            sr.n_it = pk->hint_n_it;
-            if (pk->hint_n_it > 0) sr.avg_it = (double)pk->hint_n_it;
+            if (!pk->cpl_comm) {
+                sr.n_it = pk->hint_n_it;
+                if (pk->hint_n_it > 0) sr.avg_it = (double)pk->hint_n_it;
+            }
             for (int span = s0; span <= s1; ++span) {
                 if (p.direction < 0 && (p.amp == SSF_AMP_EDFA || p.amp == SSF_AMP_IDEAL))
                     launch_amp(Tcur(), (S)std::exp(-d.alpha_lin / 2 * p.Lspan), nullptr);

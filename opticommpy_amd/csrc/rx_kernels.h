@@ -319,6 +319,51 @@ template <class Ctx> SSF_HD void conv_sums_body(Ctx &ctx, const ConvSumsArgs &a)
 }
 
 // =====================================================================================================
+// The amplifier and the passive optics the reference also exports by themselves, as element-wise device passes (inside
+// ssfm / manakovSSF the amplifier is the span epilogue, fused_kernels.h: amp_body; inside the coherent receivers the splitter and
+// the hybrid ride in the loads of the filters, det_sample above):
+//   OPT_EDFA    out = in sqrt(G) + noise         optic/models/devices.py:671-726  (noise: the caller's array -- the reference's seeded
+//               np.random draws -- or CN(0, 2 sigma^2) from Philox4x32-10: sample = n, row = row0 + column)
+//   OPT_PBS     (Ex, Ey) = [ex, ey] @ [[c, -s], [s, c]]   optic/models/devices.py:223-260  (a one-column input is [ex, 0])
+//   OPT_HYBRID  T @ [Es, 0, 0, Elo], T the 2x4 90-degree hybrid's 4 x 4 matrix   optic/models/devices.py:462-500  -> (4, n)
+enum { OPT_EDFA = 0, OPT_PBS = 1, OPT_HYBRID = 2 };      // (= ssf_internal.h: kOptEdfa ...)
+struct OpticsArgs {
+    int op, ncols;
+    const Cd *a, *b;        // EDFA: field, noise (or null); PBS: field (n, ncols); HYBRID: Es, Elo
+    Cd *o0, *o1;            // EDFA: out; PBS: Ex, Ey; HYBRID: (4, n)
+    long long n;            // EDFA: elements (samples x columns); PBS / HYBRID: samples
+    double p0, p1;          // EDFA: sqrt(G_lin), sigma per quadrature (0: no device noise); PBS: cos, sin
+    unsigned long long seed;
+    unsigned row0;
+};
+template <class Ctx> SSF_HD void optics_body(Ctx &ctx, const OpticsArgs &a) {
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < a.n; i += (long long)ctx.nblocks * ctx.nthreads) {
+        if (a.op == OPT_EDFA) {
+            Cd e = mk<double>(a.a[i].re * a.p0, a.a[i].im * a.p0);
+            if (a.b) e = e + a.b[i];
+            if (a.p1 > 0) {
+                double re, im;
+                gauss_pair((unsigned long long)(i / a.ncols), a.row0 + (unsigned)(i % a.ncols), 0u, a.seed, a.p1, re, im);
+                e = e + mk<double>(re, im);
+            }
+            a.o0[i] = e;
+        } else if (a.op == OPT_PBS) {
+            const Cd ex = a.ncols == 2 ? a.a[2 * i] : a.a[i];
+            const Cd ey = a.ncols == 2 ? a.a[2 * i + 1] : mk<double>(0.0, 0.0);
+            a.o0[i] = mk<double>(ex.re * a.p0 + ey.re * a.p1, ex.im * a.p0 + ey.im * a.p1);
+            a.o1[i] = mk<double>(ey.re * a.p0 - ex.re * a.p1, ey.im * a.p0 - ex.im * a.p1);
+        } else {
+            const Cd s = mk<double>(0.5 * a.a[i].re, 0.5 * a.a[i].im), l = mk<double>(0.5 * a.b[i].re, 0.5 * a.b[i].im);
+            const Cd js = mk<double>(-s.im, s.re), jl = mk<double>(-l.im, l.re);
+            a.o0[i] = s - l;                        //  Es/2        - Elo/2
+            a.o0[a.n + i] = js + jl;                // j Es/2       + j Elo/2
+            a.o0[2 * a.n + i] = js - l;             // j Es/2       - Elo/2
+            a.o0[3 * a.n + i] = jl - s;             // - Es/2       + j Elo/2
+        }
+    }
+}
+
+// =====================================================================================================
 // WDM transmitter (optic/models/tx.py:42-228): after the pulse-shaping filter
 // (an overlap-save launch on the zero-stuffed symbols) each (channel, polarisation) needs
 //   max |x|                       -> absmax_body      sigTx / np.max(np.abs(sigTx))        (tx.py:204)

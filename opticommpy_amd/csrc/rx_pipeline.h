@@ -232,8 +232,10 @@ template <class Backend> struct RxCore {
         int kind, K, nfft, x;
         double a, b;
         unsigned long long h;
+        unsigned long long h2 = 0;    // content keys (kinds 3, 4): a second, independent hash of the same values (with the length in K / nfft:
+                                      // 128 bits of content + length -- a single 64-bit FNV collision would silently apply the wrong filter)
         bool operator==(const FilterKey &o) const {
-            return kind == o.kind && K == o.K && nfft == o.nfft && x == o.x && a == o.a && b == o.b && h == o.h;
+            return kind == o.kind && K == o.K && nfft == o.nfft && x == o.x && a == o.a && b == o.b && h == o.h && h2 == o.h2;
         }
     };
     template <class Gen> Cd *cached_filter(const FilterKey &k, Gen &&gen) {
@@ -276,8 +278,22 @@ template <class Backend> struct RxCore {
         }
         return h;
     }
+    static unsigned long long content_hash2(const zc *v, size_t n) {             // splitmix64-mixed words, position-dependent sum
+        unsigned long long h = 0x9E3779B97F4A7C15ull;
+        for (size_t i = 0; i < n; ++i) {
+            unsigned long long w[2];
+            std::memcpy(w, &v[i], 16);
+            for (int q = 0; q < 2; ++q) {
+                unsigned long long z = w[q] + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * i + q + 1);
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                h = (h << 5 | h >> 59) + (z ^ (z >> 31));
+            }
+        }
+        return h;
+    }
     Cd *taps_filter(const zc *taps, int K, int nfft) {
-        FilterKey k{3, K, nfft, 0, 0.0, 0.0, content_hash(taps, (size_t)K)};
+        FilterKey k{3, K, nfft, 0, 0.0, 0.0, content_hash(taps, (size_t)K), content_hash2(taps, (size_t)K)};
         return cached_filter(k, [&] { return ols_filter_from_taps(taps, K, nfft); });
     }
     static void iq_gains(const ssf_rx_params &p, int k, Cd *k1o, Cd *k2o) {      // core.py:952-959
@@ -323,7 +339,10 @@ template <class Backend> struct RxCore {
         if (ntaps % 2 == 0) ++ntaps;                                 // devices.py:361-365
         const Cd *sig = resident(in0, (size_t)N * nm);
         const Cd *dlo = iq_only ? nullptr : resident(lo, (size_t)N);
-        Cd *result = be.is_resident(out) ? (Cd *)out : dalloc((size_t)N * nm);
+        // (a device result that IS one of the inputs goes through a scratch block like fir / decimate's: the filters read the
+        //  neighbourhood of every sample they write -- iqMixing with a skew reads in0 itself)
+        const bool alias = out == in0 || (!iq_only && out == lo);
+        Cd *result = be.is_resident(out) && !alias ? (Cd *)out : dalloc((size_t)N * nm);
         if (!sig || (!iq_only && !dlo) || !result) return fail(SSF_ERR_OOM, "out of device memory");
         double *dun = nullptr;
         if (noisy && un) {
@@ -539,6 +558,37 @@ template <class Backend> struct RxCore {
         return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
     }
 
+    // edfa / pbs / opticalHybrid2x4 by themselves (rx_kernels.h: optics_body): host or device pointers, a device result is written in place
+    int optics(int op, long long n, int ncols, double p0, double p1, unsigned long long seed, unsigned row0, const void *a,
+               const void *b, void *o0, void *o1) {
+        if (n < 1 || !a || !o0) return fail(SSF_ERR_BAD_ARG, "bad argument");
+        if (op == OPT_PBS && ((ncols != 1 && ncols != 2) || !o1)) return fail(SSF_ERR_BAD_ARG, "pbs: E must be (N,) or (N, 2)");
+        if (op == OPT_HYBRID && !b) return fail(SSF_ERR_BAD_ARG, "opticalHybrid2x4: Elo is NULL");
+        if (op == OPT_EDFA && ncols < 1) return fail(SSF_ERR_BAD_ARG, "edfa: bad column count");
+        const size_t n_in = op == OPT_PBS ? (size_t)n * ncols : (size_t)n, n_o0 = op == OPT_HYBRID ? 4 * (size_t)n : (size_t)n;
+        OpticsArgs g{};
+        g.op = op;
+        g.ncols = ncols;
+        g.a = resident(a, n_in);
+        g.b = b ? resident(b, (size_t)n) : nullptr;
+        // (element-wise: an in-place EDFA is fine; the splitter's and the hybrid's outputs must not be their inputs)
+        const bool alias0 = op != OPT_EDFA && (o0 == a || o0 == b), alias1 = o1 && (o1 == a || o1 == b || o1 == o0);
+        g.o0 = be.is_resident(o0) && !alias0 ? (Cd *)o0 : dalloc(n_o0);
+        g.o1 = !o1 ? nullptr : be.is_resident(o1) && !alias1 ? (Cd *)o1 : dalloc((size_t)n);
+        if (!g.a || (b && !g.b) || !g.o0 || (o1 && !g.o1)) return fail(SSF_ERR_OOM, "out of device memory");
+        g.n = n;
+        g.p0 = p0;
+        g.p1 = p1;
+        g.seed = seed;
+        g.row0 = row0;
+        be.launch_optics(g);
+        be.sync();
+        if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
+        if ((void *)g.o0 != o0) be.d2h_big(o0, g.o0, sizeof(Cd) * n_o0);
+        if (o1 && (void *)g.o1 != o1) be.d2h_big(o1, g.o1, sizeof(Cd) * (size_t)n);
+        return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+
     // firFilter (core.py:87-125): 'same'-mode convolution of every column with the taps
     int fir(long long sigLen, int ncols, int ntaps, const void *taps, const void *in, void *out) {
         if (sigLen < 1 || ncols < 1 || ntaps < 1) return fail(SSF_ERR_BAD_ARG, "bad size");
@@ -738,7 +788,7 @@ template <class Backend> struct RxCore {
         fused::ols_permute_filter(H.data(), lg);
         const size_t n = (size_t)sigLen * ncols;
         const Cd *a = resident(in, n);
-        const FilterKey key{4, K, nfft, 0, 0.0, 0.0, content_hash((const zc *)Hfft, (size_t)nfft)};   // (edc designs the same filter call after call)
+        const FilterKey key{4, K, nfft, 0, 0.0, 0.0, content_hash((const zc *)Hfft, (size_t)nfft), content_hash2((const zc *)Hfft, (size_t)nfft)};   // (edc designs the same filter call after call)
         Cd *b = result_buffer(out, in, n), *dH = cached_filter(key, [&] { return H; });
         if (!a || !b || !dH) return fail(SSF_ERR_OOM, "out of device memory");
         int rc = ols(a, ncols, sigLen, sigLen, b, ncols, sigLen, ncols, dH, 0, K, nfft, 0);

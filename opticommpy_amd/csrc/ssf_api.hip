@@ -377,11 +377,11 @@ int ssf_device_copy_bandwidth(int device, int64_t bytes, int32_t launches, doubl
 
 int ssf_linear_channel(ssf_plan *plan, double Fs, double Fc, double alpha, double D, double L, const void *in,
                        void *out) {
-    int rc = ssf_upload(plan, in);
+    int rc = in ? ssf_upload(plan, in) : SSF_OK;                    // NULL: the field the plan holds (ssf_upload_aos)
     if (rc) return rc;
     SSF_NEED_ENGINE(plan);
     if ((rc = plan->engine->linear_channel(Fs, Fc, alpha, D, L))) return rc;
-    return ssf_download(plan, out);
+    return out ? ssf_download(plan, out) : SSF_OK;                  // NULL: left in the plan (ssf_download_aos)
 }
 
 int ssf_overlap_save(int device, int64_t sigLen, int32_t nrows, int32_t precision, int32_t nfft, int32_t K,
@@ -588,6 +588,34 @@ int ssf_delay_signal(int device, int64_t N, double delay, double Fs, const void 
     std::string err;
     int rc = ssf::rx_delay(device, N, delay, Fs, in, out, &err);
     return rc ? set_err(rc, "ssf_delay_signal: " + err) : SSF_OK;
+}
+
+int ssf_edfa(int device, int64_t n, int32_t ncols, double G_lin, double p_noise, int64_t rng_seed, int32_t rng_row_offset,
+             const void *field_in, const void *noise, void *field_out) {
+    if (!field_in || !field_out || n < 1 || ncols < 1) return set_err(SSF_ERR_BAD_ARG, "ssf_edfa: bad argument");
+    if (!(G_lin > 0) || p_noise < 0) return set_err(SSF_ERR_BAD_ARG, "ssf_edfa: the gain must be positive, the noise power non-negative");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    const double sigma = (!noise && rng_seed != 0) ? std::sqrt(p_noise / 2) : 0.0;                  // core.py:739-763
+    int rc = ssf::rx_optics(device, ssf::kOptEdfa, n, ncols, std::sqrt(G_lin), sigma, (unsigned long long)rng_seed,
+                            (unsigned)rng_row_offset, field_in, noise, field_out, nullptr, &err);
+    return rc ? set_err(rc, "ssf_edfa: " + err) : SSF_OK;
+}
+
+int ssf_pbs(int device, int64_t N, int32_t ncols, double theta, const void *E, void *Ex, void *Ey) {
+    if (!E || !Ex || !Ey || N < 1) return set_err(SSF_ERR_BAD_ARG, "ssf_pbs: bad argument");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::rx_optics(device, ssf::kOptPbs, N, ncols, std::cos(theta), std::sin(theta), 0, 0, E, nullptr, Ex, Ey, &err);
+    return rc ? set_err(rc, "ssf_pbs: " + err) : SSF_OK;
+}
+
+int ssf_optical_hybrid_2x4(int device, int64_t N, const void *Es, const void *Elo, void *Eo) {
+    if (!Es || !Elo || !Eo || N < 1) return set_err(SSF_ERR_BAD_ARG, "ssf_optical_hybrid_2x4: bad argument");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::rx_optics(device, ssf::kOptHybrid, N, 1, 0.0, 0.0, 0, 0, Es, Elo, Eo, nullptr, &err);
+    return rc ? set_err(rc, "ssf_optical_hybrid_2x4: " + err) : SSF_OK;
 }
 
 int ssf_nlin_phase_rot(int device, int64_t n, double gamma, const void *Ex, const void *Ey, const double *Pch, double *phi) {

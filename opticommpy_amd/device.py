@@ -161,15 +161,6 @@ def is_device(x):
     return isinstance(x, DeviceArray)
 
 
-def host_only(name, *arrays):
-    """Host-glue functions (a few numpy lines of the reference, no kernel behind them) refuse DeviceArrays instead of downloading
-    them silently through ``np.asarray``: a chain that is meant to stay in HBM must not leave it unnoticed."""
-    for a in arrays:
-        if isinstance(a, DeviceArray):
-            raise TypeError(f"{name} is host glue and takes numpy arrays: pass x.get() explicitly (the receivers / channel "
-                            "models / filters keep DeviceArrays in HBM)")
-
-
 def arg(x, dtype):
     """(pointer, keepalive) of an array argument of the C ABI: numpy arrays are made contiguous in
     ``dtype``; a DeviceArray must already have it (converting would be a hidden device round trip)."""

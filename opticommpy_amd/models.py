@@ -417,19 +417,25 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
         # is reduced over the communicator before anything runs.
         ch = getattr(_coupling, "h", None)
         attached = False
+        bad_comm = None                       # (an error of THIS rank is raised after the collective below: the other ranks are in it)
         if ch is not None and _state["engine"] != _lib.ENGINE_ROCFFT:
             pl = _get_plan(N, ncols, prec)
             if pl.lib.ssf_plan_pipeline(pl.h) == 0:
                 rc = pl.lib.ssf_set_coupling_comm(pl.h, ch)
                 if rc == -1:                  # SSF_ERR_BAD_ARG: the communicator lives on another device than the plan
-                    raise ValueError("run_coupled: " + (pl.lib.ssf_last_error(pl.h) or b"bad argument").decode())
+                    bad_comm = "run_coupled: " + (pl.lib.ssf_last_error(pl.h) or b"bad argument").decode()
                 attached = rc == 0
-        try:
-            any_failed = float(_coupling.allreduce(np.array([0.0 if attached else 1.0]), "max")[0]) > 0.0
+        try:                                  # 0: attached, 1: this rank falls back to the host reducer, 2: this rank cannot run at all
+            worst = float(_coupling.allreduce(np.array([2.0 if bad_comm else 0.0 if attached else 1.0]), "max")[0])
         except Exception:
             if attached:
                 pl.lib.ssf_set_coupling_comm(pl.h, None)
             raise
+        if worst >= 2.0:                      # every rank leaves here, together
+            if attached:
+                pl.lib.ssf_set_coupling_comm(pl.h, None)
+            raise ValueError(bad_comm or "run_coupled: another rank's communicator does not live on its plan's device")
+        any_failed = worst > 0.0
         dev_coupling = attached and not any_failed
         if attached and not dev_coupling:
             pl.lib.ssf_set_coupling_comm(pl.h, None)
@@ -460,7 +466,9 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
                 def noise_fn(span):
                     return _span_noise(ncols, N, p_noise, seed, True, pl.dtype)
             else:                         # product path: ASE generated on the device (Philox, per-span streams;
-                cp.rng_seed = _device_seed(seed)   # x and y rows get independent noise, unlike channels.py:444-445)
+                cp.rng_seed = _device_seed(seed)   # x and y rows get INDEPENDENT noise -- the CPU reference re-seeds between its
+                #                                    two edfa calls and so adds the same draw to x and y, channels.py:444-445; the cupy
+                #                                    twin does not, modelsGPU.py:486-490: statistical parity either way)
 
     except BaseException:
         if dev_coupling:
@@ -534,9 +542,13 @@ def manakovDBP(Ei, param, _trace=False):
 # edfa, linearFiberChannel, setPowerforParSSFM
 # ----------------------------------------------------------------------------
 def edfa(Ei, param=None):
-    """Simple EDFA model: gain + ASE noise (optic/models/modelsGPU.py:56-114 ==
-    optic/models/devices.py:671-726).  Host-side numpy: it is a once-per-call
-    elementwise op on data that already lives on the host at this API level."""
+    """Simple EDFA model: gain + ASE noise (optic/models/modelsGPU.py:56-114 == optic/models/devices.py:671-726), one
+    element-wise device pass (``ssf_edfa``).  Parameters: G [20 dB], NF [4.5 dB], Fc [193.1e12], Fs (mandatory), seed [None].
+
+    numpy in, numpy out: the noise is the reference's own draw -- ``gaussianComplexNoise(Ei.shape, p_noise, seed)`` from numpy's
+    global generator, seeded or not -- added on the device.  DeviceArray (complex128) in, DeviceArray out: the field never leaves
+    HBM and the noise is generated there (Philox4x32-10 keyed by ``param.seed``, fresh entropy without one): statistical
+    parity, as inside ``ssfm`` / ``manakovSSF``.  The result is complex128 like the reference's (its noise is)."""
     Fs = _require_fs(param)
     G = getattr(param, "G", 20)
     NF = getattr(param, "NF", 4.5)
@@ -545,33 +557,54 @@ def edfa(Ei, param=None):
     assert G > 0, "EDFA gain should be a positive scalar"
     assert NF >= 3, "The minimal EDFA noise figure is 3 dB"
     G_lin, p_noise = _edfa_noise_power(G, NF, Fc, Fs)
-    _dev.host_only("edfa (by itself; inside ssfm / manakovSSF the amplifier runs on the device)", Ei)
-    Ei = np.asarray(Ei)
-    return Ei * np.sqrt(G_lin) + gaussianComplexNoise(Ei.shape, p_noise, seed)
+    lib = _lib.load()
+    on_dev = _dev.is_device(Ei)
+    shape = tuple(Ei.shape)
+    n = int(np.prod(shape))
+    ncols = int(shape[1]) if len(shape) > 1 else 1
+    in_ptr, _keep = _dev.arg(Ei, np.complex128)
+    out = _dev.empty(on_dev, shape, np.complex128)
+    if n == 0:
+        return out
+    if on_dev:
+        noise_ptr, dev_seed = None, _device_seed(seed)
+    else:
+        noise = np.ascontiguousarray(gaussianComplexNoise(shape, p_noise, seed), dtype=np.complex128)
+        noise_ptr, dev_seed = noise.ctypes.data_as(C.c_void_p), 0
+    _lib.raise_for(lib, None, lib.ssf_edfa(_state["device"], n, ncols, float(G_lin), float(p_noise), dev_seed,
+                                           int(getattr(param, "_rng_row_offset", 0)), in_ptr, noise_ptr, _dev.out_ptr(out)))
+    return out
 
 
 def linearFiberChannel(Ei, param):
-    """Linear fiber channel (optic/models/channels.py:30-109) as one fused
-    FFT . H . IFFT on the GPU.  Parameters: L [50], alpha [0.2], D [17], Fc
-    [193.1e12], Fs (mandatory), returnParameters [False]."""
+    """Linear fiber channel (optic/models/channels.py:30-109) as one fused FFT . H . IFFT on the GPU.  Parameters: L [50],
+    alpha [0.2], D [17], Fc [193.1e12], Fs (mandatory), returnParameters [False].
+
+    The field crosses the ABI in the reference's own (N, modes) layout (the transposition runs on the device); a complex128
+    DeviceArray stays in HBM and a DeviceArray comes back.  Like the reference's, the result is complex128 whatever the input's
+    precision (its operator is: ``fft(Ei) * exp(...)``, channels.py:97); a complex64 input is cast up first, so the forward
+    transform -- which numpy >= 2 runs in single precision for such an input -- is evaluated in double here."""
     Fs = _require_fs(param)
     param.L = getattr(param, "L", 50)
     param.alpha = getattr(param, "alpha", 0.2)
     param.D = getattr(param, "D", 17)
     param.Fc = getattr(param, "Fc", 193.1e12)
     param.returnParameters = getattr(param, "returnParameters", False)
-    _dev.host_only("linearFiberChannel (numpy in, numpy out: its field crosses the bus once each way)", Ei)
-    Ei = np.asarray(Ei)
+    on_dev = _dev.is_device(Ei)
+    if not on_dev:
+        Ei = np.asarray(Ei)
     N = Ei.shape[0]
+    one_d = Ei.ndim == 1
     E2 = Ei.reshape(N, -1)
-    pl = _get_plan(N, E2.shape[1], _lib.SSF_C128)
-    soa = np.ascontiguousarray(E2.T, dtype=np.complex128)
-    res = np.empty_like(soa)
+    nm = E2.shape[1]
+    pl = _get_plan(N, nm, _lib.SSF_C128)
+    in_ptr, _keep = _dev.arg(E2, np.complex128)
+    pl.check(pl.lib.ssf_upload_aos(pl.h, in_ptr))
     pl.check(pl.lib.ssf_linear_channel(pl.h, float(Fs), float(param.Fc), float(param.alpha), float(param.D),
-                                       float(param.L), soa.ctypes.data_as(C.c_void_p),
-                                       res.ctypes.data_as(C.c_void_p)))
-    Eo = np.ascontiguousarray(res.T)
-    if E2.shape[1] == 1:
+                                       float(param.L), None, None))
+    Eo = _dev.empty(on_dev, (N, nm), np.complex128)
+    pl.check(pl.lib.ssf_download_aos(pl.h, -1, _dev.out_ptr(Eo)))
+    if nm == 1 or one_d:
         Eo = Eo.reshape(N)
     return (Eo, param) if param.returnParameters else Eo
 

@@ -58,6 +58,14 @@ class _HipBackend:
         _lib.raise_for(lib, None, lib.ssf_decimate(self._dev(), N, ncols, int(SpSin), int(dec), x, out, sd))
         return list(sd)
 
+    def pbs(self, N, ncols, theta, E, Ex, Ey):
+        lib = _lib.load()
+        _lib.raise_for(lib, None, lib.ssf_pbs(self._dev(), N, ncols, float(theta), E, Ex, Ey))
+
+    def hybrid(self, N, Es, Elo, Eo):
+        lib = _lib.load()
+        _lib.raise_for(lib, None, lib.ssf_optical_hybrid_2x4(self._dev(), N, Es, Elo, Eo))
+
     def rx(self, mode, N, nmodes, p, in0, lo, un, out):
         lib = _lib.load()
         _lib.raise_for(lib, None, lib.ssf_rx_run(self._dev(), mode, N, nmodes, C.byref(p), in0, lo,
@@ -209,31 +217,38 @@ def decimate(sigIn, param):
     return out.flatten() if input1D else out
 
 
-# ------------------------------------------------------------------------- passive optics (host glue)
+# ------------------------------------------------------------------------- passive optics
 def pbs(E, θ=0):
-    """Polarisation beam splitter (optic/models/devices.py:223-260): 2x2 rotation, host glue.  Inside
-    pdmCoherentReceiver the same rotation runs on the device."""
-    _dev.host_only("pbs", E)
-    E = np.asarray(E)
-    if E.ndim == 1:
-        E = np.repeat(E, 2).reshape(-1, 2)
-        E[:, 1] = 0
-    elif E.shape[1] > 2:
+    """Polarisation beam splitter (optic/models/devices.py:223-260): the input field rotated by θ and split, one element-wise
+    device pass (``ssf_pbs``; inside pdmCoherentReceiver the same rotation rides in the first filter's loads).  ``E``: (N, 2), or
+    (N,) taken as the x polarisation; numpy or complex128 DeviceArray.  Returns ``(Ex, Ey)``, (N,) each, of the caller's kind."""
+    on_dev = _dev.is_device(E)
+    if not on_dev:
+        E = np.asarray(E)
+    if E.ndim == 2 and E.shape[1] > 2:
         logg.error("E need to be a (N,2) or a (N,) np.array")
-    rot = np.array([[np.cos(θ), -np.sin(θ)], [np.sin(θ), np.cos(θ)]]) + 1j * 0
-    E = E @ rot
-    return E[:, 0], E[:, 1]
+    if E.ndim not in (1, 2) or (E.ndim == 2 and E.shape[1] != 2):
+        raise ValueError("pbs: E must have shape (N, 2) or (N,)")
+    N = E.shape[0]
+    ptr, _keep = _dev.arg(E, np.complex128)
+    Ex, Ey = _dev.empty(on_dev, (N,), np.complex128), _dev.empty(on_dev, (N,), np.complex128)
+    _backend.pbs(N, 1 if E.ndim == 1 else 2, θ, ptr, _dev.out_ptr(Ex), _dev.out_ptr(Ey))
+    return Ex, Ey
 
 
 def opticalHybrid2x4(Es, Elo):
-    """2x4 90-degree optical hybrid (optic/models/devices.py:462-500): constant 4x4 matrix, host glue."""
-    _dev.host_only("opticalHybrid2x4", Es, Elo)
-    assert Es.shape == (len(Es),), "Es need to have a (N,) shape"
-    assert Elo.shape == (len(Elo),), "Elo need to have a (N,) shape"
-    assert Es.shape == Elo.shape, "Es and Elo need to have the same (N,) shape"
-    T = np.array([[1 / 2, 1j / 2, 1j / 2, -1 / 2], [1j / 2, -1 / 2, 1 / 2, 1j / 2],
-                  [1j / 2, 1 / 2, -1j / 2, -1 / 2], [-1 / 2, 1j / 2, -1 / 2, 1j / 2]])
-    return T @ np.array([Es, np.zeros((Es.size,)), np.zeros((Es.size,)), Elo])
+    """2x4 90-degree optical hybrid (optic/models/devices.py:462-500): the four outputs ``T @ [Es, 0, 0, Elo]`` as a (4, N) array, one
+    element-wise device pass (``ssf_optical_hybrid_2x4``); numpy or complex128 DeviceArrays (both of one kind)."""
+    assert tuple(Es.shape) == (len(Es),), "Es need to have a (N,) shape"
+    assert tuple(Elo.shape) == (len(Elo),), "Elo need to have a (N,) shape"
+    assert tuple(Es.shape) == tuple(Elo.shape), "Es and Elo need to have the same (N,) shape"
+    on_dev = _dev.is_device(Es) or _dev.is_device(Elo)
+    ps, _k1 = _dev.arg(Es, np.complex128)
+    pl, _k2 = _dev.arg(Elo, np.complex128)
+    N = len(Es)
+    Eo = _dev.empty(on_dev, (4, N), np.complex128)
+    _backend.hybrid(N, ps, pl, _dev.out_ptr(Eo))
+    return Eo
 
 
 # ------------------------------------------------------------------------------ detection

@@ -289,6 +289,7 @@ struct EmuBackend {
     void *filter_lookup(const void *, size_t) { return nullptr; }                  // (no filter cache: every call builds its own)
     void *filter_store(const void *, size_t, const void *, size_t) { return nullptr; }
     void launch_front(const ssf::rx::FrontArgs &a) { ++launches; run_grid(ew_grid(a.f.N), 64, 64, [&](EmuCtx &c) { ssf::rx::front_body(c, a); }); }
+    void launch_optics(const ssf::rx::OpticsArgs &a) { run_grid(ew_grid(a.n), 64, 64, [&](EmuCtx &c) { ssf::rx::optics_body(c, a); }); }
     void launch_nlin_phase(const ssf::rx::NlinPhaseArgs &a) { run_grid(ew_grid(a.n), 64, 64, [&](EmuCtx &c) { ssf::rx::nlin_phase_body(c, a); }); }
     void launch_conv_sums(const ssf::rx::ConvSumsArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::conv_sums_body(c, a); }); }
     void launch_absmax(const ssf::rx::AbsMaxArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::absmax_body(c, a); }); }
@@ -477,6 +478,12 @@ int emu_convergence_condition(int64_t n, const void *xfd, const void *yfd, const
     EmuBackend be;
     ssf::rx::RxCore<EmuBackend> core(be);
     return core.convergence(n, xfd, yfd, xc, yc, lim);
+}
+int emu_optics(int op, int64_t n, int ncols, double p0, double p1, unsigned long long seed, unsigned row0, const void *a, const void *b,
+               void *o0, void *o1) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    return core.optics(op, n, ncols, p0, p1, seed, row0, a, b, o0, o1);
 }
 int emu_delay(int64_t N, double delay, double Fs, const void *in, void *out) {
     EmuBackend be;

@@ -147,6 +147,21 @@ def edc(sigIn, param):
     return res.flatten() if one_d else res
 
 
+def edfa(Ei, G_lin, p_noise, seed=0, row0=0, noise=None):
+    """ssf_edfa's kernel (rx_kernels.h: optics_body, OPT_EDFA) on the emulator: Ei sqrt(G_lin) + noise (supplied, or Philox when seed != 0)."""
+    e = load()
+    e.emu_optics.argtypes = EmuRxBackend._OPTICS
+    x = np.ascontiguousarray(Ei, dtype=np.complex128)
+    out = np.empty_like(x)
+    nz = None if noise is None else np.ascontiguousarray(noise, dtype=np.complex128)
+    sigma = float(np.sqrt(p_noise / 2)) if (nz is None and seed) else 0.0
+    rc = e.emu_optics(0, x.size, x.shape[1] if x.ndim > 1 else 1, float(np.sqrt(G_lin)), sigma, int(seed), int(row0),
+                      x.ctypes.data_as(C.c_void_p), None if nz is None else nz.ctypes.data_as(C.c_void_p),
+                      out.ctypes.data_as(C.c_void_p), None)
+    assert rc == 0, f"emu_optics rc={rc}"
+    return out
+
+
 class EmuRxBackend:
     """Drop-in for opticommpy_amd.rx._backend: the receiver pipeline (rx_pipeline.h + rx_kernels.h) on the
     CPU emulator instead of the GPU.  Same marshalling code (opticommpy_amd/rx.py) in front of it."""
@@ -182,6 +197,16 @@ class EmuRxBackend:
         sd = (C.c_int32 * ncols)()
         self._check(self.e.emu_decimate(N, ncols, int(SpSin), int(dec), x, out, sd))
         return list(sd)
+
+    _OPTICS = [C.c_int, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def pbs(self, N, ncols, theta, E, Ex, Ey):
+        self.e.emu_optics.argtypes = self._OPTICS
+        self._check(self.e.emu_optics(1, N, ncols, float(np.cos(theta)), float(np.sin(theta)), 0, 0, E, None, Ex, Ey))
+
+    def hybrid(self, N, Es, Elo, Eo):
+        self.e.emu_optics.argtypes = self._OPTICS
+        self._check(self.e.emu_optics(2, N, 1, 0.0, 0.0, 0, 0, Es, Elo, Eo, None))
 
     def rx(self, mode, N, nmodes, p, in0, lo, un, out):
         self._check(self.e.emu_rx_run(mode, N, nmodes, C.byref(p), in0, lo,
