@@ -644,8 +644,8 @@ def notebook_leg(sizes=(200_000, 800_000, 2_000_000), sample_km=12.0):
         assert sig.shape == (N, 2), sig.shape
 
         def ch(**kw):
-            return bag(oa.parameters, Ltotal=500, Lspan=50, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, hz=0.5, maxIter=5,
-                       tol=1e-5, nlprMethod=True, maxNlinPhaseRot=2e-2, prgsBar=False, Fs=32e9 * 4, seed=11, **kw)
+            return bag(oa.parameters, **dict(dict(Ltotal=500, Lspan=50, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, hz=0.5, maxIter=5,
+                                                  tol=1e-5, nlprMethod=True, maxNlinPhaseRot=2e-2, prgsBar=False, Fs=32e9 * 4, seed=11), **kw))
         oa.manakovSSF(sig, ch(Ltotal=50))                           # plan, kernels, clocks: one span, untimed
         t0 = time.perf_counter()
         out = oa.manakovSSF(sig, ch())                               # the notebook's timed statement

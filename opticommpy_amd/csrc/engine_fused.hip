@@ -51,8 +51,8 @@ int fused_overlap_save(int device, int64_t sigLen, int nrows, int precision, int
 
 bool fused_supports(int64_t N, int nrows, int precision) {
     if (N >= 256 && (N & (N - 1)) && nrows >= 1) {          // 2^a 3^b 5^c: mixed-radix rows
-        int l1, n2;
-        return fused::choose_mixed_split(N, precision, &l1, &n2);
+        int l1, n2, n1, c;
+        return fused::choose_mixed_split(N, precision, &l1, &n2) || fused::choose_mixed2_split(N, precision, &n1, &n2, &c);
     }
     if (N < 256 || (N & (N - 1)) || nrows < 1) return false;
     int l = 0;

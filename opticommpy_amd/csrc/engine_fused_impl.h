@@ -96,6 +96,11 @@ __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const 
     SSF_DEV_CTX(1);
     col_body<T, LG, MODE, true>(ctx, unit_view(a, (int)blockIdx.y));
 }
+// column lengths with factors 3 / 5 (fused_kernels.h: col_mixed_body): the tile in LDS, mixed-radix passes
+template <typename T, int MODE> __global__ void __launch_bounds__(256, 2) k_col_mixed(const ColArgs<T> a) {
+    SSF_DEV_CTX(1);
+    col_mixed_body<T, MODE>(ctx, unit_view(a, (int)blockIdx.y));
+}
 // eight values per thread (at most 128 registers, four waves per SIMD): 512-thread workgroups, two per CU
 template <typename T, int LG, int MODE> __global__ void __launch_bounds__(512, 4) k_col8(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
@@ -216,6 +221,16 @@ template <typename T, int LG> ColFn<T> pick_col_mode(int mode) {
     case CM_MK: return k_col<T, LG, CM_MK>;
     case CM_PLAIN_FWD: return k_col<T, LG, CM_PLAIN_FWD>;
     default: return k_col<T, LG, CM_PLAIN_INV>;
+    }
+}
+template <typename T> ColFn<T> pick_col_mixed(int mode) {
+    switch (mode) {
+    case CM_NLSE_FIRST: return k_col_mixed<T, CM_NLSE_FIRST>;
+    case CM_NLSE_STEP: return k_col_mixed<T, CM_NLSE_STEP>;
+    case CM_NLSE_LAST: return k_col_mixed<T, CM_NLSE_LAST>;
+    case CM_MK: return k_col_mixed<T, CM_MK>;
+    case CM_PLAIN_FWD: return k_col_mixed<T, CM_PLAIN_FWD>;
+    default: return k_col_mixed<T, CM_PLAIN_INV>;
     }
 }
 template <typename T> ColFn<T> pick_col_ragged(int lg1, int mode) {
@@ -459,7 +474,7 @@ struct HipBackend {
     }
     template <typename T> void launch_col(const ColArgs<T> &a, int grid, int block, size_t lds, int units = 1) {
         ColFn<T> f;
-        const int cols = (block / a.npol) / ((1 << a.log2N1) / (a.vpt == 8 ? 8 : 16));      // columns per workgroup and polarisation row
+        const int cols = a.N1mix ? a.mix_cols : (block / a.npol) / ((1 << a.log2N1) / (a.vpt == 8 ? 8 : 16));      // columns per workgroup and polarisation row
         if constexpr (std::is_same<T, pf2>::value) {
             if (a.vpt == 8) {
                 switch (a.log2N1) {
@@ -482,7 +497,8 @@ struct HipBackend {
             default: f = k_col_pk<0>; break;
             }
         } else {
-            f = a.N2 ? pick_col_ragged<T>(a.log2N1, a.mode) : a.vpt == 8 ? pick_col8<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
+            f = a.N1mix ? pick_col_mixed<T>(a.mode)
+                : a.N2  ? pick_col_ragged<T>(a.log2N1, a.mode) : a.vpt == 8 ? pick_col8<T>(a.log2N1, a.mode) : pick_col<T>(a.log2N1, a.mode);
             if (!a.N2 && a.vpt != 8 && a.mode == CM_MK && col_il)
                 if (ColFn<T> fi = pick_col_il<T>(a.log2N1, cols)) f = fi;
         }
@@ -502,6 +518,7 @@ struct HipBackend {
     // silently serve with the general kernel: that one advances the state at EVERY launch, which is fine, but the pattern's
     // chunk sizes assume idle launches)
     template <typename T> bool can_split_cols(const ColArgs<T> &a, int block) const {
+        if (a.N1mix) return false;
         const int cols = (block / a.npol) / ((1 << a.log2N1) / (a.vpt == 8 ? 8 : 16));
         return !a.N2 && a.vpt != 8 && pick_col_sg<T>(a.log2N1, cols, SG_FIN) != nullptr;
     }

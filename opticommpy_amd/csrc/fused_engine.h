@@ -118,6 +118,48 @@ inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
     return false;
 }
 
+// Lengths 2^a 3^b 5^c that choose_mixed_split does not take -- fewer than four factors of two, or a row above kMixMaxRow whatever
+// power of two goes into the columns (2 000 000 = 2^7 x 15 625) -- split as N1 x N2 with BOTH factors mixed-radix: the column stage
+// is col_mixed_body (a tile of C columns x N1 of both polarisations in LDS), the row stage the mixed-radix rows as before.
+// Preference: both stages at two workgroups per CU, then wide global segments (C), then columns near 256.
+constexpr int kMix2MaxCol = 1024;
+inline size_t mix2_col_lds(int N1, int C, int npol, int elem_bytes) { return (size_t)kColMixScratch + (size_t)npol * C * N1 * elem_bytes; }
+inline bool choose_mixed2_split(int64_t N, int precision, int *N1o, int *N2o, int *Co) {
+    if (N < 4096 || (N & (N - 1)) == 0) return false;
+    int64_t rest = N;
+    for (int q : {2, 3, 5})
+        while (rest % q == 0) rest /= q;
+    if (rest != 1) return false;
+    const int s = precision == SSF_C128 ? 16 : 8;
+    int force_n1 = 0, force_c = 0;
+    if (const char *e = tune_env("SSF_MIX2")) {                 // experiments: "N1,C"
+        force_n1 = std::atoi(e);
+        if (const char *q = std::strchr(e, ',')) force_c = std::atoi(q + 1);
+    }
+    double best = 1e300;
+    for (int n1 = 16; n1 <= kMix2MaxCol; ++n1) {
+        if (N % n1 || (force_n1 && n1 != force_n1)) continue;
+        const int64_t n2 = N / n1;
+        if (n2 < 64 || n2 > kMixMaxRow) continue;
+        MixPlan mp;
+        if (!mix_make_plan(n1, &mp) || !mix_make_plan((int)n2, &mp)) continue;
+        for (int C : {8, 4, 2}) {
+            if (force_c && C != force_c) continue;
+            const size_t cl = mix2_col_lds(n1, C, 2, s), rl = 4096 + (size_t)n2 * s;
+            if (cl > 156 * 1024) continue;
+            double score = (cl <= 80 * 1024 ? 0.0 : 4.0) + ((rl <= 72 * 1024 && n2 <= 4096) ? 0.0 : 3.0) + (C == 8 ? 0.0 : C == 4 ? 1.0 : 3.0) +
+                           0.5 * std::fabs(std::log2((double)n1 / 256.0));
+            if (score < best) {
+                best = score;
+                *N1o = n1;
+                *N2o = (int)n2;
+                *Co = C;
+            }
+        }
+    }
+    return best < 1e300;
+}
+
 // T = double / float: one complex row per polarisation (nrows rows);  T = pf2: the packed pair of the complex64
 // Manakov path (fused_core.h), nrows = number of polarisation PAIRS, 16-byte elements -- created and driven by the
 // float core (run_manakov_packed), only its Manakov span loop is used.
@@ -134,6 +176,10 @@ template <typename T, class Backend> class FusedCore {
     int mix_rows = 1;            // rows per workgroup there
     MixPlan mix_plan{};          // radices of the row passes, chosen for the threads a row gets
     cx<double> *wtab = nullptr;  // cis(-2 pi k / N2mix)
+    int N1mix = 0, mix_cols = 0; // > 0: column length / columns per workgroup of the mixed-radix COLUMN stage (col_mixed_body; then sp.l1 is unused too)
+    MixPlan mix_plan1{};         // radices of its passes
+    cx<double> *wtab1 = nullptr; // cis(-2 pi k / N1mix)
+    int n1() const { return N1mix ? N1mix : 1 << sp.l1; }      // column length
     int row_tw_off = 0;          // LDS offset of the row workgroups' twiddle table (single precision; 0 = none)
     size_t field_bytes;
     C *G = nullptr, *T0 = nullptr, *T1 = nullptr, *Ehd = nullptr, *noise_d = nullptr;
@@ -189,14 +235,25 @@ template <typename T, class Backend> class FusedCore {
         if ((N & (N - 1)) == 0) {
             choose_split(log2N, precision, &sp, kPacked);
         } else {
-            choose_mixed_split(N, precision, &sp.l1, &N2mix);
-            sp.l2 = 0;
+            sp.l1 = sp.l2 = 0;
+            // (experiment builds: SSF_MIX2="N1,C" puts a length the radix-2^n columns would take on the mixed-radix column stage)
+            if (tune_env("SSF_MIX2") && choose_mixed2_split(N, precision, &N1mix, &N2mix, &mix_cols)) {
+            } else if (!choose_mixed_split(N, precision, &sp.l1, &N2mix)) {
+                N2mix = 0;
+                if (!choose_mixed2_split(N, precision, &N1mix, &N2mix, &mix_cols)) N1mix = N2mix = mix_cols = 0;
+            }
         }
         field_bytes = sizeof(C) * (size_t)N * (size_t)nrows;
     }
 
     // npol = 2: a workgroup carries both rows of a polarisation pair (x threads | y threads)
     void col_geometry(int groups, int npol, int *block, int *grid, size_t *lds) const {
+        if (N1mix) {                                           // mixed-radix columns: the tile lives in LDS (col_mixed_body)
+            *block = 256;
+            *grid = groups * ((N2mix + mix_cols - 1) / mix_cols);
+            *lds = mix2_col_lds(N1mix, mix_cols, npol, (int)sizeof(C));
+            return;
+        }
         const int tpf = (1 << sp.l1) / col_v, N2 = N2mix ? N2mix : 1 << sp.l2;
         int half = col_v == 8 ? 512 / npol : 256;              // (eight values per thread: 512-thread workgroups, two per CU)
         if (const char *e = tune_env("SSF_COL_HALF")) {        // tuning knob: threads per polarisation row
@@ -235,7 +292,11 @@ template <typename T, class Backend> class FusedCore {
         col_v = underfilled && sp.l1 != 7 ? 8 : 16;
         if (const char *e = tune_env("SSF_COL_V")) col_v = std::atoi(e) == 8 ? 8 : 16;
         if (N2mix || sp.l1 < 6 || sp.l1 > 10) col_v = 16;      // (ragged tiles / very short or very long columns: 16-value kernels only)
-        const int64_t nfft = (int64_t)rows_u() << sp.l1;       // row transforms of one unit
+        if (N1mix && !mix_make_plan(N1mix, &mix_plan1, 256 / (2 * mix_cols))) {
+            err = "fused engine: no pass plan for the column length";
+            return SSF_ERR_UNSUPPORTED;
+        }
+        const int64_t nfft = (int64_t)rows_u() * n1();         // row transforms of one unit
         if (N2mix) {               // rows in LDS after 4 KiB of scratch; 128 threads per row while 16 values per thread suffice
             int tpr = 128;
             if (const char *e = tune_env("SSF_MIX_TPR")) tpr = std::max(64, std::min(1024, std::atoi(e)));
@@ -301,6 +362,16 @@ template <typename T, class Backend> class FusedCore {
             }
             be.h2d(wtab, w.data(), sizeof(cx<double>) * (size_t)N2mix);
         }
+        if (N1mix) {
+            if (!(wtab1 = (cx<double> *)be.alloc(sizeof(cx<double>) * (size_t)N1mix))) return oom();
+            std::vector<cx<double>> w((size_t)N1mix);
+            for (int q = 0; q < N1mix; ++q) {
+                const double a = -2.0 * 3.14159265358979323846 * (double)q / (double)N1mix;
+                w[(size_t)q].re = std::cos(a);
+                w[(size_t)q].im = std::sin(a);
+            }
+            be.h2d(wtab1, w.data(), sizeof(cx<double>) * (size_t)N1mix);
+        }
         be.prepare(row_lds, std::max(col_lds_mk, col_lds_1));
         return SSF_OK;
     }
@@ -320,7 +391,7 @@ template <typename T, class Backend> class FusedCore {
         if (!own_G) G = nullptr;
         if (cpl_work) be.free(cpl_work);
         for (void *p : {(void *)G, (void *)T0, (void *)T1, (void *)Ehd, (void *)P, (void *)Theta, (void *)ctrl, (void *)linops, (void *)gbar,
-                        (void *)part, (void *)wtab, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
+                        (void *)part, (void *)wtab, (void *)wtab1, (void *)tr_hz, (void *)tr_lim, (void *)tr_it, (void *)noise_d})
             if (p) be.free(p);
         for (C *s : snaps) be.free(s);
     }
@@ -379,7 +450,8 @@ template <typename T, class Backend> class FusedCore {
         a.G = G;
         a.log2N1 = sp.l1;
         a.log2N2 = sp.l2;
-        a.nfft = (int)((int64_t)rows_u() << sp.l1);
+        a.nfft = (int)((int64_t)rows_u() * n1());
+        a.N1mix = N1mix;
         a.u_elems = (long long)rows_u() * N;
         a.u_part = npart_max;
         a.N2 = N2mix ? N2mix : 1 << sp.l2;
@@ -405,6 +477,10 @@ template <typename T, class Backend> class FusedCore {
         a.log2N2 = sp.l2;
         a.N2 = N2mix;
         a.N = N;
+        a.N1mix = N1mix;
+        a.mix_cols = mix_cols;
+        if (N1mix) a.plan1 = mix_plan1;
+        a.wtab1 = wtab1;
         a.npol = npol;
         a.mode = mode;
         a.ngroups = pairs_u();

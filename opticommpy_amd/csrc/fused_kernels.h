@@ -483,7 +483,10 @@ template <typename T> struct RowArgs {
     int u_part;
     int prio;                 // 1: issue priority by phase (s_setprio); 0 when several plans share the GPU (lanes)
     int tw_off;               // single precision: byte offset of the workgroup's twiddle table in LDS (kTwLdsBytes behind the transform area)
+    int N1mix;                // > 0: the column length when it is not 1 << log2N1 (col_mixed_body: N = N1mix x N2, both 2^a 3^b 5^c)
 };
+// number of rows (column length) of the N1 x N2 matrix a row stage works on
+template <typename T> SSF_HD long long row_n1(const RowArgs<T> &a) { return a.N1mix ? (long long)a.N1mix : 1ll << a.log2N1; }
 
 // linear operator for the V registers of a last-radix-V butterfly (V = 16 | 8): bins k0 + (N/V) q, signed q' = q or q - V;
 // phase cth (k0 + dk q')^2 = A * B^q' * C_|q'| with C_m = cis(cth dk^2 m^2) = the control block's table at 16/V * m
@@ -668,7 +671,7 @@ SSF_HD bool row_ctrl(Ctx &ctx, const RowArgs<T> &a, const double (&part)[2][4], 
     } else if (act) {
         lo = c.lin;
     }
-    if (act && c_state == ST_AFTER_S && c_gscale) lo.mag *= (double)(1ll << a.log2N1);   // (G = spectrum / N1: mk_col_stage)
+    if (act && c_state == ST_AFTER_S && c_gscale) lo.mag *= (double)row_n1(a);           // (G = spectrum / N1: mk_col_stage)
     if (act) n_state = c_state == ST_AFTER_S ? ST_NEED_H : c_state == ST_RECOVER_ROW ? ST_RECOVER_B : ST_NEED_I;
     if (lead) {
         ctrl_forward(a.cin, a.cout, (int)((new_lin ? offsetof(Ctrl, lin) : sizeof(Ctrl)) / 8));
@@ -752,8 +755,8 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
     ctx.mark(1);
     mix_dif<-1>(ctx, p, t, T_, x, a.wtab);
     ctx.mark(2);
-    const int N1 = 1 << a.log2N1;
-    const int k1 = (int)(rr & (N1 - 1));
+    const int N1 = (int)row_n1(a);
+    const int k1 = a.N1mix ? (int)(rr % N1) : (int)(rr & (N1 - 1));
     // x linear operator: folded into the first pass of the inverse transform (mixed_fft.h: mix_apply_op), which reads
     // the spectrum in runs of bins N / R apart.  (As a pass of its own over the row in LDS it was 6 of the 30 us of
     // a launch at rows of 3750: one read-modify-write per bin, each waiting for the one before it.)
@@ -1008,6 +1011,11 @@ template <typename T> struct ColArgs {
     int u_part;
     int prio;                 // see RowArgs
     int sg;                   // Manakov: stage groups the launched kernel carries (0 = SG_ALL); read by the launcher only
+    // column lengths with factors 3 / 5 (col_mixed_body): N = N1mix x N2, the tile (mix_cols columns x N1mix, both polarisations)
+    // lives in LDS and is transformed by the mixed-radix passes of mixed_fft.h
+    int N1mix, mix_cols;      // column length (0: 1 << log2N1), columns per workgroup (a power of two)
+    MixPlan plan1;            // pass plan of a column
+    const cx<double> *wtab1;  // cis(-2 pi k / N1mix), k < N1mix
 };
 
 // Arguments of unit u of a batch of independent units: every pointer moved to the unit's block.  The kernel bodies never
@@ -1640,6 +1648,228 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
         for (int q = 0; q < V; ++q) g.st(a.G, g.rowbase + g.freq_off(q), v[q]);
         ctx.mark(5);
         ctx.flush(do_inv ? 0 : 1);
+    }
+}
+
+// ------------------------------------------------------------- column stage for ANY 2^a 3^b 5^c column length
+// The radix-2^n column kernels above want a power-of-two column length, which leaves lengths whose power-of-two part is too
+// small for the rest to fit a row (2 000 000 = 2^7 x 5^6: the top size of the reference's own benchmark,
+// examples/benchmarck_GPU_processing.ipynb: rows of 15 625) to the host-driven Bluestein path.  This kernel takes any
+// N = N1 x N2 with both factors 2^a 3^b 5^c: a tile of C adjacent columns x N1 of BOTH polarisations lives in LDS (columns
+// interleaved: slot ((pol N1 + pos) C + c), so a global row segment of C samples is C consecutive slots), the transforms are the
+// in-place mixed-radix passes of mixed_fft.h over elements C slots apart, and the time-domain work is a loop over the tile's
+// samples -- x and y of a sample are both in LDS, so nothing is exchanged between threads.  Same stages, same control block, same
+// partial sums as col_body (mk_col_stage); the sample set of the lim_0 bound / sparse field store is every sixteenth time row.
+// A general-purpose kernel: far from the roofline of the specialised ones, but device-resident and one launch per stage.
+constexpr int kColMixScratch = 8192;            // bytes of LDS in front of the tile: block reductions
+template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, const ColArgs<T> &a) {
+    static_assert(sizeof(T) == sizeof(scalar_t<T>), "one row per polarisation (no packed pairs)");
+    constexpr bool kMk = MODE == CM_MK;
+    const int N1 = a.N1mix, C = a.mix_cols, N2 = a.N2, npol = a.npol;
+    const long long N = a.N;
+    int lgC = 0;
+    while ((1 << lgC) < C) ++lgC;
+    const int tpp = (N2 + C - 1) / C;                         // tiles per field group
+    const int grp = ctx.bid / tpp;
+    int tile = ctx.bid - grp * tpp;
+    if (tpp % 8 == 0) tile = (tile & 7) * (tpp >> 3) + (tile >> 3);        // contiguous runs of tiles per XCD (see ColGeom)
+    const int n2base = tile * C;
+    const long long rowbase0 = (long long)grp * npol * N, pbase = (long long)grp * N;
+    double *red = (double *)ctx.lds;
+    cx<T> *X = (cx<T> *)(ctx.lds + kColMixScratch);
+
+    bool do_inv, do_fwd;
+    MkColStage st;
+    if (kMk) {
+        mk_col_stage(ctx, a, st, SG_ALL);
+        if (st.op < 0) return;
+        do_inv = st.do_inv;
+        do_fwd = st.do_fwd;
+    } else {
+        do_inv = MODE == CM_NLSE_STEP || MODE == CM_NLSE_LAST || MODE == CM_PLAIN_INV;
+        do_fwd = MODE == CM_NLSE_STEP || MODE == CM_NLSE_FIRST || MODE == CM_PLAIN_FWD;
+    }
+    const int op = st.op;
+    cx<T> *Tcur = a.T0, *Tnew = a.T1;
+    T *Pcur = a.P, *Palt = a.P;
+    if (kMk) {
+        Tcur = st.c.cur ? a.T1 : a.T0;
+        Tnew = st.c.cur ? a.T0 : a.T1;
+        const long long psz = N * a.ngroups;
+        Pcur = a.P + (st.c.pcur ? psz : 0);
+        Palt = a.P + (st.c.pcur ? 0 : psz);
+    }
+    // frequency side: thread (c, t) walks k1 = t, t + Tt, ... of column c; the inter-pass twiddle cis(sign 2 pi n2 k1 / N) follows
+    // by a chain of products from two bases (N1 / Tt <= a few dozen products: 1e-15)
+    const int fc = ctx.tid & (C - 1), ft = ctx.tid >> lgC, Tt = ctx.nthreads >> lgC;
+    const int fn2 = n2base + fc;
+    const bool fvalid = fn2 < N2;
+    cx<double> w0 = mk<double>(1.0, 0.0), ws = w0;
+    if (do_inv || do_fwd) {
+        w0 = cis2pi<double>((double)(((long long)fn2 * ft) % N) / (double)N);
+        ws = cis2pi<double>((double)(((long long)fn2 * Tt) % N) / (double)N);
+    }
+    // time side: element e of the tile = (position pos in the transform's digit-reversed order, column c); time row n1 = mix_bin(pos)
+    const int ne = N1 << lgC;
+    // one transform per (polarisation, column): nthreads / (npol C) threads each
+    const int ntr = npol << lgC, tr = ctx.tid % ntr, tt = ctx.tid / ntr, tpt = ctx.nthreads / ntr;
+    cx<T> *xt = X + ((size_t)(tr >> lgC) * N1 << lgC) + (tr & (C - 1));
+
+    if (do_inv) {                                                     // G -> x cis(+...) -> inverse column transform
+        cx<double> w = w0;
+        for (int k1 = ft; k1 < N1; k1 += Tt) {
+            for (int pol = 0; pol < npol; ++pol) {
+                const cx<T> v = fvalid ? a.G[rowbase0 + (long long)pol * N + (long long)k1 * N2 + fn2] : mk<T>((T)0, (T)0);
+                X[(((size_t)pol * N1 + k1) << lgC) + fc] = mul_by_d(v, w);
+            }
+            w = w * ws;
+        }
+        ctx.sync();
+        mix_dif_strided<+1>(ctx, a.plan1, tt, tpt, xt, a.wtab1, C);
+    }
+    // ---- time-domain work on the tile ----------------------------------------------------------------------------
+    // src -> X (time order), for the stages that start from a time-domain buffer
+    auto load_time = [&](const cx<T> *src) {
+        for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
+            const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
+            const long long toff = (long long)mix_bin(a.plan1, pos) * N2 + n2;
+            for (int pol = 0; pol < npol; ++pol)
+                X[(((size_t)pol * N1 + pos) << lgC) + c] = n2 < N2 ? src[rowbase0 + (long long)pol * N + toff] : mk<T>((T)0, (T)0);
+        }
+    };
+    auto store_time = [&](cx<T> *dst, bool sparse) {
+        for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
+            const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
+            if (n2 >= N2) continue;
+            const int n1 = mix_bin(a.plan1, pos);
+            if (sparse && (n1 & 15)) continue;
+            for (int pol = 0; pol < npol; ++pol) dst[rowbase0 + (long long)pol * N + (long long)n1 * N2 + n2] = X[(((size_t)pol * N1 + pos) << lgC) + c];
+        }
+    };
+    if (MODE == CM_NLSE_FIRST || MODE == CM_PLAIN_FWD) {
+        load_time(a.T0);
+    } else if (MODE == CM_NLSE_STEP) {                                // channels.py:225
+        for (int e = ctx.tid; e < ne; e += ctx.nthreads) X[e] = X[e] * cis_t<T>(a.g_hz * norm2(X[e]));
+    } else if (MODE == CM_NLSE_LAST || MODE == CM_PLAIN_INV) {
+        store_time(a.T0, false);
+    } else if (kMk) {
+        const T shz = (T)(a.k.sgn * st.c.hz), c8g = (T)a.k.c8g;
+        // step start (channels.py:388-395): Pch -> Pbuf, block max of phi -> pmax
+        auto step_start = [&](T *Pbuf) {
+            double m = -INFINITY;
+            for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
+                const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
+                if (n2 >= N2) continue;
+                const T ax = norm2(X[e]), ay = norm2(X[((size_t)N1 << lgC) + e]);
+                const T pw = ax + ay;
+                Pbuf[pbase + (long long)mix_bin(a.plan1, pos) * N2 + n2] = pw;
+                const T phi = c8g * (pw + ax + ay) / (T)2;
+                m = (double)phi > m ? (double)phi : m;
+            }
+            if (a.k.adaptive) {
+                m = block_max(ctx, m, red);
+                if (ctx.tid == 0) a.pmax[ctx.bid] = m;
+            }
+        };
+        // first rotation of a step (channels.py:409-417): X <- X cis(shz phi(Pch, Pch))
+        auto rotate0 = [&]() {
+            for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
+                const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
+                if (n2 >= N2) continue;
+                const T pw = Pcur[pbase + (long long)mix_bin(a.plan1, pos) * N2 + n2];
+                const cx<T> rot = cis_t<T>(shz * (c8g * (pw + pw) / (T)2));
+                X[e] = X[e] * rot;
+                X[((size_t)N1 << lgC) + e] = X[((size_t)N1 << lgC) + e] * rot;
+            }
+        };
+        if (op == 0) {
+            load_time(Tcur);
+            ctx.sync();
+            step_start(Pcur);
+        } else if (op == 4) {
+            load_time(a.Ehd);
+        } else if (op == 1) {
+            store_time(a.Ehd, false);
+            rotate0();
+        } else if (op == 3 || op == 5) {
+            if (op == 5) store_time(Tcur, false);
+            ctx.sync();
+            load_time(a.Ehd);
+            ctx.sync();
+            rotate0();
+        } else {                                                      // op 2: iterate `it` is in the tile
+            double n0 = 0, d0 = 0, n1s = 0, d1 = 0, psum = 0;
+            const bool first = st.c.it == 0, final_ = st.final_;
+            if (first) {                                              // lim_0 against the field at the step start
+                for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
+                    const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
+                    if (n2 >= N2) continue;
+                    const int n1 = mix_bin(a.plan1, pos);
+                    if (!st.exact0 && (n1 & 15)) continue;
+                    for (int pol = 0; pol < npol; ++pol) {
+                        const cx<T> e0 = Tcur[rowbase0 + (long long)pol * N + (long long)n1 * N2 + n2], v = X[(((size_t)pol * N1 + pos) << lgC) + c];
+                        const double dr = (double)v.re - (double)e0.re, di = (double)v.im - (double)e0.im;
+                        n0 += dr * dr + di * di;
+                        d0 += (double)e0.re * e0.re + (double)e0.im * e0.im;
+                    }
+                }
+            }
+            if (final_) {                                             // the field after this step (channels.py:438-439)
+                store_time(Tnew, st.sparse);
+            } else {
+                // next iterate (channels.py:436, 414-417): X <- E_hd rot_{it+1}; sums of lim_{it+1} (see the note at the top of this file)
+                for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
+                    const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
+                    if (n2 >= N2) continue;
+                    const long long toff = (long long)mix_bin(a.plan1, pos) * N2 + n2;
+                    const T pw = Pcur[pbase + toff];
+                    const T ax = norm2(X[e]), ay = norm2(X[((size_t)N1 << lgC) + e]);
+                    const T ang = shz * (c8g * (pw + ax + ay) / (T)2);
+                    const T prev = first ? shz * (c8g * (pw + pw) / (T)2) : a.Theta[pbase + toff];
+                    psum += (double)pw;
+                    a.Theta[pbase + toff] = ang;
+                    const double sh = sin_half_angle((double)ang - (double)prev);
+                    const cx<T> rot = cis_t<T>(ang);
+                    const cx<T> hx = a.Ehd[rowbase0 + toff], hy = a.Ehd[rowbase0 + N + toff];
+                    const double w = (double)norm2(hx) + (double)norm2(hy);
+                    n1s += w * (4.0 * sh * sh);
+                    d1 += w;
+                    X[e] = hx * rot;
+                    X[((size_t)N1 << lgC) + e] = hy * rot;
+                }
+                if (!st.exact0) d0 = psum;                            // exact denominator of the bound: sum Pch over the tile
+            }
+            if (first) {
+                block_sum2(ctx, n0, d0, red);
+                if (ctx.tid == 0) {
+                    a.pnum0[ctx.bid] = n0;
+                    a.pden0[ctx.bid] = d0;
+                }
+            }
+            if (!final_) {
+                block_sum2(ctx, n1s, d1, red);
+                if (ctx.tid == 0) {
+                    a.pnum[ctx.bid] = n1s;
+                    a.pden[ctx.bid] = d1;
+                }
+            } else if (st.more) {
+                ctx.sync();
+                step_start(Palt);                                     // next step: Pch (the field's spectrum is in G already)
+            }
+        }
+    }
+    // ---- forward column transform -> x cis(-...) -> G ---------------------------------------------------------------
+    if (do_fwd) {
+        ctx.sync();
+        mix_dit_strided<-1>(ctx, a.plan1, tt, tpt, xt, a.wtab1, C);
+        cx<double> w = conj(w0);
+        const cx<double> wsc = conj(ws);
+        for (int k1 = ft; k1 < N1; k1 += Tt) {
+            if (fvalid)
+                for (int pol = 0; pol < npol; ++pol)
+                    a.G[rowbase0 + (long long)pol * N + (long long)k1 * N2 + fn2] = mul_by_d(X[(((size_t)pol * N1 + k1) << lgC) + fc], w);
+            w = w * wsc;
+        }
     }
 }
 

@@ -264,16 +264,19 @@ template <int R, typename T> SSF_HD void mix_apply_op(const MixPlan &p, const Mi
 // one pass of radix R for this thread's butterflies; DIF: transform then twiddle, DIT: twiddle then transform.
 // The twiddles cis(sign 2 pi j q / M) are a chain of products from the base, evaluated in double (see
 // tw_powers for why single precision does not build it in float) and consumed as they are produced.
-template <int SIGN, int R, bool DIF, typename T, class Ctx>
+// STR: the transform's elements are `es` slots apart (the column stage keeps the C columns of a tile interleaved in LDS:
+// col_mixed_body); rows are contiguous (STR = false: no multiplication by a run-time stride in their index arithmetic)
+template <int SIGN, int R, bool DIF, bool STR = false, typename T, class Ctx>
 SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab,
-                     bool use_op, const MixRowOp &op) {
+                     bool use_op, const MixRowOp &op, int es = 1) {
     const int M = p.M[i], s = p.S[i], nbf = p.L / R, wstep = p.W[i];
+    const int se = STR ? s * es : s;
     for (int bf = t; bf < nbf; bf += nthreads) {
         const int blk = bf / s, j = bf - blk * s;
-        cx<T> *base = x + blk * M + j;
+        cx<T> *base = x + (STR ? (blk * M + j) * es : blk * M + j);
         cx<T> v[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = base[s * q];
+        for (int q = 0; q < R; ++q) v[q] = base[se * q];
         if constexpr (!DIF && R <= kMixMaxOpRadix) {               // (only given for the stride-1 pass: j = 0, bf = blk)
             if (use_op) mix_apply_op<R>(p, op, blk, v);
         }
@@ -322,28 +325,28 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
             }
         }
 #pragma unroll
-        for (int sl = 0; sl < R; ++sl) base[s * dft_slot_bin<R>(sl)] = v[sl];
+        for (int sl = 0; sl < R; ++sl) base[se * dft_slot_bin<R>(sl)] = v[sl];
     }
     ctx.sync();
 }
 
-template <int SIGN, bool DIF, typename T, class Ctx>
+template <int SIGN, bool DIF, bool STR = false, typename T, class Ctx>
 SSF_HD void mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab,
-                         bool use_op, const MixRowOp &op) {
+                         bool use_op, const MixRowOp &op, int es = 1) {
     switch (p.r[i]) {
-    case 25: mix_pass<SIGN, 25, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 20: mix_pass<SIGN, 20, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 16: mix_pass<SIGN, 16, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 15: mix_pass<SIGN, 15, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 12: mix_pass<SIGN, 12, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 10: mix_pass<SIGN, 10, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 9: mix_pass<SIGN, 9, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 8: mix_pass<SIGN, 8, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 6: mix_pass<SIGN, 6, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 5: mix_pass<SIGN, 5, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 4: mix_pass<SIGN, 4, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    case 3: mix_pass<SIGN, 3, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
-    default: mix_pass<SIGN, 2, DIF>(ctx, p, i, t, nthreads, x, wtab, use_op, op); break;
+    case 25: mix_pass<SIGN, 25, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 20: mix_pass<SIGN, 20, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 16: mix_pass<SIGN, 16, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 15: mix_pass<SIGN, 15, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 12: mix_pass<SIGN, 12, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 10: mix_pass<SIGN, 10, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 9: mix_pass<SIGN, 9, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 8: mix_pass<SIGN, 8, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 6: mix_pass<SIGN, 6, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 5: mix_pass<SIGN, 5, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 4: mix_pass<SIGN, 4, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    case 3: mix_pass<SIGN, 3, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    default: mix_pass<SIGN, 2, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
     }
 }
 
@@ -365,6 +368,17 @@ template <int SIGN, typename T, class Ctx>
 SSF_HD void mix_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab = nullptr) {
     const MixRowOp none{};
     mix_dit<SIGN>(ctx, p, t, nthreads, x, wtab, false, none);
+}
+// the same pair over elements `es` slots apart (column stage: the columns of a tile interleaved in LDS)
+template <int SIGN, typename T, class Ctx>
+SSF_HD void mix_dif_strided(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab, int es) {
+    const MixRowOp none{};
+    for (int i = 0; i < p.npass; ++i) mix_pass_any<SIGN, true, true>(ctx, p, i, t, nthreads, x, wtab, false, none, es);
+}
+template <int SIGN, typename T, class Ctx>
+SSF_HD void mix_dit_strided(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab, int es) {
+    const MixRowOp none{};
+    for (int i = p.npass - 1; i >= 0; --i) mix_pass_any<SIGN, false, true>(ctx, p, i, t, nthreads, x, wtab, false, none, es);
 }
 
 }  // namespace fused

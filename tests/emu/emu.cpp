@@ -204,6 +204,17 @@ struct EmuBackend {
             else run_grid(grid, block, lds, [&](EmuCtx &c) { col_pk_body<0>(c, a); });
             return;
         } else {
+        if (a.N1mix) {                                      // mixed-radix columns (col_mixed_body)
+            switch (a.mode) {
+            case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_NLSE_FIRST>(c, a); }); break;
+            case CM_NLSE_STEP: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_NLSE_STEP>(c, a); }); break;
+            case CM_NLSE_LAST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_NLSE_LAST>(c, a); }); break;
+            case CM_MK: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_MK>(c, a); }); break;
+            case CM_PLAIN_FWD: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_PLAIN_FWD>(c, a); }); break;
+            default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_PLAIN_INV>(c, a); }); break;
+            }
+            return;
+        }
         if (a.vpt == 8 && !a.N2) {                          // eight values per thread (no ragged variant)
             switch (a.mode) {
             case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_body<T, 0, CM_NLSE_FIRST, false, 8>(c, a); }); break;
@@ -383,8 +394,8 @@ extern "C" {
 
 int emu_supported(int64_t N, int precision) {
     if (N >= 2 && (N & (N - 1))) {
-        int l1, n2;
-        return ssf::fused::choose_mixed_split(N, precision, &l1, &n2) ? 1 : 0;
+        int l1, n2, n1, c;
+        return (ssf::fused::choose_mixed_split(N, precision, &l1, &n2) || ssf::fused::choose_mixed2_split(N, precision, &n1, &n2, &c)) ? 1 : 0;
     }
     if (N < 2 || (N & (N - 1))) return 0;
     int l = 0;
@@ -393,6 +404,12 @@ int emu_supported(int64_t N, int precision) {
     return ssf::fused::choose_split(l, precision, &s) ? 1 : 0;
 }
 
+// the N1 x N2 split (and columns per workgroup) of the mixed-radix column stage, 0 when the length does not go there
+int emu_mixed2_split(int64_t N, int precision, int *n1, int *n2, int *c) {
+    int l1, m2;
+    if (!getenv("SSF_MIX2") && ssf::fused::choose_mixed_split(N, precision, &l1, &m2)) return 0;
+    return ssf::fused::choose_mixed2_split(N, precision, n1, n2, c) ? 1 : 0;
+}
 int emu_split(int64_t N, int precision, int *l1, int *l2) {
     int l = 0;
     while ((1ll << l) < N) ++l;

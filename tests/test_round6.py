@@ -121,3 +121,139 @@ def test_linear_fiber_channel_on_device_arrays_and_in_the_reference_layout():
     assert o64.dtype == r64.dtype == np.complex128 and rel_l2(o64, r64) <= 5e-6
     back, prm = oa.linearFiberChannel(od, bag(returnParameters=True, **dict(lp, D=-17, alpha=-0.2)))    # and a chain stays in HBM
     assert prm.returnParameters and rel_l2(back.get(), E) <= 1e-12
+
+
+# ------------------------------------------------------------------------------------------ mixed-radix COLUMN stage (emulator)
+# N = N1 x N2 with both factors 2^a 3^b 5^c (fused_kernels.h: col_mixed_body): what takes the lengths whose power-of-two part is too
+# small for the radix-2^n columns -- the reference benchmark's 2 000 000 = 2^7 x 5^6 among them -- onto the device-resident pipeline.
+def _mix2(N, prec=1):
+    import ctypes as C
+    e = eb.load()
+    e.emu_mixed2_split.argtypes = [C.c_int64, C.c_int] + [C.POINTER(C.c_int)] * 3
+    n1, n2, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    return (n1.value, n2.value, c.value) if e.emu_mixed2_split(N, prec, C.byref(n1), C.byref(n2), C.byref(c)) else None
+
+
+def test_the_split_of_the_reference_benchmarks_top_size():
+    for N in (2_000_000, 5_000_000, 15_625, 10_125, 9_000):
+        sp = _mix2(N)
+        assert sp is not None and sp[0] * sp[1] == N and 16 <= sp[0] <= 1024 and 64 <= sp[1] <= 8192 and sp[2] in (2, 4, 8), (N, sp)
+    assert _mix2(2_000_000) == (500, 4000, 4)                     # two workgroups per CU in both stages (fused_engine.h)
+    assert _mix2(240_000) is None and _mix2(1 << 20) is None      # (the radix-2^n columns keep what they take)
+    assert _mix2(7 * 4096) is None                                # (not 5-smooth: Bluestein)
+
+
+MK = dict(Fs=512e9, Ltotal=4.0, Lspan=2.0, hz=0.25, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, maxIter=10, tol=1e-5, prgsBar=False)
+
+
+@pytest.mark.parametrize("N, power", [(9000, 8.4), (10125, 13.0), (15625, 3.0)])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_manakov_on_the_mixed_radix_column_stage_against_the_oracle(N, power, adaptive):
+    assert _mix2(N) is not None
+    E = synth_field(N, 2, 31, power)
+    cfg = dict(MK, nlprMethod=adaptive, maxNlinPhaseRot=5e-3, amp="ideal", saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E, bag(orc.parameters, **cfg), trace=tr)
+    out, info = eb.run("manakovSSF", E, cfg)
+    assert rel_l2(out.T, ref) <= 1e-11
+    assert list(info["iters"]) == list(tr["iters"]) and np.allclose(info["hz"], tr["hz"], rtol=1e-9)
+    for a, b in zip(info["lims"], tr["lims"]):
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-14)
+    back, _ = eb.run("manakovDBP", ref, cfg)                       # ... and backwards
+    assert rel_l2(back.T, orc.manakovDBP(ref, bag(orc.parameters, **cfg))) <= 1e-11
+
+
+def test_mixed_radix_columns_complex64_two_pairs_and_the_rare_stages():
+    N = 9000
+    E4 = np.concatenate([synth_field(N, 2, 41, 8.0), synth_field(N, 2, 42, 2.0)], axis=1)
+    cfg = dict(MK, nlprMethod=False, amp=None, saveSpanN=[])
+    out, info = eb.run("manakovSSF", E4, cfg)                      # two coupled pairs (K = 2)
+    tr = {}
+    ref = orc.manakovSSF(E4, bag(orc.parameters, **cfg), trace=tr)
+    assert rel_l2(out.T, ref) <= 1e-11 and list(info["iters"]) == list(tr["iters"])
+    E = synth_field(N, 2, 43, 8.0)
+    c64 = dict(cfg, prec="complex64")
+    o64, i64 = eb.run("manakovSSF", E.astype(np.complex64), c64)
+    r128 = orc.manakovSSF(E.astype(np.complex64).astype(np.complex128), bag(orc.parameters, **cfg))
+    assert rel_l2(o64.T, r128) <= 5e-5
+    # weak nonlinearity: lim_0 < tol at every step -> iterate 0 is rebuilt as the final one (ST_REDO0); without a trace the bound of
+    # lim_0 cannot exclude it either: rebuilt once to measure, once as final -- the same field either way
+    weak = synth_field(N, 2, 44, -10.0)
+    wcfg = dict(func="manakovSSF", alpha=0.0, D=1e-5, gamma=1e-6, Fc=193.1e12, Fs=64e9, maxIter=10, tol=1e-5, prgsBar=False,
+                Ltotal=0.4, Lspan=0.2, hz=0.05, nlprMethod=False, amp=None, saveSpanN=[])
+    tr = {}
+    wref = orc.manakovSSF(weak, bag(orc.parameters, **{k: v for k, v in wcfg.items() if k != "func"}), trace=tr)
+    assert set(tr["iters"]) == {1}
+    w1, wi1 = eb.run("manakovSSF", weak, wcfg)
+    w2, wi2 = eb.run("manakovSSF", weak, wcfg, trace=False)
+    assert list(wi1["iters"]) == list(tr["iters"]) and rel_l2(w1.T, wref) <= 1e-11 and np.array_equal(w1, w2)
+    assert wi1["rebuilt_iterates"] == wi1["steps"] and wi2["rebuilt_iterates"] == 2 * wi2["steps"] and wi2["iterations"] == wi1["iterations"]
+    # a tolerance around the bound of lim_0 (~ lim_0 / 4): some steps need the exact lim_0, whose step-start field was stored at one
+    # sample in sixteen only -- recovered from E_hd (ST_RECOVER_A / _ROW / _B); same steps, iterations and field as the traced run
+    mid = synth_field(N, 2, 45, 0.0)
+    mcfg = dict(cfg, Ltotal=20, Lspan=20, hz=0.5)
+    _, it = eb.run("manakovSSF", mid, mcfg)
+    lim0 = sorted(float(x[0]) for x in it["lims"])
+    hit = 0
+    for f in (0.26, 0.255, 0.22):
+        c2 = dict(mcfg, tol=lim0[len(lim0) // 2] * f)
+        tr = {}
+        mref = orc.manakovSSF(mid, bag(orc.parameters, **c2), trace=tr)
+        a, ia = eb.run("manakovSSF", mid, c2)
+        b, ib = eb.run("manakovSSF", mid, c2, trace=False)
+        assert list(ia["iters"]) == list(tr["iters"]) and rel_l2(a.T, mref) <= 1e-11 and rel_l2(b, a) <= 1e-13
+        assert (ia["steps"], ia["iterations"]) == (ib["steps"], ib["iterations"]) and ia["recovered_fields"] == 0
+        hit += ib["recovered_fields"]
+    assert hit > 0
+
+
+def test_ssfm_and_linear_channel_on_the_mixed_radix_column_stage():
+    N = 10125
+    E = synth_field(N, 1, 51, 5.0)[:, 0]
+    cfg = dict(Fs=512e9, Ltotal=3.0, Lspan=1.5, hz=0.25, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, amp="ideal", prgsBar=False, saveSpanN=[])
+    out, info = eb.run("ssfm_final", E, cfg)
+    ref = orc.ssfm(E, bag(orc.parameters, **cfg))
+    assert rel_l2(out[0], ref) <= 1e-12
+    lp = bag(orc.parameters, Fs=512e9, L=3.0, alpha=0.2, D=16, Fc=193.1e12)
+    E2 = synth_field(N, 2, 52, 0.0)
+    assert rel_l2(eb.linear_channel(E2, 512e9, 193.1e12, 0.2, 16, 3.0), orc.linearFiberChannel(E2, lp)) <= 1e-13
+
+
+def test_forcing_a_radix_2n_length_onto_the_mixed_columns_gives_the_same_field(monkeypatch):
+    """12 000 = 2^5 x 375 runs on the radix-2^n columns; forced onto the mixed-radix column stage (experiment knob SSF_MIX2, read by
+    the emulator's experiment build) both pipelines must agree with the oracle and with each other to rounding."""
+    N = 12000
+    E = synth_field(N, 2, 61, 8.4)
+    cfg = dict(MK, nlprMethod=False, amp="ideal", saveSpanN=[])
+    a, ia = eb.run("manakovSSF", E, cfg)
+    monkeypatch.setenv("SSF_MIX2", "125,8")
+    assert _mix2(N) == (125, 96, 8)
+    b, ib = eb.run("manakovSSF", E, cfg)
+    ref = orc.manakovSSF(E, bag(orc.parameters, **cfg))
+    assert rel_l2(a.T, ref) <= 1e-11 and rel_l2(b.T, ref) <= 1e-11 and rel_l2(a, b) <= 1e-12
+    assert list(ia["iters"]) == list(ib["iters"])
+
+
+# ------------------------------------------------------------------------------------------ GPU: the reference benchmark's own lengths
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [2_000_000, 200_000])
+def test_reference_notebook_lengths_run_device_resident_and_match_the_oracle(N):
+    """examples/benchmarck_GPU_processing.ipynb: 16-QAM, SpS 4, adaptive step, 5e4 ... 5e5 symbols = 2e5 ... 2e6 samples.  2e6 =
+    2^7 x 5^6 used to fall to the host-driven Bluestein path; it now runs on the device-resident pipeline (mixed-radix column stage)."""
+    E = synth_field(N, 2, 71, -2.0 + 3.0)
+    cfg = dict(Fs=128e9, Ltotal=12.0, Lspan=12.0, hz=0.5, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, maxIter=5, tol=1e-5, nlprMethod=True,
+               maxNlinPhaseRot=2e-2, amp="ideal", saveSpanN=[], prgsBar=False)
+    tr = {}
+    ref = orc.manakovSSF(E, bag(orc.parameters, **cfg), trace=tr)
+    out = oa.manakovSSF(E, bag(**cfg), _trace=True)
+    assert oa.last_run["pipeline"] == "fused-device"
+    assert rel_l2(out, ref) <= 1e-10
+    assert [int(x) for x in oa.last_run["iters"]] == [int(x) for x in tr["iters"]]
+    assert np.allclose(oa.last_run["hz"], tr["hz"], rtol=1e-9)
+    fix = dict(cfg, nlprMethod=False, hz=2.0)                              # fixed step, complex64, and backwards
+    o64 = oa.manakovSSF(E.astype(np.complex64), bag(prec=np.complex64, **fix))
+    assert oa.last_run["pipeline"] == "fused-device" and o64.dtype == np.complex64
+    r128 = orc.manakovSSF(E.astype(np.complex64).astype(np.complex128), bag(orc.parameters, **fix))
+    assert rel_l2(o64, r128) <= 5e-4
+    back = oa.manakovDBP(ref, bag(**fix))
+    assert rel_l2(back, orc.manakovDBP(ref, bag(orc.parameters, **fix))) <= 1e-10
