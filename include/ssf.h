@@ -440,6 +440,20 @@ enum ssf_rx_mode {
 int  ssf_rx_run(int device, int32_t mode, int64_t N, int32_t nmodes, const ssf_rx_params *params,
                 const void *in0, const void *lo, const double *unit_normals, void *out);
 
+/* ---- the receiver side of the coherent notebooks in ONE call: pdmCoherentReceiver -> firFilter (matched filter) -> decimate -> edc
+ * (examples/test_WDM_transmission.ipynb cells 17 - 23; optic/models/devices.py:574-668, optic/dsp/core.py:87-125, 435-491,
+ * optic/dsp/equalization.py:36-122), with the results of the four calls made one after the other.  What one call adds: the
+ * stages' launches follow each other on the stream with one host wait at the end, decimate's variance search rides in the matched
+ * filter's stores and its gather in the compensating filter's loads (no pass over the filtered signal of its own, the decimated
+ * signal never materialised).
+ *   Es (N, 2), Elo (N,) complex128, host or device;  taps: ntaps complex128 (<= 4096), host
+ *   SpSin / decFactor as ssf_decimate (N % SpSin == 0)
+ *   edc_Hfft: edc_nfft complex128 = fft(zero-padded impulse response) as ssf_overlap_save takes it, edc_K its taps, host
+ *   sig_out ((N + decFactor - 1) / decFactor, 2) complex128, host or device;  sampDelay (may be NULL): the two sampling phases */
+int  ssf_rx_chain(int device, int64_t N, const ssf_rx_params *params, const void *Es, const void *Elo, const void *taps,
+                  int32_t ntaps, int32_t SpSin, int32_t decFactor, const void *edc_Hfft, int32_t edc_K, int32_t edc_nfft,
+                  void *sig_out, int32_t *sampDelay);
+
 /* ---- WDM transmitter: the signal path of simpleWDMTx, optic/models/tx.py:178-217.
  * For every channel and polarisation: zero-stuffing to SpS samples per symbol + pulse-shaping FIR
  * ('same' mode, one overlap-save launch), normalisation to unit peak, IQ modulator with the

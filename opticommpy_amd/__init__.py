@@ -17,11 +17,11 @@ from .models import (  # noqa: F401
 from .device import DeviceArray, to_device  # noqa: F401
 from .rx import (  # noqa: F401
     balancedPD, coherentReceiver, decimate, delaySignal, firFilter, iqMixing, lowPassFIR, opticalHybrid2x4, pbs,
-    pdmCoherentReceiver, photodiode,
+    pdmCoherentReceiver, pdmCoherentReceiverChain, photodiode,
 )
 
 from .wdm_tx import basicLaserModel, grayMapping, phaseNoise, pulseShape, simpleWDMTx  # noqa: F401
 
 __all__ = ["simpleWDMTx", "basicLaserModel", "pulseShape", "phaseNoise", "grayMapping", "DeviceArray", "to_device", "firFilter", "lowPassFIR", "decimate", "delaySignal", "iqMixing", "pbs", "photodiode", "balancedPD",
-           "opticalHybrid2x4", "coherentReceiver", "pdmCoherentReceiver", "parameters", "ssfm", "manakovSSF", "manakovDBP", "nlinPhaseRot", "convergenceCondition", "edfa", "edc", "blockwiseFFTConv", "linearFiberChannel",
+           "opticalHybrid2x4", "coherentReceiver", "pdmCoherentReceiver", "pdmCoherentReceiverChain", "parameters", "ssfm", "manakovSSF", "manakovDBP", "nlinPhaseRot", "convergenceCondition", "edfa", "edc", "blockwiseFFTConv", "linearFiberChannel",
            "setPowerforParSSFM", "checkGPU", "last_run", "set_device", "set_engine"]

@@ -123,6 +123,8 @@ SYMBOLS = {
                                C.POINTER(C.c_int32)]),
     "ssf_rx_run": (C.c_int, [C.c_int, C.c_int32, C.c_int64, C.c_int32, C.POINTER(RxParams), C.c_void_p, C.c_void_p,
                              C.POINTER(C.c_double), C.c_void_p]),
+    "ssf_rx_chain": (C.c_int, [C.c_int, C.c_int64, C.POINTER(RxParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                               C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
     "ssf_wdm_tx": (C.c_int, [C.c_int, C.POINTER(TxParams), C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                              C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_double)]),
     "ssf_device_copy_bandwidth": (C.c_int, [C.c_int, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),

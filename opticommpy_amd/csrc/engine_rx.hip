@@ -79,6 +79,14 @@ __global__ void __launch_bounds__(256) k_tx_shift_add(const ShiftAddArgs a) {
     SSF_RX_CTX();
     shift_add_body(ctx, a);
 }
+template <int LG, int C, int MODE> __global__ void __launch_bounds__(fused::ols_threads(LG, C)) k_rx_chain_ols(const ChainOlsArgs a) {
+    SSF_RX_CTX();
+    chain_ols_body<LG, C, MODE>(ctx, a);
+}
+__global__ void __launch_bounds__(256) k_rx_chain_finish(const ChainFinishArgs a) {
+    SSF_RX_CTX();
+    chain_finish_body(ctx, a);
+}
 __global__ void __launch_bounds__(256) k_rx_dec_sum(const DecSumArgs a) {
     SSF_RX_CTX();
     dec_sum_body(ctx, a);
@@ -214,6 +222,25 @@ struct HipRxBackend {
     void launch_shift_add(const ShiftAddArgs &a) {
         k_tx_shift_add<<<ew_grid(a.N), 256, 0, st>>>(a);
         chk(hipGetLastError(), "launch k_tx_shift_add");
+    }
+    void launch_chain_ols(const ChainOlsArgs &a, int mode) {
+        const fused::OlsLaunch o = fused::ols_launch(a.o.log2nfft, a.o.nrows, a.o.njobs);
+        const bool found = chain_ols_dispatch(o, [&](auto lg, auto cc) {
+            constexpr int LG = decltype(lg)::value, C = decltype(cc)::value;
+            if (mode == CH_STATS) {
+                arm(k_rx_chain_ols<LG, C, CH_STATS>);
+                k_rx_chain_ols<LG, C, CH_STATS><<<(unsigned)o.grid, o.threads, o.lds_bytes, st>>>(a);
+            } else {
+                arm(k_rx_chain_ols<LG, C, CH_GATHER>);
+                k_rx_chain_ols<LG, C, CH_GATHER><<<(unsigned)o.grid, o.threads, o.lds_bytes, st>>>(a);
+            }
+        });
+        if (!found) chk(hipErrorInvalidConfiguration, "k_rx_chain_ols: no kernel for this transform size");
+        chk(hipGetLastError(), "launch k_rx_chain_ols");
+    }
+    void launch_chain_finish(const ChainFinishArgs &a) {
+        k_rx_chain_finish<<<1, 256, sizeof(double) * (3 * 256 + 256), st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_chain_finish");
     }
     void launch_dec_sum(const DecSumArgs &a, int nblocks, int nthreads) {
         k_rx_dec_sum<<<(unsigned)nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, st>>>(a);
@@ -366,6 +393,12 @@ int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, voi
 int tx_wdm(int device, const ssf_tx_params *p, const void *symbols, const double *taps, const double *phi, const double *amp,
            const double *deltaF, void *out, double *power_out, std::string *err) {
     return with_core(device, err, [&](RxCore<Pooled> &c) { return c.wdm_tx(*p, symbols, taps, phi, amp, deltaF, out, power_out); });
+}
+int rx_chain(int device, int64_t N, const ssf_rx_params *p, const void *Es, const void *Elo, const void *taps, int ntaps, int SpSin,
+             int decFactor, const void *edcH, int edcK, int edc_nfft, void *out, int32_t *sampDelay, std::string *err) {
+    return with_core(device, err, [&](RxCore<Pooled> &c) {
+        return c.chain(N, *p, Es, Elo, taps, ntaps, SpSin, decFactor, edcH, edcK, edc_nfft, out, sampDelay);
+    });
 }
 int rx_optics(int device, int op, int64_t n, int ncols, double p0, double p1, unsigned long long seed, unsigned row0, const void *a,
               const void *b, void *o0, void *o1, std::string *err) {

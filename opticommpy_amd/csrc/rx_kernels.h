@@ -602,5 +602,121 @@ template <class Ctx> SSF_HD void dec_gather_body(Ctx &ctx, const DecGatherArgs &
     }
 }
 
+// =====================================================================================================
+// Receiver chain in one call (RxCore::chain): receiver -> matched filter -> decimate -> edc.  Two fusions around the decimation
+// (core.py:435-491) that a sequence of separate calls cannot have:
+//   CH_STATS   the matched filter's STORES also accumulate, per (sampling phase, column) class, sum x and sum |x|^2 of what they
+//              write -- decimate's variance search without its two passes over the filtered signal.  (Every thread's sixteen
+//              outputs are tpf samples apart, so with SpS | tpf they belong to ONE class: three register accumulators per thread.)
+//              var = sum |x|^2 / M - |sum x / M|^2: one pass instead of np.var's two; the chosen phase is the largest variance's,
+//              and phases differ by far more than the rounding of either form.
+//   CH_GATHER  the compensating filter's LOADS pick sample (j dec + delay[col]) mod N of the filtered signal -- the decimated
+//              signal is never written or read.
+enum { CH_PLAIN = 0, CH_STATS = 1, CH_GATHER = 2 };
+struct ChainOlsArgs {
+    fused::OlsArgs<double> o;
+    double *part;        // CH_STATS: (nblocks, nclass, 3) partial sums: re, im, |x|^2
+    int SpS;             // CH_STATS: samples per symbol of the filtered signal (classes = SpS x columns)
+    const int *delay;    // CH_GATHER: sampling phase per column (device memory: chain_finish_body)
+    int dec;             // CH_GATHER: decimation factor
+    long long Nfull;     // CH_GATHER: length of the signal that is sampled
+};
+template <int LG, int C, int MODE, class Ctx> SSF_HD void chain_ols_body(Ctx &ctx, const ChainOlsArgs &a) {
+    double sre = 0, sim = 0, spw = 0;
+    int cls = -1;
+    fused::ols_body_x<double, LG, C>(
+        ctx, a.o,
+        [&](long long src, int m) -> Cd {
+            if constexpr (MODE == CH_GATHER) return a.o.in[((src * a.dec + a.delay[m]) % a.Nfull) * a.o.in_ld + m];
+            else return a.o.in[src * a.o.in_ld + m];
+        },
+        [&](long long n, int m, Cd v) {
+            a.o.out[n * a.o.out_ld + m] = v;
+            if constexpr (MODE == CH_STATS) {
+                cls = (int)(n % a.SpS) * a.o.nrows + m;
+                sre += v.re;
+                sim += v.im;
+                spw += v.re * v.re + v.im * v.im;
+            }
+        });
+    if constexpr (MODE == CH_STATS) {              // per-class sums of this workgroup (fixed order: deterministic)
+        const int nclass = a.SpS * a.o.nrows;
+        double *red = (double *)ctx.lds;           // nthreads x (re, im, pw), classes behind them
+        int *rc = (int *)(red + 3 * (size_t)ctx.nthreads);
+        ctx.sync();                                // (the transform's LDS traffic is over)
+        red[3 * ctx.tid] = sre;
+        red[3 * ctx.tid + 1] = sim;
+        red[3 * ctx.tid + 2] = spw;
+        rc[ctx.tid] = cls;
+        ctx.sync();
+        for (int c = ctx.tid; c < nclass; c += ctx.nthreads) {
+            double t0 = 0, t1 = 0, t2 = 0;
+            for (int t = 0; t < ctx.nthreads; ++t)
+                if (rc[t] == c) {
+                    t0 += red[3 * t];
+                    t1 += red[3 * t + 1];
+                    t2 += red[3 * t + 2];
+                }
+            double *o = a.part + ((size_t)ctx.bid * nclass + c) * 3;
+            o[0] = t0;
+            o[1] = t1;
+            o[2] = t2;
+        }
+    }
+}
+// the partials added up (one workgroup, fixed order), the variances, and per column the first phase of the largest one (core.py:478)
+struct ChainFinishArgs {
+    const double *part;  // (nblocks, nclass, 3)
+    int *delay;          // ncols sampling phases out
+    int nblocks, nclass, ncols, SpS;
+    double M;            // samples per class
+};
+template <class Ctx> SSF_HD void chain_finish_body(Ctx &ctx, const ChainFinishArgs &a) {
+    double *red = (double *)ctx.lds;               // nthreads x 3 doubles, then nclass variances
+    double *var = red + 3 * (size_t)ctx.nthreads;
+    const int nseg = ctx.nthreads / a.nclass, used = nseg * a.nclass;
+    double s0 = 0, s1 = 0, s2 = 0;
+    if (ctx.tid < used)
+        for (int w = ctx.tid / a.nclass; w < a.nblocks; w += nseg) {
+            const double *q = a.part + ((size_t)w * a.nclass + ctx.tid % a.nclass) * 3;
+            s0 += q[0];
+            s1 += q[1];
+            s2 += q[2];
+        }
+    red[3 * ctx.tid] = s0;
+    red[3 * ctx.tid + 1] = s1;
+    red[3 * ctx.tid + 2] = s2;
+    ctx.sync();
+    if (ctx.tid < a.nclass) {
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int g = 0; g < nseg; ++g) {
+            t0 += red[3 * (g * a.nclass + ctx.tid)];
+            t1 += red[3 * (g * a.nclass + ctx.tid) + 1];
+            t2 += red[3 * (g * a.nclass + ctx.tid) + 2];
+        }
+        const double mr = t0 / a.M, mi = t1 / a.M;
+        var[ctx.tid] = t2 / a.M - (mr * mr + mi * mi);
+    }
+    ctx.sync();
+    if (ctx.tid < a.ncols) {
+        int best = 0;
+        for (int ph = 1; ph < a.SpS; ++ph)
+            if (var[ph * a.ncols + ctx.tid] > var[best * a.ncols + ctx.tid]) best = ph;
+        a.delay[ctx.tid] = best;
+    }
+}
+// f(LG, C) for the instantiation a chain launch needs (the matched filter and the compensating filter of a 2-polarisation chain:
+// transforms of 2048 ... 8192 points); false: no such kernel -- the chain then runs its stages one by one
+template <class F> inline bool chain_ols_dispatch(const fused::OlsLaunch &o, F &&f) {
+    using std::integral_constant;
+    if (o.lg == 11 && o.C == 2) f(integral_constant<int, 11>{}, integral_constant<int, 2>{});
+    else if (o.lg == 12 && o.C == 2) f(integral_constant<int, 12>{}, integral_constant<int, 2>{});
+    else if (o.lg == 13 && o.C == 1) f(integral_constant<int, 13>{}, integral_constant<int, 1>{});
+    else if (o.lg == 10 && o.C == 2) f(integral_constant<int, 10>{}, integral_constant<int, 2>{});
+    else return false;
+    return true;
+}
+inline bool chain_ols_supported(const fused::OlsLaunch &o) { return ((o.lg >= 10 && o.lg <= 12) && o.C == 2) || (o.lg == 13 && o.C == 1); }
+
 }  // namespace rx
 }  // namespace ssf

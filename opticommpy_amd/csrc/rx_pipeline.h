@@ -170,6 +170,11 @@ template <class Backend> struct RxCore {
     // y[:keep] = roll(blockwiseFFTConv(in zero-extended to sigLen, filter), -roll) for `ncols` columns
     int ols(const Cd *in, int in_ld, long long inLen, long long sigLen, Cd *out, int out_ld, long long keep, int ncols,
             const Cd *H, int Hstride, int K, int nfft, int roll, int in_up = 1) {
+        be.launch_ols(ols_args(in, in_ld, inLen, sigLen, out, out_ld, keep, ncols, H, Hstride, K, nfft, roll, in_up));
+        return SSF_OK;
+    }
+    fused::OlsArgs<double> ols_args(const Cd *in, int in_ld, long long inLen, long long sigLen, Cd *out, int out_ld, long long keep, int ncols,
+                                    const Cd *H, int Hstride, int K, int nfft, int roll, int in_up = 1) {
         const OlsGeom g = ols_geometry(sigLen, K, nfft);
         fused::OlsArgs<double> a{};
         a.in = in;
@@ -189,8 +194,7 @@ template <class Backend> struct RxCore {
         a.Hstride = Hstride;
         a.roll = roll;
         a.in_up = in_up;
-        be.launch_ols(a);
-        return SSF_OK;
+        return a;
     }
 
     // delaySignal on columns [c0, c0 + 2) of a (N, ld) array with delays (dl[0], dl[1]) of equal magnitude
@@ -469,10 +473,113 @@ template <class Backend> struct RxCore {
             }
             be.launch_iqf(f);
         }
+        if (in_chain) return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());      // (chain(): more launches follow on the stream)
         be.sync();
         if (!be.ok()) return fail(SSF_ERR_HIP, be.last_error());
         if ((void *)result != out) be.d2h_big(out, result, sizeof(Cd) * (size_t)N * nm);
         return be.ok() ? SSF_OK : fail(SSF_ERR_HIP, be.last_error());
+    }
+    bool in_chain = false;
+
+    // pdmCoherentReceiver -> firFilter (matched filter) -> decimate -> edc in ONE call (include/ssf.h: ssf_rx_chain): the stages'
+    // launches follow each other on the stream, the host waits once at the end; the decimation's variance search rides in the
+    // matched filter's stores and its gather in the compensating filter's loads (rx_kernels.h: chain_ols_body).  Results are those
+    // of the four calls made one after the other (reference: optic/models/devices.py:574-668, optic/dsp/core.py:87-125, 435-491,
+    // optic/dsp/equalization.py:36-122).
+    int chain(long long N, const ssf_rx_params &p, const void *Es, const void *Elo, const void *taps, int ntaps, int SpSin,
+              int decFactor, const void *edcH, int edcK, int edc_nfft, void *out, int *sampDelay_out) {
+        const int nm = 2;
+        if (N < 1 || ntaps < 1 || SpSin < 1 || decFactor < 1 || edcK < 1 || edcK > edc_nfft) return fail(SSF_ERR_BAD_ARG, "bad size");
+        if (N % SpSin) return fail(SSF_ERR_BAD_ARG, "cannot reshape array: length is not a multiple of SpSin");   // core.py:477
+        if (ntaps > kMaxNfft / 2) return fail(SSF_ERR_UNSUPPORTED, "receiver chain: matched filter of at most 4096 taps");
+        const long long Nout = (N + decFactor - 1) / decFactor;
+        // 1. receiver into a device block
+        Cd *S = dalloc((size_t)N * nm);
+        if (!S) return fail(SSF_ERR_OOM, "out of device memory");
+        in_chain = true;
+        int rc = run(SSF_RX_PDM_COHERENT, N, nm, p, Es, Elo, nullptr, S);
+        in_chain = false;
+        if (rc) return rc;
+        // 2. matched filter; the class sums of the decimation in its stores where the geometry allows
+        const int nfft = fir_nfft(ntaps);
+        Cd *F = dalloc((size_t)N * nm), *dH = taps_filter((const zc *)taps, ntaps, nfft);
+        int *ddelay = (int *)be.alloc(sizeof(int) * 8);
+        if (ddelay) owned.push_back(ddelay);
+        if (!F || !dH || !ddelay) return fail(SSF_ERR_OOM, "out of device memory");
+        const OlsGeom g = ols_geometry(N, ntaps, nfft);
+        const fused::OlsLaunch lo = fused::ols_launch(g.lg, nm, g.numBlocks * nm);
+        const int nclass = SpSin * nm;
+        const bool fuse_stats = chain_ols_supported(lo) && ((nfft / 16) % SpSin) == 0 && nclass <= 256;
+        ChainOlsArgs ca{};
+        ca.o = ols_args(S, nm, N, N, F, nm, N, nm, dH, 0, ntaps, nfft, 0);
+        if (fuse_stats) {
+            double *dpart = (double *)be.alloc(sizeof(double) * 3 * (size_t)lo.grid * nclass);
+            if (!dpart) return fail(SSF_ERR_OOM, "out of device memory");
+            owned.push_back(dpart);
+            ca.part = dpart;
+            ca.SpS = SpSin;
+            be.launch_chain_ols(ca, CH_STATS);
+            ChainFinishArgs fa{dpart, ddelay, (int)lo.grid, nclass, nm, SpSin, (double)(N / SpSin)};
+            be.launch_chain_finish(fa);
+        } else {                                                     // the filter, then decimate's own two passes
+            be.launch_ols(ca.o);
+            const int nthreads = 256 / nclass * nclass;
+            if (nclass > 256) return fail(SSF_ERR_UNSUPPORTED, "decimate: SpSin * columns <= 256");
+            const int nblocks = (int)std::max<long long>(1, std::min<long long>(512, (N * nm + 4 * nthreads - 1) / (4 * nthreads)));
+            Cd *dmean = dalloc((size_t)nclass);
+            double *dpart = (double *)be.alloc(sizeof(double) * 2 * (size_t)nblocks * nclass);
+            if (dpart) owned.push_back(dpart);
+            if (!dmean || !dpart) return fail(SSF_ERR_OOM, "out of device memory");
+            DecSumArgs sa{F, nullptr, dpart, N * nm, nclass};
+            DecFinishArgs fa{dpart, dmean, ddelay, nblocks, nclass, nm, SpSin, (double)(N / SpSin)};
+            be.launch_dec_sum(sa, nblocks, nthreads);
+            be.launch_dec_finish(fa);
+            sa.mean = dmean;
+            fa.mean = nullptr;
+            be.launch_dec_sum(sa, nblocks, nthreads);
+            be.launch_dec_finish(fa);
+        }
+        // 3. edc on the decimated signal, gathered in its loads
+        std::vector<zc> H((size_t)edc_nfft);
+        for (int i = 0; i < edc_nfft; ++i) H[(size_t)i] = ((const zc *)edcH)[i] / (double)edc_nfft;
+        int lg = 0;
+        while ((1 << lg) < edc_nfft) ++lg;
+        if ((1 << lg) != edc_nfft || lg < 4 || lg > 13) return fail(SSF_ERR_UNSUPPORTED, "receiver chain: edc block size must be a power of two in [16, 8192]");
+        fused::ols_permute_filter(H.data(), lg);
+        const FilterKey key{4, edcK, edc_nfft, 0, 0.0, 0.0, content_hash((const zc *)edcH, (size_t)edc_nfft), content_hash2((const zc *)edcH, (size_t)edc_nfft)};
+        Cd *dHe = cached_filter(key, [&] { return H; });
+        Cd *b = be.is_resident(out) && out != Es && out != Elo ? (Cd *)out : dalloc((size_t)Nout * nm);
+        if (!dHe || !b) return fail(SSF_ERR_OOM, "out of device memory");
+        const OlsGeom ge = ols_geometry(Nout, edcK, edc_nfft);
+        const fused::OlsLaunch le = fused::ols_launch(ge.lg, nm, ge.numBlocks * nm);
+        ChainOlsArgs ce{};
+        ce.o = ols_args(F, nm, Nout, Nout, b, nm, Nout, nm, dHe, 0, edcK, edc_nfft, 0);
+        if (chain_ols_supported(le)) {
+            ce.delay = ddelay;
+            ce.dec = decFactor;
+            ce.Nfull = N;
+            be.launch_chain_ols(ce, CH_GATHER);
+        } else {                                                     // gather by itself, then the filter
+            Cd *dec = dalloc((size_t)Nout * nm);
+            if (!dec) return fail(SSF_ERR_OOM, "out of device memory");
+            DecGatherArgs ga{};
+            ga.in = F;
+            ga.out = dec;
+            ga.N = N;
+            ga.Nout = Nout;
+            ga.ncols = nm;
+            ga.dec = decFactor;
+            ga.delay = ddelay;
+            be.launch_dec_gather(ga);
+            ce.o.in = dec;
+            be.launch_ols(ce.o);
+        }
+        if (sampDelay_out) {
+            int dl[8];
+            be.d2h(dl, ddelay, sizeof(int) * (size_t)nm);            // (waits for the stream)
+            for (int c = 0; c < nm; ++c) sampDelay_out[c] = dl[c];
+        }
+        return finish(out, b, (size_t)Nout * nm);
     }
 
     // run one of the ssf_rx_mode pipelines; in0 / lo / un / out are HOST pointers

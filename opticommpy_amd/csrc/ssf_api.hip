@@ -653,6 +653,16 @@ int ssf_rx_run(int device, int32_t mode, int64_t N, int32_t nmodes, const ssf_rx
     return rc ? set_err(rc, "ssf_rx_run: " + err) : SSF_OK;
 }
 
+int ssf_rx_chain(int device, int64_t N, const ssf_rx_params *params, const void *Es, const void *Elo, const void *taps, int32_t ntaps,
+                 int32_t SpSin, int32_t decFactor, const void *edc_Hfft, int32_t edc_K, int32_t edc_nfft, void *sig_out,
+                 int32_t *sampDelay) {
+    if (!params || !Es || !Elo || !taps || !edc_Hfft || !sig_out) return set_err(SSF_ERR_BAD_ARG, "ssf_rx_chain: NULL argument");
+    if (int rc = rx_check_device(device)) return rc;
+    std::string err;
+    int rc = ssf::rx_chain(device, N, params, Es, Elo, taps, ntaps, SpSin, decFactor, edc_Hfft, edc_K, edc_nfft, sig_out, sampDelay, &err);
+    return rc ? set_err(rc, "ssf_rx_chain: " + err) : SSF_OK;
+}
+
 int ssf_wdm_tx(int device, const ssf_tx_params *params, const void *symbols, const double *taps, const double *phi,
                const double *amp, const double *deltaF, void *sig_out, double *power_out) {
     if (!params || !symbols || !taps || !amp || !deltaF || !sig_out) return set_err(SSF_ERR_BAD_ARG, "ssf_wdm_tx: NULL argument");

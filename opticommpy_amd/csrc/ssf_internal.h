@@ -133,6 +133,8 @@ int rx_fir_long(int device, int64_t inLen, int64_t outLen, int ncols, int64_t nt
 int rx_overlap_save(int device, int64_t sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out,
                     std::string *err);
 int rx_delay(int device, int64_t N, double delay, double Fs, const void *in, void *out, std::string *err);
+int rx_chain(int device, int64_t N, const ssf_rx_params *p, const void *Es, const void *Elo, const void *taps, int ntaps, int SpSin,
+             int decFactor, const void *edcH, int edcK, int edc_nfft, void *out, int32_t *sampDelay, std::string *err);
 enum { kOptEdfa = 0, kOptPbs = 1, kOptHybrid = 2 };      // (= rx_kernels.h: OPT_EDFA / OPT_PBS / OPT_HYBRID)
 int rx_optics(int device, int op, int64_t n, int ncols, double p0, double p1, unsigned long long seed, unsigned row0, const void *a,
               const void *b, void *o0, void *o1, std::string *err);

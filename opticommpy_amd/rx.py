@@ -66,6 +66,11 @@ class _HipBackend:
         lib = _lib.load()
         _lib.raise_for(lib, None, lib.ssf_optical_hybrid_2x4(self._dev(), N, Es, Elo, Eo))
 
+    def rx_chain(self, N, p, Es, Elo, taps, SpSin, dec, H, K, nfft, out):
+        lib = _lib.load()
+        _lib.raise_for(lib, None, lib.ssf_rx_chain(self._dev(), N, C.byref(p), Es, Elo, taps.ctypes.data_as(C.c_void_p), len(taps),
+                                                   SpSin, dec, H.ctypes.data_as(C.c_void_p), int(K), int(nfft), out, None))
+
     def rx(self, mode, N, nmodes, p, in0, lo, un, out):
         lib = _lib.load()
         _lib.raise_for(lib, None, lib.ssf_rx_run(self._dev(), mode, N, nmodes, C.byref(p), in0, lo,
@@ -384,6 +389,13 @@ def pdmCoherentReceiver(Es, Elo, paramFE, paramPD=None, _unit_normals=None):
         Es = np.asarray(Es)
     if Es.ndim != 2 or Es.shape[1] != 2:
         raise ValueError("Es must be a (N, 2) polarisation-multiplexed field")
+    p = _pdm_fields(paramFE, paramPD)
+    lo = Elo if _dev.is_device(Elo) else np.asarray(Elo).reshape(-1)
+    return _rx(_MODE["pdmCoherentReceiver"], len(Es), 2, p, Es, lo.reshape(-1), _unit_normals, (len(Es), 2), np.complex128, 8)
+
+
+def _pdm_fields(paramFE, paramPD):
+    """ssf_rx_params of a pdmCoherentReceiver call (devices.py:617-651)."""
     Fs = _fs(paramFE)
     if paramPD is None:
         paramPD = parameters()
@@ -397,5 +409,40 @@ def pdmCoherentReceiver(Es, Elo, paramFE, paramPD=None, _unit_normals=None):
         p.ampImb[k] = getattr(paramFE, "ampImb" + s, 0)
         p.phaseImb[k] = getattr(paramFE, "phaseImb" + s, 0)
         p.timeSkew[k] = getattr(paramFE, "timeSkew" + s, 0)
+    return p
+
+
+def pdmCoherentReceiverChain(Es, Elo, paramFE, paramPD, h, paramDec, paramEDC):
+    """``edc(decimate(firFilter(h, pdmCoherentReceiver(Es, Elo, paramFE, paramPD)), paramDec), paramEDC)`` -- the receiver side of the
+    coherent notebooks (examples/test_WDM_transmission.ipynb cells 17 - 23) -- as ONE call into the library (``ssf_rx_chain``): the
+    same result as the four calls, one host wait instead of four, decimate's variance search in the matched filter's stores and its
+    gather in the compensating filter's loads.  No reference equivalent (the reference has the four functions); every argument is
+    the corresponding call's.  ``Es``: (N, 2) numpy or complex128 DeviceArray (then a DeviceArray comes back)."""
+    from . import models as _m
+    assert len(Es) == len(Elo), "Es and Elo need to have the same length"
+    on_dev = _dev.is_device(Es)
+    if not on_dev:
+        Es = np.asarray(Es)
+    if Es.ndim != 2 or Es.shape[1] != 2:
+        raise ValueError("Es must be a (N, 2) polarisation-multiplexed field")
+    N = len(Es)
+    p = _pdm_fields(paramFE, paramPD)
+    taps = np.ascontiguousarray(h, dtype=np.complex128)
+    if len(taps) > _FIR_MAX_TAPS:
+        raise ValueError("pdmCoherentReceiverChain: a matched filter of at most %d taps (use the separate calls)" % _FIR_MAX_TAPS)
+    decFactor = int(paramDec.SpSin / paramDec.SpSout)
+    if N % paramDec.SpSin:
+        raise ValueError(f"cannot reshape array of size {N} into shape ({paramDec.SpSin})")
+    K, Nfft, Hf = _m._edc_filter(paramEDC, _m._require_fs(paramEDC))
+    if Nfft < K:
+        raise ValueError("FFT size is smaller than filter length")
+    if K > _m._OLS_MAX_TAPS:
+        raise ValueError("pdmCoherentReceiverChain: a compensating filter of at most %d taps (use the separate calls)" % _m._OLS_MAX_TAPS)
+    nfft = _m._ols_block(K)
+    H = _m._edc_block_response(K, nfft, Hf)
+    ip, _k0 = _dev.arg(Es, np.complex128)
     lo = Elo if _dev.is_device(Elo) else np.asarray(Elo).reshape(-1)
-    return _rx(_MODE["pdmCoherentReceiver"], len(Es), 2, p, Es, lo.reshape(-1), _unit_normals, (len(Es), 2), np.complex128, 8)
+    lp, _k1 = _dev.arg(lo.reshape(-1), np.complex128)
+    out = _dev.empty(on_dev, ((N + decFactor - 1) // decFactor, 2), np.complex128)
+    _backend.rx_chain(N, p, ip, lp, taps, int(paramDec.SpSin), decFactor, H, K, nfft, _dev.out_ptr(out))
+    return out

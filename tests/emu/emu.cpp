@@ -307,6 +307,20 @@ struct EmuBackend {
     void launch_pn(const ssf::rx::PnArgs &a, int nchunks) { run_grid(nchunks, 64, 64 * sizeof(double), [&](EmuCtx &c) { ssf::rx::pn_body(c, a); }); }
     void launch_iqm(const ssf::rx::IqmArgs &a, int nblocks) { run_grid(nblocks, 64, 4096, [&](EmuCtx &c) { ssf::rx::iqm_body(c, a); }); }
     void launch_shift_add(const ssf::rx::ShiftAddArgs &a) { run_grid(ew_grid(a.N), 64, 64, [&](EmuCtx &c) { ssf::rx::shift_add_body(c, a); }); }
+    void launch_chain_ols(const ssf::rx::ChainOlsArgs &a, int mode) {
+        ++launches;
+        const ssf::fused::OlsLaunch o = ssf::fused::ols_launch(a.o.log2nfft, a.o.nrows, a.o.njobs);
+        const bool found = ssf::rx::chain_ols_dispatch(o, [&](auto lg, auto cc) {
+            constexpr int LG = decltype(lg)::value, C = decltype(cc)::value;
+            if (mode == ssf::rx::CH_STATS) run_grid((int)o.grid, o.threads, o.lds_bytes, [&](EmuCtx &c) { ssf::rx::chain_ols_body<LG, C, ssf::rx::CH_STATS>(c, a); });
+            else run_grid((int)o.grid, o.threads, o.lds_bytes, [&](EmuCtx &c) { ssf::rx::chain_ols_body<LG, C, ssf::rx::CH_GATHER>(c, a); });
+        });
+        if (!found) {
+            fprintf(stderr, "emu: no chain kernel for this transform size\n");
+            abort();
+        }
+    }
+    void launch_chain_finish(const ssf::rx::ChainFinishArgs &a) { ++launches; run_grid(1, 256, sizeof(double) * (3 * 256 + 256), [&](EmuCtx &c) { ssf::rx::chain_finish_body(c, a); }); }
     void launch_dec_sum(const ssf::rx::DecSumArgs &a, int nblocks, int nthreads) {
         run_grid(nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, [&](EmuCtx &c) { ssf::rx::dec_sum_body(c, a); });
     }
@@ -471,6 +485,15 @@ int emu_rx_run(int mode, int64_t N, int nmodes, const ssf_rx_params *p, const vo
     EmuBackend be;
     ssf::rx::RxCore<EmuBackend> core(be);
     int rc = core.run(mode, N, nmodes, *p, in0, lo, un, out);
+    g_rx_launches = be.launches;
+    if (rc) fprintf(stderr, "emu: %s\n", core.err.c_str());
+    return rc;
+}
+int emu_rx_chain(int64_t N, const ssf_rx_params *p, const void *Es, const void *Elo, const void *taps, int ntaps, int SpSin, int dec,
+                 const void *edcH, int edcK, int edc_nfft, void *out, int32_t *sd) {
+    EmuBackend be;
+    ssf::rx::RxCore<EmuBackend> core(be);
+    int rc = core.chain(N, *p, Es, Elo, taps, ntaps, SpSin, dec, edcH, edcK, edc_nfft, out, sd);
     g_rx_launches = be.launches;
     if (rc) fprintf(stderr, "emu: %s\n", core.err.c_str());
     return rc;

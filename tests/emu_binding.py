@@ -208,6 +208,12 @@ class EmuRxBackend:
         self.e.emu_optics.argtypes = self._OPTICS
         self._check(self.e.emu_optics(2, N, 1, 0.0, 0.0, 0, 0, Es, Elo, Eo, None))
 
+    def rx_chain(self, N, p, Es, Elo, taps, SpSin, dec, H, K, nfft, out):
+        self.e.emu_rx_chain.argtypes = [C.c_int64, C.POINTER(_lib.RxParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
+        self._check(self.e.emu_rx_chain(N, C.byref(p), Es, Elo, taps.ctypes.data_as(C.c_void_p), len(taps), SpSin, dec,
+                                        H.ctypes.data_as(C.c_void_p), int(K), int(nfft), out, None))
+
     def rx(self, mode, N, nmodes, p, in0, lo, un, out):
         self._check(self.e.emu_rx_run(mode, N, nmodes, C.byref(p), in0, lo,
                                       C.cast(un, C.POINTER(C.c_double)) if un is not None else None, out))

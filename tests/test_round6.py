@@ -257,3 +257,53 @@ def test_reference_notebook_lengths_run_device_resident_and_match_the_oracle(N):
     assert rel_l2(o64, r128) <= 5e-4
     back = oa.manakovDBP(ref, bag(**fix))
     assert rel_l2(back, orc.manakovDBP(ref, bag(orc.parameters, **fix))) <= 1e-10
+
+
+# ------------------------------------------------------------------------------------------ receiver chain in one call
+def _chain_case(N, ntaps, sps, L_edc, seed=81, **fe_kw):
+    E = synth_field(N, 2, seed, 0.0)
+    lo = np.sqrt(5e-3) * np.exp(1j * 2 * np.pi * 2e8 * np.arange(N) / 64e9)
+    fe = dict(Fs=64e9, polRotation=0.3, polDelay=2e-12, **fe_kw)
+    pd = dict(Fs=64e9, ideal=True)
+    rng = np.random.default_rng(seed)
+    h = rng.normal(size=ntaps) * np.hanning(ntaps)
+    dec = dict(SpSin=sps, SpSout=2)
+    edcp = dict(Fs=64e9 * 2 / sps, L=L_edc, D=16, Fc=193.1e12, Rs=32e9)
+    return E, lo, fe, pd, h, dec, edcp
+
+
+def _oracle_chain(E, lo, fe, pd, h, dec, edcp):
+    s = orx.pdmCoherentReceiver(E, lo, bag(orc.parameters, **fe), bag(orc.parameters, **pd))
+    s = orx.firFilter(h, s)
+    s = orx.decimate(s, bag(orc.parameters, **dec))
+    return orc.edc(s, bag(orc.parameters, **edcp))
+
+
+@pytest.mark.parametrize("N, ntaps, sps, L", [(1 << 14, 129, 16, 800), (12288, 255, 8, 400), (1 << 13, 33, 4, 5)])
+def test_receiver_chain_in_one_call_on_the_emulator(emu_rx, N, ntaps, sps, L):
+    """fused geometry (2048-point matched filter, SpS | 128), another one, and one whose transforms have no chain kernel (the stages
+    then run one by one inside the same call): always the result of the four reference functions in a row."""
+    case = _chain_case(N, ntaps, sps, L)
+    E, lo, fe, pd, h, dec, edcp = case
+    out = oa.pdmCoherentReceiverChain(E, lo, bag(**fe), bag(**pd), h, bag(**dec), bag(**edcp))
+    ref = _oracle_chain(*case)
+    assert out.shape == ref.shape and out.dtype == np.complex128
+    assert np.max(np.abs(out - ref)) <= 1e-11 * np.max(np.abs(ref))
+
+
+@pytest.mark.gpu
+def test_receiver_chain_in_one_call_on_the_gpu_equals_the_four_calls():
+    from opticommpy_amd import device
+    case = _chain_case(1 << 18, 1024, 16, 800, ampImbX=0.5, timeSkewY=1e-12)
+    E, lo, fe, pd, h, dec, edcp = case
+    Ed, Ld = oa.to_device(E), oa.to_device(lo)
+    c0 = device.transfer_counts()
+    one = oa.pdmCoherentReceiverChain(Ed, Ld, bag(**fe), bag(**pd), h, bag(**dec), bag(**edcp))
+    four = oa.edc(oa.decimate(oa.firFilter(h, oa.pdmCoherentReceiver(Ed, Ld, bag(**fe), bag(**pd))), bag(**dec)), bag(**edcp))
+    assert isinstance(one, oa.DeviceArray) and device.transfer_counts() == c0
+    a, b = one.get(), four.get()
+    assert np.max(np.abs(a - b)) <= 1e-13 * np.max(np.abs(b))
+    ref = _oracle_chain(*case)
+    assert np.max(np.abs(a - ref)) <= 1e-11 * np.max(np.abs(ref))
+    host = oa.pdmCoherentReceiverChain(E, lo, bag(**fe), bag(**pd), h, bag(**dec), bag(**edcp))       # numpy in, numpy out
+    assert np.array_equal(host, a)
