@@ -20,6 +20,13 @@ struct DevCtxCore {
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         return v;
     }
+    // the value the neighbouring lane (lane ^ 1) passes: two DPP moves (quad_perm [1, 0, 3, 2]), no LDS, no barrier
+    __device__ __forceinline__ double xchg(double v) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+        return __hiloint2double(hi, lo);
+    }
     __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));

@@ -804,6 +804,18 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
 #ifndef SSF_SPEC_G
 #define SSF_SPEC_G 0
 #endif
+// Experiments of round 6 on the double-precision Manakov column stage (appendix #48, #49):
+//  SSF_PAIR_DPP   the x / y partner threads of a sample sit in NEIGHBOURING lanes (pol = tid & 1) and swap powers, rotations and
+//                 |d rot|^2 with DPP moves (ctx.xchg) instead of through LDS: no LDS traffic and no barrier for the pair exchange
+//  SSF_THETA_F32  the phase array of the latest rotation is kept in single precision: it only enters the convergence measure
+//                 (4 sin^2((theta_new - theta_old) / 2), relative error ~1e-8 of lim), never the field -- 4 instead of 8 bytes
+//                 read and written per sample and iteration
+#ifndef SSF_PAIR_DPP
+#define SSF_PAIR_DPP 0
+#endif
+#ifndef SSF_THETA_F32
+#define SSF_THETA_F32 0
+#endif
 template <typename T> constexpr bool wt_rows() {
     return sizeof(scalar_t<T>) == 8 ? (SSF_WT_ROWS & 1) != 0 : sizeof(T) == 8 ? (SSF_WT_ROWS & 2) != 0 : (SSF_WT_ROWS & 4) != 0;
 }
@@ -1070,6 +1082,8 @@ template <typename T> SSF_HD ColArgs<T> unit_view(const ColArgs<T> &a, int u) {
 // only partly filled, and its surplus threads (valid == false) load zeros and store nothing.
 template <typename T, int LG, class Ctx, bool RAGGED = false, int V = 16> struct ColGeom {
     static constexpr int kV = V;
+    static constexpr bool kDppT = SSF_PAIR_DPP && V == 16 && sizeof(T) == 8;    // (the polarisation-split double-precision kernels)
+    bool dpp;                 // the partner thread is the neighbouring lane (Manakov stage only)
     PassPlan p;
     int half, pol, t, C, c, b, n2, N2;
     bool valid;
@@ -1079,8 +1093,14 @@ template <typename T, int LG, class Ctx, bool RAGGED = false, int V = 16> struct
     SSF_HD ColGeom(Ctx &ctx, const ColArgs<T> &a) {
         p = make_plan(LG > 0 ? LG : a.log2N1, V == 16 ? 4 : 3);
         half = ctx.nthreads / a.npol;
-        pol = ctx.tid / half;
-        t = ctx.tid - pol * half;
+        dpp = kDppT && a.npol == 2;
+        if (kDppT && a.npol == 2) {
+            pol = ctx.tid & 1;
+            t = ctx.tid >> 1;
+        } else {
+            pol = ctx.tid / half;
+            t = ctx.tid - pol * half;
+        }
         C = half / p.tpf;
         c = t % C;
         b = t / C;
@@ -1168,6 +1188,13 @@ template <int SIGN, bool RAGGED, typename T, class G> SSF_HD void global_twiddle
 // The caller guarantees (barrier) that `sh` is free on entry.
 template <typename U, class Ctx, class G> SSF_HD void pair_swap(Ctx &ctx, const G &g, const U *mine, U *other, U *sh) {
     constexpr int V = G::kV;
+    if constexpr (G::kDppT) {
+        if (g.dpp) {
+#pragma unroll
+            for (int idx = 0; idx < V; ++idx) other[idx] = (U)ctx.xchg((double)mine[idx]);
+            return;
+        }
+    }
 #pragma unroll
     for (int idx = 0; idx < V; ++idx) sh[(size_t)(g.pol * V + idx) * g.half + g.t] = mine[idx];
     ctx.sync();
@@ -1195,6 +1222,18 @@ template <typename T, class Ctx, class G>
 SSF_HD void pair_cis(Ctx &ctx, const G &g, const T *ang_own, cx<T> *rot, cx<T> *sh) {
     constexpr int V = G::kV, H = V / 2;
     cx<T> own[H], oth[H];
+    if constexpr (G::kDppT) {
+        if (g.dpp) {
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                own[j] = cis_t<T>(ang_own[j]);
+                oth[j] = mk<T>((T)ctx.xchg((double)own[j].re), (T)ctx.xchg((double)own[j].im));
+            }
+#pragma unroll
+            for (int idx = 0; idx < V; ++idx) rot[idx] = pick16(g, idx, own, oth);
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < H; ++j) {
         own[j] = cis_t<T>(ang_own[j]);
@@ -1216,7 +1255,7 @@ SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T>
     T mine[V], oth[V];
 #pragma unroll
     for (int idx = 0; idx < V; ++idx) mine[idx] = norm2(v[idx]);
-    if (lds_busy) ctx.sync();
+    if (lds_busy && !(G::kDppT && g.dpp)) ctx.sync();
     pair_swap(ctx, g, mine, oth, shT);
     const T c8g = (T)a.k.c8g;
     double m = -INFINITY;
@@ -1233,6 +1272,63 @@ SSF_HD void mk_step_start(Ctx &ctx, const G &g, const ColArgs<T> &a, const cx<T>
         if (ctx.tid == 0) a.pmax[ctx.bid] = m;
     }
     ctx.sync();                                  // scratch reads done before the FFT reuses the LDS
+}
+// the phase array of the latest rotation (see SSF_THETA_F32)
+template <typename T, class G> SSF_HD T theta_ld(const G &g, const T *th, long long i) {
+    if constexpr (SSF_THETA_F32 && sizeof(T) == 8) return (T)g.ld((const float *)th, i);
+    else return g.ld(th, i);
+}
+template <typename T, class G> SSF_HD void theta_st(const G &g, T *th, long long i, T x) {
+    if constexpr (SSF_THETA_F32 && sizeof(T) == 8) g.st((float *)th, i, (float)x);
+    else g.st(th, i, x);
+}
+// mk_advance with the partner in the neighbouring lane (SSF_PAIR_DPP): the same arithmetic, every exchange a DPP move -- no LDS, no
+// barrier; rotation and |d rot|^2 of a sample are applied as soon as its owner has them
+template <typename T, class Ctx, class G>
+SSF_HD void mk_advance_dpp(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, const T *Pbuf, T shz, bool first,
+                           double &num, double &den, double &pch_sum) {
+    constexpr int V = G::kV, H = V / 2;
+    T pw8[H], prev8[H], ang8[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        const long long t = own_time_off(g, j);
+        pw8[j] = g.ld(Pbuf, g.pbase + t);
+        prev8[j] = first ? (T)0 : theta_ld(g, a.Theta, g.pbase + t);
+    }
+    const T c8g = (T)a.k.c8g;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        const T lo = norm2(v[j]), hi = norm2(v[j + H]);
+        const T nown = g.pol ? hi : lo, noth = g.pol ? lo : hi;
+        const T po = (T)ctx.xchg((double)noth);                  // the partner's power of the sample I own
+        const T ax = g.pol ? po : nown, ay = g.pol ? nown : po;
+        const T pw = pw8[j];
+        pch_sum += (double)pw;
+        ang8[j] = shz * (c8g * (pw + ax + ay) / (T)2);
+        if (first) prev8[j] = shz * (c8g * (pw + pw) / (T)2);
+    }
+    ctx.mark(6);
+#pragma unroll
+    for (int idx = 0; idx < V; ++idx) v[idx] = g.ld(a.Ehd, g.rowbase + g.time_off(idx));
+    ctx.mark(7);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        const T ang = ang8[j];
+        const double s = sin_half_angle((double)ang - (double)prev8[j]);
+        theta_st(g, a.Theta, g.pbase + own_time_off(g, j), ang);
+        const cx<T> ro = cis_t<T>(ang);
+        const T dd = (T)(4.0 * s * s);
+        const cx<T> rp = mk<T>((T)ctx.xchg((double)ro.re), (T)ctx.xchg((double)ro.im));
+        const T dp = (T)ctx.xchg((double)dd);
+        // register j is owned by the x thread, register j + H by the y thread
+        const cx<T> r_lo = g.pol ? rp : ro, r_hi = g.pol ? ro : rp;
+        const T d_lo = g.pol ? dp : dd, d_hi = g.pol ? dd : dp;
+        const double w0 = (double)norm2(v[j]), w1 = (double)norm2(v[j + H]);
+        num += w0 * (double)d_lo + w1 * (double)d_hi;
+        den += w0 + w1;
+        v[j] = v[j] * r_lo;
+        v[j + H] = v[j + H] * r_hi;
+    }
 }
 // next iterate (channels.py:436, 414-417): v holds E_fd(it) on entry and E_hd * rot_{it+1} on exit;
 // accumulates the sums of lim_{it+1} = |E_hd (rot_{it+1} - rot_it)| / |E_hd| (see the header note).
@@ -1254,7 +1350,7 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
     for (int j = 0; j < H; ++j) {
         const long long t = own_time_off(g, j);
         pw8[j] = g.ld(Pbuf, g.pbase + t);
-        prev8[j] = first ? (T)0 : g.ld(a.Theta, g.pbase + t);
+        prev8[j] = first ? (T)0 : theta_ld(g, a.Theta, g.pbase + t);
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) {
@@ -1290,7 +1386,7 @@ SSF_HD void mk_advance(Ctx &ctx, const G &g, const ColArgs<T> &a, cx<T> *v, cons
         const T ang = ang8[j], prev = prev8[j];
         // |rot_new - rot_old|^2 = 4 sin^2((theta_new - theta_old) / 2)
         const double s = sin_half_angle((double)ang - (double)prev);
-        g.st(a.Theta, g.pbase + t, ang);                          // read and written by the owner only
+        theta_st(g, a.Theta, g.pbase + t, ang);                   // read and written by the owner only
         shC[(size_t)own_idx(g, j) * g.half + g.t] = cis_t<T>(ang);
         shD[(size_t)own_idx(g, j) * g.half + g.t] = (T)(4.0 * s * s);
     }
@@ -1453,6 +1549,8 @@ template <class Ctx, class Args> SSF_HD void mk_col_stage(Ctx &ctx, const Args &
     }
 }
 
+// (the DPP variant only exists where the geometry can have it: a run-time test of a compile-time false costs nothing)
+#define G_DPP(g) (std::remove_reference<decltype(g)>::type::kDppT && (g).dpp)
 // MODE is one of CM_*; the Manakov mode picks its stage from the Ctrl state.
 // CI > 0: the workgroup's CI columns (per polarisation row) are interleaved in LDS (lds_put); the launch must have exactly CI of them.
 // SG: the stage groups this instantiation carries (Manakov mode; see stage_group).
@@ -1583,7 +1681,7 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
                 }
             }
             cx<T> rot[V];
-            ctx.sync();                              // inverse transform's LDS reads are done
+            if (!G_DPP(g)) ctx.sync();               // inverse transform's LDS reads are done
             pair_cis(ctx, g, ang, rot, shC);
 #pragma unroll
             for (int idx = 0; idx < V; ++idx) v[idx] = v[idx] * rot[idx];
@@ -1612,7 +1710,8 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
                 for (int idx = 0; idx < V; ++idx)
                     if (!sparse || lim0_bound_sample<V>(idx, g.b)) g.st(Tnew, g.rowbase + g.time_off(idx), v[idx]);
             } else if (kgADV) {
-                mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
+                if (G_DPP(g)) mk_advance_dpp(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
+                else mk_advance(ctx, g, a, v, Pcur, shz, c.it == 0, n1, d1, psum);
                 if (!exact0) d0 = psum;              // exact denominator of the bound: sum Pch over the tile
             }
             if (c.it == 0) {

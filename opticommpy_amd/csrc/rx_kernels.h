@@ -125,14 +125,9 @@ struct DetArgs {
     double lo_scale[2];       // LO split by the PBS at pi / 4 (devices.py:653): cos, -sin; (1, 1) for one polarisation
     PdModel pd;
 };
-// the detected sample sI + j sQ of polarisation p at time n (devices.py:487-499, 562-563; photodiode slots as front_body)
-template <int NOISE = 2> SSF_HD Cd det_sample(const DetArgs &a, long long n, int p) {
-    Cd es;
-    if (a.pbs) {
-        const Cd e0 = a.in0[2 * n], e1 = a.in0[2 * n + 1];
-        es = p == 0 ? mk<double>(e0.re * a.c + e1.re * a.s, e0.im * a.c + e1.im * a.s)
-                    : mk<double>(e1.re * a.c - e0.re * a.s, e1.im * a.c - e0.im * a.s);
-    } else es = a.in0[n * a.nm + p];
+// the detected sample sI + j sQ of polarisation p at time n (devices.py:487-499, 562-563; photodiode slots as front_body) from the
+// signal sample `es` behind the PBS (and the polarisation delay filters)
+template <int NOISE = 2> SSF_HD Cd det_core(const DetArgs &a, long long n, int p, Cd es) {
     Cd lo = a.lo[n];
     const double ks = sel2(a.es_scale, p), kl = sel2(a.lo_scale, p);
     es = mk<double>(es.re * ks, es.im * ks);
@@ -147,11 +142,20 @@ template <int NOISE = 2> SSF_HD Cd det_sample(const DetArgs &a, long long n, int
     const double sQ = pd_current(a.pd, e2, z[4], z[5]) - pd_current(a.pd, e3, z[6], z[7]);
     return mk<double>(sI, sQ);
 }
+template <int NOISE = 2> SSF_HD Cd det_sample(const DetArgs &a, long long n, int p) {
+    Cd es;
+    if (a.pbs) {
+        const Cd e0 = a.in0[2 * n], e1 = a.in0[2 * n + 1];
+        es = p == 0 ? mk<double>(e0.re * a.c + e1.re * a.s, e0.im * a.c + e1.im * a.s)
+                    : mk<double>(e1.re * a.c - e0.re * a.s, e1.im * a.c - e0.im * a.s);
+    } else es = a.in0[n * a.nm + p];
+    return det_core<NOISE>(a, n, p, es);
+}
 // IQ imbalance (core.py:952-960): s' = k1 s + k2 conj(s)
 SSF_HD Cd iq_mix(Cd k1, Cd k2, Cd s) { return k1 * s + k2 * fused::conj(s); }
 
 enum { PRE_PLAIN = 0, PRE_PBS = 1, PRE_DET = 2, PRE_IQ = 3, PRE_PD = 4 };
-enum { POST_PLAIN = 0, POST_IQF = 1, POST_PART = 2, POST_REAL = 3 };
+enum { POST_PLAIN = 0, POST_IQF = 1, POST_PART = 2, POST_REAL = 3, POST_DET = 4 };
 struct RxOlsArgs {
     fused::OlsArgs<double> o; // geometry, filters, o.in (PRE_PLAIN / PRE_IQ), o.out
     int pre, post;
@@ -193,6 +197,9 @@ template <int LG, int C, int PRE, int NOISE, class Ctx> SSF_HD void rx_ols_body(
                 o[m & 1] = v.re;
             } else if (a.post == POST_REAL) {            // `return ipd.real` (devices.py:399)
                 ((double *)a.o.out)[n] = v.re;
+            } else if (a.post == POST_DET) {             // the polarisation delay filter's stores detect: hybrid, ideal photodiodes, IQ
+                const Cd t = det_core<0>(a.det, n, m, v);         // imbalance and the zero-skew rule (det_loop) -- no pass of their own
+                a.o.out[n * a.o.out_ld + m] = n == a.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(sel2(a.k1, m), sel2(a.k2, m), t);
             } else a.o.out[n * a.o.out_ld + m] = v;
         });
 }
@@ -623,7 +630,6 @@ struct ChainOlsArgs {
 };
 template <int LG, int C, int MODE, class Ctx> SSF_HD void chain_ols_body(Ctx &ctx, const ChainOlsArgs &a) {
     double sre = 0, sim = 0, spw = 0;
-    int cls = -1;
     fused::ols_body_x<double, LG, C>(
         ctx, a.o,
         [&](long long src, int m) -> Cd {
@@ -633,31 +639,41 @@ template <int LG, int C, int MODE, class Ctx> SSF_HD void chain_ols_body(Ctx &ct
         [&](long long n, int m, Cd v) {
             a.o.out[n * a.o.out_ld + m] = v;
             if constexpr (MODE == CH_STATS) {
-                cls = (int)(n % a.SpS) * a.o.nrows + m;
                 sre += v.re;
                 sim += v.im;
                 spw += v.re * v.re + v.im * v.im;
             }
         });
-    if constexpr (MODE == CH_STATS) {              // per-class sums of this workgroup (fixed order: deterministic)
-        const int nclass = a.SpS * a.o.nrows;
-        double *red = (double *)ctx.lds;           // nthreads x (re, im, pw), classes behind them
-        int *rc = (int *)(red + 3 * (size_t)ctx.nthreads);
+    if constexpr (MODE == CH_STATS) {
+        // per-class sums of every block group of this workgroup (fixed order: deterministic).  The threads of one group and column
+        // whose butterflies are SpS apart share a class; the first SpS butterflies of each add their chain up -- tpf / SpS terms --
+        // and leave one partial per (group, class): part[(workgroup * groups + group) * nclass + class]
+        constexpr int tpf = 1 << (LG - 4);
+        const int nclass = a.SpS * a.o.nrows, tpg = tpf * C, gpw = ctx.nthreads / tpg;
+        const int g = ctx.tid / tpg, r = ctx.tid - g * tpg, b = r / C;
+        double *red = (double *)ctx.lds;           // nthreads x (re, im, pw)
         ctx.sync();                                // (the transform's LDS traffic is over)
         red[3 * ctx.tid] = sre;
         red[3 * ctx.tid + 1] = sim;
         red[3 * ctx.tid + 2] = spw;
-        rc[ctx.tid] = cls;
         ctx.sync();
-        for (int c = ctx.tid; c < nclass; c += ctx.nthreads) {
+        if (b < a.SpS) {
             double t0 = 0, t1 = 0, t2 = 0;
-            for (int t = 0; t < ctx.nthreads; ++t)
-                if (rc[t] == c) {
-                    t0 += red[3 * t];
-                    t1 += red[3 * t + 1];
-                    t2 += red[3 * t + 2];
-                }
-            double *o = a.part + ((size_t)ctx.bid * nclass + c) * 3;
+            for (int t = ctx.tid; t < (g + 1) * tpg; t += a.SpS * C) {
+                t0 += red[3 * t];
+                t1 += red[3 * t + 1];
+                t2 += red[3 * t + 2];
+            }
+            // the class of this chain: the one its threads stored under -- or, for a chain that stored nothing (beyond the signal's
+            // end, an idle group), any class with zeros; every (group, class) slot is written exactly once because the SpS chains of a
+            // column cover the SpS phases
+            const long long job = (long long)ctx.bid * gpw + g;
+            const int ncg = a.o.nrows / C;
+            const long long jb = ncg == 1 ? job : job / ncg;
+            const int m = (int)(job - jb * ncg) * C + (r - b * C);
+            const long long n0 = (jb + a.o.blk0) * a.o.d - a.o.discard - a.o.D - a.o.Dx;
+            const int ph = (int)(((n0 + b) % a.SpS + a.SpS) % a.SpS);
+            double *o = a.part + (((size_t)ctx.bid * gpw + g) * nclass + (size_t)ph * a.o.nrows + m) * 3;
             o[0] = t0;
             o[1] = t1;
             o[2] = t2;
@@ -677,11 +693,20 @@ template <class Ctx> SSF_HD void chain_finish_body(Ctx &ctx, const ChainFinishAr
     const int nseg = ctx.nthreads / a.nclass, used = nseg * a.nclass;
     double s0 = 0, s1 = 0, s2 = 0;
     if (ctx.tid < used)
-        for (int w = ctx.tid / a.nclass; w < a.nblocks; w += nseg) {
-            const double *q = a.part + ((size_t)w * a.nclass + ctx.tid % a.nclass) * 3;
-            s0 += q[0];
-            s1 += q[1];
-            s2 += q[2];
+        for (int w = ctx.tid / a.nclass; w < a.nblocks; w += 4 * nseg) {      // four partials in flight, added in order
+            double v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ww = w + u * nseg;
+                const double *q = a.part + ((size_t)(ww < a.nblocks ? ww : w) * a.nclass + ctx.tid % a.nclass) * 3;
+                for (int k = 0; k < 3; ++k) v[u][k] = ww < a.nblocks ? q[k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s0 += v[u][0];
+                s1 += v[u][1];
+                s2 += v[u][2];
+            }
         }
     red[3 * ctx.tid] = s0;
     red[3 * ctx.tid + 1] = s1;

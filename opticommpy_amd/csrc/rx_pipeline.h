@@ -371,6 +371,18 @@ template <class Backend> struct RxCore {
             det.nm = nm;
             det.es_scale[0] = det.es_scale[1] = 1.0;
             det.lo_scale[0] = det.lo_scale[1] = 1.0;
+            const double q = 1.602176634e-19, kB = 1.380649e-23;     // scipy.constants (CODATA 2018, exact)
+            det.pd.R = p.R;
+            det.pd.IpdSat = p.IpdSat;
+            det.pd.saturate = !quiet && p.currentSaturation;
+            det.pd.shot = !quiet && p.shotNoise;
+            det.pd.thermal = !quiet && p.thermalNoise;
+            det.pd.shot_k = fs_pd * q;
+            det.pd.Id = p.Id;
+            det.pd.thermal_sigma = std::sqrt(fs_pd * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
+            det.pd.seed = (unsigned long long)p.rng_seed;
+            det.pd.un = dun;
+            bool detected_already = false;
             if (mode == SSF_RX_PDM_COHERENT) {
                 det.pbs = 1;
                 det.c = std::cos(p.polRotation);
@@ -387,25 +399,28 @@ template <class Backend> struct RxCore {
                     const long long padLen = (long long)std::ceil(std::fabs(dl[0] * p.Fs));
                     Cd *dH = delay_filters(dl, 2, p.Fs, K, nfft), *fld = dalloc((size_t)N * 2);
                     if (!dH || !fld) return fail(SSF_ERR_OOM, "out of device memory");
-                    RxOlsArgs r = rx_ols_args(N, N + padLen, fld, 2, N, 2, dH, nfft, K, nfft, 1);
+                    // ideal photodiodes and no skew: what follows the delay filters is element-wise (hybrid, photodiodes, IQ imbalance)
+                    // and rides in their stores -- the notebook's receiver is ONE launch (round 6; two before)
+                    const bool det_in_stores = !lowpass && !skew && !det.pd.shot && !det.pd.thermal;
+                    RxOlsArgs r = rx_ols_args(N, N + padLen, det_in_stores ? result : fld, 2, N, 2, dH, nfft, K, nfft, 1);
                     r.pre = PRE_PBS;
                     r.det = det;
+                    if (det_in_stores) {
+                        r.post = POST_DET;
+                        r.N = N;
+                        for (int k = 0; k < nm; ++k) {
+                            r.k1[k] = k1[k];
+                            r.k2[k] = k2[k];
+                        }
+                        detected_already = true;
+                        detected = result;
+                    }
                     be.launch_rx_ols(r);
                     det.in0 = fld;
                     det.pbs = 0;
                 }
             }
-            const double q = 1.602176634e-19, kB = 1.380649e-23;     // scipy.constants (CODATA 2018, exact)
-            det.pd.R = p.R;
-            det.pd.IpdSat = p.IpdSat;
-            det.pd.saturate = !quiet && p.currentSaturation;
-            det.pd.shot = !quiet && p.shotNoise;
-            det.pd.thermal = !quiet && p.thermalNoise;
-            det.pd.shot_k = fs_pd * q;
-            det.pd.Id = p.Id;
-            det.pd.thermal_sigma = std::sqrt(fs_pd * (4 * kB * (p.Tc + 273.15) * p.B / p.RL) / (2 * p.B));
-            det.pd.seed = (unsigned long long)p.rng_seed;
-            det.pd.un = dun;
+            if (!detected_already) {
             Cd *dst = skew ? dalloc((size_t)N * nm) : result;
             if (!dst) return fail(SSF_ERR_OOM, "out of device memory");
             if (lowpass) {
@@ -434,6 +449,7 @@ template <class Backend> struct RxCore {
                 be.launch_det(d);
             }
             detected = dst;
+            }
         }
         if (skew) {                                                  // iqMixing with a skew (core.py:962-968)
             // sI delayed by -skew/2, sQ by +skew/2; the zero padding of delaySignal (core.py:905-909) differs between the
@@ -493,6 +509,11 @@ template <class Backend> struct RxCore {
         if (N % SpSin) return fail(SSF_ERR_BAD_ARG, "cannot reshape array: length is not a multiple of SpSin");   // core.py:477
         if (ntaps > kMaxNfft / 2) return fail(SSF_ERR_UNSUPPORTED, "receiver chain: matched filter of at most 4096 taps");
         const long long Nout = (N + decFactor - 1) / decFactor;
+        const int nfft = fir_nfft(ntaps);
+        const OlsGeom g = ols_geometry(N, ntaps, nfft);
+        const fused::OlsLaunch lo = fused::ols_launch(g.lg, nm, g.numBlocks * nm);
+        const int nclass = SpSin * nm;
+        const bool fuse_stats = chain_ols_supported(lo) && ((nfft / 16) % SpSin) == 0 && nclass <= 256;
         // 1. receiver into a device block
         Cd *S = dalloc((size_t)N * nm);
         if (!S) return fail(SSF_ERR_OOM, "out of device memory");
@@ -501,25 +522,21 @@ template <class Backend> struct RxCore {
         in_chain = false;
         if (rc) return rc;
         // 2. matched filter; the class sums of the decimation in its stores where the geometry allows
-        const int nfft = fir_nfft(ntaps);
         Cd *F = dalloc((size_t)N * nm), *dH = taps_filter((const zc *)taps, ntaps, nfft);
         int *ddelay = (int *)be.alloc(sizeof(int) * 8);
         if (ddelay) owned.push_back(ddelay);
         if (!F || !dH || !ddelay) return fail(SSF_ERR_OOM, "out of device memory");
-        const OlsGeom g = ols_geometry(N, ntaps, nfft);
-        const fused::OlsLaunch lo = fused::ols_launch(g.lg, nm, g.numBlocks * nm);
-        const int nclass = SpSin * nm;
-        const bool fuse_stats = chain_ols_supported(lo) && ((nfft / 16) % SpSin) == 0 && nclass <= 256;
         ChainOlsArgs ca{};
         ca.o = ols_args(S, nm, N, N, F, nm, N, nm, dH, 0, ntaps, nfft, 0);
         if (fuse_stats) {
-            double *dpart = (double *)be.alloc(sizeof(double) * 3 * (size_t)lo.grid * nclass);
+            const int nparts = (int)lo.grid * (lo.threads / ((nfft / 16) * lo.C));      // one partial per block group
+            double *dpart = (double *)be.alloc(sizeof(double) * 3 * (size_t)nparts * nclass);
             if (!dpart) return fail(SSF_ERR_OOM, "out of device memory");
             owned.push_back(dpart);
             ca.part = dpart;
             ca.SpS = SpSin;
             be.launch_chain_ols(ca, CH_STATS);
-            ChainFinishArgs fa{dpart, ddelay, (int)lo.grid, nclass, nm, SpSin, (double)(N / SpSin)};
+            ChainFinishArgs fa{dpart, ddelay, nparts, nclass, nm, SpSin, (double)(N / SpSin)};
             be.launch_chain_finish(fa);
         } else {                                                     // the filter, then decimate's own two passes
             be.launch_ols(ca.o);

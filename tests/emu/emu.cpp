@@ -33,6 +33,7 @@ struct EmuCtx {
     void flush(int) {}
     void issue_fence() {}
     template <int P> void setprio() {}
+    double xchg(double v);                    // the value thread tid ^ 1 passes (DevCtxCore::xchg: DPP)
     double wave_sum(double v) { return v; }
     double wave_max(double v) { return v; }
 };
@@ -52,6 +53,7 @@ struct Pool {
     Fiber *cur = nullptr;
     const std::function<void(EmuCtx &)> *body = nullptr;
     std::vector<char> lds;
+    std::vector<double> xch;
     ~Pool() {
         for (auto &x : f) free(x.stack);
     }
@@ -72,8 +74,18 @@ void EmuCtx::sync() {
     swapcontext(&me->uc, &p.main_uc);
 }
 
+double EmuCtx::xchg(double v) {
+    Pool &p = g_pool;
+    p.xch[(size_t)tid] = v;
+    sync();
+    const double r = p.xch[(size_t)(tid ^ 1)];
+    sync();                                    // (nobody overwrites a value its partner has not read yet)
+    return r;
+}
+
 void run_block(int bid, int nblocks, int nthreads, size_t lds_bytes, const std::function<void(EmuCtx &)> &body) {
     Pool &p = g_pool;
+    if (p.xch.size() < (size_t)nthreads) p.xch.resize((size_t)nthreads);
     if ((int)p.f.size() < nthreads) {
         const size_t old = p.f.size();
         p.f.resize((size_t)nthreads);
@@ -320,7 +332,7 @@ struct EmuBackend {
             abort();
         }
     }
-    void launch_chain_finish(const ssf::rx::ChainFinishArgs &a) { ++launches; run_grid(1, 256, sizeof(double) * (3 * 256 + 256), [&](EmuCtx &c) { ssf::rx::chain_finish_body(c, a); }); }
+    void launch_chain_finish(const ssf::rx::ChainFinishArgs &a) { ++launches; run_grid(1, 1024, sizeof(double) * (3 * 1024 + 256), [&](EmuCtx &c) { ssf::rx::chain_finish_body(c, a); }); }
     void launch_dec_sum(const ssf::rx::DecSumArgs &a, int nblocks, int nthreads) {
         run_grid(nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, [&](EmuCtx &c) { ssf::rx::dec_sum_body(c, a); });
     }

@@ -16,7 +16,7 @@ def load():
     global _emu
     if _emu is None:
         subprocess.check_call(["make", "-C", EMU_DIR, "-s"])
-        _emu = C.CDLL(os.path.join(EMU_DIR, "libssf_emu.so"))
+        _emu = C.CDLL(os.environ.get("SSF_EMU_LIB") or os.path.join(EMU_DIR, "libssf_emu.so"))      # (SSF_EMU_LIB: a variant build, A/B experiments)
         _emu.emu_run.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(_lib.Params), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.POINTER(_lib.Stats), C.POINTER(_lib.Trace),
                                  C.POINTER(C.c_long)]

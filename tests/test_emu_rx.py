@@ -100,7 +100,8 @@ def test_a_coherent_receiver_call_is_at_most_three_launches():
     """Round 5: every stage that is not a filter rides in the loads / stores of the filter next to it (rx_kernels.h:
     rx_ols_body).  All stages on = polarisation-delay filters (PBS in the loads), low-pass filter (detection in the loads), skew
     filters (IQ imbalance in the loads, I + jQ in the stores) = 3 launches (4 when the two polarisations' skews need different
-    zero padding); the notebook's receiver (polarisation delay, ideal photodiodes) = 2; defaults (band-limited photodiodes) = 1."""
+    zero padding); the notebook's receiver (polarisation delay, ideal photodiodes) = 1 since round 6 (the detection rides in the delay
+    filters' stores: POST_DET; 2 before); defaults (band-limited photodiodes) = 1."""
     e = eb.load()
     e.emu_rx_launches.restype = __import__("ctypes").c_long
     rng = np.random.default_rng(6)
@@ -115,7 +116,7 @@ def test_a_coherent_receiver_call_is_at_most_three_launches():
         return o
     for fe, pd, want in ((dict(polRotation=0.2, pdl=1.0, polDelay=2e-12, ampImbX=0.5, timeSkewX=1e-12, timeSkewY=-1e-12), dict(B=25e9, seed=1), 3),
                          (dict(polRotation=0.2, polDelay=2e-12, timeSkewX=1e-12), dict(B=25e9, seed=1), 4),
-                         (dict(polRotation=np.pi / 3, polDelay=3 / 32e9), dict(B=32e9, ideal=True), 2),
+                         (dict(polRotation=np.pi / 3, polDelay=3 / 32e9), dict(B=32e9, ideal=True), 1),
                          (dict(), dict(B=30e9, seed=2), 1), (dict(), dict(B=30e9, ideal=True), 1)):
         out = oa.pdmCoherentReceiver(Es, Elo, bag(dict(Fs=96e9, **fe)), bag(dict(Fs=96e9, **pd)))
         assert out.shape == (N, 2) and e.emu_rx_launches() == want, (fe, e.emu_rx_launches())

@@ -260,11 +260,11 @@ def test_reference_notebook_lengths_run_device_resident_and_match_the_oracle(N):
 
 
 # ------------------------------------------------------------------------------------------ receiver chain in one call
-def _chain_case(N, ntaps, sps, L_edc, seed=81, **fe_kw):
+def _chain_case(N, ntaps, sps, L_edc, seed=81, pd=None, **fe_kw):
     E = synth_field(N, 2, seed, 0.0)
     lo = np.sqrt(5e-3) * np.exp(1j * 2 * np.pi * 2e8 * np.arange(N) / 64e9)
     fe = dict(Fs=64e9, polRotation=0.3, polDelay=2e-12, **fe_kw)
-    pd = dict(Fs=64e9, ideal=True)
+    pd = pd or dict(Fs=64e9, ideal=True)
     rng = np.random.default_rng(seed)
     h = rng.normal(size=ntaps) * np.hanning(ntaps)
     dec = dict(SpSin=sps, SpSout=2)
@@ -289,6 +289,17 @@ def test_receiver_chain_in_one_call_on_the_emulator(emu_rx, N, ntaps, sps, L):
     ref = _oracle_chain(*case)
     assert out.shape == ref.shape and out.dtype == np.complex128
     assert np.max(np.abs(out - ref)) <= 1e-11 * np.max(np.abs(ref))
+
+
+def test_receiver_chain_with_band_limited_photodiodes_and_with_skew_on_the_emulator(emu_rx):
+    """the receiver's detection is NOT left to the matched filter's loads when a filter of its own (the photodiodes' low-pass) or
+    the skew filters follow it"""
+    for kw in (dict(pd=dict(Fs=64e9, B=20e9, N=127, shotNoise=False, thermalNoise=False)), dict(timeSkewX=2e-12, ampImbY=0.4, phaseImbX=0.1)):
+        case = _chain_case(1 << 13, 129, 16, 600, seed=83, **kw)
+        E, lo, fe, pd, h, dec, edcp = case
+        out = oa.pdmCoherentReceiverChain(E, lo, bag(**fe), bag(**pd), h, bag(**dec), bag(**edcp))
+        ref = _oracle_chain(*case)
+        assert np.max(np.abs(out - ref)) <= 1e-11 * np.max(np.abs(ref)), kw
 
 
 @pytest.mark.gpu
