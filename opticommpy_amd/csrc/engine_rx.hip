@@ -87,6 +87,10 @@ __global__ void __launch_bounds__(1024) k_rx_chain_finish(const ChainFinishArgs 
     SSF_RX_CTX();
     chain_finish_body(ctx, a);
 }
+__global__ void __launch_bounds__(256) k_rx_dec_stats(const DecStatsArgs a) {
+    SSF_RX_CTX();
+    dec_stats_body(ctx, a);
+}
 __global__ void __launch_bounds__(256) k_rx_dec_sum(const DecSumArgs a) {
     SSF_RX_CTX();
     dec_sum_body(ctx, a);
@@ -243,6 +247,10 @@ struct HipRxBackend {
         //  few memory round trips instead of a few dozen with 256 threads: 9.3 -> 3 us at 342 x 32 partials)
         k_rx_chain_finish<<<1, 1024, sizeof(double) * (3 * 1024 + 256), st>>>(a);
         chk(hipGetLastError(), "launch k_rx_chain_finish");
+    }
+    void launch_dec_stats(const DecStatsArgs &a, int nblocks, int nthreads) {
+        k_rx_dec_stats<<<(unsigned)nblocks, nthreads, 3 * sizeof(double) * (size_t)nthreads, st>>>(a);
+        chk(hipGetLastError(), "launch k_rx_dec_stats");
     }
     void launch_dec_sum(const DecSumArgs &a, int nblocks, int nthreads) {
         k_rx_dec_sum<<<(unsigned)nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, st>>>(a);

@@ -680,6 +680,44 @@ template <int LG, int C, int MODE, class Ctx> SSF_HD void chain_ols_body(Ctx &ct
         }
     }
 }
+// decimate by itself, ONE pass over the signal (round 6; two passes + two reductions before): per (phase, column) class sum x and
+// sum |x|^2 together, left as (nblocks, nclass, 3) partials for chain_finish_body, which forms the variances sum |x|^2 / M -
+// |sum x / M|^2 and picks the phases -- the same search as the receiver chain's (chain_ols_body, CH_STATS)
+struct DecStatsArgs {
+    const Cd *in;        // (N, ncols)
+    double *part;        // (nblocks, nclass, 3): sum re, sum im, sum |x|^2
+    long long total;     // N * ncols
+    int nclass, ncols;
+};
+template <class Ctx> SSF_HD void dec_stats_body(Ctx &ctx, const DecStatsArgs &a) {
+    double *red = (double *)ctx.lds;               // nthreads x 3 doubles
+    // sums of x - k with k = the column's first sample: the variance does not change, and a signal that is mostly offset (a
+    // photocurrent) does not lose its variance in the difference of two large numbers
+    const Cd k = a.in[(ctx.tid % a.nclass) % a.ncols];
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (long long i = (long long)ctx.bid * ctx.nthreads + ctx.tid; i < a.total; i += (long long)ctx.nblocks * ctx.nthreads) {
+        const Cd e = mk<double>(a.in[i].re - k.re, a.in[i].im - k.im);
+        s0 += e.re;
+        s1 += e.im;
+        s2 += e.re * e.re + e.im * e.im;
+    }
+    red[3 * ctx.tid] = s0;
+    red[3 * ctx.tid + 1] = s1;
+    red[3 * ctx.tid + 2] = s2;
+    ctx.sync();
+    if (ctx.tid < a.nclass) {                      // threads of one class are tid, tid + nclass, ... (the grid stride keeps the class)
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int t = ctx.tid; t < ctx.nthreads; t += a.nclass) {
+            t0 += red[3 * t];
+            t1 += red[3 * t + 1];
+            t2 += red[3 * t + 2];
+        }
+        double *o = a.part + ((size_t)ctx.bid * a.nclass + ctx.tid) * 3;
+        o[0] = t0;
+        o[1] = t1;
+        o[2] = t2;
+    }
+}
 // the partials added up (one workgroup, fixed order), the variances, and per column the first phase of the largest one (core.py:478)
 struct ChainFinishArgs {
     const double *part;  // (nblocks, nclass, 3)

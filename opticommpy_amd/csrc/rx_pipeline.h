@@ -869,22 +869,20 @@ template <class Backend> struct RxCore {
         // the grid stride must keep the class too: nblocks * nthreads is a multiple of nclass by construction
         const int nblocks = (int)std::max<long long>(1, std::min<long long>(512, (N * ncols + 4 * nthreads - 1) / (4 * nthreads)));
         const Cd *a = resident(in, (size_t)N * ncols);
-        Cd *b = result_buffer(out, in, (size_t)Nout * ncols), *dmean = dalloc((size_t)nclass);
-        double *dpart = (double *)be.alloc(sizeof(double) * 2 * (size_t)nblocks * nclass);
+        Cd *b = result_buffer(out, in, (size_t)Nout * ncols);
+        double *dpart = (double *)be.alloc(sizeof(double) * 3 * (size_t)nblocks * nclass);
         int *ddelay = (int *)be.alloc(sizeof(int) * 8);
         if (dpart) owned.push_back(dpart);
         if (ddelay) owned.push_back(ddelay);
-        if (!a || !b || !dmean || !dpart || !ddelay) return fail(SSF_ERR_OOM, "out of device memory");
-        // mean per (phase, column) class, then the variance about it (two passes, as np.var), each pass's partials added up by one
-        // small launch in the workgroup order: five launches back to back, no host round trip in between
-        DecSumArgs sa{a, nullptr, dpart, N * ncols, nclass};
-        DecFinishArgs fa{dpart, dmean, ddelay, nblocks, nclass, ncols, SpSin, (double)(N / SpSin)};
-        be.launch_dec_sum(sa, nblocks, nthreads);
-        be.launch_dec_finish(fa);
-        sa.mean = dmean;
-        fa.mean = nullptr;
-        be.launch_dec_sum(sa, nblocks, nthreads);
-        be.launch_dec_finish(fa);
+        if (!a || !b || !dpart || !ddelay) return fail(SSF_ERR_OOM, "out of device memory");
+        // per (phase, column) class sum x and sum |x|^2 in ONE pass (round 6: two passes -- mean, then variance about it -- and two
+        // reductions before), the partials added up and the phases picked by one small launch: three launches back to back with the
+        // gather, no host round trip in between.  var = sum |x|^2 / M - |sum x / M|^2: the phases' variances differ by far more than
+        // the rounding of either form (np.var's two-pass form included)
+        DecStatsArgs sa{a, dpart, N * ncols, nclass, ncols};
+        be.launch_dec_stats(sa, nblocks, nthreads);
+        ChainFinishArgs fa{dpart, ddelay, nblocks, nclass, ncols, SpSin, (double)(N / SpSin)};
+        be.launch_chain_finish(fa);
         DecGatherArgs ga{};
         ga.in = a;
         ga.out = b;

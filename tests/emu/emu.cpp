@@ -333,6 +333,9 @@ struct EmuBackend {
         }
     }
     void launch_chain_finish(const ssf::rx::ChainFinishArgs &a) { ++launches; run_grid(1, 1024, sizeof(double) * (3 * 1024 + 256), [&](EmuCtx &c) { ssf::rx::chain_finish_body(c, a); }); }
+    void launch_dec_stats(const ssf::rx::DecStatsArgs &a, int nblocks, int nthreads) {
+        run_grid(nblocks, nthreads, 3 * sizeof(double) * (size_t)nthreads, [&](EmuCtx &c) { ssf::rx::dec_stats_body(c, a); });
+    }
     void launch_dec_sum(const ssf::rx::DecSumArgs &a, int nblocks, int nthreads) {
         run_grid(nblocks, nthreads, 2 * sizeof(double) * (size_t)nthreads, [&](EmuCtx &c) { ssf::rx::dec_sum_body(c, a); });
     }
