@@ -65,6 +65,22 @@ def test_oracle_reproduces_the_reference_over_a_full_span():
     np.testing.assert_allclose(projection(out), d["out_proj"], rtol=1e-12)          # (a BLAS product: see above)
 
 
+@pytest.mark.parametrize("name", ["long_nb_n200000", "long_nb_n2000000"])
+def test_oracle_reproduces_the_reference_at_its_own_benchmark_lengths(name):
+    """long_nb_*: the REFERENCE on its published GPU benchmark's settings (examples/benchmarck_GPU_processing.ipynb: Fs 128 GS/s, adaptive
+    step, maxIter 5) at 2e5 samples (a full 50 km span) and at its top size 2e6 = 2^7 x 5^6 (the first 12 km) -- tools/gen_golden.py
+    notebook.  The oracle is held to them bit for bit here; the HIP path -- 2e6 on the mixed-radix column stage -- under -m gpu
+    (test_hip_reproduces_the_reference_long_runs)."""
+    d, cfg = load_golden(name)
+    tr = {}
+    out = orc.manakovSSF(_input(cfg), make_param(orc.parameters, _run_cfg(cfg)), trace=tr)
+    assert tr["iters"] == list(d["iters"])
+    np.testing.assert_allclose(np.concatenate([np.asarray(r, dtype=float) for r in tr["lims"]]), d["lims"], rtol=1e-12)
+    np.testing.assert_allclose(tr["hz"], d["hz"], rtol=0, atol=0) if "hz" in d else None
+    assert np.array_equal(out[:: int(cfg["dec"])], d["out_dec"])
+    np.testing.assert_allclose(projection(out), d["out_proj"], rtol=1e-12)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", LONG)
 def test_hip_reproduces_the_reference_long_runs(name):
@@ -80,6 +96,8 @@ def test_hip_reproduces_the_reference_long_runs(name):
         finally:
             oa.set_engine("auto")
         assert run["steps"] == len(d["iters"])
+        if name.startswith("long_nb_"):
+            assert run["pipeline"] == "fused-device"          # (2 000 000 = 2^7 x 5^6: the mixed-radix column stage, not Bluestein)
         _check(d, cfg, out, run["iters"], run["lims"])
 
 

@@ -20,7 +20,7 @@ Output: tests/golden/<case>.npz, each holding
               output decimated by cfg["dec"], its per-column power and a seeded random projection of the full
               output (so an error anywhere in the array shows), see long_vectors()
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|rx_edges|tx|bfc|mixed|rx_chain20|chain|long|long20|cfg3|long_c3 [128|64|merge]|units45 [log2n]]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [rx|rx_edges|tx|bfc|mixed|rx_chain20|chain|long|long20|notebook|cfg3|long_c3 [128|64|merge]|units45 [log2n]]
 """
 import json
 import os
@@ -498,6 +498,17 @@ def long_vectors():
               + f"  {time.time()-t0:.0f} s", flush=True)
 
 
+def notebook_vectors():
+    """The reference's published GPU benchmark (examples/benchmarck_GPU_processing.ipynb cells 8 - 10: Fs 128 GS/s, adaptive step,
+    maxIter 5) at two of its signal lengths: 2e5 samples over one full 50 km span, and its top size 2e6 = 2^7 x 5^6 -- the length
+    that needs the mixed-radix COLUMN stage on the device -- over the first 12 km; amp='ideal' (deterministic)."""
+    os.makedirs(OUT, exist_ok=True)
+    nb = dict(Fs=128e9, Fc=193.1e12, alpha=0.2, D=16, gamma=1.3, hz=0.5, maxIter=5, tol=1e-5, nlprMethod=True, maxNlinPhaseRot=2e-2,
+              prgsBar=False, amp="ideal", saveSpanN=[])
+    run_long("long_nb_n200000", "manakovSSF", (200000, 2, 71, 1.0), dict(nb, Ltotal=50, Lspan=50), dec=100)
+    run_long("long_nb_n2000000", "manakovSSF", (2000000, 2, 71, 1.0), dict(nb, Ltotal=12, Lspan=12), dec=1000)
+
+
 def long20_vector():
     """BASELINE config 2 at its full size: 2^20 samples, one 80 km span, 1001 steps (about 15 minutes of reference time)."""
     os.makedirs(OUT, exist_ok=True)
@@ -764,7 +775,9 @@ def units45_vector(steps=8, log2n=20):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "long20":  # only the full-size config-2 vector
+    if len(sys.argv) > 1 and sys.argv[1] == "notebook":   # the reference benchmark's own lengths (2e5, 2e6 samples), adaptive step
+        notebook_vectors()
+    elif len(sys.argv) > 1 and sys.argv[1] == "long20":  # only the full-size config-2 vector
         long20_vector()
     elif len(sys.argv) > 1 and sys.argv[1] == "cfg3":    # config 3's own field, a few steps, complex128 and complex64
         cfg3_vector()
