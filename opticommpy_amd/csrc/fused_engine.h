@@ -26,7 +26,9 @@ namespace fused {
 #ifndef SSF_EXPERIMENTS
 #define SSF_EXPERIMENTS 0
 #endif
-inline const char *tune_env(const char *name) {
+// (static: one copy per translation unit -- the experiment library links units built with and without SSF_EXPERIMENTS, and a merged
+//  inline function would be whichever copy the linker keeps; the same for the split rules below, which call it)
+static inline const char *tune_env(const char *name) {
 #if SSF_EXPERIMENTS
     return std::getenv(name);
 #else
@@ -41,7 +43,7 @@ struct Split {
 
 // How N = 2^m is split.  Columns want >= 256 B contiguous per row of a tile
 // (C = 4096/N1 columns x sizeof(complex)); rows are bounded by the 160 KiB LDS.
-inline bool choose_split(int log2N, int precision, Split *s, bool packed = false) {
+static inline bool choose_split(int log2N, int precision, Split *s, bool packed = false) {
     if (log2N < 8) return false;
     if (const char *e = tune_env("SSF_SPLIT_L1")) {        // tuning knob: force log2 N1
         const int l1 = std::atoi(e);
@@ -80,7 +82,7 @@ inline bool choose_split(int log2N, int precision, Split *s, bool packed = false
 // by the mixed-radix row kernel (mixed_fft.h).  Rows of up to 8192 values (16 per thread, 512 threads, one row per workgroup:
 // 132 KiB of LDS in double precision).
 constexpr int64_t kMixMaxRow = 8192;
-inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
+static inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
     (void)precision;
     if (N < 1 || (N & (N - 1)) == 0) return false;
     int a = 0;
@@ -124,18 +126,15 @@ inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2) {
 // Preference: both stages at two workgroups per CU, then wide global segments (C), then columns near 256.
 constexpr int kMix2MaxCol = 1024;
 inline size_t mix2_col_lds(int N1, int C, int npol, int elem_bytes) { return (size_t)kColMixScratch + (size_t)npol * C * N1 * elem_bytes; }
-inline bool choose_mixed2_split(int64_t N, int precision, int *N1o, int *N2o, int *Co) {
+// (force_n1 / force_c: the experiment knob SSF_MIX2 = "N1,C", parsed by the CALLER -- this function is emitted once per library, and
+//  the linker may keep the copy of a translation unit that was built without the experiment switches)
+static inline bool choose_mixed2_split(int64_t N, int precision, int *N1o, int *N2o, int *Co, int force_n1 = 0, int force_c = 0) {
     if (N < 4096 || (N & (N - 1)) == 0) return false;
     int64_t rest = N;
     for (int q : {2, 3, 5})
         while (rest % q == 0) rest /= q;
     if (rest != 1) return false;
     const int s = precision == SSF_C128 ? 16 : 8;
-    int force_n1 = 0, force_c = 0;
-    if (const char *e = tune_env("SSF_MIX2")) {                 // experiments: "N1,C"
-        force_n1 = std::atoi(e);
-        if (const char *q = std::strchr(e, ',')) force_c = std::atoi(q + 1);
-    }
     double best = 1e300;
     for (int n1 = 16; n1 <= kMix2MaxCol; ++n1) {
         if (N % n1 || (force_n1 && n1 != force_n1)) continue;
@@ -237,7 +236,12 @@ template <typename T, class Backend> class FusedCore {
         } else {
             sp.l1 = sp.l2 = 0;
             // (experiment builds: SSF_MIX2="N1,C" puts a length the radix-2^n columns would take on the mixed-radix column stage)
-            if (tune_env("SSF_MIX2") && choose_mixed2_split(N, precision, &N1mix, &N2mix, &mix_cols)) {
+            int f1 = 0, fc = 0;
+            if (const char *e = tune_env("SSF_MIX2")) {
+                f1 = std::atoi(e);
+                if (const char *q = std::strchr(e, ',')) fc = std::atoi(q + 1);
+            }
+            if (f1 > 0 && choose_mixed2_split(N, precision, &N1mix, &N2mix, &mix_cols, f1, fc)) {
             } else if (!choose_mixed_split(N, precision, &sp.l1, &N2mix)) {
                 N2mix = 0;
                 if (!choose_mixed2_split(N, precision, &N1mix, &N2mix, &mix_cols)) N1mix = N2mix = mix_cols = 0;

@@ -206,8 +206,11 @@ def simpleWDMTx(param, device_output=False):
 
     symbols = np.empty((nCh, nPol, nSymbols), dtype=np.complex128)
     # Laser phase noise.  With a seed the random walk is the reference's own np.random draws (phaseNoise below: host, N values
-    # per channel, uploaded); WITHOUT one nothing can be reproduced anyway, and the walk is generated on the device (Philox, two
-    # launches per channel: ssf_tx_params.pn_seed) -- no N-sample draw on the host, no N-sample upload.
+    # per channel, uploaded).  WITHOUT param.seed the walk is generated on the device (Philox, two launches per channel:
+    # ssf_tx_params.pn_seed) -- no N-sample draw on the host, no N-sample upload.  A deliberate, documented deviation (statistical
+    # parity): the reference draws its N - 1 normals per channel from numpy's GLOBAL stream even then (tx.py:199, also for a zero
+    # linewidth), so a caller who seeds np.random globally and leaves param.seed = None gets a reproducible reference run whose
+    # symbols after channel 0 / mode 0 this call does not reproduce draw for draw; pass param.seed for that.
     device_pn = bool(param.laserLinewidth) and param.seed is None
     phi = np.empty((nCh, N)) if (param.laserLinewidth and not device_pn) else None
     seed = param.seed

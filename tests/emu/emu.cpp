@@ -435,9 +435,13 @@ int emu_supported(int64_t N, int precision) {
 
 // the N1 x N2 split (and columns per workgroup) of the mixed-radix column stage, 0 when the length does not go there
 int emu_mixed2_split(int64_t N, int precision, int *n1, int *n2, int *c) {
-    int l1, m2;
-    if (!getenv("SSF_MIX2") && ssf::fused::choose_mixed_split(N, precision, &l1, &m2)) return 0;
-    return ssf::fused::choose_mixed2_split(N, precision, n1, n2, c) ? 1 : 0;
+    int l1, m2, f1 = 0, fc = 0;
+    if (const char *e = getenv("SSF_MIX2")) {
+        f1 = atoi(e);
+        if (const char *q = strchr(e, ',')) fc = atoi(q + 1);
+    }
+    if (!f1 && ssf::fused::choose_mixed_split(N, precision, &l1, &m2)) return 0;
+    return ssf::fused::choose_mixed2_split(N, precision, n1, n2, c, f1, fc) ? 1 : 0;
 }
 int emu_split(int64_t N, int precision, int *l1, int *l2) {
     int l = 0;

@@ -29,14 +29,16 @@ def main():
     for case in range(cases):
         lg = int(rng.integers(8, 15))
         N = 1 << lg
-        pick = rng.integers(0, 5)
-        if pick == 0:
+        pick = rng.integers(0, 6)
+        if pick == 5:                                               # fused engine, mixed-radix COLUMN stage (round 6): no power-of-two column split
+            N = int(rng.choice([9000, 10125, 15625, 16875, 25000, 28125, 40500, 50625, 8 * 3125 * 3]))
+        elif pick == 0:
             N = int(rng.choice([1500, 3000, 6000, 10000, 97, 1009, 1234, 6006, 31]))   # general-length engine (Bluestein on the fused kernels)
         elif pick == 1:                                             # fused engine, mixed-radix rows
             N = int(rng.choice([128 * 75, 128 * 81, 128 * 125, 256 * 45, 512 * 27, 1024 * 15, 128 * 225, 256 * 135,
                                 48000, 128 * 405, 512 * 125, 1024 * 75]))
         K = int(rng.choice([1, 1, 1, 2, 3]))
-        c64 = bool(rng.integers(0, 4) == 0) and pick >= 2        # complex64: packed polarisation pairs (power-of-two lengths)
+        c64 = bool(rng.integers(0, 4) == 0) and pick >= 2        # complex64: packed polarisation pairs (power-of-two lengths); one row per polarisation on the mixed-radix column stage
         func = str(rng.choice(["manakovSSF", "manakovSSF", "manakovDBP", "ssfm"]))
         p_dbm = float(rng.choice([-20, -5, 0, 6, 10, 14]))
         adaptive = bool(rng.integers(0, 2)) and func != "ssfm"
