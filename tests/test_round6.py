@@ -318,3 +318,44 @@ def test_receiver_chain_in_one_call_on_the_gpu_equals_the_four_calls():
     assert np.max(np.abs(a - ref)) <= 1e-11 * np.max(np.abs(ref))
     host = oa.pdmCoherentReceiverChain(E, lo, bag(**fe), bag(**pd), h, bag(**dec), bag(**edcp))       # numpy in, numpy out
     assert np.array_equal(host, a)
+
+
+@pytest.mark.gpu
+def test_mixed_radix_column_stage_through_the_whole_public_api():
+    """Snapshots, the EDFA epilogue (supplied and device noise), a coupled K = 2 call, independent units per launch and ssfm with
+    saveSpanN at a length of the mixed-radix column stage (9 000 = 2^3 x 3^2 x 5^3)."""
+    from opticommpy_amd import mgpu
+    N = 9000
+    E = synth_field(N, 2, 91, 6.0)
+    base = dict(Fs=512e9, Ltotal=6.0, Lspan=2.0, hz=0.25, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, maxIter=10, tol=1e-5, nlprMethod=True,
+                maxNlinPhaseRot=5e-3, prgsBar=False)
+    snap = dict(base, amp="ideal", saveSpanN=[1, 3])
+    out = oa.manakovSSF(E, bag(**snap))
+    assert oa.last_run["pipeline"] == "fused-device" and out.shape == (N, 4)
+    assert rel_l2(out, orc.manakovSSF(E, bag(orc.parameters, **snap))) <= 1e-10
+    rng = np.random.default_rng(2)
+    noise = 1e-4 * (rng.normal(size=(3, 2, N)) + 1j * rng.normal(size=(3, 2, N)))
+    ed = dict(base, amp="edfa", NF=5.0, saveSpanN=[])
+    assert rel_l2(oa.manakovSSF(E, bag(**ed), _noise=noise), orc.manakovSSF(E, bag(orc.parameters, **ed), noise=noise)) <= 1e-10
+    o1 = oa.manakovSSF(E, bag(seed=3, **dict(ed, Ltotal=2.0)))
+    oz = oa.manakovSSF(E, bag(**dict(ed, Ltotal=2.0)), _noise=np.zeros((1, 2, N), complex))
+    _, p_noise = orc.edfa_noise_power(0.2 * 2.0, 5.0, 193.1e12, 512e9)
+    assert np.mean(np.abs(o1 - oz) ** 2) == pytest.approx(p_noise, rel=0.1)
+    E4 = np.concatenate([E, synth_field(N, 2, 92, 0.0)], axis=1)               # one coupled call with two pairs
+    k2 = dict(base, amp=None, saveSpanN=[])
+    tr = {}
+    ref = orc.manakovSSF(E4, bag(orc.parameters, **k2), trace=tr)
+    got = oa.manakovSSF(E4, bag(**k2), _trace=True)
+    assert rel_l2(got, ref) <= 1e-10 and [int(x) for x in oa.last_run["iters"]] == [int(x) for x in tr["iters"]]
+    units = [synth_field(N, 2, 93 + u, 3.0 * u) for u in range(3)]            # independent units: one batch per launch == one call each
+    fx = dict(base, nlprMethod=False, amp="ideal", saveSpanN=[])
+    batch = mgpu.run_sharded(units, bag(**fx))
+    for u, o in zip(units, batch):
+        assert np.array_equal(o, oa.manakovSSF(u, bag(**fx)))
+    assert rel_l2(batch[2], orc.manakovSSF(units[2], bag(orc.parameters, **fx))) <= 1e-10
+    e1 = E[:, 0].copy()
+    sc = dict(Fs=512e9, Ltotal=4.0, Lspan=2.0, hz=0.25, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, amp="ideal", prgsBar=False, saveSpanN=[1, 2])
+    s = oa.ssfm(e1, bag(**sc))
+    assert s.shape == (N, 2) and rel_l2(s, orc.ssfm(e1, bag(orc.parameters, **sc))) <= 1e-10
+    back = oa.manakovDBP(ref[:, :2].copy(), bag(**dict(k2, amp="ideal")))
+    assert rel_l2(back, orc.manakovDBP(ref[:, :2].copy(), bag(orc.parameters, **dict(k2, amp="ideal")))) <= 1e-10
