@@ -151,7 +151,7 @@ MK = dict(Fs=512e9, Ltotal=4.0, Lspan=2.0, hz=0.25, alpha=0.2, D=16, gamma=1.3, 
 def test_manakov_on_the_mixed_radix_column_stage_against_the_oracle(N, power, adaptive):
     assert _mix2(N) is not None
     E = synth_field(N, 2, 31, power)
-    cfg = dict(MK, nlprMethod=adaptive, maxNlinPhaseRot=5e-3, amp="ideal", saveSpanN=[])
+    cfg = dict(MK, nlprMethod=adaptive, maxNlinPhaseRot=2e-2, amp="ideal", saveSpanN=[])
     tr = {}
     ref = orc.manakovSSF(E, bag(orc.parameters, **cfg), trace=tr)
     out, info = eb.run("manakovSSF", E, cfg)
@@ -164,7 +164,7 @@ def test_manakov_on_the_mixed_radix_column_stage_against_the_oracle(N, power, ad
 
 
 def test_mixed_radix_columns_complex64_two_pairs_and_the_rare_stages():
-    N = 9000
+    N = 5625                                                       # = 3^2 x 5^4: odd, 75 x 75
     E4 = np.concatenate([synth_field(N, 2, 41, 8.0), synth_field(N, 2, 42, 2.0)], axis=1)
     cfg = dict(MK, nlprMethod=False, amp=None, saveSpanN=[])
     out, info = eb.run("manakovSSF", E4, cfg)                      # two coupled pairs (K = 2)
@@ -195,7 +195,7 @@ def test_mixed_radix_columns_complex64_two_pairs_and_the_rare_stages():
     _, it = eb.run("manakovSSF", mid, mcfg)
     lim0 = sorted(float(x[0]) for x in it["lims"])
     hit = 0
-    for f in (0.26, 0.255, 0.22):
+    for f in (0.26, 0.255):
         c2 = dict(mcfg, tol=lim0[len(lim0) // 2] * f)
         tr = {}
         mref = orc.manakovSSF(mid, bag(orc.parameters, **c2), trace=tr)
