@@ -127,8 +127,7 @@ struct DetArgs {
 };
 // the detected sample sI + j sQ of polarisation p at time n (devices.py:487-499, 562-563; photodiode slots as front_body) from the
 // signal sample `es` behind the PBS (and the polarisation delay filters)
-template <int NOISE = 2> SSF_HD Cd det_core(const DetArgs &a, long long n, int p, Cd es) {
-    Cd lo = a.lo[n];
+template <int NOISE = 2> SSF_HD Cd det_core(const DetArgs &a, long long n, int p, Cd es, Cd lo) {
     const double ks = sel2(a.es_scale, p), kl = sel2(a.lo_scale, p);
     es = mk<double>(es.re * ks, es.im * ks);
     lo = mk<double>(lo.re * kl, lo.im * kl);
@@ -149,13 +148,13 @@ template <int NOISE = 2> SSF_HD Cd det_sample(const DetArgs &a, long long n, int
         es = p == 0 ? mk<double>(e0.re * a.c + e1.re * a.s, e0.im * a.c + e1.im * a.s)
                     : mk<double>(e1.re * a.c - e0.re * a.s, e1.im * a.c - e0.im * a.s);
     } else es = a.in0[n * a.nm + p];
-    return det_core<NOISE>(a, n, p, es);
+    return det_core<NOISE>(a, n, p, es, a.lo[n]);
 }
 // IQ imbalance (core.py:952-960): s' = k1 s + k2 conj(s)
 SSF_HD Cd iq_mix(Cd k1, Cd k2, Cd s) { return k1 * s + k2 * fused::conj(s); }
 
-enum { PRE_PLAIN = 0, PRE_PBS = 1, PRE_DET = 2, PRE_IQ = 3, PRE_PD = 4 };
-enum { POST_PLAIN = 0, POST_IQF = 1, POST_PART = 2, POST_REAL = 3, POST_DET = 4 };
+enum { PRE_PLAIN = 0, PRE_PBS = 1, PRE_DET = 2, PRE_IQ = 3, PRE_PD = 4, PRE_PBS_DET = 5 };   // (5: PRE_PBS loads, POST_DET stores -- compile-time)
+enum { POST_PLAIN = 0, POST_IQF = 1, POST_PART = 2, POST_REAL = 3 };
 struct RxOlsArgs {
     fused::OlsArgs<double> o; // geometry, filters, o.in (PRE_PLAIN / PRE_IQ), o.out
     int pre, post;
@@ -174,7 +173,7 @@ template <int LG, int C, int PRE, int NOISE, class Ctx> SSF_HD void rx_ols_body(
     fused::ols_body_x<double, LG, C>(
         ctx, a.o,
         [&](long long src, int m) -> Cd {
-            if constexpr (PRE == PRE_PBS) {
+            if constexpr (PRE == PRE_PBS || PRE == PRE_PBS_DET) {
                 const Cd e0 = a.det.in0[2 * src], e1 = a.det.in0[2 * src + 1];
                 return m == 0 ? mk<double>(e0.re * a.det.c + e1.re * a.det.s, e0.im * a.det.c + e1.im * a.det.s)
                               : mk<double>(e1.re * a.det.c - e0.re * a.det.s, e1.im * a.det.c - e0.im * a.det.s);
@@ -189,6 +188,11 @@ template <int LG, int C, int PRE, int NOISE, class Ctx> SSF_HD void rx_ols_body(
             } else return a.o.in[src * a.o.in_ld + m];
         },
         [&](long long n, int m, Cd v) {
+            if constexpr (PRE == PRE_PBS_DET) {          // the polarisation delay filter's stores detect: hybrid, ideal photodiodes, IQ
+                const Cd t = det_core<0>(a.det, n, m, v, a.det.lo[n]);   // imbalance and the zero-skew rule (det_loop) -- no pass of their own
+                a.o.out[n * a.o.out_ld + m] = n == a.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(sel2(a.k1, m), sel2(a.k2, m), t);
+                return;                                  // (its own instantiation: 54.0 -> 52.5 us without the other stores' code beside it; the
+            }                                            //  LO samples fetched ahead of the store loop -- 64 more registers -- 68 us: round 6)
             if (a.post == POST_IQF) {
                 const Cd t = iq_mix(sel2(a.k1, m), sel2(a.k2, m), v);
                 a.o.out[n * a.o.out_ld + m] = n == a.N - 1 ? mk<double>(0.0, 0.0) : t;
@@ -197,9 +201,6 @@ template <int LG, int C, int PRE, int NOISE, class Ctx> SSF_HD void rx_ols_body(
                 o[m & 1] = v.re;
             } else if (a.post == POST_REAL) {            // `return ipd.real` (devices.py:399)
                 ((double *)a.o.out)[n] = v.re;
-            } else if (a.post == POST_DET) {             // the polarisation delay filter's stores detect: hybrid, ideal photodiodes, IQ
-                const Cd t = det_core<0>(a.det, n, m, v);         // imbalance and the zero-skew rule (det_loop) -- no pass of their own
-                a.o.out[n * a.o.out_ld + m] = n == a.N - 1 ? mk<double>(0.0, 0.0) : iq_mix(sel2(a.k1, m), sel2(a.k2, m), t);
             } else a.o.out[n * a.o.out_ld + m] = v;
         });
 }
@@ -225,9 +226,10 @@ template <class F> inline bool rx_ols_dispatch(const RxOlsArgs &a, const fused::
         });
         return true;
     }
-    if ((o.lg != 11 && o.lg != 12) || (a.pre != PRE_PBS && a.pre != PRE_IQ)) return false;
+    if ((o.lg != 11 && o.lg != 12) || (a.pre != PRE_PBS && a.pre != PRE_IQ && a.pre != PRE_PBS_DET)) return false;
     auto stage = [&](auto lg, auto cc) {
         if (a.pre == PRE_PBS) f(lg, cc, integral_constant<int, PRE_PBS>{}, integral_constant<int, 0>{});
+        else if (a.pre == PRE_PBS_DET) f(lg, cc, integral_constant<int, PRE_PBS_DET>{}, integral_constant<int, 0>{});
         else f(lg, cc, integral_constant<int, PRE_IQ>{}, integral_constant<int, 0>{});
     };
     if (o.C == 2) {

@@ -403,10 +403,9 @@ template <class Backend> struct RxCore {
                     // and rides in their stores -- the notebook's receiver is ONE launch (round 6; two before)
                     const bool det_in_stores = !lowpass && !skew && !det.pd.shot && !det.pd.thermal;
                     RxOlsArgs r = rx_ols_args(N, N + padLen, det_in_stores ? result : fld, 2, N, 2, dH, nfft, K, nfft, 1);
-                    r.pre = PRE_PBS;
+                    r.pre = det_in_stores ? PRE_PBS_DET : PRE_PBS;
                     r.det = det;
                     if (det_in_stores) {
-                        r.post = POST_DET;
                         r.N = N;
                         for (int k = 0; k < nm; ++k) {
                             r.k1[k] = k1[k];
@@ -557,14 +556,10 @@ template <class Backend> struct RxCore {
             be.launch_dec_finish(fa);
         }
         // 3. edc on the decimated signal, gathered in its loads
-        std::vector<zc> H((size_t)edc_nfft);
-        for (int i = 0; i < edc_nfft; ++i) H[(size_t)i] = ((const zc *)edcH)[i] / (double)edc_nfft;
         int lg = 0;
         while ((1 << lg) < edc_nfft) ++lg;
         if ((1 << lg) != edc_nfft || lg < 4 || lg > 13) return fail(SSF_ERR_UNSUPPORTED, "receiver chain: edc block size must be a power of two in [16, 8192]");
-        fused::ols_permute_filter(H.data(), lg);
-        const FilterKey key{4, edcK, edc_nfft, 0, 0.0, 0.0, content_hash((const zc *)edcH, (size_t)edc_nfft), content_hash2((const zc *)edcH, (size_t)edc_nfft)};
-        Cd *dHe = cached_filter(key, [&] { return H; });
+        Cd *dHe = response_filter(edcH, edcK, edc_nfft);
         Cd *b = be.is_resident(out) && out != Es && out != Elo ? (Cd *)out : dalloc((size_t)Nout * nm);
         if (!dHe || !b) return fail(SSF_ERR_OOM, "out of device memory");
         const OlsGeom ge = ols_geometry(Nout, edcK, edc_nfft);
@@ -902,16 +897,24 @@ template <class Backend> struct RxCore {
 
     // blockwiseFFTConv with a caller-supplied frequency response (edc: ssf_overlap_save); Hfft = fft(zero-padded
     // impulse response), nfft values
+    // the device image of a caller-supplied block response (edc): scaled by the ifft's 1 / NFFT and put in the kernels' register
+    // order -- built only when the cache does not hold it (edc designs the same filter call after call; building it first cost
+    // every call 10 - 20 us of host time in front of its first launch)
+    Cd *response_filter(const void *Hfft, int K, int nfft) {
+        const FilterKey key{4, K, nfft, 0, 0.0, 0.0, content_hash((const zc *)Hfft, (size_t)nfft), content_hash2((const zc *)Hfft, (size_t)nfft)};
+        return cached_filter(key, [&] {
+            std::vector<zc> H((size_t)nfft);
+            for (int i = 0; i < nfft; ++i) H[(size_t)i] = ((const zc *)Hfft)[i] / (double)nfft;
+            int lg = 0;
+            while ((1 << lg) < nfft) ++lg;
+            fused::ols_permute_filter(H.data(), lg);
+            return H;
+        });
+    }
     int overlap_save(long long sigLen, int ncols, int nfft, int K, const void *Hfft, const void *in, void *out) {
-        std::vector<zc> H((size_t)nfft);
-        for (int i = 0; i < nfft; ++i) H[(size_t)i] = ((const zc *)Hfft)[i] / (double)nfft;    // the ifft's 1/NFFT folded in
-        int lg = 0;
-        while ((1 << lg) < nfft) ++lg;
-        fused::ols_permute_filter(H.data(), lg);
         const size_t n = (size_t)sigLen * ncols;
         const Cd *a = resident(in, n);
-        const FilterKey key{4, K, nfft, 0, 0.0, 0.0, content_hash((const zc *)Hfft, (size_t)nfft), content_hash2((const zc *)Hfft, (size_t)nfft)};   // (edc designs the same filter call after call)
-        Cd *b = result_buffer(out, in, n), *dH = cached_filter(key, [&] { return H; });
+        Cd *b = result_buffer(out, in, n), *dH = response_filter(Hfft, K, nfft);
         if (!a || !b || !dH) return fail(SSF_ERR_OOM, "out of device memory");
         int rc = ols(a, ncols, sigLen, sigLen, b, ncols, sigLen, ncols, dH, 0, K, nfft, 0);
         if (rc) return rc;

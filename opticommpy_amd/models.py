@@ -623,14 +623,34 @@ def _ols_block(K):
     return nfft
 
 
+_EDC_F = {}
+
+
 def _edc_filter(param, Fs):
-    """(NfilterCoeffs, Nfft, H) as optic/dsp/equalization.py:85-110 derives them."""
+    """(NfilterCoeffs, Nfft, H) as optic/dsp/equalization.py:85-110 derives them.  A receiver loop asks for the same link call after
+    call: the last few designs are kept by their parameters (a dozen small numpy calls are 20 us in front of a 0.1 ms call)."""
     L = getattr(param, "L", 50)
     D = getattr(param, "D", 16)
     Fc = getattr(param, "Fc", 193.1e12)
     Rs = getattr(param, "Rs", 32e9)
     NfilterCoeffs = getattr(param, "NfilterCoeffs", None)
     Nfft = getattr(param, "Nfft", None)
+    try:
+        key = (float(L), float(D), float(Fc), float(Rs), float(Fs), NfilterCoeffs, Nfft)
+        hit = _EDC_F.get(key)
+    except (TypeError, ValueError):
+        key = hit = None
+    if hit is not None:
+        return hit
+    res = _edc_design(L, D, Fc, Rs, Fs, NfilterCoeffs, Nfft)
+    if key is not None:
+        if len(_EDC_F) >= 8:
+            _EDC_F.pop(next(iter(_EDC_F)))
+        _EDC_F[key] = res
+    return res
+
+
+def _edc_design(L, D, Fc, Rs, Fs, NfilterCoeffs, Nfft):
     c_kms = 299792458.0 / 1e3
     lam = c_kms / Fc
     b2 = -(D * lam**2) / (2 * np.pi * c_kms)
