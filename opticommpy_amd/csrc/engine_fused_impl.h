@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col(const ColArgs
 // row lengths with factors 3 / 5 (mixed_fft.h): mixed-radix row stage, column stage with ragged last tiles
 template <typename T, int MAXT> __global__ void __launch_bounds__(MAXT, MAXT <= 256 ? 2 : 1) k_row_mixed(const RowArgs<T> a) {
     SSF_DEV_CTX(0);
-    row_mixed_body<T>(ctx, unit_view(a, (int)blockIdx.y));
+    row_mixed_body<T>(ctx, unit_view(a, (int)blockIdx.y), a.plan);
 }
 template <typename T, int LG, int MODE>
 __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const ColArgs<T> a) {
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(MODE == CM_MK ? 512 : 256) k_col_ragged(const 
 // column lengths with factors 3 / 5 (fused_kernels.h: col_mixed_body): the tile in LDS, mixed-radix passes
 template <typename T, int MODE> __global__ void __launch_bounds__(256, 2) k_col_mixed(const ColArgs<T> a) {
     SSF_DEV_CTX(1);
-    col_mixed_body<T, MODE>(ctx, unit_view(a, (int)blockIdx.y));
+    col_mixed_body<T, MODE>(ctx, unit_view(a, (int)blockIdx.y), a.plan1);
 }
 // eight values per thread (at most 128 registers, four waves per SIMD): 512-thread workgroups, two per CU
 template <typename T, int LG, int MODE> __global__ void __launch_bounds__(512, 4) k_col8(const ColArgs<T> a) {

@@ -703,12 +703,15 @@ template <typename T> SSF_HD cx<T> lin_at_n(const LinOp &lo, long long k, long l
 
 // Row stage for row lengths with factors 3 and 5 (mixed_fft.h): one row per workgroup, the row lives in LDS
 // (after the 4 KiB the control logic uses), G -> forward transform -> x linear operator -> inverse -> G.
-template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowArgs<T> &a) {
+// p: the pass plan, indexed at run time (p.r[i], p.S[i] ...).  It must be the plan IN THE KERNEL ARGUMENTS (scalar loads with a computed
+// offset): `a` is usually unit_view()'s modified COPY of the arguments, and a run-time index into a local copy puts the whole copy
+// into scratch memory -- 420 bytes per lane and a memory round trip for every p.S[i] (round 6: SQ_INSTS_VMEM_RD 139 per wave
+// against 34 in the radix-2^n rows; profiles/r6_mixed_rows.txt).  The wrappers pass the kernel parameter's own member.
+template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowArgs<T> &a, const MixPlan &p) {
     constexpr int kMaxPerThread = 16;                      // L <= 16 * threads per row
     const int L = a.N2, R_ = a.rows_per_wg, T_ = ctx.nthreads / R_;
     const int f = ctx.tid / T_, t = ctx.tid - f * T_;      // row within the workgroup, thread within the row
     cx<T> *x = (cx<T> *)(ctx.lds + 4096) + (size_t)f * L;
-    const MixPlan &p = a.plan;                             // (host-made: indexed from the kernel arguments, not from scratch)
     const long long rr = (long long)ctx.bid * R_ + f;      // global row index (grid is exact)
     cx<T> *g = a.G + rr * L;
     const cx<T> *gin = a.src ? a.src + rr * L : g;
@@ -1761,7 +1764,8 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
 // partial sums as col_body (mk_col_stage); the sample set of the lim_0 bound / sparse field store is every sixteenth time row.
 // A general-purpose kernel: far from the roofline of the specialised ones, but device-resident and one launch per stage.
 constexpr int kColMixScratch = 8192;            // bytes of LDS in front of the tile: block reductions
-template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, const ColArgs<T> &a) {
+// (plan1: the column pass plan in the kernel arguments themselves -- see row_mixed_body)
+template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, const ColArgs<T> &a, const MixPlan &plan1) {
     static_assert(sizeof(T) == sizeof(scalar_t<T>), "one row per polarisation (no packed pairs)");
     constexpr bool kMk = MODE == CM_MK;
     const int N1 = a.N1mix, C = a.mix_cols, N2 = a.N2, npol = a.npol;
@@ -1824,14 +1828,14 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
             w = w * ws;
         }
         ctx.sync();
-        mix_dif_strided<+1>(ctx, a.plan1, tt, tpt, xt, a.wtab1, C);
+        mix_dif_strided<+1>(ctx, plan1, tt, tpt, xt, a.wtab1, C);
     }
     // ---- time-domain work on the tile ----------------------------------------------------------------------------
     // src -> X (time order), for the stages that start from a time-domain buffer
     auto load_time = [&](const cx<T> *src) {
         for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
             const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
-            const long long toff = (long long)mix_bin(a.plan1, pos) * N2 + n2;
+            const long long toff = (long long)mix_bin(plan1, pos) * N2 + n2;
             for (int pol = 0; pol < npol; ++pol)
                 X[(((size_t)pol * N1 + pos) << lgC) + c] = n2 < N2 ? src[rowbase0 + (long long)pol * N + toff] : mk<T>((T)0, (T)0);
         }
@@ -1840,7 +1844,7 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
         for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
             const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
             if (n2 >= N2) continue;
-            const int n1 = mix_bin(a.plan1, pos);
+            const int n1 = mix_bin(plan1, pos);
             if (sparse && (n1 & 15)) continue;
             for (int pol = 0; pol < npol; ++pol) dst[rowbase0 + (long long)pol * N + (long long)n1 * N2 + n2] = X[(((size_t)pol * N1 + pos) << lgC) + c];
         }
@@ -1861,7 +1865,7 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
                 if (n2 >= N2) continue;
                 const T ax = norm2(X[e]), ay = norm2(X[((size_t)N1 << lgC) + e]);
                 const T pw = ax + ay;
-                Pbuf[pbase + (long long)mix_bin(a.plan1, pos) * N2 + n2] = pw;
+                Pbuf[pbase + (long long)mix_bin(plan1, pos) * N2 + n2] = pw;
                 const T phi = c8g * (pw + ax + ay) / (T)2;
                 m = (double)phi > m ? (double)phi : m;
             }
@@ -1875,7 +1879,7 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
             for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
                 const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
                 if (n2 >= N2) continue;
-                const T pw = Pcur[pbase + (long long)mix_bin(a.plan1, pos) * N2 + n2];
+                const T pw = Pcur[pbase + (long long)mix_bin(plan1, pos) * N2 + n2];
                 const cx<T> rot = cis_t<T>(shz * (c8g * (pw + pw) / (T)2));
                 X[e] = X[e] * rot;
                 X[((size_t)N1 << lgC) + e] = X[((size_t)N1 << lgC) + e] * rot;
@@ -1903,7 +1907,7 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
                 for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
                     const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
                     if (n2 >= N2) continue;
-                    const int n1 = mix_bin(a.plan1, pos);
+                    const int n1 = mix_bin(plan1, pos);
                     if (!st.exact0 && (n1 & 15)) continue;
                     for (int pol = 0; pol < npol; ++pol) {
                         const cx<T> e0 = Tcur[rowbase0 + (long long)pol * N + (long long)n1 * N2 + n2], v = X[(((size_t)pol * N1 + pos) << lgC) + c];
@@ -1920,7 +1924,7 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
                 for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
                     const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
                     if (n2 >= N2) continue;
-                    const long long toff = (long long)mix_bin(a.plan1, pos) * N2 + n2;
+                    const long long toff = (long long)mix_bin(plan1, pos) * N2 + n2;
                     const T pw = Pcur[pbase + toff];
                     const T ax = norm2(X[e]), ay = norm2(X[((size_t)N1 << lgC) + e]);
                     const T ang = shz * (c8g * (pw + ax + ay) / (T)2);
@@ -1960,7 +1964,7 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
     // ---- forward column transform -> x cis(-...) -> G ---------------------------------------------------------------
     if (do_fwd) {
         ctx.sync();
-        mix_dit_strided<-1>(ctx, a.plan1, tt, tpt, xt, a.wtab1, C);
+        mix_dit_strided<-1>(ctx, plan1, tt, tpt, xt, a.wtab1, C);
         cx<double> w = conj(w0);
         const cx<double> wsc = conj(ws);
         for (int k1 = ft; k1 < N1; k1 += Tt) {

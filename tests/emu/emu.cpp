@@ -171,7 +171,7 @@ struct EmuBackend {
         if (getenv("SSF_EMU_DEBUG") && launches < 8) fprintf(stderr, "emu row: vpt %d block %d grid %d lds %zu\n", a.vpt, block, grid, lds);
         if constexpr (!std::is_same<T, ssf::fused::pf2>::value) {
             if (a.mixed) {
-                run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_mixed_body<T>(c, a); });
+                run_grid(grid, block, lds, [&](EmuCtx &c) { ssf::fused::row_mixed_body<T>(c, a, a.plan); });
                 return;
             }
         }
@@ -218,12 +218,12 @@ struct EmuBackend {
         } else {
         if (a.N1mix) {                                      // mixed-radix columns (col_mixed_body)
             switch (a.mode) {
-            case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_NLSE_FIRST>(c, a); }); break;
-            case CM_NLSE_STEP: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_NLSE_STEP>(c, a); }); break;
-            case CM_NLSE_LAST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_NLSE_LAST>(c, a); }); break;
-            case CM_MK: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_MK>(c, a); }); break;
-            case CM_PLAIN_FWD: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_PLAIN_FWD>(c, a); }); break;
-            default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_PLAIN_INV>(c, a); }); break;
+            case CM_NLSE_FIRST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_NLSE_FIRST>(c, a, a.plan1); }); break;
+            case CM_NLSE_STEP: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_NLSE_STEP>(c, a, a.plan1); }); break;
+            case CM_NLSE_LAST: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_NLSE_LAST>(c, a, a.plan1); }); break;
+            case CM_MK: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_MK>(c, a, a.plan1); }); break;
+            case CM_PLAIN_FWD: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_PLAIN_FWD>(c, a, a.plan1); }); break;
+            default: run_grid(grid, block, lds, [&](EmuCtx &c) { col_mixed_body<T, CM_PLAIN_INV>(c, a, a.plan1); }); break;
             }
             return;
         }
@@ -415,7 +415,7 @@ static int rows_lin_t(int64_t N, int nrows, const void *in, void *out, double hz
     a.plan = plan;
     a.wtab = w.data();
     a.rows_per_wg = rows_wg;
-    run_grid(nrows / rows_wg, tpr * rows_wg, 4096 + (size_t)rows_wg * (size_t)N * sizeof(cx<T>), [&](EmuCtx &c) { row_mixed_body<T>(c, a); });
+    run_grid(nrows / rows_wg, tpr * rows_wg, 4096 + (size_t)rows_wg * (size_t)N * sizeof(cx<T>), [&](EmuCtx &c) { row_mixed_body<T>(c, a, a.plan); });
     return SSF_OK;
 }
 
