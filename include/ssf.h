@@ -463,7 +463,9 @@ int  ssf_rx_chain(int device, int64_t N, const ssf_rx_params *params, const void
  * host-side numpy draws in the reference: optic/comm/sources.py:137-212, optic/dsp/core.py:792-826).
  *   symbols   (nChannels, nPolModes, nSymbols) complex128
  *   taps      ntaps float64 (<= 4096)
- *   phi       (nChannels, N) float64 LO phase per channel, or NULL for an ideal laser; N = nSymbols * SpS
+ *   phi       (nChannels, N) float64 LO phase per channel -- or (1, N), one walk shared by every channel, with params->phi_rows = 1
+ *             (what a SEEDED reference run produces: tx.py:199 reseeds np.random with the same param.seed for every channel) --
+ *             or NULL for an ideal laser; N = nSymbols * SpS
  *   amp       nChannels: sqrt(Pch / nPolModes);   deltaF: nChannels grid offsets [Hz]
  *   sig_out   (N, nPolModes) complex128 (host or device);  power_out (may be NULL): nChannels * nPolModes */
 typedef struct {
@@ -476,6 +478,8 @@ typedef struct {
      * reference's own np.random draws in `phi`).  No N-sample array crosses the bus then. */
     double   pn_sigma;
     uint64_t pn_seed;
+    int32_t  phi_rows;   /* rows of `phi`: 0 or nChannels = one per channel; 1 = one row for all channels (uploaded once) */
+    int32_t  reserved;
 } ssf_tx_params;
 int  ssf_wdm_tx(int device, const ssf_tx_params *params, const void *symbols, const double *taps, const double *phi,
                 const double *amp, const double *deltaF, void *sig_out, double *power_out);

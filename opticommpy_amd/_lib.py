@@ -66,7 +66,7 @@ class TxParams(C.Structure):
     """ssf_tx_params (include/ssf.h)."""
     _fields_ = [("Fs", C.c_double), ("mzmScale", C.c_double), ("nSymbols", C.c_int64), ("SpS", C.c_int32),
                 ("nChannels", C.c_int32), ("nPolModes", C.c_int32), ("ntaps", C.c_int32),
-                ("pn_sigma", C.c_double), ("pn_seed", C.c_uint64)]
+                ("pn_sigma", C.c_double), ("pn_seed", C.c_uint64), ("phi_rows", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DeviceInfo(C.Structure):

@@ -124,7 +124,6 @@ static inline bool choose_mixed_split(int64_t N, int precision, int *l1, int *N2
 // power of two goes into the columns (2 000 000 = 2^7 x 15 625) -- split as N1 x N2 with BOTH factors mixed-radix: the column stage
 // is col_mixed_body (a tile of C columns x N1 of both polarisations in LDS), the row stage the mixed-radix rows as before.
 // Preference: both stages at two workgroups per CU, then wide global segments (C), then columns near 256.
-constexpr int kMix2MaxCol = 1024;
 inline size_t mix2_col_lds(int N1, int C, int npol, int elem_bytes) { return (size_t)kColMixScratch + (size_t)npol * C * N1 * elem_bytes; }
 // (force_n1 / force_c: the experiment knob SSF_MIX2 = "N1,C", parsed by the CALLER -- this function is emitted once per library, and
 //  the linker may keep the copy of a translation unit that was built without the experiment switches)
@@ -296,9 +295,19 @@ template <typename T, class Backend> class FusedCore {
         col_v = underfilled && sp.l1 != 7 ? 8 : 16;
         if (const char *e = tune_env("SSF_COL_V")) col_v = std::atoi(e) == 8 ? 8 : 16;
         if (N2mix || sp.l1 < 6 || sp.l1 > 10) col_v = 16;      // (ragged tiles / very short or very long columns: 16-value kernels only)
-        if (N1mix && !mix_make_plan(N1mix, &mix_plan1, 256 / (2 * mix_cols))) {
+        if (N1mix && !mix_make_plan(N1mix, &mix_plan1, 256 / (2 * mix_cols), false)) {
             err = "fused engine: no pass plan for the column length";
             return SSF_ERR_UNSUPPORTED;
+        }
+        if (const char *e = N1mix ? tune_env("SSF_MIX_PLAN1") : nullptr) {   // experiments: the column passes, "10,5,10"
+            int r[kMixMaxPass], n = 0;
+            for (const char *q = e; *q && n < kMixMaxPass;) {
+                r[n++] = std::atoi(q);
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            MixPlan mp;
+            if (mix_plan_from_radices(N1mix, r, n, &mp)) mix_plan1 = mp;
         }
         const int64_t nfft = (int64_t)rows_u() * n1();         // row transforms of one unit
         if (N2mix) {               // rows in LDS after 4 KiB of scratch; 128 threads per row while 16 values per thread suffice

@@ -756,12 +756,10 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
     }
     ctx.sync();
     ctx.mark(1);
-    mix_dif<-1>(ctx, p, t, T_, x, a.wtab);
-    ctx.mark(2);
     const int N1 = (int)row_n1(a);
     const int k1 = a.N1mix ? (int)(rr % N1) : (int)(rr & (N1 - 1));
-    // x linear operator: folded into the first pass of the inverse transform (mixed_fft.h: mix_apply_op), which reads
-    // the spectrum in runs of bins N / R apart.  (As a pass of its own over the row in LDS it was 6 of the 30 us of
+    // x linear operator: applied between the two butterflies of the stride-1 pass (mixed_fft.h: mix_pass_mid, mix_apply_op), which
+    // holds the spectrum in runs of bins N / R apart.  (As a pass of its own over the row in LDS it was 6 of the 30 us of
     // a launch at rows of 3750: one read-modify-write per bin, each waiting for the one before it.)
     MixRowOp op;
     {
@@ -776,8 +774,9 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
         op.N1 = N1;
         op.N = a.N;
     }
+    ctx.mark(2);
     ctx.mark(3);
-    mix_dit<+1>(ctx, p, t, T_, x, a.wtab, true, op);
+    mix_dif_op_dit(ctx, p, t, T_, x, a.wtab, op);                // (phase stamps: the whole sandwich is booked as "inv FFT")
     ctx.mark(4);
     for (int i = t; i < L; i += T_) g[i] = x[i];
     ctx.mark(5);
@@ -1763,7 +1762,8 @@ SSF_HD void col_body(Ctx &ctx, const ColArgs<T> &a) {
 // samples -- x and y of a sample are both in LDS, so nothing is exchanged between threads.  Same stages, same control block, same
 // partial sums as col_body (mk_col_stage); the sample set of the lim_0 bound / sparse field store is every sixteenth time row.
 // A general-purpose kernel: far from the roofline of the specialised ones, but device-resident and one launch per stage.
-constexpr int kColMixScratch = 8192;            // bytes of LDS in front of the tile: block reductions
+constexpr int kColMixScratch = 8192;            // bytes of LDS in front of the tile: block reductions (lower half), bin table (upper half)
+constexpr int kMix2MaxCol = 1024;               // longest column of this stage
 // (plan1: the column pass plan in the kernel arguments themselves -- see row_mixed_body)
 template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, const ColArgs<T> &a, const MixPlan &plan1) {
     static_assert(sizeof(T) == sizeof(scalar_t<T>), "one row per polarisation (no packed pairs)");
@@ -1780,6 +1780,12 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
     const long long rowbase0 = (long long)grp * npol * N, pbase = (long long)grp * N;
     double *red = (double *)ctx.lds;
     cx<T> *X = (cx<T> *)(ctx.lds + kColMixScratch);
+    // time row n1 of tile position pos (digit reversal): a table in the scratch area's upper half instead of mix_bin()'s run-time
+    // divisions per element and loop
+    unsigned short *binlut = (unsigned short *)(ctx.lds + kColMixScratch / 2);
+    static_assert(kMix2MaxCol * sizeof(unsigned short) <= kColMixScratch / 2, "bin table fits the scratch area");
+    for (int pos = ctx.tid; pos < N1; pos += ctx.nthreads) binlut[pos] = (unsigned short)mix_bin(plan1, pos);
+    ctx.sync();
 
     bool do_inv, do_fwd;
     MkColStage st;
@@ -1818,33 +1824,83 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
     const int ntr = npol << lgC, tr = ctx.tid % ntr, tt = ctx.tid / ntr, tpt = ctx.nthreads / ntr;
     cx<T> *xt = X + ((size_t)(tr >> lgC) * N1 << lgC) + (tr & (C - 1));
 
+    // Global loads go out in batches of U per thread, all of a batch issued before the first is consumed: the trip counts are run-time
+    // values, the compiler does not pipeline such loops by itself, and an iteration that waits for its own loads costs a memory
+    // latency each (round 6, 2 000 000 = 500 x 4000: G loads 6.9 us and time-domain work 12.7 us of a workgroup's 36 us,
+    // profiles/r6_mixed_phases.txt).  Addresses of elements a thread does not have are clamped to valid ones, their values dropped.
+    constexpr int U = 4;
+    ctx.mark(0);
     if (do_inv) {                                                     // G -> x cis(+...) -> inverse column transform
         cx<double> w = w0;
-        for (int k1 = ft; k1 < N1; k1 += Tt) {
-            for (int pol = 0; pol < npol; ++pol) {
-                const cx<T> v = fvalid ? a.G[rowbase0 + (long long)pol * N + (long long)k1 * N2 + fn2] : mk<T>((T)0, (T)0);
-                X[(((size_t)pol * N1 + k1) << lgC) + fc] = mul_by_d(v, w);
+        const int fn2c = fvalid ? fn2 : N2 - 1;
+        for (int k0 = ft; k0 < N1; k0 += U * Tt) {
+            cx<T> v[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k1 = k0 + u * Tt < N1 ? k0 + u * Tt : ft;
+#pragma unroll
+                for (int pol = 0; pol < 2; ++pol)
+                    if (pol < npol) v[u][pol] = a.G[rowbase0 + (long long)pol * N + (long long)k1 * N2 + fn2c];
             }
-            w = w * ws;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k1 = k0 + u * Tt;
+                if (k1 < N1) {
+#pragma unroll
+                    for (int pol = 0; pol < 2; ++pol)
+                        if (pol < npol) X[(((size_t)pol * N1 + k1) << lgC) + fc] = fvalid ? mul_by_d(v[u][pol], w) : mk<T>((T)0, (T)0);
+                    w = w * ws;
+                }
+            }
         }
         ctx.sync();
+        ctx.mark(1);
         mix_dif_strided<+1>(ctx, plan1, tt, tpt, xt, a.wtab1, C);
+        ctx.mark(2);
     }
     // ---- time-domain work on the tile ----------------------------------------------------------------------------
+    // element e of the tile: position e >> lgC of the transform's digit-reversed order, column e & (C - 1); el() gives its offset in a
+    // time-domain row buffer (0 for an element outside the tile or the field: a valid address whose value is not used)
+    struct El {
+        int pos, c;
+        long long toff;
+        bool in, ok;      // inside the tile; ... and inside the field (ragged last tile)
+    };
+    auto el = [&](int e) {
+        El r;
+        r.in = e < ne;
+        r.pos = r.in ? e >> lgC : 0;
+        r.c = e & (C - 1);
+        r.ok = r.in && n2base + r.c < N2;
+        r.toff = r.ok ? (long long)binlut[r.pos] * N2 + n2base + r.c : 0;
+        return r;
+    };
     // src -> X (time order), for the stages that start from a time-domain buffer
     auto load_time = [&](const cx<T> *src) {
-        for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
-            const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
-            const long long toff = (long long)mix_bin(plan1, pos) * N2 + n2;
-            for (int pol = 0; pol < npol; ++pol)
-                X[(((size_t)pol * N1 + pos) << lgC) + c] = n2 < N2 ? src[rowbase0 + (long long)pol * N + toff] : mk<T>((T)0, (T)0);
+        for (int e0 = ctx.tid; e0 < ne; e0 += U * ctx.nthreads) {
+            El q[U];
+            cx<T> v[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                q[u] = el(e0 + u * ctx.nthreads);
+#pragma unroll
+                for (int pol = 0; pol < 2; ++pol)
+                    if (pol < npol) v[u][pol] = src[rowbase0 + (long long)pol * N + q[u].toff];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (q[u].in) {
+#pragma unroll
+                    for (int pol = 0; pol < 2; ++pol)
+                        if (pol < npol) X[(((size_t)pol * N1 + q[u].pos) << lgC) + q[u].c] = q[u].ok ? v[u][pol] : mk<T>((T)0, (T)0);
+                }
         }
     };
     auto store_time = [&](cx<T> *dst, bool sparse) {
         for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
             const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
             if (n2 >= N2) continue;
-            const int n1 = mix_bin(plan1, pos);
+            const int n1 = binlut[pos];
             if (sparse && (n1 & 15)) continue;
             for (int pol = 0; pol < npol; ++pol) dst[rowbase0 + (long long)pol * N + (long long)n1 * N2 + n2] = X[(((size_t)pol * N1 + pos) << lgC) + c];
         }
@@ -1857,15 +1913,16 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
         store_time(a.T0, false);
     } else if (kMk) {
         const T shz = (T)(a.k.sgn * st.c.hz), c8g = (T)a.k.c8g;
+        const size_t yoff = (size_t)N1 << lgC;                        // the y polarisation's half of the tile
         // step start (channels.py:388-395): Pch -> Pbuf, block max of phi -> pmax
         auto step_start = [&](T *Pbuf) {
             double m = -INFINITY;
             for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
                 const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
                 if (n2 >= N2) continue;
-                const T ax = norm2(X[e]), ay = norm2(X[((size_t)N1 << lgC) + e]);
+                const T ax = norm2(X[e]), ay = norm2(X[yoff + e]);
                 const T pw = ax + ay;
-                Pbuf[pbase + (long long)mix_bin(plan1, pos) * N2 + n2] = pw;
+                Pbuf[pbase + (long long)binlut[pos] * N2 + n2] = pw;
                 const T phi = c8g * (pw + ax + ay) / (T)2;
                 m = (double)phi > m ? (double)phi : m;
             }
@@ -1876,13 +1933,22 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
         };
         // first rotation of a step (channels.py:409-417): X <- X cis(shz phi(Pch, Pch))
         auto rotate0 = [&]() {
-            for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
-                const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
-                if (n2 >= N2) continue;
-                const T pw = Pcur[pbase + (long long)mix_bin(plan1, pos) * N2 + n2];
-                const cx<T> rot = cis_t<T>(shz * (c8g * (pw + pw) / (T)2));
-                X[e] = X[e] * rot;
-                X[((size_t)N1 << lgC) + e] = X[((size_t)N1 << lgC) + e] * rot;
+            for (int e0 = ctx.tid; e0 < ne; e0 += U * ctx.nthreads) {
+                El q[U];
+                T pw[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    q[u] = el(e0 + u * ctx.nthreads);
+                    pw[u] = Pcur[pbase + q[u].toff];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (q[u].ok) {
+                        const int e = e0 + u * ctx.nthreads;
+                        const cx<T> rot = cis_t<T>(shz * (c8g * (pw[u] + pw[u]) / (T)2));
+                        X[e] = X[e] * rot;
+                        X[yoff + e] = X[yoff + e] * rot;
+                    }
             }
         };
         if (op == 0) {
@@ -1907,7 +1973,7 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
                 for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
                     const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
                     if (n2 >= N2) continue;
-                    const int n1 = mix_bin(plan1, pos);
+                    const int n1 = binlut[pos];
                     if (!st.exact0 && (n1 & 15)) continue;
                     for (int pol = 0; pol < npol; ++pol) {
                         const cx<T> e0 = Tcur[rowbase0 + (long long)pol * N + (long long)n1 * N2 + n2], v = X[(((size_t)pol * N1 + pos) << lgC) + c];
@@ -1921,24 +1987,35 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
                 store_time(Tnew, st.sparse);
             } else {
                 // next iterate (channels.py:436, 414-417): X <- E_hd rot_{it+1}; sums of lim_{it+1} (see the note at the top of this file)
-                for (int e = ctx.tid; e < ne; e += ctx.nthreads) {
-                    const int pos = e >> lgC, c = e & (C - 1), n2 = n2base + c;
-                    if (n2 >= N2) continue;
-                    const long long toff = (long long)mix_bin(plan1, pos) * N2 + n2;
-                    const T pw = Pcur[pbase + toff];
-                    const T ax = norm2(X[e]), ay = norm2(X[((size_t)N1 << lgC) + e]);
-                    const T ang = shz * (c8g * (pw + ax + ay) / (T)2);
-                    const T prev = first ? shz * (c8g * (pw + pw) / (T)2) : a.Theta[pbase + toff];
-                    psum += (double)pw;
-                    a.Theta[pbase + toff] = ang;
-                    const double sh = sin_half_angle((double)ang - (double)prev);
-                    const cx<T> rot = cis_t<T>(ang);
-                    const cx<T> hx = a.Ehd[rowbase0 + toff], hy = a.Ehd[rowbase0 + N + toff];
-                    const double w = (double)norm2(hx) + (double)norm2(hy);
-                    n1s += w * (4.0 * sh * sh);
-                    d1 += w;
-                    X[e] = hx * rot;
-                    X[((size_t)N1 << lgC) + e] = hy * rot;
+                for (int e0 = ctx.tid; e0 < ne; e0 += U * ctx.nthreads) {
+                    El q[U];
+                    T pw[U], prev[U];
+                    cx<T> hx[U], hy[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        q[u] = el(e0 + u * ctx.nthreads);
+                        pw[u] = Pcur[pbase + q[u].toff];
+                        prev[u] = first ? (T)0 : a.Theta[pbase + q[u].toff];
+                        hx[u] = a.Ehd[rowbase0 + q[u].toff];
+                        hy[u] = a.Ehd[rowbase0 + N + q[u].toff];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (q[u].ok) {
+                            const int e = e0 + u * ctx.nthreads;
+                            const T ax = norm2(X[e]), ay = norm2(X[yoff + e]);
+                            const T ang = shz * (c8g * (pw[u] + ax + ay) / (T)2);
+                            const T pv = first ? shz * (c8g * (pw[u] + pw[u]) / (T)2) : prev[u];
+                            psum += (double)pw[u];
+                            a.Theta[pbase + q[u].toff] = ang;
+                            const double sh = sin_half_angle((double)ang - (double)pv);
+                            const cx<T> rot = cis_t<T>(ang);
+                            const double w = (double)norm2(hx[u]) + (double)norm2(hy[u]);
+                            n1s += w * (4.0 * sh * sh);
+                            d1 += w;
+                            X[e] = hx[u] * rot;
+                            X[yoff + e] = hy[u] * rot;
+                        }
                 }
                 if (!st.exact0) d0 = psum;                            // exact denominator of the bound: sum Pch over the tile
             }
@@ -1962,9 +2039,11 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
         }
     }
     // ---- forward column transform -> x cis(-...) -> G ---------------------------------------------------------------
+    ctx.mark(3);
     if (do_fwd) {
         ctx.sync();
         mix_dit_strided<-1>(ctx, plan1, tt, tpt, xt, a.wtab1, C);
+        ctx.mark(4);
         cx<double> w = conj(w0);
         const cx<double> wsc = conj(ws);
         for (int k1 = ft; k1 < N1; k1 += Tt) {
@@ -1973,6 +2052,8 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
                     a.G[rowbase0 + (long long)pol * N + (long long)k1 * N2 + fn2] = mul_by_d(X[(((size_t)pol * N1 + k1) << lgC) + fc], w);
             w = w * wsc;
         }
+        ctx.mark(5);
+        ctx.flush(do_inv ? 0 : 1);
     }
 }
 

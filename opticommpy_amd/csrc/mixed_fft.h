@@ -31,7 +31,11 @@ struct MixPlan {
 constexpr int kMixRadices[] = {25, 20, 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
 constexpr double kMixRadixCost[] = {440, 335, 256, 237, 180, 145, 125, 108, 80, 65, 48, 30, 20};   // (fitted to plan sweeps at L = 1875, 375: tools/exp/mix_plan_sweep.py)
 constexpr double kMixBarrierCost = 100;
-constexpr double kMixOpCostFixed = 350, kMixOpCostPerValue = 12;   // mix_apply_op: four sin/cos per butterfly + two products per value
+// The plan's last pass of a ROW is the stride-1 pass, which runs as one pass for both directions with the row operator between its two
+// butterflies (mix_pass_mid): cost of one such butterfly, measured rather than modelled (round 6, after the operator's two starts
+// moved out of the unrolled loop: plan sweeps at L = 4000, 3750, 3125 with 256 threads, profiles/r6_mix_plan_sweeps.txt -- radix 10
+// beats 16 by 9 % of a row launch although it needs two rounds of butterflies, 8 and 15 sit in between).
+constexpr double kMixMidCost[] = {0, 0, 270, 270, 270, 270, 290, 0, 480, 480, 470, 0, 700, 0, 0, 900, 1100};   // indexed by the radix
 constexpr int kMixMaxOpRadix = 16;   // the plan's last pass also applies the row operator (mix_apply_op): no room for that at 20 / 25
 
 inline bool mix_plan_from_radices(int L, const int *r, int n, MixPlan *p) {
@@ -50,18 +54,16 @@ inline bool mix_plan_from_radices(int L, const int *r, int n, MixPlan *p) {
     return rest == 1 && p->npass > 0;
 }
 
-inline bool mix_make_plan(int L, MixPlan *p, int T = 0) {
+// with_op: the plan is a ROW's (its last pass is mix_pass_mid: radix <= kMixMaxOpRadix, costed by kMixMidCost); a column stage's
+// plan (col_mixed_body: no operator inside the transform) may end on any radix
+inline bool mix_make_plan(int L, MixPlan *p, int T = 0, bool with_op = true) {
     // enumerate ordered factorisations; the cost of a pass depends on its radix and on L only
     int cur[kMixMaxPass], best_r[kMixMaxPass], best_n = 0;
     double best = 1e300;
     struct Rec {
-        static void go(int L, int rest, int T, int depth, double cost, int *cur, double *best, int *best_r, int *best_n) {
+        static void go(int L, int rest, int T, bool with_op, int depth, double cost, int *cur, double *best, int *best_r, int *best_n) {
             if (rest == 1) {
-                if (depth > 0 && T > 0) {                              // the last pass also applies the row operator
-                    const int rl = cur[depth - 1];
-                    cost += (double)(((L / rl) + T - 1) / T) * (kMixOpCostFixed + kMixOpCostPerValue * rl);
-                }
-                if (depth > 0 && cur[depth - 1] <= kMixMaxOpRadix && cost < *best) {
+                if (depth > 0 && cost < *best) {
                     *best = cost;
                     *best_n = depth;
                     for (int i = 0; i < depth; ++i) best_r[i] = cur[i];
@@ -72,15 +74,18 @@ inline bool mix_make_plan(int L, MixPlan *p, int T = 0) {
             for (int c = 0; c < (int)(sizeof(kMixRadices) / sizeof(int)); ++c) {
                 const int r = kMixRadices[c];
                 if (rest % r) continue;
+                const bool mid = with_op && rest == r;                 // the stride-1 pass of a row
+                if (mid && r > kMixMaxOpRadix) continue;
                 double pass;
-                if (T > 0) pass = (double)(((L / r) + T - 1) / T) * kMixRadixCost[c] + kMixBarrierCost;
+                if (T > 0) pass = (double)(((L / r) + T - 1) / T) * (mid ? kMixMidCost[r] : kMixRadixCost[c]) + kMixBarrierCost;
                 else pass = 1.0;                                       // fewest passes; ties: largest radix first (loop order)
+                if (T > 0) pass += 1e-3 * r * (kMixMaxPass - depth);   // ties: the larger radix later (500 = 20 x 25: 63.0 us against 65.9 as 25 x 20)
                 cur[depth] = r;
-                go(L, rest / r, T, depth + 1, cost + pass, cur, best, best_r, best_n);
+                go(L, rest / r, T, with_op, depth + 1, cost + pass, cur, best, best_r, best_n);
             }
         }
     };
-    Rec::go(L, L, T, 0, 0.0, cur, &best, best_r, &best_n);
+    Rec::go(L, L, T, with_op, 0, 0.0, cur, &best, best_r, &best_n);
     if (!best_n) return false;
     return mix_plan_from_radices(L, best_r, best_n, p);
 }
@@ -240,20 +245,27 @@ struct MixRowOp {
 template <int R, typename T> SSF_HD void mix_apply_op(const MixPlan &p, const MixRowOp &op, int blk, cx<T> *v) {
     const long long k0 = op.k1 + op.N1 * (long long)mix_bin(p, blk * R);
     const long long D = op.N / R, npos = (op.N + 1) / 2;
-    cx<double> u = mk<double>(0.0, 0.0), vv = u;
-    bool wrapped = false;
+    // the run of non-negative bins starts at q = 0, the run of negative ones at qs (the first q with k0 + q D >= npos; R: none).
+    // Both starts are evaluated up front, side by side (four independent sin/cos evaluations), and the loop below only picks:
+    // as a restart inside the unrolled loop the evaluation was emitted R times (code size) behind a divergent branch each.
+    int qs = R;
+#pragma unroll
+    for (int q = R - 1; q >= 0; --q)
+        if (k0 + q * D >= npos) qs = q;
+    const double fa = (double)(qs == 0 ? k0 - op.N : k0);
+    const double fb = (double)(k0 + (qs < R ? qs : 0) * D - op.N);
+    double ca, sa, cva, sva, cb, sb, cvb, svb;
+    cis_rad_d(op.cth * fa * fa, ca, sa);
+    cis_rad_d(op.cth * (2.0 * fa * op.D + op.D * op.D), cva, sva);
+    cis_rad_d(op.cth * fb * fb, cb, sb);
+    cis_rad_d(op.cth * (2.0 * fb * op.D + op.D * op.D), cvb, svb);
+    cx<double> u = mk<double>(op.mag * ca, op.mag * sa), vv = mk<double>(cva, sva);
+    const cx<double> ub = mk<double>(op.mag * cb, op.mag * sb), vb = mk<double>(cvb, svb);
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const long long kbin = k0 + q * D;
-        const bool neg = kbin >= npos;
-        if (q == 0 || (neg && !wrapped)) {           // (re)start: first value, and the first negative bin
-            const double fk = (double)(neg ? kbin - op.N : kbin);
-            double c, s;
-            cis_rad_d(op.cth * fk * fk, c, s);
-            u = mk<double>(op.mag * c, op.mag * s);
-            cis_rad_d(op.cth * (2.0 * fk * op.D + op.D * op.D), c, s);
-            vv = mk<double>(c, s);
-            wrapped = neg;
+        if (q > 0 && q == qs) {
+            u = ub;
+            vv = vb;
         }
         v[q] = mul_by_d(v[q], u);
         u = u * vv;
@@ -330,22 +342,37 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
     ctx.sync();
 }
 
+// experiment builds: SSF_MIX_RADIX_SET = list of the radices the kernels carry (code-size experiments; a plan with another radix
+// would fall into the smallest carried one: experiment libraries only)
+#ifdef SSF_MIX_RADIX_SET
+constexpr bool mix_has_radix(int r) {
+    constexpr int set[] = {SSF_MIX_RADIX_SET};
+    for (int q : set)
+        if (q == r) return true;
+    return false;
+}
+#else
+constexpr bool mix_has_radix(int) { return true; }
+#endif
+#define SSF_MIX_CASE(R, ...) \
+    case R:                  \
+        if constexpr (mix_has_radix(R)) { __VA_ARGS__; break; }
 template <int SIGN, bool DIF, bool STR = false, typename T, class Ctx>
 SSF_HD void mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab,
                          bool use_op, const MixRowOp &op, int es = 1) {
     switch (p.r[i]) {
-    case 25: mix_pass<SIGN, 25, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 20: mix_pass<SIGN, 20, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 16: mix_pass<SIGN, 16, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 15: mix_pass<SIGN, 15, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 12: mix_pass<SIGN, 12, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 10: mix_pass<SIGN, 10, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 9: mix_pass<SIGN, 9, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 8: mix_pass<SIGN, 8, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 6: mix_pass<SIGN, 6, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 5: mix_pass<SIGN, 5, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 4: mix_pass<SIGN, 4, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
-    case 3: mix_pass<SIGN, 3, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    SSF_MIX_CASE(25, mix_pass<SIGN, 25, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(20, mix_pass<SIGN, 20, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(16, mix_pass<SIGN, 16, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(15, mix_pass<SIGN, 15, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(12, mix_pass<SIGN, 12, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(10, mix_pass<SIGN, 10, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(9, mix_pass<SIGN, 9, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(8, mix_pass<SIGN, 8, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(6, mix_pass<SIGN, 6, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(5, mix_pass<SIGN, 5, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(4, mix_pass<SIGN, 4, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
+    SSF_MIX_CASE(3, mix_pass<SIGN, 3, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
     default: mix_pass<SIGN, 2, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
     }
 }
@@ -368,6 +395,47 @@ template <int SIGN, typename T, class Ctx>
 SSF_HD void mix_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab = nullptr) {
     const MixRowOp none{};
     mix_dit<SIGN>(ctx, p, t, nthreads, x, wtab, false, none);
+}
+// Forward transform, row operator, inverse transform of a row in LDS.  The last forward pass and the first inverse pass (stride 1)
+// work on the same R values of the same thread: they run as one pass, the values stay in registers between the two butterflies (one LDS
+// round trip and one barrier less per row; same operations in the same order as mix_dif<-1> followed by mix_dit<+1> with the operator).
+template <int R, typename T, class Ctx>
+SSF_HD void mix_pass_mid(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const MixRowOp &op) {
+    const int nbf = p.L / R;
+    for (int bf = t; bf < nbf; bf += nthreads) {
+        cx<T> *base = x + bf * R;
+        cx<T> v[R], w[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = base[q];
+        dft_small<-1, R>(v);
+#pragma unroll
+        for (int k = 0; k < R; ++k) w[k] = v[dft_bin_slot<R>(k)];      // slot order -> bin order (a renaming)
+        mix_apply_op<R>(p, op, bf, w);
+        dft_small<+1, R>(w);
+#pragma unroll
+        for (int sl = 0; sl < R; ++sl) base[dft_slot_bin<R>(sl)] = w[sl];
+    }
+    ctx.sync();
+}
+template <typename T, class Ctx>
+SSF_HD void mix_dif_op_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab, const MixRowOp &op) {
+    const MixRowOp none{};
+    const int last = p.npass - 1;
+    for (int i = 0; i < last; ++i) mix_pass_any<-1, true>(ctx, p, i, t, nthreads, x, wtab, false, none);
+    switch (p.r[last]) {
+    SSF_MIX_CASE(16, mix_pass_mid<16>(ctx, p, t, nthreads, x, op))
+    SSF_MIX_CASE(15, mix_pass_mid<15>(ctx, p, t, nthreads, x, op))
+    SSF_MIX_CASE(12, mix_pass_mid<12>(ctx, p, t, nthreads, x, op))
+    SSF_MIX_CASE(10, mix_pass_mid<10>(ctx, p, t, nthreads, x, op))
+    SSF_MIX_CASE(9, mix_pass_mid<9>(ctx, p, t, nthreads, x, op))
+    SSF_MIX_CASE(8, mix_pass_mid<8>(ctx, p, t, nthreads, x, op))
+    SSF_MIX_CASE(6, mix_pass_mid<6>(ctx, p, t, nthreads, x, op))
+    SSF_MIX_CASE(5, mix_pass_mid<5>(ctx, p, t, nthreads, x, op))
+    SSF_MIX_CASE(4, mix_pass_mid<4>(ctx, p, t, nthreads, x, op))
+    SSF_MIX_CASE(3, mix_pass_mid<3>(ctx, p, t, nthreads, x, op))
+    default: mix_pass_mid<2>(ctx, p, t, nthreads, x, op); break;
+    }
+    for (int i = last - 1; i >= 0; --i) mix_pass_any<+1, false>(ctx, p, i, t, nthreads, x, wtab, false, none);
 }
 // the same pair over elements `es` slots apart (column stage: the columns of a tile interleaved in LDS)
 template <int SIGN, typename T, class Ctx>

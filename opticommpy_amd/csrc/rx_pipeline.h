@@ -767,7 +767,7 @@ template <class Backend> struct RxCore {
     }
 
     // simpleWDMTx's signal path (tx.py:178-217) for all channels and polarisations; symbols (nCh, nPol, nSymbols),
-    // taps (ntaps real), phi (nCh, N) or null, amp[nCh] = sqrt(Pch / nPol), deltaF[nCh]; out (N, nPol), N = nSymbols * SpS
+    // taps (ntaps real), phi (nCh, N) -- (1, N) with p.phi_rows = 1 -- or null, amp[nCh] = sqrt(Pch / nPol), deltaF[nCh]; out (N, nPol), N = nSymbols * SpS
     int wdm_tx(const ssf_tx_params &p, const void *symbols, const double *taps, const double *phi, const double *amp,
                const double *deltaF, void *out, double *power_out) {
         const long long nS = p.nSymbols, N = nS * p.SpS;
@@ -798,7 +798,8 @@ template <class Backend> struct RxCore {
         std::vector<double> part((size_t)nblocks);
         const double erLin = std::pow(10.0, 60.0 / 10), gamma = 2 * std::sqrt(erLin) / (erLin + 1);   // devices.py:185-188 defaults
         for (int ch = 0; ch < nCh; ++ch) {
-            if (phi) be.h2d_big(dphi, phi + (size_t)ch * N, sizeof(double) * (size_t)N);
+            if (phi && p.phi_rows != 0 && p.phi_rows != 1 && p.phi_rows != nCh) return fail(SSF_ERR_BAD_ARG, "ssf_wdm_tx: phi_rows is 0, 1 or nChannels");
+            if (phi && (p.phi_rows != 1 || ch == 0)) be.h2d_big(dphi, phi + (p.phi_rows == 1 ? 0 : (size_t)ch * N), sizeof(double) * (size_t)N);
             if (dev_pn) {
                 PnArgs pa{nullptr, dcs, N, p.pn_sigma, (unsigned long long)p.pn_seed, (unsigned)ch};
                 be.launch_pn(pa, pn_chunks);

@@ -212,8 +212,13 @@ def simpleWDMTx(param, device_output=False):
     # linewidth), so a caller who seeds np.random globally and leaves param.seed = None gets a reproducible reference run whose
     # symbols after channel 0 / mode 0 this call does not reproduce draw for draw; pass param.seed for that.
     device_pn = bool(param.laserLinewidth) and param.seed is None
-    phi = np.empty((nCh, N)) if (param.laserLinewidth and not device_pn) else None
+    # WITH a seed the reference reseeds np.random with the SAME param.seed before every channel's walk (tx.py:199): every channel
+    # gets the same N - 1 draws.  They are drawn once and one row crosses the bus (ssf_tx_params.phi_rows = 1); np.random's global
+    # state is left as the reference leaves it -- the state after the walk's draws when that is the last thing the loop draws
+    # (one polarisation), the last symbol source's otherwise.  (Round 5 drew them per channel: 11 x 19 ms at 2^20 samples.)
+    phi = None
     seed = param.seed
+    walk_state = None
     for ch in range(nCh):                                          # the reference's draw order (tx.py:184-210)
         logg.info("channel %d\t fc : %3.4f THz" % (ch, (param.Fc + freqGrid[ch]) / 1e12))
         for mode in range(nPol):
@@ -222,12 +227,19 @@ def simpleWDMTx(param, device_output=False):
             if param.seed is not None:
                 seed += 1
             if mode == 0 and param.seed is not None:
-                pn = phaseNoise(param.laserLinewidth, N, 1 / Fs, seed=param.seed)      # drawn even when the linewidth is 0: the
-                if phi is not None:                                                     # draws move the seeded stream (tx.py:199)
-                    phi[ch] = pn
+                if ch == 0 and param.laserLinewidth:
+                    phi = np.ascontiguousarray(phaseNoise(param.laserLinewidth, N, 1 / Fs, seed=param.seed).reshape(1, N))
+                    walk_state = np.random.get_state()
+                elif nPol == 1 and ch == nCh - 1:                  # the loop's last draw: leave the stream where the reference does
+                    if walk_state is not None:
+                        np.random.set_state(walk_state)
+                    else:
+                        phaseNoise(param.laserLinewidth, N, 1 / Fs, seed=param.seed)
 
     p = _lib.TxParams(Fs=Fs, mzmScale=float(param.mzmScale), nSymbols=nSymbols, SpS=int(param.SpS), nChannels=nCh,
                       nPolModes=nPol, ntaps=len(pulse))
+    if phi is not None:
+        p.phi_rows = 1
     if device_pn:
         from .models import _device_seed
         p.pn_sigma = float(np.sqrt(2 * np.pi * param.laserLinewidth / Fs))

@@ -78,3 +78,26 @@ def test_laser_phase_noise_is_generated_on_the_device_when_there_is_no_seed(monk
     a, _, _ = oa.simpleWDMTx(make_param(oa.parameters, dict(kw, seed=5)))
     b, _, _ = oa.simpleWDMTx(make_param(oa.parameters, dict(kw, seed=5)))
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("nPol,lw,nCh", [(1, 0.0, 3), (1, 2e5, 3), (2, 2e5, 2), (2, 0.0, 2), (1, 2e5, 1)])
+def test_seeded_phase_walk_is_drawn_once_and_the_global_stream_ends_where_the_reference_leaves_it(nPol, lw, nCh):
+    """tx.py:199 reseeds np.random with the same param.seed before every channel's walk: all channels share one walk, which is drawn
+    once and uploaded as one row (ssf_tx_params.phi_rows = 1).  Field, symbols AND np.random's state after the call are the
+    oracle's (which draws per channel, as the reference does)."""
+    from oracle import tx_oracle
+    kw = dict(M=16, nBits=4 * 512, SpS=8, nChannels=nCh, nPolModes=nPol, laserLinewidth=lw, seed=21, nFilterTaps=64, prgsBar=False)
+    ref, symb_ref, _ = tx_oracle.simpleWDMTx(make_param(oa.parameters, kw))
+    want = np.random.random_sample(4)                      # what a caller drawing from the global stream sees next
+    calls = []
+    real = wdm_tx.phaseNoise
+    wdm_tx.phaseNoise = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        sig, symb, _ = oa.simpleWDMTx(make_param(oa.parameters, kw))
+    finally:
+        wdm_tx.phaseNoise = real
+    got = np.random.random_sample(4)
+    assert np.array_equal(symb, symb_ref)
+    assert np.max(np.abs(sig - ref)) <= 1e-12 * np.max(np.abs(ref))
+    assert np.array_equal(got, want)
+    assert len(calls) == (1 if (lw or nPol == 1) else 0)
