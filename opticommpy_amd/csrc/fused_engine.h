@@ -147,6 +147,16 @@ static inline bool choose_mixed2_split(int64_t N, int precision, int *N1o, int *
             if (cl > 156 * 1024) continue;
             double score = (cl <= 80 * 1024 ? 0.0 : 4.0) + ((rl <= 72 * 1024 && n2 <= 4096) ? 0.0 : 3.0) + (C == 8 ? 0.0 : C == 4 ? 1.0 : 3.0) +
                            0.5 * std::fabs(std::log2((double)n1 / 256.0));
+            // short fields: both launches should still put a workgroup on every CU (200 000 = 125 x 1600: C = 4, 400 column
+            // workgroups, 7 127 steps/s; C = 8, 200 workgroups, 6 724; 250 x 800 with C = 8: 5 681 -- profiles/r6_mix2_short.txt)
+            const double col_wgs = (double)((n2 + C - 1) / C), row_wgs = (2 * n1 >= 1024 && n2 <= 2048) ? (double)n1 : 2.0 * n1;
+            score += 4.0 * std::max(0.0, std::log2(256.0 / col_wgs)) + 4.0 * std::max(0.0, std::log2(256.0 / row_wgs));
+            // ... and a column length whose passes take one round of butterflies each with the threads a transform gets (125 = 5 x 5 x 5
+            // with 32 threads: column launch 19.3 us; 200 = 5 x 5 x 8, two rounds in two passes: 24.2 us)
+            MixPlan cp;
+            const int tcol = 256 / (2 * C);
+            if (mix_make_plan(n1, &cp, tcol, false))
+                for (int i = 0; i < cp.npass; ++i) score += 0.5 * (double)((n1 / cp.r[i] + tcol - 1) / tcol - 1);
             if (score < best) {
                 best = score;
                 *N1o = n1;
@@ -156,6 +166,29 @@ static inline bool choose_mixed2_split(int64_t N, int precision, int *N1o, int *
         }
     }
     return best < 1e300;
+}
+
+// The split of a length that is not a power of two.  l1 > 0: power-of-two columns (2^l1) x mixed-radix rows (N2); N1 > 0: both factors
+// mixed-radix (column stage col_mixed_body, C columns per workgroup).  f1 / fc: the experiment knob SSF_MIX2 (force the second kind).
+// A length with fewer than seven factors of two (200 000 = 2^6 x 3125) takes the second kind although the first exists: 2 x 64 rows
+// of 3125 leave most of 256 CUs idle, 125 x 1600 fills them: 5 293 -> 7 127 steps/s (profiles/r6_mix2_short.txt).
+static inline bool choose_nonpow2_split(int64_t N, int precision, int f1, int fc, bool l1_forced, int *l1, int *N1, int *N2, int *C) {
+    *l1 = *N1 = *N2 = *C = 0;
+    if (f1 > 0 && choose_mixed2_split(N, precision, N1, N2, C, f1, fc)) return true;
+    if (!choose_mixed_split(N, precision, l1, N2)) {
+        *l1 = *N2 = 0;
+        return choose_mixed2_split(N, precision, N1, N2, C);
+    }
+    if (*l1 < 7 && !l1_forced) {
+        int n1 = 0, n2 = 0, c = 0;
+        if (choose_mixed2_split(N, precision, &n1, &n2, &c)) {
+            *l1 = 0;
+            *N1 = n1;
+            *N2 = n2;
+            *C = c;
+        }
+    }
+    return true;
 }
 
 // T = double / float: one complex row per polarisation (nrows rows);  T = pf2: the packed pair of the complex64
@@ -240,11 +273,8 @@ template <typename T, class Backend> class FusedCore {
                 f1 = std::atoi(e);
                 if (const char *q = std::strchr(e, ',')) fc = std::atoi(q + 1);
             }
-            if (f1 > 0 && choose_mixed2_split(N, precision, &N1mix, &N2mix, &mix_cols, f1, fc)) {
-            } else if (!choose_mixed_split(N, precision, &sp.l1, &N2mix)) {
-                N2mix = 0;
-                if (!choose_mixed2_split(N, precision, &N1mix, &N2mix, &mix_cols)) N1mix = N2mix = mix_cols = 0;
-            }
+            if (!choose_nonpow2_split(N, precision, f1, fc, tune_env("SSF_MIX_L1") != nullptr, &sp.l1, &N1mix, &N2mix, &mix_cols))
+                sp.l1 = N1mix = N2mix = mix_cols = 0;
         }
         field_bytes = sizeof(C) * (size_t)N * (size_t)nrows;
     }

@@ -440,8 +440,9 @@ int emu_mixed2_split(int64_t N, int precision, int *n1, int *n2, int *c) {
         f1 = atoi(e);
         if (const char *q = strchr(e, ',')) fc = atoi(q + 1);
     }
-    if (!f1 && ssf::fused::choose_mixed_split(N, precision, &l1, &m2)) return 0;
-    return ssf::fused::choose_mixed2_split(N, precision, n1, n2, c, f1, fc) ? 1 : 0;
+    if (!ssf::fused::choose_nonpow2_split(N, precision, f1, fc, getenv("SSF_MIX_L1") != nullptr, &l1, n1, &m2, c)) return 0;
+    *n2 = m2;
+    return *n1 > 0 ? 1 : 0;
 }
 int emu_split(int64_t N, int precision, int *l1, int *l2) {
     int l = 0;

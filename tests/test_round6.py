@@ -139,7 +139,8 @@ def test_the_split_of_the_reference_benchmarks_top_size():
         sp = _mix2(N)
         assert sp is not None and sp[0] * sp[1] == N and 16 <= sp[0] <= 1024 and 64 <= sp[1] <= 8192 and sp[2] in (2, 4, 8), (N, sp)
     assert _mix2(2_000_000) == (500, 4000, 4)                     # two workgroups per CU in both stages (fused_engine.h)
-    assert _mix2(240_000) is None and _mix2(1 << 20) is None      # (the radix-2^n columns keep what they take)
+    assert _mix2(240_000) is None and _mix2(800_000) is None and _mix2(1 << 20) is None      # (the radix-2^n columns keep what they take ...
+    assert _mix2(200_000) == (125, 1600, 4)                       #  ... when the length has at least seven factors of two: 2 x 64 rows of 3125 would not fill the chip)
     assert _mix2(7 * 4096) is None                                # (not 5-smooth: Bluestein)
 
 
