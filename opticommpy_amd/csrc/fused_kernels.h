@@ -708,7 +708,6 @@ template <typename T> SSF_HD cx<T> lin_at_n(const LinOp &lo, long long k, long l
 // into scratch memory -- 420 bytes per lane and a memory round trip for every p.S[i] (round 6: SQ_INSTS_VMEM_RD 139 per wave
 // against 34 in the radix-2^n rows; profiles/r6_mixed_rows.txt).  The wrappers pass the kernel parameter's own member.
 template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowArgs<T> &a, const MixPlan &p) {
-    constexpr int kMaxPerThread = 16;                      // L <= 16 * threads per row
     const int L = a.N2, R_ = a.rows_per_wg, T_ = ctx.nthreads / R_;
     const int f = ctx.tid / T_, t = ctx.tid - f * T_;      // row within the workgroup, thread within the row
     cx<T> *x = (cx<T> *)(ctx.lds + 4096) + (size_t)f * L;
@@ -736,33 +735,22 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
         }
         ctx.issue_fence();
     }
-    cx<T> v[kMaxPerThread];
     ctx.mark(0);
-#pragma unroll
-    for (int m = 0; m < kMaxPerThread; ++m) {
-        const int i = t + T_ * m;
-        v[m] = i < L ? gin[i] : mk<T>((T)0, (T)0);
-    }
-    if (a.use_ctrl) {
-        ctx.issue_fence();
-        if (!row_ctrl(ctx, a, part, lo)) return;
-    } else {
-        lo = *a.lin;
-    }
-#pragma unroll
-    for (int m = 0; m < kMaxPerThread; ++m) {
-        const int i = t + T_ * m;
-        if (i < L) x[i] = v[m];
-    }
-    ctx.sync();
-    ctx.mark(1);
     const int N1 = (int)row_n1(a);
     const int k1 = a.N1mix ? (int)(rr % N1) : (int)(rr & (N1 - 1));
     // x linear operator: applied between the two butterflies of the stride-1 pass (mixed_fft.h: mix_pass_mid, mix_apply_op), which
     // holds the spectrum in runs of bins N / R apart.  (As a pass of its own over the row in LDS it was 6 of the 30 us of
     // a launch at rows of 3750: one read-modify-write per bin, each waiting for the one before it.)
     MixRowOp op;
-    {
+    // The row is staged into LDS with the control logic behind its loads, and goes from the last pass's butterflies straight back to
+    // global memory (mix_dif_op_dit; SSF_MIX_IO).
+    auto ctrl = [&]() {
+        if (a.use_ctrl) {
+            ctx.issue_fence();
+            if (!row_ctrl(ctx, a, part, lo)) return false;
+        } else {
+            lo = *a.lin;
+        }
         const int Rl = p.r[p.npass - 1];
         op.cth = lo.cth;
         op.mag = lo.mag;
@@ -773,12 +761,10 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
         op.k1 = k1;
         op.N1 = N1;
         op.N = a.N;
-    }
-    ctx.mark(2);
-    ctx.mark(3);
-    mix_dif_op_dit(ctx, p, t, T_, x, a.wtab, op);                // (phase stamps: the whole sandwich is booked as "inv FFT")
+        return true;
+    };
+    if (!mix_dif_op_dit(ctx, p, t, T_, x, a.wtab, op, gin, g, ctrl)) return;
     ctx.mark(4);
-    for (int i = t; i < L; i += T_) g[i] = x[i];
     ctx.mark(5);
     ctx.flush(0);
 }

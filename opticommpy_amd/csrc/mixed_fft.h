@@ -278,17 +278,37 @@ template <int R, typename T> SSF_HD void mix_apply_op(const MixPlan &p, const Mi
 // tw_powers for why single precision does not build it in float) and consumed as they are produced.
 // STR: the transform's elements are `es` slots apart (the column stage keeps the C columns of a tile interleaved in LDS:
 // col_mixed_body); rows are contiguous (STR = false: no multiplication by a run-time stride in their index arithmetic)
-template <int SIGN, int R, bool DIF, bool STR = false, typename T, class Ctx>
-SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab,
-                     bool use_op, const MixRowOp &op, int es = 1) {
+// IO (rows only, pass 0 -- the one whose block is the whole row): 1 = the butterflies read the row from global memory (`g`) instead
+// of LDS, and `hook` runs once per thread after the first round's loads are issued (the row stage's control logic: it waits for
+// other data and may end the launch -- it returns false, so does the pass); 2 = the butterflies write the row to global memory.
+// Either way a row crosses LDS once less (round 6: no staging copy in front of the forward transform or behind the inverse one).
+struct MixNoHook {
+    SSF_HD bool operator()() const { return true; }
+};
+template <int SIGN, int R, bool DIF, bool STR = false, int IO = 0, typename T, class Ctx, class Hook = MixNoHook>
+SSF_HD bool mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab,
+                     bool use_op, const MixRowOp &op, int es = 1, const cx<T> *gsrc = nullptr, cx<T> *gdst = nullptr, Hook hook = Hook()) {
     const int M = p.M[i], s = p.S[i], nbf = p.L / R, wstep = p.W[i];
     const int se = STR ? s * es : s;
-    for (int bf = t; bf < nbf; bf += nthreads) {
-        const int blk = bf / s, j = bf - blk * s;
+    bool first = IO == 1;
+    for (int bf = t; bf < nbf || first; bf += nthreads) {
+        const bool act = bf < nbf;
+        const int blk = act ? bf / s : 0, j = act ? bf - blk * s : 0;
         cx<T> *base = x + (STR ? (blk * M + j) * es : blk * M + j);
         cx<T> v[R];
+        if constexpr (IO == 1) {
+            const cx<T> *gb = gsrc + (blk * M + j);
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = base[se * q];
+            for (int q = 0; q < R; ++q) v[q] = gb[se * q];            // (an idle thread reads the first butterfly's values and drops them)
+            if (first) {
+                first = false;
+                if (!hook()) return false;
+            }
+            if (!act) break;
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[q] = base[se * q];
+        }
         if constexpr (!DIF && R <= kMixMaxOpRadix) {               // (only given for the stride-1 pass: j = 0, bf = blk)
             if (use_op) mix_apply_op<R>(p, op, blk, v);
         }
@@ -336,10 +356,17 @@ SSF_HD void mix_pass(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<
                 if (kq + NCH < R) ch[kq % NCH] = ch[kq % NCH] * wn;
             }
         }
+        if constexpr (IO == 2) {
+            cx<T> *gb = gdst + (blk * M + j);
 #pragma unroll
-        for (int sl = 0; sl < R; ++sl) base[se * dft_slot_bin<R>(sl)] = v[sl];
+            for (int sl = 0; sl < R; ++sl) gb[se * dft_slot_bin<R>(sl)] = v[sl];
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < R; ++sl) base[se * dft_slot_bin<R>(sl)] = v[sl];
+        }
     }
-    ctx.sync();
+    if constexpr (IO != 2) ctx.sync();
+    return true;
 }
 
 // experiment builds: SSF_MIX_RADIX_SET = list of the radices the kernels carry (code-size experiments; a plan with another radix
@@ -357,24 +384,26 @@ constexpr bool mix_has_radix(int) { return true; }
 #define SSF_MIX_CASE(R, ...) \
     case R:                  \
         if constexpr (mix_has_radix(R)) { __VA_ARGS__; break; }
-template <int SIGN, bool DIF, bool STR = false, typename T, class Ctx>
-SSF_HD void mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab,
-                         bool use_op, const MixRowOp &op, int es = 1) {
+template <int SIGN, bool DIF, bool STR = false, int IO = 0, typename T, class Ctx, class Hook = MixNoHook>
+SSF_HD bool mix_pass_any(Ctx &ctx, const MixPlan &p, int i, int t, int nthreads, cx<T> *x, const cx<double> *wtab,
+                         bool use_op, const MixRowOp &op, int es = 1, const cx<T> *gsrc = nullptr, cx<T> *gdst = nullptr, Hook hook = Hook()) {
+    bool ok = true;
     switch (p.r[i]) {
-    SSF_MIX_CASE(25, mix_pass<SIGN, 25, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(20, mix_pass<SIGN, 20, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(16, mix_pass<SIGN, 16, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(15, mix_pass<SIGN, 15, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(12, mix_pass<SIGN, 12, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(10, mix_pass<SIGN, 10, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(9, mix_pass<SIGN, 9, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(8, mix_pass<SIGN, 8, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(6, mix_pass<SIGN, 6, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(5, mix_pass<SIGN, 5, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(4, mix_pass<SIGN, 4, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    SSF_MIX_CASE(3, mix_pass<SIGN, 3, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es))
-    default: mix_pass<SIGN, 2, DIF, STR>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es); break;
+    SSF_MIX_CASE(25, ok = mix_pass<SIGN, 25, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(20, ok = mix_pass<SIGN, 20, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(16, ok = mix_pass<SIGN, 16, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(15, ok = mix_pass<SIGN, 15, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(12, ok = mix_pass<SIGN, 12, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(10, ok = mix_pass<SIGN, 10, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(9, ok = mix_pass<SIGN, 9, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(8, ok = mix_pass<SIGN, 8, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(6, ok = mix_pass<SIGN, 6, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(5, ok = mix_pass<SIGN, 5, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(4, ok = mix_pass<SIGN, 4, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    SSF_MIX_CASE(3, ok = mix_pass<SIGN, 3, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook))
+    default: ok = mix_pass<SIGN, 2, DIF, STR, IO>(ctx, p, i, t, nthreads, x, wtab, use_op, op, es, gsrc, gdst, hook); break;
     }
+    return ok;
 }
 
 // x (L values in LDS, all threads of the transform past a barrier): forward, natural -> digit-reversed
@@ -417,11 +446,48 @@ SSF_HD void mix_pass_mid(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> 
     }
     ctx.sync();
 }
-template <typename T, class Ctx>
-SSF_HD void mix_dif_op_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab, const MixRowOp &op) {
+constexpr int kMixPerThread = 16;   // a row has at most 16 values per thread of its transform (fused_engine.h sizes the workgroups so)
+#ifndef SSF_MIX_IO
+#define SSF_MIX_IO 2      // bit 0: first forward pass reads the row from global memory; bit 1: last inverse pass writes it there
+#endif
+// (measured, round 6, row launch at 2 000 000 / 800 000: neither 66.7 / 35.8 us, bit 1 alone 65.2 / 35.4, bit 0 alone 79.2 / 43.2 -- the
+//  control logic inlined behind the first butterflies' loads in every radix's body costs far more than the staging copy it saves)
+// gin / gout: the row in global memory.  With at least two passes the last inverse pass writes it there, and -- experiment builds --
+// the first forward pass reads it from there (mix_pass IO); `hook` as in mix_pass (it must leave `op` filled in: the stride-1 pass uses it).  Returns
+// false when the hook ended the launch.  A single-pass row (shorter than any the engine asks for) is staged through LDS.
+template <typename T, class Ctx, class Hook>
+SSF_HD bool mix_dif_op_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T> *x, const cx<double> *wtab, const MixRowOp &op,
+                           const cx<T> *gin, cx<T> *gout, Hook hook) {
     const MixRowOp none{};
     const int last = p.npass - 1;
-    for (int i = 0; i < last; ++i) mix_pass_any<-1, true>(ctx, p, i, t, nthreads, x, wtab, false, none);
+    constexpr bool io_in = (SSF_MIX_IO & 1) != 0, io_out = (SSF_MIX_IO & 2) != 0;
+    bool staged = true;
+    if constexpr (io_in) {
+        if (last > 0) {
+            staged = false;
+            if (!mix_pass_any<-1, true, false, 1>(ctx, p, 0, t, nthreads, x, wtab, false, none, 1, gin, (cx<T> *)nullptr, hook)) return false;
+            for (int i = 1; i < last; ++i) mix_pass_any<-1, true>(ctx, p, i, t, nthreads, x, wtab, false, none);
+        }
+    }
+    if (staged) {
+        // (all of a thread's loads issued before the hook and before the first LDS store, straight-line: L <= kMixPerThread * nthreads is
+        //  the caller's contract.  Measured, row launch at 2 000 000: a load-store loop with a run-time trip count 66.7 us, this 64.7 us,
+        //  the same values in a chunk loop around the hook 83.6 us -- the array went to scratch memory.)
+        cx<T> v[kMixPerThread];
+#pragma unroll
+        for (int m = 0; m < kMixPerThread; ++m) {
+            const int i = t + nthreads * m;
+            v[m] = i < p.L ? gin[i] : mk<T>((T)0, (T)0);
+        }
+        if (!hook()) return false;
+#pragma unroll
+        for (int m = 0; m < kMixPerThread; ++m) {
+            const int i = t + nthreads * m;
+            if (i < p.L) x[i] = v[m];
+        }
+        ctx.sync();
+        for (int i = 0; i < last; ++i) mix_pass_any<-1, true>(ctx, p, i, t, nthreads, x, wtab, false, none);
+    }
     switch (p.r[last]) {
     SSF_MIX_CASE(16, mix_pass_mid<16>(ctx, p, t, nthreads, x, op))
     SSF_MIX_CASE(15, mix_pass_mid<15>(ctx, p, t, nthreads, x, op))
@@ -435,7 +501,19 @@ SSF_HD void mix_dif_op_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T
     SSF_MIX_CASE(3, mix_pass_mid<3>(ctx, p, t, nthreads, x, op))
     default: mix_pass_mid<2>(ctx, p, t, nthreads, x, op); break;
     }
-    for (int i = last - 1; i >= 0; --i) mix_pass_any<+1, false>(ctx, p, i, t, nthreads, x, wtab, false, none);
+    bool direct = false;
+    if constexpr (io_out) {
+        if (last > 0) {
+            direct = true;
+            for (int i = last - 1; i >= 1; --i) mix_pass_any<+1, false>(ctx, p, i, t, nthreads, x, wtab, false, none);
+            mix_pass_any<+1, false, false, 2>(ctx, p, 0, t, nthreads, x, wtab, false, none, 1, (const cx<T> *)nullptr, gout);
+        }
+    }
+    if (!direct) {
+        for (int i = last - 1; i >= 0; --i) mix_pass_any<+1, false>(ctx, p, i, t, nthreads, x, wtab, false, none);
+        for (int i = t; i < p.L; i += nthreads) gout[i] = x[i];
+    }
+    return true;
 }
 // the same pair over elements `es` slots apart (column stage: the columns of a tile interleaved in LDS)
 template <int SIGN, typename T, class Ctx>
