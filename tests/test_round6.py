@@ -192,7 +192,7 @@ def test_mixed_radix_columns_complex64_two_pairs_and_the_rare_stages():
     # a tolerance around the bound of lim_0 (~ lim_0 / 4): some steps need the exact lim_0, whose step-start field was stored at one
     # sample in sixteen only -- recovered from E_hd (ST_RECOVER_A / _ROW / _B); same steps, iterations and field as the traced run
     mid = synth_field(N, 2, 45, 0.0)
-    mcfg = dict(cfg, Ltotal=20, Lspan=20, hz=0.5)
+    mcfg = dict(cfg, Ltotal=10, Lspan=10, hz=0.5)
     _, it = eb.run("manakovSSF", mid, mcfg)
     lim0 = sorted(float(x[0]) for x in it["lims"])
     hit = 0
