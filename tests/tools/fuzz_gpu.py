@@ -31,7 +31,8 @@ def main():
         N = 1 << lg
         pick = rng.integers(0, 6)
         if pick == 5:                                               # fused engine, mixed-radix COLUMN stage (round 6): no power-of-two column split
-            N = int(rng.choice([9000, 10125, 15625, 16875, 25000, 28125, 40500, 50625, 8 * 3125 * 3]))
+            N = int(rng.choice([9000, 10125, 15625, 16875, 25000, 28125, 40500, 50625, 8 * 3125 * 3,
+                                20000, 36000, 100000]))      # (the last three: fewer than seven factors of two -> the two-factor split by rule)
         elif pick == 0:
             N = int(rng.choice([1500, 3000, 6000, 10000, 97, 1009, 1234, 6006, 31]))   # general-length engine (Bluestein on the fused kernels)
         elif pick == 1:                                             # fused engine, mixed-radix rows
