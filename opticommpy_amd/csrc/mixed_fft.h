@@ -56,7 +56,7 @@ inline bool mix_plan_from_radices(int L, const int *r, int n, MixPlan *p) {
 
 // with_op: the plan is a ROW's (its last pass is mix_pass_mid: radix <= kMixMaxOpRadix, costed by kMixMidCost); a column stage's
 // plan (col_mixed_body: no operator inside the transform) may end on any radix
-inline bool mix_make_plan(int L, MixPlan *p, int T = 0, bool with_op = true) {
+inline bool mix_make_plan(int L, MixPlan *p, int T = 0, bool with_op = true, double *cost_out = nullptr) {
     // enumerate ordered factorisations; the cost of a pass depends on its radix and on L only
     int cur[kMixMaxPass], best_r[kMixMaxPass], best_n = 0;
     double best = 1e300;
@@ -87,6 +87,7 @@ inline bool mix_make_plan(int L, MixPlan *p, int T = 0, bool with_op = true) {
     };
     Rec::go(L, L, T, with_op, 0, 0.0, cur, &best, best_r, &best_n);
     if (!best_n) return false;
+    if (cost_out) *cost_out = best;
     return mix_plan_from_radices(L, best_r, best_n, p);
 }
 
