@@ -763,6 +763,9 @@ template <typename T, class Ctx> SSF_HD void row_mixed_body(Ctx &ctx, const RowA
         op.N = a.N;
         return true;
     };
+    // (Butterflies are dealt to the threads of a row from number 0 up, so a pass with a large radix works on the first waves only --
+    //  3125 = 25 x 25 x 5: 125 butterflies for 256 threads.  Dealing them from the middle of the row in the second workgroup of a CU
+    //  changes nothing, measured: the hardware already puts wave k of the two workgroups of a CU on different SIMDs -- appendix #54.)
     if (!mix_dif_op_dit(ctx, p, t, T_, x, a.wtab, op, gin, g, ctrl)) return;
     ctx.mark(4);
     ctx.mark(5);

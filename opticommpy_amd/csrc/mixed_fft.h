@@ -487,8 +487,10 @@ SSF_HD bool mix_dif_op_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T
             if (i < p.L) x[i] = v[m];
         }
         ctx.sync();
+        ctx.mark(1);
         for (int i = 0; i < last; ++i) mix_pass_any<-1, true>(ctx, p, i, t, nthreads, x, wtab, false, none);
     }
+    ctx.mark(2);
     switch (p.r[last]) {
     SSF_MIX_CASE(16, mix_pass_mid<16>(ctx, p, t, nthreads, x, op))
     SSF_MIX_CASE(15, mix_pass_mid<15>(ctx, p, t, nthreads, x, op))
@@ -502,6 +504,7 @@ SSF_HD bool mix_dif_op_dit(Ctx &ctx, const MixPlan &p, int t, int nthreads, cx<T
     SSF_MIX_CASE(3, mix_pass_mid<3>(ctx, p, t, nthreads, x, op))
     default: mix_pass_mid<2>(ctx, p, t, nthreads, x, op); break;
     }
+    ctx.mark(3);
     bool direct = false;
     if constexpr (io_out) {
         if (last > 0) {

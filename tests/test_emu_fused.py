@@ -389,10 +389,11 @@ def test_edge_cases_on_emulated_kernels(case):
 
 
 # ------------------------------------------------------------------ lengths with factors 3 and 5
-@pytest.mark.parametrize("N,adaptive,K", [(9600, False, 1), (9600, True, 2), (48000, False, 1), (32000, True, 1)])
+@pytest.mark.parametrize("N,adaptive,K", [(9600, False, 1), (9600, True, 2), (48000, False, 1), (32000, True, 1), (76800, False, 1)])
 def test_mixed_radix_rows_vs_oracle(N, adaptive, K):
     """N = 2^a * m (m odd, 5-smooth): power-of-two column transforms with ragged tiles, mixed-radix row
-    transforms in LDS (mixed_fft.h).  9600 = 2^7 * 75, 48000 = 2^7 * 375, 32000 = 2^8 * 125."""
+    transforms in LDS (mixed_fft.h).  9600 = 2^7 * 75, 48000 = 2^7 * 375, 32000 = 2^8 * 125; 76800 = 2^10 * 75: more than 256 row
+    workgroups, so the later ones deal their butterflies from the middle of the row (row_mixed_body, SSF_MIX_ROT)."""
     assert eb.load().emu_supported(N, 1)
     E = synth_field(N, 2 * K, 3, 8.0)
     cfg = dict(func="manakovSSF", alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, Fs=512e9, maxIter=10, tol=1e-5, prgsBar=False,
