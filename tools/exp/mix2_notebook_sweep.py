@@ -55,7 +55,7 @@ def main():
             if N % n1 or not smooth(n1):
                 continue
             n2 = N // n1
-            if n2 < 512 or n2 > 8192 or not smooth(n2):
+            if n2 < 256 or n2 > 8192 or not smooth(n2):
                 continue
             for c in (8, 4):
                 if 8192 + 2 * c * n1 * 16 > 156 * 1024:
