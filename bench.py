@@ -686,12 +686,13 @@ def notebook_leg(sizes=(200_000, 800_000, 2_000_000), sample_km=12.0):
         # Best of two: about one run in four shows ~70 ms of host time in ONE call at 200 000 samples (inside ssf_upload_aos /
         # ssf_download_aos, 10.5 ms of device time as always; not the garbage collector, not reproduced outside bench.py:
         # profiles/r6_final2_notebook_slow_call.txt).  Both times are reported (wall_s_*_each).
-        t_np_each = []
+        t_np_each, xfer = [], []                                     # xfer: [path, host-side segments in ms] of every timed call (last_run["host_ms"])
         for _ in range(2):
             prof = _slow_call_profiler()
             t0 = time.perf_counter()
             out = oa.manakovSSF(sig, ch())                           # the notebook's timed statement
             t_np_each.append(time.perf_counter() - t0)
+            xfer.append(["numpy", {k: round(float(v), 3) for k, v in oa.last_run.get("host_ms", {}).items()}])
             prof("numpy", N, t_np_each[-1], oa.last_run)
         t_np = min(t_np_each)
         lr = dict(oa.last_run)
@@ -704,6 +705,7 @@ def notebook_leg(sizes=(200_000, 800_000, 2_000_000), sample_km=12.0):
             t0 = time.perf_counter()
             out_d = oa.manakovSSF(sig_d, ch())
             t_dev_each.append(time.perf_counter() - t0)
+            xfer.append(["device", {k: round(float(v), 3) for k, v in oa.last_run.get("host_ms", {}).items()}])
             prof("device", N, t_dev_each[-1], oa.last_run)
         t_dev = min(t_dev_each)
         lr_d = dict(oa.last_run)
@@ -727,6 +729,7 @@ def notebook_leg(sizes=(200_000, 800_000, 2_000_000), sample_km=12.0):
             "wall_s_numpy_in_numpy_out": t_np, "steps_per_s_numpy_in_numpy_out": steps / t_np,
             "wall_s_device_resident": t_dev, "steps_per_s_device_resident": int(lr_d["steps"]) / t_dev,
             "timing": "best of two calls", "wall_s_numpy_in_numpy_out_each": t_np_each, "wall_s_device_resident_each": t_dev_each,
+            "host_ms_each": xfer,
             "device_ms": float(lr.get("device_ms", 0.0)),
             "algorithmic_GBs": float(lr.get("bytes_algorithmic", 0.0)) / max(float(lr.get("device_ms", 0.0)), 1e-9) / 1e6,
             "cpu_oracle": {"steps_per_s": cpu_rate, "steps": n_cpu, "seconds": t_cpu, "cores": 1,

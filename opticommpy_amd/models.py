@@ -14,6 +14,7 @@ import ctypes as C
 import logging as logg
 import os
 import threading
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -378,6 +379,7 @@ def ssfm(Ei, param=None, _trace=False, _cpu_seed_policy=False):
 # manakovSSF / manakovDBP
 # ----------------------------------------------------------------------------
 def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=None, _units=1):
+    t_in = time.perf_counter()
     Fs = _require_fs(param)
     defaults = [("Ltotal", 400), ("Lspan", 80), ("hz", 0.5), ("alpha", 0.2), ("D", 16), ("gamma", 1.3),
                 ("Fc", 193.1e12), ("prec", np.complex128), ("amp", "edfa")]
@@ -481,7 +483,9 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
         hint = int(np.ceil(param.Lspan / param.hz)) + 1
     sink, reducer = None, None
     try:                                      # (whatever fails below, the cached plan keeps no sink, no reducer, no communicator)
+        t_up0 = time.perf_counter()
         pl.check(pl.lib.ssf_upload_aos(pl.h, in_ptr))
+        t_up = time.perf_counter() - t_up0
         if save_list:
             sink = _open_sink(pl, on_dev, N, ncols, len(save_list), len(captured))
         if _coupling is not None and not dev_coupling:
@@ -494,7 +498,9 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
                     return 1
             reducer = _lib.REDUCE_FN(_reduce)
             pl.check(pl.lib.ssf_set_coupling(pl.h, C.cast(reducer, C.c_void_p), None))
+        t_ex0 = time.perf_counter()
         st = _execute(pl, cp, Nspans, save_arr, param.prgsBar, noise_fn, _trace, hint)
+        t_ex1 = time.perf_counter()
     finally:
         if reducer is not None:
             pl.lib.ssf_set_coupling(pl.h, None, None)
@@ -505,6 +511,7 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
     for _ in range(int(st.nonconverged_steps)):
         logg.warning(NONCONV_WARNING.format(param.maxIter))
 
+    t_dn = time.perf_counter()
     if save_list:                                       # (N, 2 len(saveSpanN)), on the device when the input was
         out = sink
     elif on_dev:
@@ -514,6 +521,13 @@ def _manakov(Ei, param, direction, _trace, _cpu_seed_policy, _noise, _coupling=N
         res = np.empty((N, ncols), dtype=pl.dtype)
         pl.check(pl.lib.ssf_download_aos(pl.h, -1, res.ctypes.data_as(C.c_void_p)))
         out = res if (Ei.dtype == pl.dtype) else res.astype(Ei.dtype)     # `Ech = Ei.copy(); Ech[:, 0::2] = ...`
+    t_out = time.perf_counter()
+    last_run["upload_ms"] = t_up * 1e3                  # wall time of the call's two transfers (host <-> device, or device to device
+    last_run["download_ms"] = (t_out - t_dn) * 1e3      # for a DeviceArray), beside device_ms of the spans
+    # ... and of the call's other host-side segments: before the upload (parameters, plan), between upload and execute (snapshot sink),
+    # the execute call, after it (sink closed, result)
+    last_run["host_ms"] = {"before_upload": (t_up0 - t_in) * 1e3, "upload": t_up * 1e3, "sink_open": (t_ex0 - t_up0 - t_up) * 1e3,
+                           "execute": (t_ex1 - t_ex0) * 1e3, "sink_close": (t_dn - t_ex1) * 1e3, "download": (t_out - t_dn) * 1e3}
     return (out, param) if param.returnParameters else out
 
 
