@@ -38,8 +38,43 @@ struct EmuCtx {
     double wave_max(double v) { return v; }
 };
 
+// Context switch of the fibers.  x86-64: six callee-saved registers and the stack pointer, in user space (glibc's swapcontext makes a
+// rt_sigprocmask system call per switch -- a third of the suite's CPU time was spent in the kernel); elsewhere: ucontext.
+#if defined(__x86_64__)
+#define EMU_ASM_SWITCH 1
+extern "C" void emu_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch, .-emu_switch
+)");
+#else
+#define EMU_ASM_SWITCH 0
+#endif
+
 struct Fiber {
+#if EMU_ASM_SWITCH
+    void *sp = nullptr;
+#else
     ucontext_t uc;
+#endif
     char *stack = nullptr;
     bool done = true;
     EmuCtx ctx;
@@ -49,7 +84,11 @@ constexpr size_t kStack = 96 * 1024;
 
 struct Pool {
     std::vector<Fiber> f;
+#if EMU_ASM_SWITCH
+    void *main_sp = nullptr;
+#else
     ucontext_t main_uc;
+#endif
     Fiber *cur = nullptr;
     const std::function<void(EmuCtx &)> *body = nullptr;
     std::vector<char> lds;
@@ -60,18 +99,33 @@ struct Pool {
 };
 thread_local Pool g_pool;
 
+inline void to_main(Pool &p, Fiber *me) {
+#if EMU_ASM_SWITCH
+    emu_switch(&me->sp, p.main_sp);
+#else
+    swapcontext(&me->uc, &p.main_uc);
+#endif
+}
+inline void to_fiber(Pool &p, Fiber &f) {
+#if EMU_ASM_SWITCH
+    emu_switch(&p.main_sp, f.sp);
+#else
+    swapcontext(&p.main_uc, &f.uc);
+#endif
+}
+
 void trampoline() {
     Pool &p = g_pool;
     Fiber *me = p.cur;
     (*p.body)(me->ctx);
     me->done = true;
-    swapcontext(&me->uc, &p.main_uc);
+    to_main(p, me);
+    abort();                                   // (a finished fiber is never resumed)
 }
 
 void EmuCtx::sync() {
     Pool &p = g_pool;
-    Fiber *me = p.cur;
-    swapcontext(&me->uc, &p.main_uc);
+    to_main(p, p.cur);
 }
 
 double EmuCtx::xchg(double v) {
@@ -97,11 +151,21 @@ void run_block(int bid, int nblocks, int nthreads, size_t lds_bytes, const std::
     p.body = &body;
     for (int t = 0; t < nthreads; ++t) {
         Fiber &f = p.f[(size_t)t];
+#if EMU_ASM_SWITCH
+        // the frame emu_switch pops: six registers, then `ret` into trampoline with the stack as a call would have left it
+        uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+        void **sp = (void **)(top - 8);
+        *sp = nullptr;                                         // (trampoline's "return address": it never returns)
+        *--sp = (void *)&trampoline;
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;
+        f.sp = (void *)sp;
+#else
         getcontext(&f.uc);
         f.uc.uc_stack.ss_sp = f.stack;
         f.uc.uc_stack.ss_size = kStack;
         f.uc.uc_link = nullptr;
         makecontext(&f.uc, trampoline, 0);
+#endif
         f.done = false;
         f.ctx = EmuCtx{t, bid, nthreads, nblocks, p.lds.data()};
     }
@@ -111,7 +175,7 @@ void run_block(int bid, int nblocks, int nthreads, size_t lds_bytes, const std::
             Fiber &f = p.f[(size_t)t];
             if (f.done) continue;
             p.cur = &f;
-            swapcontext(&p.main_uc, &f.uc);
+            to_fiber(p, f);
             if (f.done) --alive;
         }
     }
