@@ -237,10 +237,11 @@ def test_forcing_a_radix_2n_length_onto_the_mixed_columns_gives_the_same_field(m
 
 # ------------------------------------------------------------------------------------------ GPU: the reference benchmark's own lengths
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [2_000_000, 200_000])
+@pytest.mark.parametrize("N", [2_000_000, 200_000, 800_000, 960_000])
 def test_reference_notebook_lengths_run_device_resident_and_match_the_oracle(N):
     """examples/benchmarck_GPU_processing.ipynb: 16-QAM, SpS 4, adaptive step, 5e4 ... 5e5 symbols = 2e5 ... 2e6 samples.  2e6 =
-    2^7 x 5^6 used to fall to the host-driven Bluestein path; it now runs on the device-resident pipeline (mixed-radix column stage)."""
+    2^7 x 5^6 used to fall to the host-driven Bluestein path; it now runs on the device-resident pipeline (mixed-radix column stage).
+    800 000 = 256 x 3125 (the bench leg's middle length) and 960 000 = 256 x 3750: radix-2^n columns x mixed-radix rows at full size."""
     E = synth_field(N, 2, 71, -2.0 + 3.0)
     cfg = dict(Fs=128e9, Ltotal=12.0, Lspan=12.0, hz=0.5, alpha=0.2, D=16, gamma=1.3, Fc=193.1e12, maxIter=5, tol=1e-5, nlprMethod=True,
                maxNlinPhaseRot=2e-2, amp="ideal", saveSpanN=[], prgsBar=False)
