@@ -1105,6 +1105,15 @@ template <typename T, int LG, class Ctx, bool RAGGED = false, int V = 16> struct
         // (+1.2 %).  (Laying P / Theta out tile-major instead, one contiguous 16 KiB block per workgroup,
         // is slower: -1.5 %, the block sits in one memory channel.)
         if (tpp % 8 == 0) tile = (tile & 7) * (tpp >> 3) + (tile >> 3);
+        else if (RAGGED && tpp > 8) {
+            // The same dealing for any number of tiles (row lengths that are not powers of two: 3125 -> 391 tiles): XCD x gets the
+            // run of q + (x < r) tiles that starts at x q + min(x, r).  Here it matters more than for P / Theta: a row of such a length
+            // does not start on a 128-byte boundary, so EVERY 128-byte segment of a tile straddles two cache lines, each shared with a
+            // neighbouring tile -- dealt round-robin, two XCDs fetched every line (800 000 = 256 x 3125: 91 MB read per launch where
+            // the stage needs 46; profiles/r6_traffic_lengths.txt).
+            const int q = tpp >> 3, r = tpp & 7, x = tile & 7;
+            tile = x * q + (x < r ? x : r) + (tile >> 3);
+        }
         n2 = tile * C + c;
         valid = !RAGGED || n2 < N2;
         N = RAGGED ? a.N : 1ll << (a.log2N1 + a.log2N2);
