@@ -1774,6 +1774,10 @@ template <typename T, int MODE, class Ctx> SSF_HD void col_mixed_body(Ctx &ctx, 
     const int grp = ctx.bid / tpp;
     int tile = ctx.bid - grp * tpp;
     if (tpp % 8 == 0) tile = (tile & 7) * (tpp >> 3) + (tile >> 3);        // contiguous runs of tiles per XCD (see ColGeom)
+    else if (tpp > 8) {                                                    // ... for any number of tiles (4 columns are half a cache line)
+        const int q = tpp >> 3, r = tpp & 7, x = tile & 7;
+        tile = x * q + (x < r ? x : r) + (tile >> 3);
+    }
     const int n2base = tile * C;
     const long long rowbase0 = (long long)grp * npol * N, pbase = (long long)grp * N;
     double *red = (double *)ctx.lds;
